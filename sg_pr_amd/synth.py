@@ -1,0 +1,90 @@
+"""Seeded synthetic semantic graphs for the bench / parity configurations.
+
+The reference ships only three real graphs (data/{0,3,250}.json); KITTI graph
+JSONs live off-repo (reference README.md:54).  These generators follow the
+specification in SURVEY.md §8(d) (configs 2, 3 and 5 of BASELINE.json): the
+packed wire format is what `SGTrainer.transfer_to_torch` (reference
+sg_net.py:241-310) produces before the one-hot expansion, i.e.
+
+    centers  float32 [G, N, 3]   zero for padded slots        (sg_net.py:262)
+    labels   int32   [G, N]      -1   for padded slots        (sg_net.py:260)
+
+Every graph keeps >= k padded slots so that kNN ties are only ever between
+feature-identical nodes (SURVEY.md §7 finding 3) - the regime in which the
+reference itself is deterministic across torch.topk implementations.
+
+numpy only; no torch import here.
+"""
+import numpy as np
+
+NUM_LABELS = 12
+
+# label histogram of the three shipped graphs (classes 0,3,5..11 dominant)
+_KITTI_LABEL_P = np.array([28, 0, 0, 10, 0, 16, 7, 25, 12, 4, 7, 3], dtype=np.float64)
+_KITTI_LABEL_P /= _KITTI_LABEL_P.sum()
+
+
+def make_graphs(num_graphs, node_num, n_real_lo, n_real_hi, seed, kitti_like=False):
+    """Return (centers f32 [G,N,3], labels i32 [G,N], n_real i32 [G])."""
+    rng = np.random.default_rng(seed)
+    centers = np.zeros((num_graphs, node_num, 3), dtype=np.float32)
+    labels = -np.ones((num_graphs, node_num), dtype=np.int32)
+    n_real = rng.integers(n_real_lo, n_real_hi + 1, size=num_graphs).astype(np.int32)
+    for g in range(num_graphs):
+        n = int(n_real[g])
+        xy = rng.uniform(-50.0, 50.0, size=(n, 2))
+        z = rng.uniform(-2.0, 1.0, size=(n, 1))
+        if kitti_like:
+            lab = rng.choice(NUM_LABELS, size=n, p=_KITTI_LABEL_P)
+        else:
+            lab = rng.integers(0, NUM_LABELS, size=n)
+        lab.sort()
+        centers[g, :n, :2] = xy
+        centers[g, :n, 2:] = z
+        labels[g, :n] = lab
+    return centers, labels, n_real
+
+
+def config2_pairs(seed=0, batch=128, node_num=64):
+    """BASELINE config 2: `batch` pairs, N=64 slots, k=10, n_real ~ U{20..54}.
+
+    Graph 2b is side 1 and graph 2b+1 is side 2 of pair b."""
+    return make_graphs(2 * batch, node_num, 20, node_num - 10, seed)
+
+
+def config5_pairs(seed=0, batch=1024, node_num=256):
+    """BASELINE config 5 (stress): N=256, k=20, n_real ~ U{100..236}."""
+    return make_graphs(2 * batch, node_num, 100, node_num - 20, seed)
+
+
+def kitti_like_sequence(num_graphs=4541, node_num=100, seed=0):
+    """BASELINE config 3 stand-in: KITTI-00-sized sequence (4541 frames).
+
+    n_real ~ U{25..60}, shipped-graph label histogram, poses = planar random
+    walk with revisits so that d<=3 m and d>=20 m pairs both exist.
+    Returns (centers, labels, n_real, poses f64 [G,12])."""
+    centers, labels, n_real = make_graphs(num_graphs, node_num, 25, 60, seed, kitti_like=True)
+    rng = np.random.default_rng(seed + 7919)
+    heading = np.cumsum(rng.normal(0.0, 0.05, size=num_graphs))
+    step = np.stack([np.cos(heading), np.sin(heading)], axis=1)  # 1 m per frame
+    xz = np.cumsum(step, axis=0)
+    # revisit: the last third of the sequence re-drives the first third (+noise)
+    third = num_graphs // 3
+    if third > 0:
+        xz[-third:] = xz[:third] + rng.normal(0.0, 0.5, size=(third, 2))
+    poses = np.zeros((num_graphs, 12), dtype=np.float64)
+    poses[:, 0] = poses[:, 5] = poses[:, 10] = 1.0
+    poses[:, 3] = xz[:, 0]   # x   (utils.py:36 uses pose[3], pose[11])
+    poses[:, 11] = xz[:, 1]  # z
+    return centers, labels, n_real, poses
+
+
+def dense_features(centers, labels, num_labels=NUM_LABELS):
+    """Packed (centers, labels) -> the reference's dense `B x (3+L) x N` float32
+    tensor (sg_net.py:274-298): xyz rows then a one-hot block, all-zero for -1."""
+    g, n, _ = centers.shape
+    out = np.zeros((g, 3 + num_labels, n), dtype=np.float32)
+    out[:, :3, :] = centers.transpose(0, 2, 1)
+    gi, ni = np.nonzero(labels >= 0)
+    out[gi, 3 + labels[gi, ni], ni] = 1.0
+    return out

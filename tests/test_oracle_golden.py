@@ -1,0 +1,135 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_checkpoint_layout(oracle_sd):
+    # SURVEY.md §8 row a-ckpt: 50 keys, 48 696 scalars
+    assert len(oracle_sd) == 50
+    assert sum(v.numel() for v in oracle_sd.values()) == 48696
+    assert oracle_sd["tensor_network.weight_matrix"].shape == (32, 32, 16)
+    assert oracle_sd["dgcnn_f_conv1.0.weight"].shape == (64, 24, 1, 1)
+
+
+def test_pack_matches_reference(oracle, golden_dir):
+    g = _load(golden_dir, "kitti3_n100_k10.npz")
+    for i, n in enumerate(g["names"]):
+        d = oracle.read_graph(os.path.join(golden_dir, "data", str(n) + ".json"))
+        f = oracle.pack_graph(d["centers"], d["nodes"], 100)
+        np.testing.assert_array_equal(f.astype(np.float32), g["features"][i])
+
+
+def test_process_pair_distance(oracle, golden_dir):
+    g = _load(golden_dir, "kitti3_n100_k10.npz")
+    names = [str(n) for n in g["names"]]
+    for (i, j), dist in zip(g["pair_ij"], g["distance"]):
+        d = oracle.process_pair([os.path.join(golden_dir, "data", names[i] + ".json"),
+                                 os.path.join(golden_dir, "data", names[j] + ".json")])
+        assert d["distance"] == dist
+    assert abs(g["distance"][2] - 133.12761323772054) < 1e-9
+
+
+def test_intermediates_shipped_graphs(oracle, oracle_sd, golden_dir):
+    g = _load(golden_dir, "kitti3_n100_k10.npz")
+    feats = torch.from_numpy(g["features"])
+    with torch.no_grad():
+        e, layers = oracle.conv_pass(oracle_sd, feats, 10, want_layers=True)
+        p, a = oracle.attention(oracle_sd, e)
+    for name, val in layers.items():
+        np.testing.assert_allclose(val.numpy(), g[name], rtol=0, atol=2e-6, err_msg=name)
+    np.testing.assert_allclose(e.numpy(), g["emb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(p.numpy().reshape(3, -1), g["pooled"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(a.numpy().reshape(3, -1), g["att"], rtol=0, atol=1e-6)
+    # known answers quoted in SURVEY.md §4
+    np.testing.assert_allclose(np.linalg.norm(g["pooled"], axis=1), [13.553494, 13.984426, 14.363490], atol=2e-5)
+    # kNN neighbour SETS of the first (xyz) layer agree with the reference
+    idx = oracle.knn(feats[:, :3, :], 10).numpy()
+    assert np.array_equal(np.sort(idx, -1), np.sort(g["knn_idx"][:, 0].astype(np.int64), -1))
+
+
+def test_scores_nine_pairs(oracle, oracle_sd, golden_dir):
+    g = _load(golden_dir, "kitti3_n100_k10.npz")
+    feats = torch.from_numpy(g["features"])
+    f1 = torch.stack([feats[i] for i, _ in g["pair_ij"]])
+    f2 = torch.stack([feats[j] for _, j in g["pair_ij"]])
+    s, a1, a2 = oracle.forward(oracle_sd, f1, f2, 10)
+    np.testing.assert_allclose(s.numpy(), g["scores"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s.numpy(), g["scores_batched"], rtol=0, atol=1e-6)
+    # BASELINE.md §2 table
+    assert abs(s[2].item() - 1.3489922e-06) < 1e-9
+    assert abs(s[0].item() - 0.99934918) < 1e-6
+    # NTN vector and the pooled-only path
+    p = torch.from_numpy(g["pooled"])
+    pi = torch.stack([p[i] for i, _ in g["pair_ij"]])
+    pj = torch.stack([p[j] for _, j in g["pair_ij"]])
+    with torch.no_grad():
+        t = oracle.tensor_network(oracle_sd, pi.unsqueeze(-1), pj.unsqueeze(-1))
+    np.testing.assert_allclose(t.numpy().reshape(9, -1), g["ntn"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(oracle.score_from_pooled(oracle_sd, pi, pj).numpy(), g["scores"], atol=1e-6)
+    m = oracle.score_all_pairs(oracle_sd, p, p)
+    np.testing.assert_allclose(m.numpy().reshape(-1), g["scores"], atol=1e-6)
+
+
+def test_eval_batch_pair(oracle, oracle_sd, golden_dir):
+    g = _load(golden_dir, "kitti3_n100_k10.npz")
+    names = [str(n) for n in g["names"]]
+    batch = [[os.path.join(golden_dir, "data", names[i] + ".json"),
+              os.path.join(golden_dir, "data", names[j] + ".json")] for i, j in g["pair_ij"]]
+    pred, gt = oracle.eval_batch_pair(oracle_sd, batch, 100, 10, 3)
+    assert pred.dtype == np.float32 and gt.dtype == np.float64
+    np.testing.assert_allclose(pred, g["eval_batch_pred"], atol=1e-6)
+    np.testing.assert_array_equal(gt, g["eval_batch_gt"])
+
+
+@pytest.mark.parametrize("fname", ["synth_n64_k10.npz", "synth_n100_k10.npz", "synth_n256_k20.npz"])
+def test_synthetic(oracle, oracle_sd, golden_dir, fname):
+    from sg_pr_amd import synth
+    g = _load(golden_dir, fname)
+    k = int(g["k"])
+    dense = torch.from_numpy(synth.dense_features(g["centers"], g["labels"]))
+    s, _, _ = oracle.forward(oracle_sd, dense[0::2], dense[1::2], k)
+    np.testing.assert_allclose(s.numpy(), g["scores"], rtol=0, atol=2e-6)
+    p, a, e = oracle.embed(oracle_sd, dense, k)
+    np.testing.assert_allclose(p.numpy(), g["pooled"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(a.numpy(), g["att"], rtol=0, atol=2e-6)
+    # generator is reproducible from its seed
+    c2, l2, _ = synth.make_graphs(g["centers"].shape[0], int(g["node_num"]),
+                                  int(g["n_real"].min()), int(g["n_real"].max()), int(g["seed"]))
+    assert c2.shape == g["centers"].shape and l2.dtype == np.int32
+
+
+def test_synth_generator_reproduces_golden_inputs(golden_dir):
+    from sg_pr_amd import synth
+    g = _load(golden_dir, "synth_n64_k10.npz")
+    c, l, n = synth.make_graphs(32, 64, 20, 54, 0)
+    np.testing.assert_array_equal(c, g["centers"])
+    np.testing.assert_array_equal(l, g["labels"])
+    assert (n <= 64 - 10).all()
+
+
+def test_f1_max(oracle, golden_dir):
+    g = _load(golden_dir, "prf1.npz")
+    for c in range(int(g["ncases"])):
+        p, r, _ = oracle.precision_recall_curve(g[f"gt{c}"], g[f"score{c}"])
+        np.testing.assert_allclose(p, g[f"precision{c}"], atol=1e-12)
+        np.testing.assert_allclose(r, g[f"recall{c}"], atol=1e-12)
+        assert abs(oracle.f1_max(g[f"gt{c}"], g[f"score{c}"]) - float(g[f"f1max{c}"])) < 1e-12
+
+
+def test_f1_max_vs_sklearn(oracle):
+    metrics = pytest.importorskip("sklearn.metrics")
+    rng = np.random.default_rng(11)
+    gt = (rng.random(777) < 0.1).astype(np.float64)
+    sc = rng.random(777).astype(np.float32)
+    p, r, _ = metrics.precision_recall_curve(gt, sc)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f1 = np.nan_to_num(2 * p * r / (p + r))
+    assert abs(oracle.f1_max(gt, sc) - f1.max()) < 1e-12
