@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py - graph-pairs/sec of the SG_PR hot path on MI355X (BASELINE.json metric).
+
+Default workload (`--workload kitti00`): the KITTI-00 all-pairs similarity matrix -
+M = 4541 graphs (KITTI-00 frame count), node_num = 100, K = 10 -> 4541^2 = 20 620 681
+ordered pairs per step.  KITTI graphs are not in the reference tree (README.md:54), so the
+sequence is the seeded KITTI-like synthetic generator of sg_pr_amd.synth (`"data":
+"synthetic"`); weights are the shipped checkpoint tests/golden/model.pth.
+
+One step = one pass of the hot path over the whole job with inputs already resident in
+HBM: embed every graph of this rank's shard (fused kNN/EdgeConv/attention kernel), exchange
+the pooled vectors, score this rank's row block of the matrix (NTN + head), gather the
+matrix on rank 0.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL);
+the M graphs / M rows are sharded across ranks, weak-scaling in the driver's sense is
+not applicable to a fixed matrix, so `scaling` is "strong".
+
+Other workloads (parity-test shapes, not the headline): `--workload pairs128` (config 2:
+128 pairs, N=64, k=10, faithful per-pair forward) and `--workload stress` (config 5).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_16x16x4_f32) = vector peak
+
+
+def embed_flops_per_graph(n, k):
+    """Algorithmic FLOPs of one graph through the embed kernel, factored EdgeConv formulation
+    (SURVEY.md 8d / DESIGN.md): kNN Gram 2*N^2*sum(Cin), per-node GEMMs 2*N*sum(Cin*2*Cout),
+    gather-max N*k*sum(Cout), conv_end 2*N*64*32, attention 2*N*(32*2) + 2*32*32."""
+    cin = [3, 64, 64, 12, 64, 64]
+    cout = [64, 64, 32, 64, 64, 32]
+    gram = 2 * n * n * sum(cin)
+    gemm = 2 * n * sum(ci * 2 * co for ci, co in zip(cin, cout))
+    gmax = n * k * sum(cout)
+    end = 2 * n * 64 * 32
+    att = 2 * n * 64 + 2 * 32 * 32
+    return gram + gemm + gmax + end + att
+
+
+def embed_bytes_per_graph(n):
+    """Algorithmic HBM bytes of one graph through the embed kernel: packed input
+    (3 fp32 centre + 1 int32 label per slot) + the pooled vector out."""
+    return 16 * n + 32 * 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kitti00", choices=["kitti00", "pairs128", "stress"])
+    ap.add_argument("--graphs", type=int, default=4541, help="M for the kitti00 workload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-gather", action="store_true", help="leave the score matrix sharded (skip the gather)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from sg_pr_amd import sg_net, synth, allpairs
+    from sg_pr_amd.parser_sg import sgpr_args
+
+    args = sgpr_args()
+    args.model = os.path.join(REPO, "tests", "golden", "model.pth")
+    args.gpu = dev.index
+    if a.workload == "kitti00":
+        n, k, m = 100, 10, a.graphs
+        centers, labels, _, _ = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=0)
+        units = m * m
+        wl_name = "KITTI-00-sized all-pairs matrix (synthetic KITTI-like graphs), M=%d, node_num=100, K=10" % m
+    elif a.workload == "pairs128":
+        n, k = 64, 10
+        centers, labels, _ = synth.config2_pairs(seed=0)
+        m = centers.shape[0]
+        units = (m // 2) * world
+        wl_name = "config 2: 128 synthetic pairs per GPU, node_num=64, K=10, faithful per-pair forward"
+    else:
+        n, k = 256, 20
+        centers, labels, _ = synth.config5_pairs(seed=0)
+        m = centers.shape[0]
+        units = (m // 2) * world
+        wl_name = "config 5: 1024 synthetic pairs per GPU, node_num=256, K=20, faithful per-pair forward"
+    args.node_num, args.K = n, k
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        trainer = sg_net.SGTrainer(args, False)
+    model = trainer.model
+    eng = model.engine()
+    d_centers = torch.from_numpy(centers).to(dev)
+    d_labels = torch.from_numpy(labels).to(dev)
+
+    ev_pairs = []          # (start, stop) events around the dominant (embed) kernel
+    graphs_per_launch = [0]
+
+    if a.workload == "kitti00":
+        scorer = allpairs.AllPairsScorer(model=model)
+        lo, hi = allpairs.shard_bounds(m, world, rank)
+        graphs_per_launch[0] = hi - lo
+
+        def embed_timed(c, l):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            p = eng.embed(c, l, k)[0]
+            e1.record()
+            ev_pairs.append((e0, e1))
+            return p
+
+        scorer.embed_fn = embed_timed
+
+        def step():
+            return scorer.run(d_centers, d_labels, gather=not a.no_gather)
+    else:
+        b = m // 2
+        c1, l1 = d_centers[0::2].contiguous(), d_labels[0::2].contiguous()
+        c2, l2 = d_centers[1::2].contiguous(), d_labels[1::2].contiguous()
+        cc, ll = torch.cat((c1, c2)), torch.cat((l1, l2))
+        graphs_per_launch[0] = m
+
+        def step():
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pooled = eng.embed(cc, ll, k)[0]
+            e1.record()
+            ev_pairs.append((e0, e1))
+            return eng.score_pairs(pooled[:b], pooled[b:])
+
+    for _ in range(a.warmup):
+        step()
+    ev_pairs.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    embed_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_pairs])) if ev_pairs else float("nan")
+    del out
+
+    if rank == 0:
+        value = units * a.steps / dt
+        g = graphs_per_launch[0]
+        flops = embed_flops_per_graph(n, k) * g
+        bytes_ = embed_bytes_per_graph(n) * g
+        ach_tflops = flops / (embed_ms * 1e-3) / 1e12
+        ach_gbs = bytes_ / (embed_ms * 1e-3) / 1e9
+        res = {
+            "metric": "graph-pairs/sec", "value": value, "unit": "graph-pairs/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if a.workload == "kitti00" else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_name, "graphs": int(m), "node_num": n, "K": k,
+                       "pairs_per_step": int(units), "parallelism": "row-sharded x%d" % world,
+                       "gather_to_rank0": (not a.no_gather) if a.workload == "kitti00" else None,
+                       "checkpoint": "tests/golden/model.pth"},
+            "roofline": {"kernel": "sgpr::embed_kernel", "bound": "mfma", "achieved": ach_tflops,
+                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP32_PEAK_TFLOPS,
+                         "traffic": None, "launch_ms": embed_ms, "graphs_per_launch": int(g),
+                         "flops_per_graph": embed_flops_per_graph(n, k),
+                         "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_graph": embed_bytes_per_graph(n)}},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.model, centers, labels, n, k, a.cpu_seconds)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ckpt, centers, labels, n, k, target_s):
+    """The oracle (faithful torch-CPU restatement of the reference forward: both graphs of
+    every pair embedded, materialised edge tensors) timed on the host cores over a bounded
+    sample of pairs drawn from the same workload."""
+    from oracle import sgpr_oracle as oracle   # checker / baseline only
+    from sg_pr_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = oracle.load_checkpoint(ckpt)
+    rng = np.random.default_rng(0)
+    bsz = 128
+    m = centers.shape[0]
+
+    def batch():
+        i = rng.integers(0, m, size=bsz)
+        j = rng.integers(0, m, size=bsz)
+        f1 = torch.from_numpy(synth.dense_features(centers[i], labels[i]))
+        f2 = torch.from_numpy(synth.dense_features(centers[j], labels[j]))
+        return f1, f2
+
+    f1, f2 = batch()
+    oracle.forward(sd, f1, f2, k)                       # warm-up
+    t0 = time.perf_counter()
+    oracle.forward(sd, f1, f2, k)
+    one = time.perf_counter() - t0
+    reps = int(max(1, min(64, round(target_s / max(one, 1e-3)))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f1, f2 = batch()
+        oracle.forward(sd, f1, f2, k)
+    dt = time.perf_counter() - t0
+    return {"value": reps * bsz / dt, "unit": "graph-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d random pairs of the same workload in batches of %d (node_num=%d, K=%d), "
+                      "faithful per-pair forward incl. dense feature assembly" % (reps * bsz, bsz, n, k),
+            "threads": torch.get_num_threads()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * sgpr.h - C ABI of the MI355X-native SG_PR pair-scoring engine (libsgpr_hip.so).
+ *
+ * The reference (kxhit/SG_PR) is pure Python/PyTorch and has no FFI layer; its
+ * boundary for the hot path is the Python API of `sg_net.SG` plus the
+ * `model.pth` state-dict layout.  This header is the C-ABI a
+ * maintainer binds *below* that API: plain pointers and sizes, no torch types.
+ * Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every `d_` pointer is DEVICE memory owned by the caller (fp32 / int32,
+ *     dense row-major); `stream` is a hipStream_t passed as void* (NULL = the
+ *     null stream).  Launches are asynchronous on that stream.
+ *   - the engine owns only its packed-weights copy inside the handle; no
+ *     allocation happens inside launch calls (workspaces are passed in).
+ *   - return value 0 = SGPR_OK, negative = error; sgpr_last_error() gives the
+ *     message of the last failing call on the calling thread.
+ *   - a handle is immutable after create => safe to use from several
+ *     streams/threads.  One process per GPU.
+ */
+#ifndef SGPR_H
+#define SGPR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGPR_ABI_VERSION 1
+
+enum {
+    SGPR_OK = 0,
+    SGPR_E_INVALID = -1,   /* NULL pointer / negative count                                   */
+    SGPR_E_DIMS = -2,      /* architecture not supported by the kernels (see sgpr_dims)       */
+    SGPR_E_NODES = -3,     /* node_num outside [k, SGPR_MAX_NODES]                             */
+    SGPR_E_K = -4,         /* K outside [1, SGPR_MAX_K] or K > node_num                        */
+    SGPR_E_LABEL = -5,     /* a label outside [-1, num_labels) was seen (sgpr_check_status)    */
+    SGPR_E_HIP = -6,       /* HIP runtime error (message has hipGetErrorString)                */
+    SGPR_E_WORKSPACE = -7, /* workspace missing or too small                                   */
+    SGPR_E_BLOB = -8       /* weights blob has the wrong number of floats                      */
+};
+
+#define SGPR_MAX_NODES 256 /* one workgroup stages a whole graph in LDS */
+#define SGPR_MAX_K 32
+
+typedef struct sgpr_handle sgpr_handle;
+
+/* Architecture hyper-parameters = the `arch:` block of the reference's
+ * config.yml (parser_sg.py:12-18) + number_of_labels (sg_net.py:201-203).
+ * The HIP kernels are written for the architecture of every shipped
+ * checkpoint: {12, 64, 64, 32, 16, 16}; anything else -> SGPR_E_DIMS. */
+typedef struct sgpr_dims {
+    int32_t num_labels;
+    int32_t filters_1;
+    int32_t filters_2;
+    int32_t filters_3;
+    int32_t tensor_neurons;
+    int32_t bottle_neck_neurons;
+} sgpr_dims;
+
+/* Number of floats sgpr_create expects in `weights` for `dims`.
+ * Blob layout = the fp32 tensors of the reference state dict
+ * (sg_net.py:45-76; SURVEY.md row a-ckpt), each flattened row-major, in this order:
+ *   for blk in [dgcnn_s_conv1, dgcnn_f_conv1, dgcnn_s_conv2, dgcnn_f_conv2,
+ *               dgcnn_s_conv3, dgcnn_f_conv3, dgcnn_conv_end]:
+ *       blk.0.weight [Cout, Cin2], blk.1.weight (gamma), blk.1.bias (beta),
+ *       blk.1.running_mean, blk.1.running_var            (each [Cout])
+ *   attention.weight_matrix [F3,F3]
+ *   tensor_network.weight_matrix [F3,F3,T], .weight_matrix_block [T,2*F3], .bias [T]
+ *   fully_connected_first.weight [B,T], .bias [B]
+ *   scoring_layer.weight [1,B], .bias [1]
+ * (the seven int64 num_batches_tracked scalars are not part of the blob). */
+size_t sgpr_weights_count(const sgpr_dims* dims);
+
+/* Replaces SGTrainer.setup_model's load_state_dict + .cuda() (sg_net.py:158-176):
+ * folds eval-mode BatchNorm into the 1x1 convs, re-lays the weights out for the
+ * kernels and uploads them to `device`.  `weights` is HOST memory. */
+int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, int device, sgpr_handle** out);
+void sgpr_destroy(sgpr_handle* h);
+
+/* Bytes of device workspace sgpr_embed* needs for (G graphs, N slots); 0 when none. */
+size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k);
+
+/* Per-graph half of SG.forward: SG.dgcnn_conv_pass (sg_net.py:79-110 ->
+ * dgcnn.knn / get_graph_feature dgcnn.py:14-49, the six EdgeConv blocks
+ * sg_net.py:50-73, conv_end sg_net.py:74-76) + AttentionModule.forward
+ * (layers_batch.py:28-39), fused in one kernel, one workgroup per graph.
+ *   d_centers [G,N,3] f32 (0 for padded slots), d_labels [G,N] i32 (-1 = pad)
+ *     = the packed form of transfer_to_torch's output (sg_net.py:250-299)
+ *   d_pooled [G,F3] (required); d_att [G,N] and d_emb [G,N,F3] may be NULL. */
+int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int k,
+               float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
+               void* stream);
+
+/* Same, taking the reference's dense tensor `features` [G, 3+L, N] f32
+ * (data["features_1"], sg_net.py:119) - the sem block may hold any values. */
+int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N, int k, float* d_pooled,
+                     float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* sgpr_embed + dumps of every intermediate for parity tests:
+ *   d_layers [G,6,N,64] f32  outputs of s_conv1..3, f_conv1..3 after max-k (channels >= Cout are 0)
+ *   d_knn    [G,6,N,k]  i32  neighbour lists chosen at the input of those six layers (unordered sets). */
+int sgpr_embed_debug(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int k,
+                     float* d_pooled, float* d_att, float* d_emb, float* d_layers, int32_t* d_knn,
+                     void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Pair-coupled half of SG.forward: TenorNetworkModule.forward
+ * (layers_batch.py:70-83) + fully_connected_first/ReLU + scoring_layer/sigmoid
+ * (sg_net.py:131-136) for P pairs.  Pair p scores
+ *   (d_pooled1[idx1 ? idx1[p] : p], d_pooled2[idx2 ? idx2[p] : p]); idx may be NULL. */
+int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t* d_idx1,
+                     const float* d_pooled2, const int32_t* d_idx2, int64_t P, float* d_score, void* stream);
+
+/* Dense all-pairs form of the same tail: score[r, c] = SG-tail(rows[r], cols[c])
+ * (the NTN is asymmetric, layers_batch.py:77-83, so the full rectangle is computed).
+ * d_score is [R, ld] with ld >= M.  Workspace: sgpr_score_all_pairs_workspace_bytes. */
+size_t sgpr_score_all_pairs_workspace_bytes(const sgpr_handle* h, int R, int M);
+int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols,
+                         int M, float* d_score, int64_t ld, void* d_workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* Drop-in SG.forward (sg_net.py:112-138): dense features of both sides in,
+ * (score [B], att1 [B,N], att2 [B,N]) out; att pointers may be NULL. */
+size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k);
+int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const float* d_features_2, int B, int N,
+                       int k, float* d_score, float* d_att1, float* d_att2, void* d_workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Synchronises `stream` and returns SGPR_E_LABEL if any launch on this handle
+ * saw a label outside [-1, num_labels) since the last check (the reference
+ * raises KeyError at sg_net.py:277), else SGPR_OK.  Clears the flag. */
+int sgpr_check_status(const sgpr_handle* h, void* stream);
+
+/* LDS bytes / threads per workgroup the embed kernel uses for (N, k); 0 if unsupported. */
+size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
+
+const char* sgpr_last_error(void);
+int sgpr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGPR_H */

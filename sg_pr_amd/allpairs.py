@@ -1,0 +1,114 @@
+"""Dense all-pairs evaluation of one sequence, sharded over the GPUs of a node.
+
+The reference's eval loop (eval_batch.py:26-36) walks a pair list and embeds both
+graphs of every pair from scratch.  `SG.dgcnn_conv_pass` + `attention` depend on
+ONE graph only (sg_net.py:123-127), so for the M x M similarity matrix of a
+sequence each graph is embedded once and only the NTN + head tail runs per pair.
+
+Multi-GPU (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI):
+    rank r embeds graphs [lo_r, hi_r)                      (no communication)
+    all_gather of the pooled vectors   M x 32 fp32         (0.58 MB for KITTI-00)
+    rank r scores rows [lo_r, hi_r) against all M columns  (no communication)
+    gather of the row blocks to rank 0                     (M*M*4 bytes in total)
+Every score depends on its two graphs only, so the matrix is bit-identical for any
+world size.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous balanced split of range(total): the first total % world ranks get one extra."""
+    base, extra = divmod(int(total), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class AllPairsScorer:
+    """embed_fn(centers[g0:g1], labels[g0:g1]) -> pooled [g, F];  score_fn(rows, cols) -> [R, M].
+
+    With an `sg_net.SG` model the two callables are its HIP paths; tests inject CPU
+    stand-ins to exercise the sharding / collective logic under gloo."""
+
+    def __init__(self, model=None, embed_fn=None, score_fn=None, group=None):
+        if model is not None:
+            embed_fn = lambda c, l: model.embed(c, l)[0]   # noqa: E731
+            score_fn = model.score_all_pairs
+        if embed_fn is None or score_fn is None:
+            raise ValueError("need a model or both embed_fn and score_fn")
+        self.embed_fn = embed_fn
+        self.score_fn = score_fn
+        self.group = group
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    def pooled_all(self, centers, labels):
+        """Embed this rank's shard and all_gather: every rank returns pooled [M, F]."""
+        world, rank = self._world()
+        m = labels.shape[0]
+        lo, hi = shard_bounds(m, world, rank)
+        local = self.embed_fn(centers[lo:hi], labels[lo:hi])
+        if world == 1:
+            return local
+        cap = shard_bounds(m, world, 0)[1]               # largest shard
+        buf = local.new_zeros((cap, local.shape[1]))
+        buf[: hi - lo] = local
+        gathered = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(gathered, buf, group=self.group)
+        parts = []
+        for r in range(world):
+            l, h = shard_bounds(m, world, r)
+            parts.append(gathered[r][: h - l])
+        return torch.cat(parts, dim=0)
+
+    def score_rows(self, pooled):
+        """This rank's row block of the score matrix: [hi-lo, M]."""
+        world, rank = self._world()
+        lo, hi = shard_bounds(pooled.shape[0], world, rank)
+        return self.score_fn(pooled[lo:hi].contiguous(), pooled)
+
+    def gather_matrix(self, block, m, dst=0):
+        """Gather the row blocks on rank `dst` -> [M, M] there, None elsewhere."""
+        world, rank = self._world()
+        if world == 1:
+            return block
+        cap = shard_bounds(m, world, 0)[1]
+        buf = block.new_zeros((cap, m))
+        buf[: block.shape[0]] = block
+        if rank == dst:
+            recv = [torch.empty_like(buf) for _ in range(world)]
+            dist.gather(buf, recv, dst=dst, group=self.group)
+            parts = []
+            for r in range(world):
+                l, h = shard_bounds(m, world, r)
+                parts.append(recv[r][: h - l])
+            return torch.cat(parts, dim=0)
+        dist.gather(buf, None, dst=dst, group=self.group)
+        return None
+
+    def run(self, centers, labels, gather=True):
+        """Whole job: returns the [M, M] matrix on rank 0 (row block elsewhere / if gather=False)."""
+        pooled = self.pooled_all(centers, labels)
+        block = self.score_rows(pooled)
+        if not gather:
+            return block
+        full = self.gather_matrix(block, pooled.shape[0])
+        return full if full is not None else block
+
+
+def pose_distance_matrix(poses):
+    """Planar pose distances of a sequence (utils.py:36 for every pair): [M, M] float64 tensor."""
+    p = torch.as_tensor(poses, dtype=torch.float64)
+    xz = torch.stack((p[:, 3], p[:, 11]), dim=1)
+    return torch.cdist(xz, xz)
+
+
+def ground_truth_mask(dist_matrix, p_thresh):
+    """(gt, valid): gt = 1 where d <= p_thresh, 0 where d >= 20; pairs in between are the
+    ones the reference refuses (`exit(-1)`, sg_net.py:302-309) and are masked out."""
+    gt = (dist_matrix <= p_thresh).to(torch.float64)
+    valid = (dist_matrix <= p_thresh) | (dist_matrix >= 20)
+    return gt, valid

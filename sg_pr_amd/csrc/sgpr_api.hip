@@ -1,0 +1,395 @@
+// C-ABI entry points of libsgpr_hip.so (declared in include/sgpr.h) and the host-side
+// weight preparation: eval-mode BatchNorm folding + kernel-ready layout.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "sgpr_internal.hpp"
+
+namespace sgpr {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return SGPR_E_HIP;
+}
+
+static bool dims_supported(const sgpr_dims* d) {
+    return d && d->num_labels == kLabels && d->filters_1 == kF1 && d->filters_2 == kF2 && d->filters_3 == kF3 &&
+           d->tensor_neurons == kT && d->bottle_neck_neurons == kB;
+}
+
+struct BlockShape {
+    int cout, cin2;
+};
+
+static void block_shapes(const sgpr_dims* d, BlockShape out[7]) {
+    // order of the blob: s_conv1, f_conv1, s_conv2, f_conv2, s_conv3, f_conv3, conv_end (sg_net.py:50-76)
+    out[0] = {d->filters_1, 6};
+    out[1] = {d->filters_1, 2 * d->num_labels};
+    out[2] = {d->filters_2, 2 * d->filters_1};
+    out[3] = {d->filters_2, 2 * d->filters_1};
+    out[4] = {d->filters_3, 2 * d->filters_2};
+    out[5] = {d->filters_3, 2 * d->filters_2};
+    out[6] = {d->filters_3, 2 * d->filters_3};
+}
+
+static size_t weights_count(const sgpr_dims* d) {
+    BlockShape bs[7];
+    block_shapes(d, bs);
+    size_t n = 0;
+    for (int b = 0; b < 7; ++b) n += (size_t)bs[b].cout * bs[b].cin2 + 4 * (size_t)bs[b].cout;
+    const size_t f = d->filters_3, t = d->tensor_neurons, bn = d->bottle_neck_neurons;
+    n += f * f;                  // attention.weight_matrix
+    n += f * f * t + t * 2 * f + t;  // tensor_network
+    n += bn * t + bn;            // fully_connected_first
+    n += bn + 1;                 // scoring_layer
+    return n;
+}
+
+}  // namespace sgpr
+
+using namespace sgpr;
+
+extern "C" {
+
+size_t sgpr_weights_count(const sgpr_dims* dims) { return dims ? weights_count(dims) : 0; }
+
+int sgpr_abi_version(void) { return SGPR_ABI_VERSION; }
+
+const char* sgpr_last_error(void) { return g_last_error.c_str(); }
+
+int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, int device, sgpr_handle** out) {
+    if (!weights || !dims || !out) {
+        set_error("sgpr_create: NULL argument");
+        return SGPR_E_INVALID;
+    }
+    if (!dims_supported(dims)) {
+        set_error("sgpr_create: only the architecture {labels 12, filters 64/64/32, tensor 16, bottleneck 16} is built");
+        return SGPR_E_DIMS;
+    }
+    if (n_floats != weights_count(dims)) {
+        set_error("sgpr_create: weights blob has " + std::to_string(n_floats) + " floats, expected " +
+                  std::to_string(weights_count(dims)));
+        return SGPR_E_BLOB;
+    }
+    BlockShape bs[7];
+    block_shapes(dims, bs);
+
+    // ---- fold BN (double precision) and lay out: 6 EdgeConv layers + conv_end + tail tensors
+    std::vector<float> packed;
+    size_t off_wf[7], off_tb[7];
+    int kp_of[7];
+    const float* src = weights;
+    for (int b = 0; b < 7; ++b) {
+        const int cout = bs[b].cout, cin2 = bs[b].cin2;
+        const float* W = src;
+        const float* gamma = W + (size_t)cout * cin2;
+        const float* beta = gamma + cout;
+        const float* mean = beta + cout;
+        const float* var = mean + cout;
+        src = var + cout;
+        if (b < 6) {
+            const int cin = cin2 / 2;
+            const int kp = cin <= kKPad ? kKPad : cin;
+            kp_of[b] = kp;
+            off_wf[b] = packed.size();
+            packed.resize(packed.size() + (size_t)2 * cout * kp, 0.f);
+            float* wf = packed.data() + off_wf[b];
+            for (int c = 0; c < cout; ++c) {
+                const double s = (double)gamma[c] / sqrt((double)var[c] + 1e-5);
+                for (int i = 0; i < cin; ++i) {
+                    const double w1 = W[(size_t)c * cin2 + i];        // multiplies (x_j - x_i)   dgcnn.py:47
+                    const double w2 = W[(size_t)c * cin2 + cin + i];  // multiplies x_i
+                    wf[(size_t)c * kp + i] = (float)(s * w1);
+                    wf[(size_t)(cout + c) * kp + i] = (float)(s * (w2 - w1));
+                }
+            }
+        } else {
+            kp_of[b] = cin2;
+            off_wf[b] = packed.size();
+            packed.resize(packed.size() + (size_t)cout * cin2, 0.f);
+            float* wf = packed.data() + off_wf[b];
+            for (int c = 0; c < cout; ++c) {
+                const double s = (double)gamma[c] / sqrt((double)var[c] + 1e-5);
+                for (int i = 0; i < cin2; ++i) wf[(size_t)c * cin2 + i] = (float)(s * W[(size_t)c * cin2 + i]);
+            }
+        }
+        off_tb[b] = packed.size();
+        packed.resize(packed.size() + cout, 0.f);
+        float* tb = packed.data() + off_tb[b];
+        for (int c = 0; c < cout; ++c) {
+            const double s = (double)gamma[c] / sqrt((double)var[c] + 1e-5);
+            tb[c] = (float)((double)beta[c] - (double)mean[c] * s);
+        }
+    }
+    const size_t f = kF3, t = kT, bn = kB;
+    auto append = [&](size_t n) {
+        size_t o = packed.size();
+        packed.insert(packed.end(), src, src + n);
+        src += n;
+        return o;
+    };
+    const size_t o_att = append(f * f);
+    const size_t o_ntw = append(f * f * t);
+    const size_t o_ntb = append(t * 2 * f);
+    const size_t o_ntbias = append(t);
+    const size_t o_fc1w = append(bn * t);
+    const size_t o_fc1b = append(bn);
+    const size_t o_fc2w = append(bn);
+    const size_t o_fc2b = append(1);
+    while (packed.size() % 4) packed.push_back(0.f);
+
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    sgpr_handle* h = new sgpr_handle();
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->dims = *dims;
+    h->blob_floats = packed.size();
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), packed.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_status), sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(h->d_status, 0, sizeof(int32_t));
+    if (e != hipSuccess) {
+        if (h->d_blob) (void)hipFree(h->d_blob);
+        if (h->d_status) (void)hipFree(h->d_status);
+        delete h;
+        return hip_fail(e, "sgpr_create: device allocation / upload");
+    }
+    // blob order is s1,f1,s2,f2,s3,f3 ; kernel order is s1,s2,s3,f1,f2,f3
+    static const int blob_of_layer[6] = {0, 2, 4, 1, 3, 5};
+    for (int l = 0; l < 6; ++l) {
+        const int b = blob_of_layer[l];
+        h->w.wf[l] = h->d_blob + off_wf[b];
+        h->w.tb[l] = h->d_blob + off_tb[b];
+        h->w.kp[l] = kp_of[b];
+        h->w.cout[l] = bs[b].cout;
+    }
+    h->w.wf_end = h->d_blob + off_wf[6];
+    h->w.tb_end = h->d_blob + off_tb[6];
+    h->w.att_w = h->d_blob + o_att;
+    h->w.ntn_w = h->d_blob + o_ntw;
+    h->w.ntn_wb = h->d_blob + o_ntb;
+    h->w.ntn_bias = h->d_blob + o_ntbias;
+    h->w.fc1_w = h->d_blob + o_fc1w;
+    h->w.fc1_b = h->d_blob + o_fc1b;
+    h->w.fc2_w = h->d_blob + o_fc2w;
+    h->w.fc2_b = h->d_blob + o_fc2b;
+    *out = h;
+    return SGPR_OK;
+}
+
+void sgpr_destroy(sgpr_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_status) (void)hipFree(h->d_status);
+    delete h;
+}
+
+static int check_nk(int G, int N, int k, EmbedPlan* plan) {
+    if (G < 0) {
+        set_error("negative graph count");
+        return SGPR_E_INVALID;
+    }
+    if (N < 1 || N > SGPR_MAX_NODES) {
+        set_error("node_num " + std::to_string(N) + " outside [1, " + std::to_string(SGPR_MAX_NODES) + "]");
+        return SGPR_E_NODES;
+    }
+    if (k < 1 || k > SGPR_MAX_K || k > N) {
+        set_error("K " + std::to_string(k) + " outside [1, min(node_num, " + std::to_string(SGPR_MAX_K) + ")]");
+        return SGPR_E_K;
+    }
+    if (!make_embed_plan(N, k, plan)) {
+        set_error("no LDS plan for node_num " + std::to_string(N) + ", K " + std::to_string(k));
+        return SGPR_E_NODES;
+    }
+    return SGPR_OK;
+}
+
+static size_t embed_ws_bytes(const EmbedPlan& p, int G) {
+    return p.park_in_lds ? 0 : (size_t)G * p.NP * 32 * sizeof(float);
+}
+
+size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
+    EmbedPlan p;
+    if (!h || G < 0 || !make_embed_plan(N, k, &p)) return 0;
+    return embed_ws_bytes(p, G);
+}
+
+size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
+    EmbedPlan p;
+    if (!h || !make_embed_plan(N, k, &p)) return 0;
+    return (size_t)p.lds_bytes;
+}
+
+static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, void* ws, size_t ws_bytes, void* stream) {
+    if (h && a.G == 0) return SGPR_OK;
+    if (!h || !a.pooled || (!a.dense && (!a.centers || !a.labels))) {
+        set_error("sgpr_embed: NULL argument");
+        return SGPR_E_INVALID;
+    }
+    EmbedPlan plan;
+    int rc = check_nk(a.G, N, k, &plan);
+    if (rc != SGPR_OK) return rc;
+    const size_t need = embed_ws_bytes(plan, a.G);
+    if (need > 0 && (!ws || ws_bytes < need)) {
+        set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    a.park_ws = static_cast<float*>(ws);
+    a.status = h->d_status;
+    return launch_embed(h, plan, a, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int k,
+               float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
+               void* stream) {
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.centers = d_centers;
+    a.labels = d_labels;
+    a.G = G;
+    a.pooled = d_pooled;
+    a.att = d_att;
+    a.emb = d_emb;
+    return embed_common(h, a, N, k, d_workspace, workspace_bytes, stream);
+}
+
+int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N, int k, float* d_pooled,
+                     float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes, void* stream) {
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dense = d_features;
+    a.G = G;
+    a.pooled = d_pooled;
+    a.att = d_att;
+    a.emb = d_emb;
+    return embed_common(h, a, N, k, d_workspace, workspace_bytes, stream);
+}
+
+int sgpr_embed_debug(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int k,
+                     float* d_pooled, float* d_att, float* d_emb, float* d_layers, int32_t* d_knn,
+                     void* d_workspace, size_t workspace_bytes, void* stream) {
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.centers = d_centers;
+    a.labels = d_labels;
+    a.G = G;
+    a.pooled = d_pooled;
+    a.att = d_att;
+    a.emb = d_emb;
+    a.dbg_layers = d_layers;
+    a.dbg_knn = d_knn;
+    return embed_common(h, a, N, k, d_workspace, workspace_bytes, stream);
+}
+
+int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t* d_idx1, const float* d_pooled2,
+                     const int32_t* d_idx2, int64_t P, float* d_score, void* stream) {
+    if (!h || !d_pooled1 || !d_pooled2 || !d_score || P < 0) {
+        set_error("sgpr_score_pairs: NULL argument or negative count");
+        return SGPR_E_INVALID;
+    }
+    return launch_score_pairs(h, d_pooled1, d_idx1, d_pooled2, d_idx2, P, d_score, static_cast<hipStream_t>(stream));
+}
+
+size_t sgpr_score_all_pairs_workspace_bytes(const sgpr_handle* h, int R, int M) {
+    if (!h || R < 0 || M < 0) return 0;
+    return score_all_pairs_ws_bytes(R, M);
+}
+
+int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols, int M,
+                         float* d_score, int64_t ld, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !d_pooled_rows || !d_pooled_cols || !d_score || R < 0 || M < 0 || ld < M) {
+        set_error("sgpr_score_all_pairs: NULL argument, negative count or ld < M");
+        return SGPR_E_INVALID;
+    }
+    const size_t need = score_all_pairs_ws_bytes(R, M);
+    if (need > 0 && (!d_workspace || workspace_bytes < need)) {
+        set_error("sgpr_score_all_pairs: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    return launch_score_all_pairs(h, d_pooled_rows, R, d_pooled_cols, M, d_score, ld, d_workspace,
+                                  static_cast<hipStream_t>(stream));
+}
+
+// workspace of sgpr_forward_dense: pooled [2B][32] | embed workspace for 2B graphs
+size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k) {
+    EmbedPlan p;
+    if (!h || B < 0 || !make_embed_plan(N, k, &p)) return 0;
+    return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(p, 2 * B);
+}
+
+int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const float* d_features_2, int B, int N,
+                       int k, float* d_score, float* d_att1, float* d_att2, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!h || !d_features_1 || !d_features_2 || !d_score || B < 0) {
+        set_error("sgpr_forward_dense: NULL argument or negative batch");
+        return SGPR_E_INVALID;
+    }
+    EmbedPlan plan;
+    int rc = check_nk(2 * B, N, k, &plan);
+    if (rc != SGPR_OK) return rc;
+    const size_t need = sgpr_forward_workspace_bytes(h, B, N, k);
+    if (!d_workspace || workspace_bytes < need) {
+        set_error("sgpr_forward_dense: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    float* pooled = static_cast<float*>(d_workspace);
+    // both sides in ONE launch of 2B workgroups: graphs [0,B) = side 1, [B,2B) = side 2
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dense = d_features_1;
+    a.dense2 = d_features_2;
+    a.g_split = B;
+    a.G = 2 * B;
+    a.pooled = pooled;
+    a.park_ws = pooled + (size_t)2 * B * kF3;
+    a.status = h->d_status;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d_att1 && d_att2 && d_att2 == d_att1 + (size_t)B * N) {
+        a.att = d_att1;  // contiguous [2B, N] attention buffer
+        rc = launch_embed(h, plan, a, s);
+    } else if (!d_att1 && !d_att2) {
+        rc = launch_embed(h, plan, a, s);
+    } else {
+        // separate attention buffers: one launch per side
+        EmbedArgs a1 = a, a2 = a;
+        a1.dense2 = nullptr; a1.G = B; a1.att = d_att1;
+        a2.dense = d_features_2; a2.dense2 = nullptr; a2.G = B; a2.att = d_att2;
+        a2.pooled = pooled + (size_t)B * kF3;
+        if (a.park_ws) a2.park_ws = a.park_ws + (size_t)B * plan.NP * 32;
+        rc = launch_embed(h, plan, a1, s);
+        if (rc == SGPR_OK) rc = launch_embed(h, plan, a2, s);
+    }
+    if (rc != SGPR_OK) return rc;
+    return launch_score_pairs(h, pooled, nullptr, pooled + (size_t)B * kF3, nullptr, B, d_score, s);
+}
+
+int sgpr_check_status(const sgpr_handle* h, void* stream) {
+    if (!h) {
+        set_error("sgpr_check_status: NULL handle");
+        return SGPR_E_INVALID;
+    }
+    int32_t flag = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(&flag, h->d_status, sizeof(flag), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "sgpr_check_status");
+    if (flag) {
+        e = hipMemsetAsync(h->d_status, 0, sizeof(flag), s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_fail(e, "sgpr_check_status: reset");
+        set_error("a node label outside [-1, num_labels) was seen by the embed kernel");
+        return SGPR_E_LABEL;
+    }
+    return SGPR_OK;
+}
+
+}  // extern "C"

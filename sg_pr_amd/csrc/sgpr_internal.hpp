@@ -1,0 +1,93 @@
+// Internal declarations shared by the translation units of libsgpr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "sgpr.h"
+
+namespace sgpr {
+
+// Architecture the kernels are written for (every shipped checkpoint; sgpr.h).
+constexpr int kLabels = 12;
+constexpr int kF1 = 64, kF2 = 64, kF3 = 32;
+constexpr int kT = 16;   // tensor_neurons
+constexpr int kB = 16;   // bottle_neck_neurons
+constexpr int kKPad = 16;  // layer-1 inputs (3 / 12 channels) are zero-padded to one MFMA k-block
+
+// Device-resident, kernel-ready weights (all pointers into one allocation).
+//   EdgeConv layer l (order: s_conv1, s_conv2, s_conv3, f_conv1, f_conv2, f_conv3):
+//     wf[l] : [2*cout][kp] row-major.  rows [0,cout)      = s * W[:, :C]          (acts on x_j)
+//                                      rows [cout,2cout)  = s * (W[:, C:] - W[:, :C])  (acts on x_i)
+//     tb[l] : [cout] = beta - mean * s,  s = gamma / sqrt(var + 1e-5)   (eval BatchNorm folded)
+struct DevWeights {
+    const float* wf[6];
+    const float* tb[6];
+    int kp[6];
+    int cout[6];
+    const float* wf_end;  // [32][64] folded
+    const float* tb_end;  // [32]
+    const float* att_w;   // [32][32]
+    const float* ntn_w;   // [32][32*16]   (weight_matrix.view(F3,-1), col = j*16 + t)
+    const float* ntn_wb;  // [16][64]
+    const float* ntn_bias;  // [16]
+    const float* fc1_w;   // [16][16]
+    const float* fc1_b;   // [16]
+    const float* fc2_w;   // [16]
+    const float* fc2_b;   // [1]
+};
+
+}  // namespace sgpr
+
+struct sgpr_handle {
+    int device;
+    sgpr_dims dims;
+    float* d_blob;       // owns the packed weights
+    size_t blob_floats;
+    int32_t* d_status;   // label-error flag
+    sgpr::DevWeights w;
+};
+
+namespace sgpr {
+
+// LDS plan of the embed kernel for one (N, k); computed on the host, passed by value.
+struct EmbedPlan {
+    int N, NP, k, kmax;
+    int pitchD;      // floats per row of the distance chunk
+    int RC;          // rows per distance chunk (multiple of 16)
+    int P;           // lanes per row in the selection phase (power of two)
+    int seg;         // candidates per lane (multiple of 4)
+    int kpitch;      // bytes per row of the neighbour list
+    int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
+    int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
+    int lds_bytes;
+};
+bool make_embed_plan(int N, int k, EmbedPlan* plan);
+
+struct EmbedArgs {
+    const float* centers;   // packed input, or
+    const int32_t* labels;
+    const float* dense;     // dense [G][3+L][N] input (centers/labels NULL)
+    const float* dense2;    // optional second dense tensor: graphs g >= g_split read dense2[g - g_split]
+    int g_split;
+    int G;
+    float* pooled;
+    float* att;
+    float* emb;
+    float* dbg_layers;
+    int32_t* dbg_knn;
+    float* park_ws;         // [G][NP][32] when !park_in_lds
+    int32_t* status;
+};
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a, hipStream_t stream);
+int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,
+                       int64_t P, float* score, hipStream_t stream);
+size_t score_all_pairs_ws_bytes(int R, int M);
+int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
+                           int64_t ld, void* ws, hipStream_t stream);
+
+}  // namespace sgpr

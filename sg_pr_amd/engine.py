@@ -1,0 +1,268 @@
+"""ctypes binding of the C-ABI in include/sgpr.h (libsgpr_hip.so) + weight-blob packing.
+
+This is the only place the Python host touches the HIP engine.  PyTorch is used
+for device memory and streams only: tensors are handed over as raw pointers.
+There is NO CPU fallback: a missing library or a non-GPU tensor raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _build
+
+NUM_LABELS = 12
+F3 = 32
+
+# order of the fp32 tensors in the weights blob (include/sgpr.h, sgpr_weights_count)
+_CONV_BLOCKS = ["dgcnn_s_conv1", "dgcnn_f_conv1", "dgcnn_s_conv2", "dgcnn_f_conv2",
+                "dgcnn_s_conv3", "dgcnn_f_conv3", "dgcnn_conv_end"]
+BLOB_KEYS = []
+for _b in _CONV_BLOCKS:
+    BLOB_KEYS += [_b + ".0.weight", _b + ".1.weight", _b + ".1.bias", _b + ".1.running_mean", _b + ".1.running_var"]
+BLOB_KEYS += ["attention.weight_matrix", "tensor_network.weight_matrix", "tensor_network.weight_matrix_block",
+              "tensor_network.bias", "fully_connected_first.weight", "fully_connected_first.bias",
+              "scoring_layer.weight", "scoring_layer.bias"]
+
+SGPR_OK = 0
+ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: "SGPR_E_K", -5: "SGPR_E_LABEL",
+               -6: "SGPR_E_HIP", -7: "SGPR_E_WORKSPACE", -8: "SGPR_E_BLOB"}
+
+# every symbol include/sgpr.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
+               "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
+               "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
+               "sgpr_embed_lds_bytes", "sgpr_last_error", "sgpr_abi_version"]
+
+
+class SgprError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "SGPR_E_?"), code, message))
+        self.code = code
+
+
+class SgprDims(ctypes.Structure):
+    _fields_ = [("num_labels", ctypes.c_int32), ("filters_1", ctypes.c_int32), ("filters_2", ctypes.c_int32),
+                ("filters_3", ctypes.c_int32), ("tensor_neurons", ctypes.c_int32),
+                ("bottle_neck_neurons", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsgpr_hip.so (built in-tree by sg_pr_amd._build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("HIP engine %s is not built; run `python -m sg_pr_amd._build` "
+                          "(there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    lib.sgpr_weights_count.restype = sz
+    lib.sgpr_weights_count.argtypes = [ctypes.POINTER(SgprDims)]
+    lib.sgpr_create.restype = i32
+    lib.sgpr_create.argtypes = [vp, sz, ctypes.POINTER(SgprDims), i32, ctypes.POINTER(vp)]
+    lib.sgpr_destroy.restype = None
+    lib.sgpr_destroy.argtypes = [vp]
+    lib.sgpr_embed_workspace_bytes.restype = sz
+    lib.sgpr_embed_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    lib.sgpr_embed.restype = i32
+    lib.sgpr_embed.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_embed_dense.restype = i32
+    lib.sgpr_embed_dense.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_embed_debug.restype = i32
+    lib.sgpr_embed_debug.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_score_pairs.restype = i32
+    lib.sgpr_score_pairs.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
+    lib.sgpr_score_all_pairs_workspace_bytes.restype = sz
+    lib.sgpr_score_all_pairs_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_score_all_pairs.restype = i32
+    lib.sgpr_score_all_pairs.argtypes = [vp, vp, i32, vp, i32, vp, i64, vp, sz, vp]
+    lib.sgpr_forward_workspace_bytes.restype = sz
+    lib.sgpr_forward_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    lib.sgpr_forward_dense.restype = i32
+    lib.sgpr_forward_dense.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_check_status.restype = i32
+    lib.sgpr_check_status.argtypes = [vp, vp]
+    lib.sgpr_embed_lds_bytes.restype = sz
+    lib.sgpr_embed_lds_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_last_error.restype = ctypes.c_char_p
+    lib.sgpr_last_error.argtypes = []
+    lib.sgpr_abi_version.restype = i32
+    lib.sgpr_abi_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def default_dims():
+    return SgprDims(NUM_LABELS, 64, 64, 32, 16, 16)
+
+
+def dims_from_args(args, number_of_labels=NUM_LABELS):
+    return SgprDims(int(number_of_labels), int(args.filters_1), int(args.filters_2), int(args.filters_3),
+                    int(args.tensor_neurons), int(args.bottle_neck_neurons))
+
+
+def blob_from_state_dict(sd):
+    """Flatten a reference state dict (with or without the `module.` prefix) into the fp32 blob."""
+    parts = []
+    for key in BLOB_KEYS:
+        t = sd[key] if key in sd else sd["module." + key]
+        parts.append(t.detach().to(torch.float32).cpu().contiguous().view(-1).numpy())
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    """One packed-weights handle on one GPU (immutable after creation)."""
+
+    def __init__(self, state_dict, dims=None, device=0):
+        self._h = None
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("sg_pr_amd.Engine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        self.dims = dims if dims is not None else default_dims()
+        blob = blob_from_state_dict(state_dict)
+        want = self.lib.sgpr_weights_count(ctypes.byref(self.dims))
+        h = ctypes.c_void_p()
+        rc = self.lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(self.dims),
+                                  self.device.index, ctypes.byref(h))
+        self._check(rc)
+        assert want == blob.size
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            self.lib.sgpr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc):
+        if rc != SGPR_OK:
+            raise SgprError(rc, self.lib.sgpr_last_error().decode())
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype, name):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+        return t
+
+    def _ws(self, nbytes):
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+
+    def lds_bytes(self, node_num, k):
+        return int(self.lib.sgpr_embed_lds_bytes(self._h, node_num, k))
+
+    def check_status(self):
+        self._check(self.lib.sgpr_check_status(self._h, self._stream()))
+
+    # ------------------------------------------------------------------ per-graph half
+    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False):
+        """centers [G,N,3] f32, labels [G,N] i32 (-1 = pad) -> pooled [G,32] (+ att [G,N], emb [G,N,32])."""
+        centers = self._dev(centers, torch.float32, "centers")
+        labels = self._dev(labels, torch.int32, "labels")
+        g, n = labels.shape
+        assert centers.shape == (g, n, 3), "centers must be [G, N, 3]"
+        pooled = torch.empty(g, F3, dtype=torch.float32, device=self.device)
+        att = torch.empty(g, n, dtype=torch.float32, device=self.device) if (want_att or debug) else None
+        emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if (want_emb or debug) else None
+        ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
+        ws = self._ws(ws_bytes)
+        if debug:
+            layers = torch.zeros(g, 6, n, 64, dtype=torch.float32, device=self.device)
+            knn = torch.full((g, 6, n, k), -1, dtype=torch.int32, device=self.device)
+            rc = self.lib.sgpr_embed_debug(self._h, _ptr(centers), _ptr(labels), g, n, k, _ptr(pooled), _ptr(att),
+                                           _ptr(emb), _ptr(layers), _ptr(knn), _ptr(ws), ws_bytes, self._stream())
+            self._check(rc)
+            return pooled, att, emb, layers, knn
+        rc = self.lib.sgpr_embed(self._h, _ptr(centers), _ptr(labels), g, n, k, _ptr(pooled), _ptr(att), _ptr(emb),
+                                 _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        return pooled, att, emb
+
+    def embed_dense(self, features, k, want_att=False, want_emb=False):
+        """features [G, 3+L, N] f32 (the reference's dense layout) -> pooled (+ att, emb)."""
+        features = self._dev(features, torch.float32, "features")
+        g, ch, n = features.shape
+        if ch != 3 + self.dims.num_labels:
+            raise ValueError("features must be [G, %d, N], got %s" % (3 + self.dims.num_labels, tuple(features.shape)))
+        pooled = torch.empty(g, F3, dtype=torch.float32, device=self.device)
+        att = torch.empty(g, n, dtype=torch.float32, device=self.device) if want_att else None
+        emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if want_emb else None
+        ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
+        ws = self._ws(ws_bytes)
+        rc = self.lib.sgpr_embed_dense(self._h, _ptr(features), g, n, k, _ptr(pooled), _ptr(att), _ptr(emb), _ptr(ws),
+                                       ws_bytes, self._stream())
+        self._check(rc)
+        return pooled, att, emb
+
+    # ------------------------------------------------------------------ pair-coupled half
+    def score_pairs(self, pooled1, pooled2, idx1=None, idx2=None, out=None):
+        pooled1 = self._dev(pooled1, torch.float32, "pooled1")
+        pooled2 = self._dev(pooled2, torch.float32, "pooled2")
+        if idx1 is not None:
+            idx1 = self._dev(idx1, torch.int32, "idx1")
+        if idx2 is not None:
+            idx2 = self._dev(idx2, torch.int32, "idx2")
+        n = idx1.numel() if idx1 is not None else pooled1.shape[0]
+        n2 = idx2.numel() if idx2 is not None else pooled2.shape[0]
+        if n != n2:
+            raise ValueError("pair sides differ in length: %d vs %d" % (n, n2))
+        score = out if out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        rc = self.lib.sgpr_score_pairs(self._h, _ptr(pooled1), _ptr(idx1), _ptr(pooled2), _ptr(idx2), n, _ptr(score),
+                                       self._stream())
+        self._check(rc)
+        return score
+
+    def score_all_pairs(self, pooled_rows, pooled_cols, out=None):
+        rows = self._dev(pooled_rows, torch.float32, "pooled_rows")
+        cols = self._dev(pooled_cols, torch.float32, "pooled_cols")
+        r, m = rows.shape[0], cols.shape[0]
+        score = out if out is not None else torch.empty(r, m, dtype=torch.float32, device=self.device)
+        assert score.shape == (r, m) and score.stride(1) == 1
+        ws_bytes = self.lib.sgpr_score_all_pairs_workspace_bytes(self._h, r, m)
+        ws = self._ws(ws_bytes)
+        rc = self.lib.sgpr_score_all_pairs(self._h, _ptr(rows), r, _ptr(cols), m, _ptr(score), score.stride(0),
+                                           _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        return score
+
+    def forward_dense(self, features_1, features_2, k, want_att=True):
+        """Drop-in SG.forward on dense [B,3+L,N] inputs -> (score [B], att1 [B,N], att2 [B,N])."""
+        f1 = self._dev(features_1, torch.float32, "features_1")
+        f2 = self._dev(features_2, torch.float32, "features_2")
+        if f1.shape != f2.shape:
+            raise ValueError("features_1 / features_2 shapes differ")
+        b, ch, n = f1.shape
+        if ch != 3 + self.dims.num_labels:
+            raise ValueError("features must be [B, %d, N]" % (3 + self.dims.num_labels))
+        score = torch.empty(b, dtype=torch.float32, device=self.device)
+        att = torch.empty(2, b, n, dtype=torch.float32, device=self.device) if want_att else None
+        ws_bytes = self.lib.sgpr_forward_workspace_bytes(self._h, b, n, k)
+        ws = self._ws(ws_bytes)
+        rc = self.lib.sgpr_forward_dense(self._h, _ptr(f1), _ptr(f2), b, n, k, _ptr(score),
+                                         _ptr(att[0]) if want_att else None, _ptr(att[1]) if want_att else None,
+                                         _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        if want_att:
+            return score, att[0], att[1]
+        return score, None, None

@@ -1,0 +1,258 @@
+"""`SG` / `SGTrainer` with the reference's API (sg_net.py:18-138, 141-206, 241-310,
+434-525) backed by the MI355X HIP engine.
+
+Only inference is built (training is out of scope): the model
+must be in eval mode - BatchNorm running statistics are folded into the kernels'
+weights.  There is no CPU fallback.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as _engine
+from .layers_batch import AttentionModule, TenorNetworkModule
+from .utils import process_pair, load_paires, read_graph, pose_distance  # noqa: F401  (reference: `from utils import *`)
+
+
+class SG(torch.nn.Module):
+    """Pair scorer with the reference's constructor, parameter names and forward contract.
+
+    `state_dict()` has exactly the reference's 50 keys, so any shipped checkpoint
+    loads strictly.  `forward(data)` returns `(score[B], att1[B,N,1], att2[B,N,1])`.
+    """
+
+    def __init__(self, args, number_of_labels):
+        super(SG, self).__init__()
+        self.args = args
+        self.number_labels = number_of_labels
+        self.setup_layers()
+        self._engine = None
+        self._engine_key = None
+
+    def calculate_bottleneck_features(self):
+        self.feature_count = self.args.tensor_neurons
+
+    def setup_layers(self):
+        a = self.args
+        self.calculate_bottleneck_features()
+        self.attention = AttentionModule(a)
+        self.tensor_network = TenorNetworkModule(a)
+        self.fully_connected_first = torch.nn.Linear(self.feature_count, a.bottle_neck_neurons)
+        self.scoring_layer = torch.nn.Linear(a.bottle_neck_neurons, 1)
+
+        def block2d(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout),
+                                 nn.LeakyReLU(negative_slope=0.2))
+
+        self.dgcnn_s_conv1 = block2d(3 * 2, a.filters_1)
+        self.dgcnn_f_conv1 = block2d(self.number_labels * 2, a.filters_1)
+        self.dgcnn_s_conv2 = block2d(a.filters_1 * 2, a.filters_2)
+        self.dgcnn_f_conv2 = block2d(a.filters_1 * 2, a.filters_2)
+        self.dgcnn_s_conv3 = block2d(a.filters_2 * 2, a.filters_3)
+        self.dgcnn_f_conv3 = block2d(a.filters_2 * 2, a.filters_3)
+        self.dgcnn_conv_end = nn.Sequential(nn.Conv1d(a.filters_3 * 2, a.filters_3, kernel_size=1, bias=False),
+                                            nn.BatchNorm1d(a.filters_3), nn.LeakyReLU(negative_slope=0.2))
+
+    # ------------------------------------------------------------------ engine plumbing
+    @property
+    def module(self):
+        """The reference wraps the model in DataParallel; `.module` keeps such callers working."""
+        return self
+
+    def _device_index(self):
+        return int(getattr(self.args, "gpu", 0))
+
+    def engine(self):
+        """The packed-weights HIP handle for the current parameters (rebuilt if they change)."""
+        if self.training:
+            raise RuntimeError("sg_pr_amd.SG only runs in eval mode (BatchNorm statistics are folded into the "
+                               "HIP kernels); call model.eval() - training is not part of this engine")
+        key = tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + (self._device_index(),)
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = _engine.Engine(self.state_dict(), _engine.dims_from_args(self.args, self.number_labels),
+                                          device=self._device_index())
+            self._engine_key = key
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        # .cuda()/.to() of the torch parameters does not move the packed copy: drop it
+        self._engine_key = None
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------ reference API
+    def dgcnn_conv_pass(self, x):
+        """sg_net.py:79-110 - x [B, 3+L, N] -> node embeddings [B, N, filters_3]."""
+        _, _, emb = self.engine().embed_dense(x, int(self.args.K), want_emb=True)
+        return emb
+
+    def forward(self, data):
+        """sg_net.py:112-138 - data["features_1"/"features_2"]: [B, 3+L, N]."""
+        score, att1, att2 = self.engine().forward_dense(data["features_1"], data["features_2"], int(self.args.K))
+        return score, att1.unsqueeze(-1), att2.unsqueeze(-1)
+
+    # ------------------------------------------------------------------ packed fast paths (no one-hot tensors)
+    def embed(self, centers, labels, want_att=False, want_emb=False):
+        """Packed graphs (centers [G,N,3], labels [G,N], -1 = pad) -> pooled [G, filters_3] (+att, +emb)."""
+        return self.engine().embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb)
+
+    def score_pooled(self, pooled_1, pooled_2, idx_1=None, idx_2=None):
+        """NTN + head on pooled vectors (optionally gathered through index lists)."""
+        return self.engine().score_pairs(pooled_1, pooled_2, idx_1, idx_2)
+
+    def score_all_pairs(self, pooled_rows, pooled_cols):
+        return self.engine().score_all_pairs(pooled_rows, pooled_cols)
+
+    def forward_packed(self, centers_1, labels_1, centers_2, labels_2):
+        """Faithful per-pair scoring of packed graphs: both sides embedded, then the tail."""
+        b = labels_1.shape[0]
+        c = torch.cat((torch.as_tensor(centers_1), torch.as_tensor(centers_2)), dim=0)
+        l = torch.cat((torch.as_tensor(labels_1), torch.as_tensor(labels_2)), dim=0)
+        pooled, att, _ = self.embed(c, l, want_att=True)
+        score = self.score_pooled(pooled[:b], pooled[b:])
+        return score, att[:b].unsqueeze(-1), att[b:].unsqueeze(-1)
+
+
+def pack_graph(centers, nodes, node_num, number_of_labels=12):
+    """One side of transfer_to_torch (sg_net.py:250-272) in packed form.
+
+    Returns (centers f32 [node_num,3], labels i32 [node_num]); padded slots have
+    centre 0 / label -1.  A label outside [0, L) raises KeyError like
+    `self.global_labels[node]` (sg_net.py:277).  Graphs with more than node_num
+    nodes are rejected: the reference subsamples them with an *unseeded*
+    np.random.choice (sg_net.py:252-256), so no reproducible answer exists."""
+    n = len(nodes)
+    if n > node_num:
+        raise ValueError("graph has %d nodes > node_num=%d; the reference subsamples such graphs randomly "
+                         "(unseeded) - raise node_num (<= 256) instead" % (n, node_num))
+    lab = np.asarray(nodes).astype(np.int64).reshape(-1)
+    bad = (lab < 0) | (lab >= number_of_labels)
+    if bad.any():
+        raise KeyError(int(lab[bad][0]))
+    c = np.zeros((node_num, 3), dtype=np.float32)
+    l = -np.ones(node_num, dtype=np.int32)
+    if n:
+        c[:n] = np.asarray(centers, dtype=np.float64).reshape(n, 3)
+        l[:n] = lab
+    return c, l
+
+
+class SGTrainer(object):
+    """Inference half of the reference harness (sg_net.py:141-206, 241-310, 434-525)."""
+
+    def __init__(self, args, train=True):
+        if train:
+            raise NotImplementedError("training (SGTrainer.fit) is out of scope of the MI355X engine; "
+                                      "construct with train=False")
+        self.args = args
+        self.model_pth = self.args.model
+        self.initial_label_enumeration(train)
+        self.setup_model(train)
+        self._graph_cache = {}
+
+    def initial_label_enumeration(self, train=True):
+        """sg_net.py:178-206 - twelve SemanticKITTI-derived node classes."""
+        self.global_labels = {val: index for index, val in enumerate(range(12))}
+        self.number_of_labels = len(self.global_labels)
+        self.keepnode = getattr(self.args, "keep_node", 1)
+
+    def setup_model(self, train=True):
+        """sg_net.py:158-176 - build SG, load the DataParallel checkpoint (strip `module.`)."""
+        self.model = SG(self.args, self.number_of_labels)
+        if (not train) and self.model_pth != "":
+            print("loading model: ", self.model_pth)
+            state_dict = torch.load(self.model_pth, map_location="cpu")
+            new_state_dict = OrderedDict()
+            for k, v in state_dict.items():
+                new_state_dict[k[7:] if k.startswith("module.") else k] = v
+            self.model.load_state_dict(new_state_dict)
+        self.model.eval()
+
+    # ------------------------------------------------------------------ host packing
+    def _load_graph(self, path):
+        """Parse one graph JSON once and keep its packed form (the reference re-reads and
+        re-pads every graph for every pair it appears in: utils.py:27-28, sg_net.py:250-299)."""
+        g = self._graph_cache.get(path)
+        if g is None:
+            d = read_graph(path)
+            c, l = pack_graph(d["centers"], d["nodes"], int(self.args.node_num), self.number_of_labels)
+            g = (c, l, d["pose"])
+            self._graph_cache[path] = g
+        return g
+
+    def target_from_distance(self, distance):
+        """sg_net.py:302-309."""
+        if distance <= self.args.p_thresh:
+            return 1.0
+        if distance >= 20:
+            return 0.0
+        print("distance error: ", distance)
+        exit(-1)
+
+    def transfer_to_torch(self, data, training=True):
+        """sg_net.py:241-310 - pair dictionary -> dense `features_1/2` [(3+L), node_num] + target.
+        Unlike the reference this does not mutate `data`."""
+        if training:
+            raise NotImplementedError("augmentation / training branch is out of scope")
+        new_data = dict()
+        for side in ("1", "2"):
+            c, l = pack_graph(data["centers_" + side], data["nodes_" + side], int(self.args.node_num),
+                              self.number_of_labels)
+            onehot = np.zeros((l.shape[0], self.number_of_labels), dtype=np.float64)
+            real = l >= 0
+            onehot[np.nonzero(real)[0], l[real]] = 1.0
+            centers64 = np.zeros((l.shape[0], 3), dtype=np.float64)
+            n = len(data["nodes_" + side])
+            centers64[:n] = np.asarray(data["centers_" + side], dtype=np.float64).reshape(n, 3)
+            new_data["features_" + side] = np.concatenate((centers64, onehot), axis=1).T
+        new_data["target"] = self.target_from_distance(data["distance"])
+        return new_data
+
+    # ------------------------------------------------------------------ evaluation entry points
+    def eval_pair(self, pair_file):
+        """sg_net.py:434-457 - one pair dictionary -> (prediction, att_weights_1, att_weights_2)."""
+        data = self.transfer_to_torch(pair_file, False)
+        data_torch = {
+            "features_1": torch.FloatTensor(np.array([data["features_1"]])),
+            "features_2": torch.FloatTensor(np.array([data["features_2"]])),
+        }
+        self.model.eval()
+        r1, r2, r3 = self.model(data_torch)
+        return (r1.cpu().detach().numpy().reshape(-1), r2.cpu().detach().numpy().reshape(-1),
+                r3.cpu().detach().numpy().reshape(-1))
+
+    def eval_batch_pair(self, batch):
+        """sg_net.py:503-525 - list of [path_1, path_2] -> (pred float32 [B], gt float64 [B])."""
+        self.model.eval()
+        n = int(self.args.node_num)
+        b = len(batch)
+        centers = np.empty((2 * b, n, 3), dtype=np.float32)
+        labels = np.empty((2 * b, n), dtype=np.int32)
+        batch_target = []
+        for i, graph_pair in enumerate(batch):
+            c1, l1, pose1 = self._load_graph(graph_pair[0])
+            c2, l2, pose2 = self._load_graph(graph_pair[1])
+            centers[i], labels[i] = c1, l1
+            centers[b + i], labels[b + i] = c2, l2
+            batch_target.append(self.target_from_distance(pose_distance(pose1, pose2)))
+        prediction, _, _ = self.model.forward_packed(centers[:b], labels[:b], centers[b:], labels[b:])
+        prediction = prediction.cpu().detach().numpy().reshape(-1)
+        gt = np.array(batch_target).reshape(-1)
+        return prediction, gt
+
+    def eval_batch_pair_data(self, batch):
+        """sg_net.py:480-501 - like eval_batch_pair but on in-memory pair dictionaries."""
+        self.model.eval()
+        f1, f2, tgt = [], [], []
+        for graph_pair in batch:
+            data = self.transfer_to_torch(graph_pair, False)
+            f1.append(data["features_1"])
+            f2.append(data["features_2"])
+            tgt.append(data["target"])
+        data = {"features_1": torch.FloatTensor(np.array(f1)), "features_2": torch.FloatTensor(np.array(f2))}
+        prediction, _, _ = self.model(data)
+        return prediction.cpu().detach().numpy().reshape(-1), np.array(tgt).reshape(-1)

@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the
+reference-generated golden vectors.  Needs a real MI355X: `pytest -m gpu`.
+
+Bar (BASELINE.json north_star): similarity scores within 1e-4 of the reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-4   # north_star: "Similarity scores match the reference within 1e-4"
+FEAT_TOL = 2e-4    # intermediates (values up to ~10): folded BN + reassociated dot products
+
+
+@pytest.fixture(scope="module")
+def eng(ckpt_path):
+    from sg_pr_amd import engine
+    from oracle import sgpr_oracle
+    e = engine.Engine(sgpr_oracle.load_checkpoint(ckpt_path), device=0)
+    yield e
+    e.close()
+
+
+def _packed_from_golden_features(feats):
+    """dense [G,15,N] -> (centers [G,N,3], labels [G,N])."""
+    centers = np.ascontiguousarray(feats[:, :3, :].transpose(0, 2, 1))
+    onehot = feats[:, 3:, :]
+    labels = np.where(onehot.sum(1) > 0, onehot.argmax(1), -1).astype(np.int32)
+    return centers, labels
+
+
+def test_shipped_graphs_every_intermediate(eng, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    centers, labels = _packed_from_golden_features(g["features"])
+    pooled, att, emb, layers, knn = eng.embed(centers, labels, 10, debug=True)
+    torch.cuda.synchronize()
+    layers, knn = layers.cpu().numpy(), knn.cpu().numpy()
+    names = ["xyz1", "xyz2", "xyz3", "sem1", "sem2", "sem3"]
+    agree = []
+    for li, name in enumerate(names):
+        ref = g[name].transpose(0, 2, 1)                       # [G, N, C]
+        got = layers[:, li, :, : ref.shape[2]]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=FEAT_TOL, err_msg=name)
+        same = np.sort(knn[:, li], -1) == np.sort(g["knn_idx"][:, li].astype(np.int32), -1)
+        agree.append(same.all(-1).mean())
+    print("neighbour-set agreement per layer (xyz1..3, sem1..3):", np.round(agree, 4))
+    assert (knn >= 0).all() and (knn < 100).all()
+    assert agree[0] == 1.0                                     # xyz layer 1: no ties between distinct nodes
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=0, atol=FEAT_TOL)
+    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=1e-5, atol=5e-4)
+    # nine ordered pairs: pair-list kernel and dense all-pairs kernel
+    i1 = torch.tensor(g["pair_ij"][:, 0].astype(np.int32))
+    i2 = torch.tensor(g["pair_ij"][:, 1].astype(np.int32))
+    s = eng.score_pairs(pooled, pooled, i1, i2).cpu().numpy()
+    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=SCORE_TOL)
+    m = eng.score_all_pairs(pooled, pooled).cpu().numpy()
+    np.testing.assert_allclose(m.reshape(-1), g["scores"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(m.reshape(-1), s, rtol=0, atol=2e-6)
+    assert abs(m[0, 2] - 1.3489922e-06) < 1e-6 and abs(m[2, 0] - 2.8918e-05) < 1e-6   # asymmetric NTN
+
+
+@pytest.mark.parametrize("fname", ["synth_n64_k10.npz", "synth_n100_k10.npz", "synth_n256_k20.npz"])
+def test_synthetic_golden(eng, golden_dir, fname):
+    g = np.load(os.path.join(golden_dir, fname))
+    k = int(g["k"])
+    pooled, att, _ = eng.embed(g["centers"], g["labels"], k, want_att=True)
+    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=1e-5, atol=1e-3)
+    s = eng.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous()).cpu().numpy()
+    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=SCORE_TOL)
+
+
+def test_forward_dense_matches_oracle_config2_full(eng, oracle, oracle_sd):
+    """BASELINE config 2 at full size: 128 pairs, N=64, k=10 through the drop-in forward."""
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.config2_pairs(seed=3)
+    dense = torch.from_numpy(synth.dense_features(centers, labels))
+    f1, f2 = dense[0::2].contiguous(), dense[1::2].contiguous()
+    score, a1, a2 = eng.forward_dense(f1, f2, 10)
+    ref, r1, r2 = oracle.forward(oracle_sd, f1, f2, 10)
+    err = (score.cpu() - ref).abs().max().item()
+    print("config2 max|dscore| =", err)
+    assert err <= SCORE_TOL
+    np.testing.assert_allclose(a1.cpu().numpy(), r1.numpy()[..., 0], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(a2.cpu().numpy(), r2.numpy()[..., 0], rtol=0, atol=1e-4)
+    # packed and dense entry points are the same computation
+    p_packed, _, _ = eng.embed(centers, labels, 10)
+    p_dense, _, _ = eng.embed_dense(dense, 10)
+    assert torch.equal(p_packed, p_dense)
+
+
+def test_dense_general_sem_features(eng, oracle, oracle_sd):
+    """The dense entry accepts arbitrary (not one-hot) semantic channels like the reference."""
+    rng = np.random.default_rng(5)
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.make_graphs(8, 64, 20, 50, 9)
+    dense = synth.dense_features(centers, labels)
+    real = labels >= 0
+    soft = rng.dirichlet(np.ones(12) * 0.3, size=labels.shape).astype(np.float32)   # [G,N,12]
+    dense[:, 3:, :] = np.where(real[:, None, :], soft.transpose(0, 2, 1), 0.0)
+    dense_t = torch.from_numpy(dense)
+    p, a, e = eng.embed_dense(dense_t, 10, want_att=True, want_emb=True)
+    rp, ra, re = oracle.embed(oracle_sd, dense_t, 10)
+    s = eng.score_pairs(p[0::2].contiguous(), p[1::2].contiguous()).cpu()
+    rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
+    assert (s - rs).abs().max().item() <= SCORE_TOL
+
+
+def test_stress_shape_subset_and_invariances(eng, oracle, oracle_sd):
+    """Config 5 shape (N=256, k=20): a subset against the oracle, plus size-independent
+    properties on a larger batch: batch-position invariance and pair-list == all-pairs."""
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.config5_pairs(seed=1, batch=64)
+    pooled, att, _ = eng.embed(centers, labels, 20, want_att=True)
+    dense = torch.from_numpy(synth.dense_features(centers[:16], labels[:16]))
+    rp, ra, _ = oracle.embed(oracle_sd, dense, 20)
+    rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
+    s = eng.score_pairs(pooled[0:16:2].contiguous(), pooled[1:16:2].contiguous()).cpu()
+    print("N=256 max|dscore| =", (s - rs).abs().max().item())
+    assert (s - rs).abs().max().item() <= SCORE_TOL
+    np.testing.assert_allclose(att[:16].cpu().numpy(), ra.numpy(), rtol=0, atol=1e-4)
+    # batch invariance: reversed graph order gives bit-identical per-graph results
+    p_rev, _, _ = eng.embed(centers[::-1].copy(), labels[::-1].copy(), 20)
+    assert torch.equal(p_rev.flip(0), pooled)
+    # all-pairs rectangle == pair list over the same index pairs
+    m = eng.score_all_pairs(pooled[:40], pooled)
+    ii, jj = torch.meshgrid(torch.arange(40, dtype=torch.int32), torch.arange(128, dtype=torch.int32), indexing="ij")
+    lst = eng.score_pairs(pooled, pooled, ii.reshape(-1), jj.reshape(-1)).view(40, 128)
+    np.testing.assert_allclose(m.cpu().numpy(), lst.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_all_pairs_matrix_vs_oracle_and_f1(eng, oracle, oracle_sd):
+    """KITTI-like sequence (config 3 generator, reduced M): the dense matrix equals the oracle's
+    faithful per-pair evaluation, and F1-max computed from both agrees."""
+    from sg_pr_amd import synth, metrics, allpairs
+    centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=96, node_num=100, seed=4)
+    pooled, _, _ = eng.embed(centers, labels, 10)
+    m = eng.score_all_pairs(pooled, pooled).cpu()
+    dense = torch.from_numpy(synth.dense_features(centers, labels))
+    rp, _, _ = oracle.embed(oracle_sd, dense, 10)
+    rm = oracle.score_all_pairs(oracle_sd, rp, rp)
+    err = (m - rm).abs().max().item()
+    print("all-pairs max|dscore| =", err)
+    assert err <= SCORE_TOL
+    gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
+    assert gt[valid].sum() > 0
+    f_hip = metrics.f1_max(gt[valid].numpy(), m[valid].numpy())
+    f_ref = oracle.f1_max(gt[valid].numpy(), rm[valid].numpy())
+    print("F1-max hip/oracle:", f_hip, f_ref)
+    assert abs(f_hip - f_ref) <= 1e-3
+
+
+def test_reference_api_drop_in(golden_dir, ckpt_path):
+    """sg_net.SG / SGTrainer entry points reproduce the reference's own outputs."""
+    from sg_pr_amd import sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    args = sgpr_args()
+    args.model = ckpt_path
+    trainer = sg_net.SGTrainer(args, False)
+    names = [str(n) for n in g["names"]]
+    batch = [[os.path.join(golden_dir, "data", names[i] + ".json"),
+              os.path.join(golden_dir, "data", names[j] + ".json")] for i, j in g["pair_ij"]]
+    pred, gt = trainer.eval_batch_pair(batch)
+    assert pred.dtype == np.float32 and gt.dtype == np.float64
+    np.testing.assert_allclose(pred, g["eval_batch_pred"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_array_equal(gt, g["eval_batch_gt"])
+    # SG.forward on the dense dictionary (eval_pair.py path)
+    feats = torch.from_numpy(g["features"])
+    data = {"features_1": torch.stack([feats[i] for i, _ in g["pair_ij"]]),
+            "features_2": torch.stack([feats[j] for _, j in g["pair_ij"]])}
+    score, a1, a2 = trainer.model(data)
+    assert score.shape == (9,) and a1.shape == (9, 100, 1) and a2.shape == (9, 100, 1)
+    np.testing.assert_allclose(score.cpu().numpy(), g["scores"], rtol=0, atol=SCORE_TOL)
+    e = trainer.model.dgcnn_conv_pass(feats)
+    assert e.shape == (3, 100, 32)
+    np.testing.assert_allclose(e.cpu().numpy(), g["emb"], rtol=0, atol=FEAT_TOL)
+    from sg_pr_amd.utils import process_pair
+    p, w1, w2 = trainer.eval_pair(process_pair(batch[2]))
+    assert abs(p[0] - g["scores"][2]) <= SCORE_TOL and w1.shape == (100,)
+    # training mode is refused loudly (BN folded)
+    trainer.model.train()
+    with pytest.raises(RuntimeError):
+        trainer.model(data)
+    trainer.model.eval()
+
+
+def test_error_codes(eng):
+    from sg_pr_amd.engine import SgprError
+    c = torch.zeros(1, 300, 3)
+    l = torch.zeros(1, 300, dtype=torch.int32)
+    with pytest.raises(SgprError) as ei:
+        eng.embed(c, l, 10)
+    assert ei.value.code == -3
+    with pytest.raises(SgprError) as ei:
+        eng.embed(c[:, :8], l[:, :8], 10)       # K > node_num
+    assert ei.value.code == -4
+    bad = torch.full((2, 32), 3, dtype=torch.int32)
+    bad[1, 5] = 12                                   # label outside 0..11 (reference: KeyError)
+    eng.embed(torch.zeros(2, 32, 3), bad, 10)
+    with pytest.raises(SgprError) as ei:
+        eng.check_status()
+    assert ei.value.code == -5
+    eng.check_status()                               # flag cleared
+    # empty batch is a no-op
+    p, _, _ = eng.embed(torch.zeros(0, 64, 3), torch.zeros(0, 64, dtype=torch.int32), 10)
+    assert p.shape == (0, 32)
+
+
+def test_odd_sizes(eng, oracle, oracle_sd):
+    """Ragged shapes: node_num not a multiple of 16, K not in the tuned set."""
+    from sg_pr_amd import synth
+    for n, k in ((50, 7), (23, 5), (130, 16), (200, 32)):
+        centers, labels, _ = synth.make_graphs(6, n, max(1, n // 3), n - k, 100 + n)
+        p, a, _ = eng.embed(centers, labels, k, want_att=True)
+        dense = torch.from_numpy(synth.dense_features(centers, labels))
+        rp, ra, _ = oracle.embed(oracle_sd, dense, k)
+        s = eng.score_pairs(p[0::2].contiguous(), p[1::2].contiguous()).cpu()
+        rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
+        assert (s - rs).abs().max().item() <= SCORE_TOL, (n, k)
+        np.testing.assert_allclose(a.cpu().numpy(), ra.numpy(), rtol=0, atol=1e-4)
