@@ -208,8 +208,6 @@ def cpu_baseline(ckpt, centers, labels, n, k, target_s):
     sample of pairs drawn from the same workload."""
     from oracle import sgpr_oracle as oracle   # checker / baseline only
     from sg_pr_amd import synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     sd = oracle.load_checkpoint(ckpt)
     rng = np.random.default_rng(0)
     bsz = 128
@@ -222,11 +220,20 @@ def cpu_baseline(ckpt, centers, labels, n, k, target_s):
         f2 = torch.from_numpy(synth.dense_features(centers[j], labels[j]))
         return f1, f2
 
+    # pick the intra-op thread count that serves this shape best (all cores oversubscribe it)
+    ncpu = os.cpu_count() or 1
     f1, f2 = batch()
-    oracle.forward(sd, f1, f2, k)                       # warm-up
-    t0 = time.perf_counter()
-    oracle.forward(sd, f1, f2, k)
-    one = time.perf_counter() - t0
+    best = None
+    for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} | {min(ncpu, 8)}):
+        torch.set_num_threads(th)
+        oracle.forward(sd, f1[:32], f2[:32], k)
+        t0 = time.perf_counter()
+        oracle.forward(sd, f1, f2, k)
+        one = time.perf_counter() - t0
+        if best is None or one < best[0]:
+            best = (one, th)
+    one, cores = best
+    torch.set_num_threads(cores)
     reps = int(max(1, min(64, round(target_s / max(one, 1e-3)))))
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -236,7 +243,7 @@ def cpu_baseline(ckpt, centers, labels, n, k, target_s):
     return {"value": reps * bsz / dt, "unit": "graph-pairs/s", "cores": cores, "kind": "port",
             "sample": "%d random pairs of the same workload in batches of %d (node_num=%d, K=%d), "
                       "faithful per-pair forward incl. dense feature assembly" % (reps * bsz, bsz, n, k),
-            "threads": torch.get_num_threads()}
+            "host_cpus": ncpu}
 
 
 if __name__ == "__main__":

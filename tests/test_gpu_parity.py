@@ -39,16 +39,26 @@ def test_shipped_graphs_every_intermediate(eng, golden_dir):
     torch.cuda.synchronize()
     layers, knn = layers.cpu().numpy(), knn.cpu().numpy()
     names = ["xyz1", "xyz2", "xyz3", "sem1", "sem2", "sem3"]
+    # layer inputs (golden), used to canonicalise neighbour indices: kNN ties are only ever
+    # between feature-identical nodes (padding), any of which is an equally valid neighbour
+    f = g["features"]
+    inputs = [f[:, :3, :], g["xyz1"], g["xyz2"], f[:, 3:, :], g["sem1"], g["sem2"]]
     agree = []
     for li, name in enumerate(names):
         ref = g[name].transpose(0, 2, 1)                       # [G, N, C]
         got = layers[:, li, :, : ref.shape[2]]
         np.testing.assert_allclose(got, ref, rtol=0, atol=FEAT_TOL, err_msg=name)
-        same = np.sort(knn[:, li], -1) == np.sort(g["knn_idx"][:, li].astype(np.int32), -1)
-        agree.append(same.all(-1).mean())
+        x = inputs[li].transpose(0, 2, 1)                      # [G, N, Cin]
+        rows_ok = []
+        for b in range(x.shape[0]):
+            canon = np.array([np.flatnonzero((x[b] == x[b, j]).all(-1))[0] for j in range(x.shape[1])])
+            mine = np.sort(canon[knn[b, li]], -1)
+            theirs = np.sort(canon[g["knn_idx"][b, li].astype(np.int64)], -1)
+            rows_ok.append((mine == theirs).all(-1))
+        agree.append(np.mean(rows_ok))
     print("neighbour-set agreement per layer (xyz1..3, sem1..3):", np.round(agree, 4))
     assert (knn >= 0).all() and (knn < 100).all()
-    assert agree[0] == 1.0                                     # xyz layer 1: no ties between distinct nodes
+    assert min(agree) >= 0.98 and agree[0] == 1.0 and agree[3] == 1.0
     np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=0, atol=FEAT_TOL)
     np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=1e-5, atol=5e-4)
@@ -130,7 +140,7 @@ def test_stress_shape_subset_and_invariances(eng, oracle, oracle_sd):
     m = eng.score_all_pairs(pooled[:40], pooled)
     ii, jj = torch.meshgrid(torch.arange(40, dtype=torch.int32), torch.arange(128, dtype=torch.int32), indexing="ij")
     lst = eng.score_pairs(pooled, pooled, ii.reshape(-1), jj.reshape(-1)).view(40, 128)
-    np.testing.assert_allclose(m.cpu().numpy(), lst.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.cpu().numpy(), lst.cpu().numpy(), rtol=0, atol=2e-5)  # different summation order
 
 
 def test_all_pairs_matrix_vs_oracle_and_f1(eng, oracle, oracle_sd):
