@@ -52,11 +52,12 @@ namespace sgpr {
 
 // LDS plan of the embed kernel for one (N, k); computed on the host, passed by value.
 struct EmbedPlan {
-    int N, NP, k, kmax;
-    int pitchD;      // floats per row of the distance chunk
-    int RC;          // rows per distance chunk (multiple of 16)
+    int N, NP, k, kp;
+    int nt;          // threads per workgroup: 512 (two workgroups per CU) or 1024 (one)
+    int pitchD;      // ints per row of the ranking-key chunk
+    int RC;          // rows per key chunk (multiple of 16); RC == NP => symmetric Gram
     int P;           // lanes per row in the selection phase (power of two)
-    int seg;         // candidates per lane (multiple of 4)
+    int seg;         // candidates per lane (multiple of 4, <= 16)
     int kpitch;      // bytes per row of the neighbour list
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
@@ -78,6 +79,7 @@ struct EmbedArgs {
     int32_t* dbg_knn;
     float* park_ws;         // [G][NP][32] when !park_in_lds
     int32_t* status;
+    unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
 };
 
 void set_error(const std::string& msg);

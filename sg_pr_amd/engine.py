@@ -33,7 +33,7 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
-               "sgpr_embed_lds_bytes", "sgpr_last_error", "sgpr_abi_version"]
+               "sgpr_embed_lds_bytes", "sgpr_debug_set_profile_buffer", "sgpr_last_error", "sgpr_abi_version"]
 
 
 class SgprError(RuntimeError):
@@ -90,6 +90,8 @@ def load_library():
     lib.sgpr_check_status.argtypes = [vp, vp]
     lib.sgpr_embed_lds_bytes.restype = sz
     lib.sgpr_embed_lds_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_debug_set_profile_buffer.restype = None
+    lib.sgpr_debug_set_profile_buffer.argtypes = [vp]
     lib.sgpr_last_error.restype = ctypes.c_char_p
     lib.sgpr_last_error.argtypes = []
     lib.sgpr_abi_version.restype = i32
@@ -171,6 +173,21 @@ class Engine:
 
     def lds_bytes(self, node_num, k):
         return int(self.lib.sgpr_embed_lds_bytes(self._h, node_num, k))
+
+    PHASES = ["stage", "norms", "gram", "select", "gemm", "gather", "conv_end", "attention"]
+
+    def phase_profile(self, centers, labels, k, reps=3):
+        """Debug: fraction of workgroup cycles per phase of the embed kernel (thread-0 clocks)."""
+        buf = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self.lib.sgpr_debug_set_profile_buffer(_ptr(buf))
+        try:
+            for _ in range(reps):
+                self.embed(centers, labels, k)
+            torch.cuda.synchronize(self.device)
+        finally:
+            self.lib.sgpr_debug_set_profile_buffer(None)
+        c = buf.cpu().numpy().astype(np.float64)
+        return dict(zip(self.PHASES, c / max(c.sum(), 1.0))), c
 
     def check_status(self):
         self._check(self.lib.sgpr_check_status(self._h, self._stream()))

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-phase cycle split of the embed kernel on the three benchmark shapes (GPU box only)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from sg_pr_amd import engine, synth  # noqa: E402
+
+sd = torch.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "model.pth"), map_location="cpu")
+eng = engine.Engine(sd)
+for name, (n, k, g) in {"kitti00": (100, 10, 4541), "pairs128": (64, 10, 256), "stress": (256, 20, 512)}.items():
+    if name == "kitti00":
+        c, l, _, _ = synth.kitti_like_sequence(g, n, 0)
+    else:
+        c, l, _ = synth.make_graphs(g, n, n // 3, n - k, 0)
+    c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
+    eng.embed(c, l, k)
+    frac, cyc = eng.phase_profile(c, l, k)
+    print(name, "N=%d k=%d G=%d" % (n, k, g), " ".join("%s=%.1f%%" % (p, 100 * f) for p, f in frac.items()),
+          "| cycles/graph=%.0f" % (cyc.sum() / 3 / g))
