@@ -11,14 +11,16 @@
 //      LeakyReLU is monotone   max_m lrelu(a_j + b_i) = lrelu(max_m a_j + b_i)
 //    => two per-node GEMMs (a = W1'x, b = (W2-W1)'x + t) on the fp32 matrix cores
 //       (v_mfma_f32_16x16x4_f32, exact fp32) and a gather-max over the k neighbours.
-//  * kNN: Gram matrix X.X^T on the same MFMA path (upper triangle only when the
-//    whole key matrix fits in LDS), ranking key |x_j|^2 - 2 x_i.x_j (= the reference's
-//    -pairwise_distance up to the row constant |x_i|^2) stored as order-preserving
-//    int32, then an exact k-smallest selection per row: register sorting networks +
-//    butterfly merges, deterministic lowest-index tie-break.
-//  * 512 threads x 2 workgroups/CU (small graphs) or 1024 threads x 1 (LDS-bound);
-//    everything between the input read and the pooled vector lives in LDS/registers.
-#include <limits.h>
+//  * kNN: Gram matrix X.X^T on the same MFMA path (upper triangle only when the whole
+//    key matrix fits in LDS), ranking key |x_j|^2 - 2 x_i.x_j (= the reference's
+//    -pairwise_distance up to the row constant |x_i|^2), then an exact k-smallest
+//    selection per row: register sorting networks + butterfly merges, deterministic
+//    lowest-index tie-break.
+//  * wave specialisation: the selection is pure VALU work and the per-node GEMMs pure
+//    MFMA work on the same input, so half the waves select while the other half run
+//    the GEMMs (the two pipes of a SIMD run concurrently).
+//  * 512 threads (8 wave64) per workgroup; everything between the input read and the
+//    pooled vector lives in LDS/registers.
 #include <math.h>
 
 #include "sgpr_internal.hpp"
@@ -26,11 +28,11 @@
 namespace sgpr {
 
 constexpr int PX = 68;        // floats per row of X   (64 ch + 4: 16-B aligned, rows shift one 16-B slot)
-constexpr int PA = 68;        // floats per row of A   (gather target)
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
 constexpr int PP = 32;        // floats per row of the parked xyz3 block
-constexpr int CAP = 16;       // candidates per lane in the selection phase
-constexpr int MAXQ = 8;       // row tiles per wave in the GEMM phase
+constexpr int NT = 512;       // threads per workgroup (8 wave64; up to 256 VGPRs each)
+constexpr int NW = NT / 64;
+constexpr int CAP = 64;       // candidates per lane in the selection phase
 constexpr int kRedBytes = 4608;
 constexpr int kLdsLimit = 160 * 1024;
 
@@ -44,32 +46,33 @@ bool make_embed_plan(int N, int k, EmbedPlan* p) {
     p->NP = round_up(N, 16);
     p->k = k;
     p->kp = k <= 16 ? 16 : 32;
-    p->kpitch = round_up(k, 4);
+    p->kpitch = round_up(k, 2);           // u16 entries per row of the neighbour list
     p->pitchD = p->NP + 4;
     p->park_in_lds = N <= 128 ? 1 : 0;
+    p->pitchA = N <= 192 ? 68 : 64;       // 64 only when LDS is otherwise exhausted (bank-conflicted stores)
     int off = 0;
     p->offX = off;    off += p->NP * PX * 4;
-    p->offA = off;    off += p->NP * PA * 4;
+    p->offA = off;    off += p->NP * p->pitchA * 4;
     p->offPark = off; off += p->park_in_lds ? p->NP * PP * 4 : 0;
     p->offXX = off;   off += p->NP * 4;
-    p->offIdx = off;  off += round_up(p->NP * p->kpitch, 16);
+    p->offIdx = off;  off += round_up(p->NP * p->kpitch * 2, 16);
     p->offD = off;
     p->offRed = off;  // attention scratch aliases the key chunk (disjoint in time)
     const int rowD = p->pitchD * 4;
-    // two 512-thread workgroups per CU when a >=64-row key chunk still fits in 80 KB,
-    // else one 1024-thread workgroup owning the whole LDS
-    const bool small = off + (p->NP < 64 ? p->NP : 64) * rowD <= kLdsLimit / 2;
-    p->nt = small ? 512 : 1024;
-    const int budget = small ? kLdsLimit / 2 : kLdsLimit;
-    int rc = (budget - off) / rowD / 16 * 16;
+    p->nt = NT;
+    int rc = (kLdsLimit - off) / rowD / 16 * 16;
     if (rc > p->NP) rc = p->NP;
+    // overlapped mode: whole key matrix resident and the selection fits in half the waves
     int P = 1;
     while ((N + P - 1) / P > CAP) P *= 2;
-    if (rc * P > p->nt) rc = p->nt / P / 16 * 16;
+    p->overlap = (rc == p->NP && p->NP * P <= NT / 2) ? 1 : 0;
+    const int lanes = p->overlap ? NT / 2 : NT;
+    if (!p->overlap && rc * P > lanes) rc = lanes / P / 16 * 16;
     if (rc < 16) return false;
-    p->RC = rc;
+    while (P * 2 * rc <= lanes && (N + 2 * P - 1) / (2 * P) >= 4) P *= 2;   // spread a row over more lanes
     p->P = P;
     p->seg = round_up((N + P - 1) / P, 4);
+    p->RC = rc;
     p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
     return true;
 }
@@ -117,21 +120,18 @@ __device__ __forceinline__ void load_frag(const float* p, float4 (&f)[4]) {
 }
 
 // ------------------------------------------------------------------ selection helpers
-// order-preserving float -> int32 (so that ranking uses v_min_i32 / v_max_i32, exact ties)
-__device__ __forceinline__ int ord_key(float f) {
-    f += 0.0f;  // -0 -> +0
-    const int b = __float_as_int(f);
-    return b ^ ((b >> 31) & 0x7fffffff);
-}
+// v_med3_f32 as an exact, canonicalisation-free min / max (keys are never NaN)
+__device__ __forceinline__ float kmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
+__device__ __forceinline__ float kmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
 
-__device__ __forceinline__ void cswap(int& a, int& b) {
-    const int lo = min(a, b);
-    b = max(a, b);
+__device__ __forceinline__ void cswap(float& a, float& b) {
+    const float lo = kmin(a, b);
+    b = kmax(a, b);
     a = lo;
 }
 
 template <int N>
-__device__ __forceinline__ void bitonic_merge(int (&v)[N]) {  // bitonic in -> ascending out
+__device__ __forceinline__ void bitonic_merge(float (&v)[N]) {  // bitonic in -> ascending out
 #pragma unroll
     for (int j = N / 2; j > 0; j >>= 1)
 #pragma unroll
@@ -140,7 +140,7 @@ __device__ __forceinline__ void bitonic_merge(int (&v)[N]) {  // bitonic in -> a
 }
 
 template <int N>
-__device__ __forceinline__ void bitonic_sort(int (&v)[N]) {  // any -> ascending
+__device__ __forceinline__ void bitonic_sort(float (&v)[N]) {  // any -> ascending
 #pragma unroll
     for (int k = 2; k <= N; k <<= 1)
 #pragma unroll
@@ -155,60 +155,96 @@ __device__ __forceinline__ void bitonic_sort(int (&v)[N]) {  // any -> ascending
                 }
 }
 
+// value of lane (l ^ m) for m = 1, 2 (DPP quad permute), 4 (ds_swizzle), else ds_bpermute
+__device__ __forceinline__ float lane_xor(float v, int m) {
+    const int iv = __float_as_int(v);
+    int r;
+    if (m == 1)
+        r = __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    else if (m == 2)
+        r = __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if (m == 4)
+        r = __builtin_amdgcn_ds_swizzle(iv, 0x101F);                      // bit mode: xor 4
+    else
+        r = __shfl_xor(iv, m);
+    return __int_as_float(r);
+}
+
+// KP smallest (ascending) of the 32 candidates d[OFF..OFF+32): two sorted 16-lists, then a half-cleaner
+template <int KP, int OFF>
+__device__ __forceinline__ void list_from_32(const float (&d)[CAP], bool need_hi, float (&L)[KP]) {
+    float lo[16], hi[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        lo[u] = d[OFF + u];
+        hi[u] = d[OFF + 16 + u];
+    }
+    bitonic_sort<16>(lo);
+    if (need_hi) {
+        bitonic_sort<16>(hi);
+        if (KP == 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) L[u] = kmin(lo[u], hi[15 - u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                L[u] = lo[u];
+                L[(KP - 16) + u] = hi[15 - u];
+            }
+        }
+        bitonic_merge<KP>(L);
+    } else {
+#pragma unroll
+        for (int u = 0; u < KP; ++u) L[u] = u < 16 ? lo[u & 15] : INFINITY;
+    }
+}
+
 // Exact k-smallest selection for the rows of one key chunk.
-// P consecutive lanes share a row; lane `part` owns candidates [part*seg, (part+1)*seg).
-// Result: idx[i][0..k) = the k nearest candidates of row i under the total order
-// (key ascending, index ascending) - written as an unordered set.
+// P consecutive lanes share a row; lane `part` owns candidates [part*seg, (part+1)*seg), seg <= CAP.
+// Result: nbr[i][0..k) = (float offset of the A row of) the k nearest candidates of row i under the
+// total order (key ascending, index ascending) - written as an unordered set.
 template <int KP>
-__device__ __forceinline__ void select_phase(const EmbedPlan& p, const int* __restrict__ D, int rc0, int rows_chunk,
-                                             unsigned char* __restrict__ idx, int32_t* __restrict__ dbg_knn) {
+__device__ __forceinline__ void select_phase(const EmbedPlan& p, int k, const float* __restrict__ D, int rc0,
+                                             int rows_chunk, unsigned short* __restrict__ nbr,
+                                             int32_t* __restrict__ dbg_knn) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int P = p.P;
     const int rl = tid >> (__ffs(P) - 1), part = tid & (P - 1);
     const int i = rc0 + rl;
     const bool active = (rl < rows_chunk) && (i < p.N);
-    const int* drow = D + (active ? rl : 0) * p.pitchD;
+    const float* drow = D + (active ? rl : 0) * p.pitchD;
     const int j0 = part * p.seg;
-    const int k = p.k;
 
-    int d[CAP];
+    float d[CAP];
 #pragma unroll
     for (int q = 0; q < CAP / 4; ++q) {
-        int4 v = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
-        if (4 * q < p.seg && j0 + 4 * q < p.NP) v = *reinterpret_cast<const int4*>(drow + j0 + 4 * q);
-        d[4 * q + 0] = (j0 + 4 * q + 0 < p.N) ? v.x : INT_MAX;
-        d[4 * q + 1] = (j0 + 4 * q + 1 < p.N) ? v.y : INT_MAX;
-        d[4 * q + 2] = (j0 + 4 * q + 2 < p.N) ? v.z : INT_MAX;
-        d[4 * q + 3] = (j0 + 4 * q + 3 < p.N) ? v.w : INT_MAX;
+        float4 v = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+        if (4 * q < p.seg && j0 + 4 * q < p.NP) v = *reinterpret_cast<const float4*>(drow + j0 + 4 * q);
+        d[4 * q + 0] = (j0 + 4 * q + 0 < p.N) ? v.x : INFINITY;
+        d[4 * q + 1] = (j0 + 4 * q + 1 < p.N) ? v.y : INFINITY;
+        d[4 * q + 2] = (j0 + 4 * q + 2 < p.N) ? v.z : INFINITY;
+        d[4 * q + 3] = (j0 + 4 * q + 3 < p.N) ? v.w : INFINITY;
     }
-    int L[KP];
-    {
-        int s[CAP];
+    // this lane's KP smallest, ascending
+    float L[KP];
+    list_from_32<KP, 0>(d, p.seg > 16, L);
+    if (p.seg > 32) {
+        float L2[KP];
+        list_from_32<KP, 32>(d, p.seg > 48, L2);
 #pragma unroll
-        for (int u = 0; u < CAP; ++u) s[u] = d[u];
-        if (p.seg <= 8) {
-            int h[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) h[u] = s[u];
-            bitonic_sort<8>(h);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] = h[u];
-        } else {
-            bitonic_sort<CAP>(s);
-        }
-#pragma unroll
-        for (int u = 0; u < KP; ++u) L[u] = u < CAP ? s[u < CAP ? u : 0] : INT_MAX;
-    }
-    // butterfly merge of the P sorted lists of a row: min(L[s], O[KP-1-s]) is the KP smallest of the union, bitonic
-    for (int m = 1; m < P; m <<= 1) {
-        int o[KP];
-#pragma unroll
-        for (int s = 0; s < KP; ++s) o[s] = __shfl_xor(L[s], m);
-#pragma unroll
-        for (int s = 0; s < KP; ++s) L[s] = min(L[s], o[KP - 1 - s]);
+        for (int u = 0; u < KP; ++u) L[u] = kmin(L[u], L2[KP - 1 - u]);
         bitonic_merge<KP>(L);
     }
-    int tau = L[0];
+    // butterfly merge of the P sorted lists of a row: min(L[s], O[KP-1-s]) = the KP smallest of the union, bitonic
+    for (int m = 1; m < P; m <<= 1) {
+        float o[KP];
+#pragma unroll
+        for (int s = 0; s < KP; ++s) o[s] = lane_xor(L[s], m);
+#pragma unroll
+        for (int s = 0; s < KP; ++s) L[s] = kmin(L[s], o[KP - 1 - s]);
+        bitonic_merge<KP>(L);
+    }
+    float tau = L[0];
 #pragma unroll
     for (int s = 1; s < KP; ++s) tau = (s == k - 1) ? L[s] : tau;
     int c_less = 0;
@@ -216,44 +252,57 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, const int* __re
     for (int s = 0; s < KP; ++s) c_less += (s < k && L[s] < tau) ? 1 : 0;
     const int T = k - c_less;  // ties at tau to accept, lowest index first
 
-    int n_less = 0, n_eq = 0;
+    unsigned long long lt_mask = 0ull, eq_mask = 0ull;
+    {
+        unsigned lt0 = 0u, lt1 = 0u, eq0 = 0u, eq1 = 0u;
 #pragma unroll
-    for (int u = 0; u < CAP; ++u) {
-        n_less += d[u] < tau ? 1 : 0;
-        n_eq += d[u] == tau ? 1 : 0;
+        for (int u = 0; u < 32; ++u) {
+            lt0 |= (d[u] < tau) ? (1u << u) : 0u;
+            eq0 |= (d[u] == tau) ? (1u << u) : 0u;
+            lt1 |= (d[32 + u] < tau) ? (1u << u) : 0u;
+            eq1 |= (d[32 + u] == tau) ? (1u << u) : 0u;
+        }
+        lt_mask = ((unsigned long long)lt1 << 32) | lt0;
+        eq_mask = ((unsigned long long)eq1 << 32) | eq0;
     }
-    int e_less = 0, e_eq = 0;
+    const int n_less = __popcll(lt_mask), n_eq = __popcll(eq_mask);
+    const int packed = n_less | (n_eq << 16);
+    int e_pack = 0;
     const int base = lane & ~(P - 1);
     for (int q = 0; q < P; ++q) {
-        const int vl = __shfl(n_less, base + q);
-        const int ve = __shfl(n_eq, base + q);
-        if (q < part) {
-            e_less += vl;
-            e_eq += ve;
-        }
+        const int v = __shfl(packed, base + q);
+        if (q < part) e_pack += v;
     }
+    const int e_less = e_pack & 0xffff, e_eq = e_pack >> 16;
     if (active) {
         int pos = e_less + min(e_eq, T);
         const int my_ties = max(0, min(n_eq, T - e_eq));
-        int eqc = 0;
-        unsigned char* out = idx + i * p.kpitch;
-#pragma unroll
-        for (int u = 0; u < CAP; ++u) {
-            const bool eq = d[u] == tau;
-            const bool take = (d[u] < tau) || (eq && eqc < my_ties);
-            eqc += eq ? 1 : 0;
-            if (take) {
-                out[pos] = (unsigned char)(j0 + u);
-                if (dbg_knn) dbg_knn[(size_t)i * k + pos] = j0 + u;
-                ++pos;
+        // keep only the first my_ties tie bits
+        unsigned long long ties = eq_mask;
+        if (my_ties < n_eq) {
+            unsigned long long keep = 0ull;
+            for (int t = 0; t < my_ties; ++t) {
+                const unsigned long long low = ties & (0ull - ties);
+                keep |= low;
+                ties ^= low;
             }
+            ties = keep;
+        }
+        unsigned long long take = lt_mask | ties;
+        unsigned short* out = nbr + i * p.kpitch;
+        while (take) {
+            const int u = __ffsll((long long)take) - 1;
+            take &= take - 1;
+            out[pos] = (unsigned short)((j0 + u) * p.pitchA);
+            if (dbg_knn) dbg_knn[(size_t)i * k + pos] = j0 + u;
+            ++pos;
         }
     }
 }
 
 // ------------------------------------------------------------------ Gram tile -> ranking keys
 template <int NKB>
-__device__ __forceinline__ void gram_tile(const float* __restrict__ X, const float* __restrict__ xx, int* __restrict__ D,
+__device__ __forceinline__ void gram_tile(const float* __restrict__ X, const float* __restrict__ xx, float* __restrict__ D,
                                           int pitchD, int N, int rc0, int ti, int tj, bool mirror, int l15, int lq) {
     // ti indexes 16-row tiles inside the chunk starting at row rc0; tj indexes candidate tiles
     const int i0 = rc0 + ti * 16, j0 = tj * 16;
@@ -262,80 +311,113 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ X, const flo
     load_frag<NKB>(X + (j0 + l15) * PX + 4 * lq, b);
     const f32x4 g = tile16<NKB>(a, b);          // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
     const int j = j0 + l15;
-    const float xj = xx[j];
-    const bool jvalid = j < N;
-    int* drow = D + (ti * 16 + 4 * lq) * pitchD + j;
+    const float xj = j < N ? xx[j] : INFINITY;  // invalid candidates rank last
+    float* drow = D + (ti * 16 + 4 * lq) * pitchD + j;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) drow[r * pitchD] = jvalid ? ord_key(fmaf(-2.f, g[r], xj)) : INT_MAX;
+    for (int r = 0; r < 4; ++r) drow[r * pitchD] = fmaf(-2.f, g[r], xj);
     if (mirror) {  // the transposed tile: row j, candidates i0+4lq..+3 (one 16-B store)
-        const float4 xi = *reinterpret_cast<const float4*>(xx + i0 + 4 * lq);
         const int ib = i0 + 4 * lq;
-        int4 kv;
-        kv.x = (ib + 0 < N) ? ord_key(fmaf(-2.f, g[0], xi.x)) : INT_MAX;
-        kv.y = (ib + 1 < N) ? ord_key(fmaf(-2.f, g[1], xi.y)) : INT_MAX;
-        kv.z = (ib + 2 < N) ? ord_key(fmaf(-2.f, g[2], xi.z)) : INT_MAX;
-        kv.w = (ib + 3 < N) ? ord_key(fmaf(-2.f, g[3], xi.w)) : INT_MAX;
-        *reinterpret_cast<int4*>(D + (size_t)j * pitchD + ib) = kv;
+        float4 xi = *reinterpret_cast<const float4*>(xx + ib);
+        xi.x = (ib + 0 < N) ? xi.x : INFINITY;
+        xi.y = (ib + 1 < N) ? xi.y : INFINITY;
+        xi.z = (ib + 2 < N) ? xi.z : INFINITY;
+        xi.w = (ib + 3 < N) ? xi.w : INFINITY;
+        *reinterpret_cast<float4*>(D + (size_t)j * pitchD + ib) =
+            make_float4(fmaf(-2.f, g[0], xi.x), fmaf(-2.f, g[1], xi.y), fmaf(-2.f, g[2], xi.z), fmaf(-2.f, g[3], xi.w));
     }
 }
 
-// ------------------------------------------------------------------ GEMM row-tile loop
-template <int NKB, int NT>
-__device__ __forceinline__ void gemm_phase(const float* __restrict__ X, float* __restrict__ A,
-                                           const float* __restrict__ Wf, const float* __restrict__ tb, int cout,
-                                           int nrt, f32x4 (&breg)[MAXQ], bool& is_b_out, int& c4_out, int& rs_out,
-                                           int& RS_out) {
-    constexpr int NW = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ------------------------------------------------------------------ per-node GEMMs, gemm-wave gw of GW
+// A wave owns up to two 16-node row tiles (rt = gw, gw + GW) and computes every 16-channel column
+// tile of [a | b] for them:  a = x.W1'  -> A (LDS, the gather target);  b = x.(W2-W1)' + t replaces
+// the wave's own rows of X in place once all its column tiles are done (no other wave reads those
+// rows in this phase, so no barrier is needed).  Weight fragments stream from L1/L2.
+template <int NKB>
+__device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restrict__ A, int pitchA,
+                                          const float* __restrict__ Wf, const float* __restrict__ tb, int cout,
+                                          int nrt, int gw, int GW) {
+    const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int nct = (2 * cout) >> 4;   // 16-channel column tiles of [a | b]: 8 or 4
-    const int RS = NW / nct;           // waves sharing a column tile, striding over row tiles
-    const int ct = wave % nct, rs = wave / nct;
-    const bool is_b = ct * 16 >= cout;
     constexpr int Kp = NKB * 16;
-    float4 wreg[4];
-    load_frag<NKB>(Wf + (size_t)(ct * 16 + l15) * Kp + 4 * lq, wreg);
-    const int c4 = ct * 16 + 4 * lq;   // first of this lane's 4 output channels in [a | b]
-    float4 tb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (is_b) tb4 = *reinterpret_cast<const float4*>(tb + (c4 - cout));
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int rt = rs + q * RS;
-        if (rt < nrt) {
-            float4 xf[4];
-            load_frag<NKB>(X + (rt * 16 + l15) * PX + 4 * lq, xf);
-            const f32x4 acc = tile16<NKB>(wreg, xf);   // acc[r] = out[channel c4 + r][node rt*16 + l15]
-            if (!is_b) {
-                *reinterpret_cast<float4*>(A + (rt * 16 + l15) * PA + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
-                breg[q][0] = acc[0] + tb4.x;
-                breg[q][1] = acc[1] + tb4.y;
-                breg[q][2] = acc[2] + tb4.z;
-                breg[q][3] = acc[3] + tb4.w;
-            }
+    const int rt0 = gw, rt1 = gw + GW;
+    if (rt0 >= nrt) return;
+    const bool two = rt1 < nrt;
+    float* x0 = X + (rt0 * 16 + l15) * PX + 4 * lq;
+    float* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * PX + 4 * lq;
+    float4 xf0[4], xf1[4];
+    load_frag<NKB>(x0, xf0);
+    load_frag<NKB>(x1, xf1);
+    const int nca = cout >> 4;                       // a-type column tiles (= b-type column tiles)
+    const float* wp = Wf + (size_t)l15 * Kp + 4 * lq;
+    float* a0 = A + (rt0 * 16 + l15) * pitchA + 4 * lq;
+    float* a1 = A + ((two ? rt1 : rt0) * 16 + l15) * pitchA + 4 * lq;
+    for (int ct = 0; ct < nca; ++ct) {
+        float4 w[4];
+        load_frag<NKB>(wp + (size_t)ct * 16 * Kp, w);
+        const f32x4 r0 = tile16<NKB>(w, xf0);        // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
+        *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        if (two) {
+            const f32x4 r1 = tile16<NKB>(w, xf1);
+            *reinterpret_cast<float4*>(a1 + ct * 16) = make_float4(r1[0], r1[1], r1[2], r1[3]);
         }
     }
-    is_b_out = is_b;
-    c4_out = c4;
-    rs_out = rs;
-    RS_out = RS;
+    f32x4 b0[4], b1[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb < nca) {
+            float4 w[4];
+            load_frag<NKB>(wp + (size_t)(nca + cb) * 16 * Kp, w);
+            const float4 t4 = *reinterpret_cast<const float4*>(tb + cb * 16 + 4 * lq);
+            const f32x4 tv = {t4.x, t4.y, t4.z, t4.w};
+            b0[cb] = tile16<NKB>(w, xf0) + tv;
+            if (two) b1[cb] = tile16<NKB>(w, xf1) + tv;
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb < nca) {
+            *reinterpret_cast<float4*>(x0 - 4 * lq + cb * 16 + 4 * lq) = make_float4(b0[cb][0], b0[cb][1], b0[cb][2], b0[cb][3]);
+            if (two)
+                *reinterpret_cast<float4*>(x1 - 4 * lq + cb * 16 + 4 * lq) =
+                    make_float4(b1[cb][0], b1[cb][1], b1[cb][2], b1[cb][3]);
+        }
+    }
 }
 
-template <int KP, int NT>
-__global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void embed_kernel(const KParams kp) {
+// ------------------------------------------------------------------ gather-max over the k neighbours
+// cout/4 lanes own one row (4 channels each, 16-B LDS reads); nw = the row's u16 offsets, two per word
+__device__ __forceinline__ float4 gather_max(const float* __restrict__ A4, const uint32_t* __restrict__ nw, int k) {
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const int kw = (k + 1) >> 1;
+#pragma unroll 5
+    for (int q = 0; q < kw; ++q) {
+        const uint32_t word = nw[q];
+        const int o0 = word & 0xffffu;
+        const int o1 = (2 * q + 1 < k) ? (int)(word >> 16) : o0;
+        const float4 v0 = *reinterpret_cast<const float4*>(A4 + o0);
+        const float4 v1 = *reinterpret_cast<const float4*>(A4 + o1);
+        m.x = kmax(m.x, kmax(v0.x, v1.x));
+        m.y = kmax(m.y, kmax(v0.y, v1.y));
+        m.z = kmax(m.z, kmax(v0.z, v1.z));
+        m.w = kmax(m.w, kmax(v0.w, v1.w));
+    }
+    return m;
+}
+
+template <int KP>
+__global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW = NT / 64;
     const EmbedPlan& p = kp.p;
     float* X = reinterpret_cast<float*>(smem + p.offX);
     float* A = reinterpret_cast<float*>(smem + p.offA);
-    int* D = reinterpret_cast<int*>(smem + p.offD);
+    float* D = reinterpret_cast<float*>(smem + p.offD);
     float* xx = reinterpret_cast<float*>(smem + p.offXX);
     float* red = reinterpret_cast<float*>(smem + p.offRed);
-    unsigned char* idx = smem + p.offIdx;
+    unsigned short* nbr = reinterpret_cast<unsigned short*>(smem + p.offIdx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int g = blockIdx.x;
-    const int N = p.N, NP = p.NP, k = p.k;
+    const int N = p.N, NP = p.NP;
     const int nrt = NP >> 4;
     float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * NP * PP;
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
@@ -349,60 +431,73 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void embed_kernel(const KPar
         t_prev = t_now;                                          \
     }
 
+    // packed input: one node per thread, fetched once (both branches)
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    int lab = -1;
+    if (!kp.a.dense && tid < N) {
+        const float* c = kp.a.centers + ((size_t)g * N + tid) * 3;
+        cx = c[0];
+        cy = c[1];
+        cz = c[2];
+        lab = kp.a.labels[(size_t)g * N + tid];
+        if (lab < -1 || lab >= kLabels) atomicOr(kp.a.status, 1);
+    }
+
     for (int L = 0; L < 6; ++L) {
+        // per-iteration opaque copies: keep the compiler from hoisting (and then spilling) dozens of
+        // k- / label-derived predicates out of the layer loop
+        int k = p.k;
+        asm volatile("" : "+s"(k));
         if (L == 0 || L == 3) {
-            // ---- stage this branch's input features, zero padded to 16 channels / NP rows
+            // ---- stage this branch's input features (zero padded to 16 channels / NP rows) + squared norms
             const int br = L == 0 ? 0 : 1;
-            for (int e = tid; e < NP * 16; e += NT) {
-                const int i = e >> 4, c = e & 15;
-                float v = 0.f;
-                if (i < N) {
-                    if (kp.a.dense) {
-                        const bool second = kp.a.dense2 && g >= kp.a.g_split;
-                        const float* dn = second ? kp.a.dense2 : kp.a.dense;
-                        const int gg = second ? g - kp.a.g_split : g;
-                        const int ch = br == 0 ? c : 3 + c;
-                        const bool ok = br == 0 ? c < 3 : c < kLabels;
-                        if (ok) v = dn[((size_t)gg * (3 + kLabels) + ch) * N + i];
-                    } else if (br == 0) {
-                        if (c < 3) v = kp.a.centers[((size_t)g * N + i) * 3 + c];
-                    } else {
-                        const int lab = kp.a.labels[(size_t)g * N + i];
-                        if (c == 0 && (lab < -1 || lab >= kLabels)) atomicOr(kp.a.status, 1);
-                        v = (lab == c) ? 1.f : 0.f;
-                    }
+            if (kp.a.dense) {
+                const bool second = kp.a.dense2 && g >= kp.a.g_split;
+                const float* dn = (second ? kp.a.dense2 : kp.a.dense) +
+                                  (size_t)(second ? g - kp.a.g_split : g) * (3 + kLabels) * N;
+                for (int e = tid; e < NP * 16; e += NT) {
+                    const int c = e / NP, i = e - c * NP;       // node index fastest: coalesced [ch][N] reads
+                    const bool ok = i < N && (br == 0 ? c < 3 : c < kLabels);
+                    X[i * PX + c] = ok ? dn[(size_t)(br == 0 ? c : 3 + c) * N + i] : 0.f;
                 }
-                X[i * PX + c] = v;
+                __syncthreads();
+                for (int i = tid; i < NP; i += NT) {
+                    float s = 0.f;
+                    for (int c = 0; c < 16; ++c) s = fmaf(X[i * PX + c], X[i * PX + c], s);
+                    xx[i] = s;
+                }
+            } else if (tid < NP) {
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+                float s = 0.f;
+                if (br == 0) {
+                    r0 = make_float4(cx, cy, cz, 0.f);
+                    s = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
+                } else if (lab >= 0 && lab < kLabels) {
+                    int lb = lab;
+                    asm volatile("" : "+v"(lb));
+                    float oh[12];
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) oh[c] = (lb == c) ? 1.f : 0.f;
+                    r0 = make_float4(oh[0], oh[1], oh[2], oh[3]);
+                    r1 = make_float4(oh[4], oh[5], oh[6], oh[7]);
+                    r2 = make_float4(oh[8], oh[9], oh[10], oh[11]);
+                    s = 1.f;
+                }
+                float4* xr = reinterpret_cast<float4*>(X + tid * PX);
+                xr[0] = r0;
+                xr[1] = r1;
+                xr[2] = r2;
+                xr[3] = r3;
+                xx[tid] = s;
             }
             __syncthreads();
             SGPR_PROF(0)
         }
         const int Kp = kp.w.kp[L], cout = kp.w.cout[L];
         const bool k64 = Kp == 64;
-        int32_t* dbg_knn = kp.a.dbg_knn ? kp.a.dbg_knn + ((size_t)g * 6 + L) * N * k : nullptr;
-
-        // ---- squared norms: 4 lanes per row
-        for (int e = tid; e < NP * 4; e += NT) {
-            const int i = e >> 2, qq = e & 3;
-            const float* xr = X + i * PX + qq * (Kp >> 2);
-            float s = 0.f;
-            for (int c = 0; c < (Kp >> 2); c += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                s = fmaf(v.x, v.x, s);
-                s = fmaf(v.y, v.y, s);
-                s = fmaf(v.z, v.z, s);
-                s = fmaf(v.w, v.w, s);
-            }
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            if (qq == 0) xx[i] = s;
-        }
-        __syncthreads();
-        SGPR_PROF(1)
-
-        // ---- kNN: Gram tiles on MFMA -> ranking keys in LDS -> selection
-        if (p.RC == NP) {
-            // whole key matrix resident: upper-triangular tiles only, each also stores its transpose
+        int32_t* dbg_knn = kp.a.dbg_knn ? kp.a.dbg_knn + ((size_t)g * 6 + L) * N * p.k : nullptr;
+        if (p.overlap) {
+            // ---- Gram: whole key matrix resident: upper-triangular tiles, each also stores its transpose
             int cnt = 0;
             for (int ti = 0; ti < nrt; ++ti)
                 for (int tj = ti; tj < nrt; ++tj, ++cnt)
@@ -414,9 +509,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void embed_kernel(const KPar
                     }
             __syncthreads();
             SGPR_PROF(2)
-            select_phase<KP>(p, D, 0, NP, idx, dbg_knn);
-            if (kp.a.prof) __syncthreads();
-            SGPR_PROF(3)
+            // ---- first half of the waves: kNN selection (VALU); second half: per-node GEMMs (MFMA)
+            if (wave < NW / 2) {
+                select_phase<KP>(p, k, D, 0, NP, nbr, dbg_knn);
+            } else {
+                if (k64)
+                    gemm_rows<4>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave - NW / 2, NW / 2);
+                else
+                    gemm_rows<1>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave - NW / 2, NW / 2);
+            }
         } else {
             for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
                 const int rows_chunk = min(p.RC, NP - rc0);
@@ -430,72 +531,62 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void embed_kernel(const KPar
                 }
                 __syncthreads();
                 SGPR_PROF(2)
-                select_phase<KP>(p, D, rc0, rows_chunk, idx, dbg_knn);
+                select_phase<KP>(p, k, D, rc0, rows_chunk, nbr, dbg_knn);
                 __syncthreads();
                 SGPR_PROF(3)
             }
+            if (k64)
+                gemm_rows<4>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave, NW);
+            else
+                gemm_rows<1>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave, NW);
         }
+        __syncthreads();  // neighbour lists, A and b (in X) are complete
+        SGPR_PROF(3)
 
-        // ---- per-node GEMMs on MFMA:  a = W1'.x -> A (LDS),  b = (W2-W1)'.x + t -> registers
-        f32x4 breg[MAXQ];
-        bool is_b;
-        int c4, rs, RS;
-        if (k64)
-            gemm_phase<4, NT>(X, A, kp.w.wf[L], kp.w.tb[L], cout, nrt, breg, is_b, c4, rs, RS);
-        else
-            gemm_phase<1, NT>(X, A, kp.w.wf[L], kp.w.tb[L], cout, nrt, breg, is_b, c4, rs, RS);
-        __syncthreads();  // every wave is done reading X (and D): b may now overwrite X in place
-        if (is_b) {
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int rt = rs + q * RS;
-                if (rt < nrt)
-                    *reinterpret_cast<float4*>(X + (rt * 16 + l15) * PX + (c4 - cout)) =
-                        make_float4(breg[q][0], breg[q][1], breg[q][2], breg[q][3]);
-            }
-        }
-        __syncthreads();
-        SGPR_PROF(4)
-
-        // ---- gather-max over the k neighbours (lane == channel: conflict-free LDS rows)
-        float* ydst = L == 2 ? park : (L == 5 ? X + 32 : X);
-        const int ypitch = L == 2 ? PP : PX;
-        const int rpw = 64 / cout;           // rows per wave-iteration (1 or 2)
-        const int c = lane & (cout - 1), sub = lane / cout;
-        float* dbg = kp.a.dbg_layers ? kp.a.dbg_layers + ((size_t)g * 6 + L) * N * 64 : nullptr;
-        for (int i = wave * rpw + sub; i < NP; i += NW * rpw) {
-            float y = 0.f;
-            if (i < N) {
-                const uint32_t* idw = reinterpret_cast<const uint32_t*>(idx + i * p.kpitch);
-                float m = -INFINITY;
-#pragma unroll
-                for (int w = 0; w < KP / 4; ++w) {
-                    if (4 * w < k) {
-                        const uint32_t word = idw[w];
-                        const int ja = word & 255u;
-                        const int jb = (4 * w + 1 < k) ? (word >> 8) & 255u : ja;
-                        const int jc = (4 * w + 2 < k) ? (word >> 16) & 255u : ja;
-                        const int jd = (4 * w + 3 < k) ? (word >> 24) : ja;
-                        const float va = A[ja * PA + c], vb = A[jb * PA + c], vc = A[jc * PA + c], vd = A[jd * PA + c];
-                        m = fmaxf(m, fmaxf(fmaxf(va, vb), fmaxf(vc, vd)));
+        // ---- gather-max over the k neighbours: cout/4 lanes per row, 4 channels (16 B) per lane
+        {
+            float* ydst = L == 2 ? park : (L == 5 ? X + 32 : X);
+            const int ypitch = L == 2 ? PP : PX;
+            const int lpr = cout >> 2;                   // lanes per row: 16 or 8
+            const int rpw = 64 / lpr;                    // rows per wave-iteration: 4 or 8
+            const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
+            const bool want_norm = (L != 2 && L != 5);
+            float* dbg = kp.a.dbg_layers ? kp.a.dbg_layers + ((size_t)g * 6 + L) * N * 64 : nullptr;
+            for (int i = wave * rpw + sub; i < NP; i += NW * rpw) {
+                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < N) {
+                    const uint32_t* nw = reinterpret_cast<const uint32_t*>(nbr + i * p.kpitch);
+                    const float4 m = gather_max(A + c4, nw, k);
+                    const float4 b = *reinterpret_cast<const float4*>(X + i * PX + c4);
+                    y = make_float4(m.x + b.x, m.y + b.y, m.z + b.z, m.w + b.w);
+                    y.x = y.x > 0.f ? y.x : 0.2f * y.x;
+                    y.y = y.y > 0.f ? y.y : 0.2f * y.y;
+                    y.z = y.z > 0.f ? y.z : 0.2f * y.z;
+                    y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+                    if (dbg) {
+                        *reinterpret_cast<float4*>(dbg + (size_t)i * 64 + c4) = y;
+                        if (cout == 32)
+                            *reinterpret_cast<float4*>(dbg + (size_t)i * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-                y = m + X[i * PX + c];
-                y = y > 0.f ? y : 0.2f * y;
-                if (dbg) {
-                    dbg[(size_t)i * 64 + c] = y;
-                    if (cout == 32) dbg[(size_t)i * 64 + 32 + c] = 0.f;
+                *reinterpret_cast<float4*>(ydst + (size_t)i * ypitch + c4) = y;
+                if (want_norm) {                          // squared norm of the next layer's input row
+                    float s = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+                    s += lane_xor(s, 1);
+                    s += lane_xor(s, 2);
+                    s += lane_xor(s, 4);
+                    s += lane_xor(s, 8);                 // cout == 64 here (16 lanes per row)
+                    if ((lane & 15) == 0) xx[i] = s;
                 }
             }
-            ydst[(size_t)i * ypitch + c] = y;
         }
         __syncthreads();
         SGPR_PROF(5)
     }
 
-    for (int e = tid; e < NP * 32; e += NT) {                     // xyz3 -> channels 0..31: X = cat(xyz3, sem3)
-        const int i = e >> 5, c = e & 31;
-        X[i * PX + c] = park[(size_t)i * PP + c];
+    for (int e = tid; e < NP * 8; e += NT) {                      // xyz3 -> channels 0..31: X = cat(xyz3, sem3)
+        const int i = e >> 3, c4 = (e & 7) * 4;
+        *reinterpret_cast<float4*>(X + i * PX + c4) = *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4);
     }
     __syncthreads();
 
@@ -571,16 +662,16 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void embed_kernel(const KPar
 #undef SGPR_PROF
 }
 
-template <int KP, int NT>
+template <int KP>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_kernel<KP, NT>), dim3(kp.a.G), dim3(NT), kp.p.lds_bytes, stream, kp);
+    hipLaunchKernelGGL((embed_kernel<KP>), dim3(kp.a.G), dim3(NT), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
@@ -592,8 +683,7 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.w = h->w;
     kp.p = plan;
     kp.a = a;
-    if (plan.nt == 512) return plan.kp == 16 ? launch_t<16, 512>(kp, stream) : launch_t<32, 512>(kp, stream);
-    return plan.kp == 16 ? launch_t<16, 1024>(kp, stream) : launch_t<32, 1024>(kp, stream);
+    return plan.kp == 16 ? launch_t<16>(kp, stream) : launch_t<32>(kp, stream);
 }
 
 }  // namespace sgpr

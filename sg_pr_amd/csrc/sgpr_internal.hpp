@@ -57,8 +57,10 @@ struct EmbedPlan {
     int pitchD;      // ints per row of the ranking-key chunk
     int RC;          // rows per key chunk (multiple of 16); RC == NP => symmetric Gram
     int P;           // lanes per row in the selection phase (power of two)
-    int seg;         // candidates per lane (multiple of 4, <= 16)
-    int kpitch;      // bytes per row of the neighbour list
+    int seg;         // candidates per lane (multiple of 4, <= 32)
+    int kpitch;      // u16 entries per row of the neighbour list
+    int pitchA;      // floats per row of the gather target A
+    int overlap;     // 1: key matrix resident, selection (half the waves) overlaps the GEMMs (other half)
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
