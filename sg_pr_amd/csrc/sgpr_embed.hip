@@ -332,76 +332,166 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ X, const flo
 // tile of [a | b] for them:  a = x.W1'  -> A (LDS, the gather target);  b = x.(W2-W1)' + t replaces
 // the wave's own rows of X in place once all its column tiles are done (no other wave reads those
 // rows in this phase, so no barrier is needed).  Weight fragments stream from L1/L2.
-template <int NKB>
+template <int NKB, int COUT>
 __device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restrict__ A, int pitchA,
-                                          const float* __restrict__ Wf, const float* __restrict__ tb, int cout,
-                                          int nrt, int gw, int GW) {
+                                          const float* __restrict__ Wf, const float* __restrict__ tb, int nrt, int gw,
+                                          int GW) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int Kp = NKB * 16;
+    constexpr int NCA = COUT / 16;                   // a-type column tiles (= b-type column tiles)
+    constexpr int NCT = 2 * NCA;
     const int rt0 = gw, rt1 = gw + GW;
     if (rt0 >= nrt) return;
     const bool two = rt1 < nrt;
-    float* x0 = X + (rt0 * 16 + l15) * PX + 4 * lq;
-    float* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * PX + 4 * lq;
-    float4 xf0[4], xf1[4];
-    load_frag<NKB>(x0, xf0);
-    load_frag<NKB>(x1, xf1);
-    const int nca = cout >> 4;                       // a-type column tiles (= b-type column tiles)
+    float* x0 = X + (rt0 * 16 + l15) * PX;
+    float* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * PX;
     const float* wp = Wf + (size_t)l15 * Kp + 4 * lq;
+    float4 w[3][4];                                  // weight fragments, fetched two column tiles ahead (L1/L2)
+    load_frag<NKB>(wp, w[0]);
+    load_frag<NKB>(wp + (size_t)16 * Kp, w[1]);
+    float4 xf0[4], xf1[4];
+    load_frag<NKB>(x0 + 4 * lq, xf0);
+    load_frag<NKB>(x1 + 4 * lq, xf1);
+    float4 tv[NCA];
+#pragma unroll
+    for (int cb = 0; cb < NCA; ++cb) tv[cb] = *reinterpret_cast<const float4*>(tb + cb * 16 + 4 * lq);
     float* a0 = A + (rt0 * 16 + l15) * pitchA + 4 * lq;
     float* a1 = A + ((two ? rt1 : rt0) * 16 + l15) * pitchA + 4 * lq;
-    for (int ct = 0; ct < nca; ++ct) {
-        float4 w[4];
-        load_frag<NKB>(wp + (size_t)ct * 16 * Kp, w);
-        const f32x4 r0 = tile16<NKB>(w, xf0);        // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
-        *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-        if (two) {
-            const f32x4 r1 = tile16<NKB>(w, xf1);
-            *reinterpret_cast<float4*>(a1 + ct * 16) = make_float4(r1[0], r1[1], r1[2], r1[3]);
-        }
-    }
-    f32x4 b0[4], b1[4];
+    f32x4 b0[NCA], b1[NCA];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        if (cb < nca) {
-            float4 w[4];
-            load_frag<NKB>(wp + (size_t)(nca + cb) * 16 * Kp, w);
-            const float4 t4 = *reinterpret_cast<const float4*>(tb + cb * 16 + 4 * lq);
-            const f32x4 tv = {t4.x, t4.y, t4.z, t4.w};
-            b0[cb] = tile16<NKB>(w, xf0) + tv;
-            if (two) b1[cb] = tile16<NKB>(w, xf1) + tv;
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (ct + 2 < NCT) load_frag<NKB>(wp + (size_t)(ct + 2) * 16 * Kp, w[(ct + 2) % 3]);
+        // r[c] = out[channel ct*16 + 4lq + c][node rt*16 + l15]
+        const f32x4 r0 = tile16<NKB>(w[ct % 3], xf0);
+        f32x4 r1 = r0;
+        if (two) r1 = tile16<NKB>(w[ct % 3], xf1);
+        if (ct < NCA) {
+            *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+            if (two) *reinterpret_cast<float4*>(a1 + ct * 16) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+        } else {
+            const float4 t4 = tv[ct < NCA ? 0 : ct - NCA];
+            const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
+            b0[ct < NCA ? 0 : ct - NCA] = r0 + t;
+            b1[ct < NCA ? 0 : ct - NCA] = r1 + t;
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        if (cb < nca) {
-            *reinterpret_cast<float4*>(x0 - 4 * lq + cb * 16 + 4 * lq) = make_float4(b0[cb][0], b0[cb][1], b0[cb][2], b0[cb][3]);
-            if (two)
-                *reinterpret_cast<float4*>(x1 - 4 * lq + cb * 16 + 4 * lq) =
-                    make_float4(b1[cb][0], b1[cb][1], b1[cb][2], b1[cb][3]);
+    for (int cb = 0; cb < NCA; ++cb) {
+        *reinterpret_cast<float4*>(x0 + cb * 16 + 4 * lq) = make_float4(b0[cb][0], b0[cb][1], b0[cb][2], b0[cb][3]);
+        if (two) *reinterpret_cast<float4*>(x1 + cb * 16 + 4 * lq) = make_float4(b1[cb][0], b1[cb][1], b1[cb][2], b1[cb][3]);
+    }
+}
+
+__device__ __forceinline__ void gemm_layer(float* X, float* A, int pitchA, const float* Wf, const float* tb, int Kp,
+                                           int cout, int nrt, int gw, int GW) {
+    if (Kp != 64)
+        gemm_rows<1, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);   // first layer of a branch: 3 / 12 -> 64 channels
+    else if (cout == 64)
+        gemm_rows<4, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+    else
+        gemm_rows<4, 32>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+}
+
+// ------------------------------------------------------------------ Gram phase (whole key matrix resident)
+// upper-triangular tile t (row-major) -> (ti, tj), wave-uniform
+__device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
+    int r = 0;
+    while (t >= n - r) {
+        t -= n - r;
+        ++r;
+    }
+    ti = r;
+    tj = r + t;
+}
+
+template <int NKB>
+__device__ __forceinline__ void gram_tiles_sym(const float* __restrict__ X, const float* __restrict__ xx,
+                                               float* __restrict__ D, int pitchD, int N, int nrt, int wave) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ntiles = nrt * (nrt + 1) / 2;
+    int t = wave;
+    if (t >= ntiles) return;
+    int ti, tj;
+    tri_decode(t, nrt, ti, tj);
+    float4 a[4], b[4];
+    load_frag<NKB>(X + (ti * 16 + l15) * PX + 4 * lq, a);
+    load_frag<NKB>(X + (tj * 16 + l15) * PX + 4 * lq, b);
+    while (true) {
+        const int tn = t + NW;
+        const bool more = tn < ntiles;
+        int tin = 0, tjn = 0;
+        float4 an[4], bn[4];
+        if (more) {                                   // operands of the next tile in flight during this tile's MFMAs
+            tri_decode(tn, nrt, tin, tjn);
+            load_frag<NKB>(X + (tin * 16 + l15) * PX + 4 * lq, an);
+            load_frag<NKB>(X + (tjn * 16 + l15) * PX + 4 * lq, bn);
         }
+        const f32x4 g = tile16<NKB>(a, b);            // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
+        const int i0 = ti * 16, j = tj * 16 + l15;
+        const float xj = j < N ? xx[j] : INFINITY;    // invalid candidates rank last
+        float* drow = D + (i0 + 4 * lq) * pitchD + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) drow[r * pitchD] = fmaf(-2.f, g[r], xj);
+        if (tj != ti) {                               // the transposed tile: row j, candidates i0+4lq..+3 (one 16-B store)
+            const int ib = i0 + 4 * lq;
+            float4 xi = *reinterpret_cast<const float4*>(xx + ib);
+            xi.x = (ib + 0 < N) ? xi.x : INFINITY;
+            xi.y = (ib + 1 < N) ? xi.y : INFINITY;
+            xi.z = (ib + 2 < N) ? xi.z : INFINITY;
+            xi.w = (ib + 3 < N) ? xi.w : INFINITY;
+            *reinterpret_cast<float4*>(D + (size_t)j * pitchD + ib) = make_float4(
+                fmaf(-2.f, g[0], xi.x), fmaf(-2.f, g[1], xi.y), fmaf(-2.f, g[2], xi.z), fmaf(-2.f, g[3], xi.w));
+        }
+        if (!more) break;
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) {
+            a[q] = an[q];
+            b[q] = bn[q];
+        }
+        t = tn;
+        ti = tin;
+        tj = tjn;
     }
 }
 
 // ------------------------------------------------------------------ gather-max over the k neighbours
-// cout/4 lanes own one row (4 channels each, 16-B LDS reads); nw = the row's u16 offsets, two per word
-__device__ __forceinline__ float4 gather_max(const float* __restrict__ A4, const uint32_t* __restrict__ nw, int k) {
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+// cout/4 lanes own one row (4 channels each, 16-B LDS reads); nw = the row's u16 offsets, two per word.
+// Two rows per call so that twice as many independent LDS reads are in flight.
+__device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const uint32_t* __restrict__ nwa,
+                                            const uint32_t* __restrict__ nwb, int k, float4& ma, float4& mb) {
+    ma = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    mb = ma;
     const int kw = (k + 1) >> 1;
 #pragma unroll 5
     for (int q = 0; q < kw; ++q) {
-        const uint32_t word = nw[q];
-        const int o0 = word & 0xffffu;
-        const int o1 = (2 * q + 1 < k) ? (int)(word >> 16) : o0;
-        const float4 v0 = *reinterpret_cast<const float4*>(A4 + o0);
-        const float4 v1 = *reinterpret_cast<const float4*>(A4 + o1);
-        m.x = kmax(m.x, kmax(v0.x, v1.x));
-        m.y = kmax(m.y, kmax(v0.y, v1.y));
-        m.z = kmax(m.z, kmax(v0.z, v1.z));
-        m.w = kmax(m.w, kmax(v0.w, v1.w));
+        const uint32_t wa = nwa[q], wb = nwb[q];
+        const bool odd = 2 * q + 1 < k;
+        const int a0 = wa & 0xffffu, a1 = odd ? (int)(wa >> 16) : a0;
+        const int b0 = wb & 0xffffu, b1 = odd ? (int)(wb >> 16) : b0;
+        const float4 va0 = *reinterpret_cast<const float4*>(A4 + a0);
+        const float4 va1 = *reinterpret_cast<const float4*>(A4 + a1);
+        const float4 vb0 = *reinterpret_cast<const float4*>(A4 + b0);
+        const float4 vb1 = *reinterpret_cast<const float4*>(A4 + b1);
+        ma.x = kmax(ma.x, kmax(va0.x, va1.x));
+        ma.y = kmax(ma.y, kmax(va0.y, va1.y));
+        ma.z = kmax(ma.z, kmax(va0.z, va1.z));
+        ma.w = kmax(ma.w, kmax(va0.w, va1.w));
+        mb.x = kmax(mb.x, kmax(vb0.x, vb1.x));
+        mb.y = kmax(mb.y, kmax(vb0.y, vb1.y));
+        mb.z = kmax(mb.z, kmax(vb0.z, vb1.z));
+        mb.w = kmax(mb.w, kmax(vb0.w, vb1.w));
     }
-    return m;
+}
+
+__device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
+    float4 y = make_float4(m.x + b.x, m.y + b.y, m.z + b.z, m.w + b.w);
+    y.x = y.x > 0.f ? y.x : 0.2f * y.x;
+    y.y = y.y > 0.f ? y.y : 0.2f * y.y;
+    y.z = y.z > 0.f ? y.z : 0.2f * y.z;
+    y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+    return live ? y : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <int KP>
@@ -498,25 +588,20 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         int32_t* dbg_knn = kp.a.dbg_knn ? kp.a.dbg_knn + ((size_t)g * 6 + L) * N * p.k : nullptr;
         if (p.overlap) {
             // ---- Gram: whole key matrix resident: upper-triangular tiles, each also stores its transpose
-            int cnt = 0;
-            for (int ti = 0; ti < nrt; ++ti)
-                for (int tj = ti; tj < nrt; ++tj, ++cnt)
-                    if (cnt % NW == wave) {
-                        if (k64)
-                            gram_tile<4>(X, xx, D, p.pitchD, N, 0, ti, tj, tj != ti, l15, lq);
-                        else
-                            gram_tile<1>(X, xx, D, p.pitchD, N, 0, ti, tj, tj != ti, l15, lq);
-                    }
+            if (k64)
+                gram_tiles_sym<4>(X, xx, D, p.pitchD, N, nrt, wave);
+            else
+                gram_tiles_sym<1>(X, xx, D, p.pitchD, N, nrt, wave);
             __syncthreads();
             SGPR_PROF(2)
             // ---- first half of the waves: kNN selection (VALU); second half: per-node GEMMs (MFMA)
+            const unsigned long long t_gemm0 = (kp.a.prof && tid == NT / 2) ? clock64() : 0ull;
             if (wave < NW / 2) {
                 select_phase<KP>(p, k, D, 0, NP, nbr, dbg_knn);
+                if (prof) atomicAdd(&kp.a.prof[1], (unsigned long long)(clock64() - t_prev));   // selection alone
             } else {
-                if (k64)
-                    gemm_rows<4>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave - NW / 2, NW / 2);
-                else
-                    gemm_rows<1>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave - NW / 2, NW / 2);
+                gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave - NW / 2, NW / 2);
+                if (kp.a.prof && tid == NT / 2) atomicAdd(&kp.a.prof[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
             }
         } else {
             for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
@@ -535,10 +620,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
                 __syncthreads();
                 SGPR_PROF(3)
             }
-            if (k64)
-                gemm_rows<4>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave, NW);
-            else
-                gemm_rows<1>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], cout, nrt, wave, NW);
+            gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
         }
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
@@ -552,31 +634,43 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
             const bool want_norm = (L != 2 && L != 5);
             float* dbg = kp.a.dbg_layers ? kp.a.dbg_layers + ((size_t)g * 6 + L) * N * 64 : nullptr;
-            for (int i = wave * rpw + sub; i < NP; i += NW * rpw) {
-                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < N) {
-                    const uint32_t* nw = reinterpret_cast<const uint32_t*>(nbr + i * p.kpitch);
-                    const float4 m = gather_max(A + c4, nw, k);
-                    const float4 b = *reinterpret_cast<const float4*>(X + i * PX + c4);
-                    y = make_float4(m.x + b.x, m.y + b.y, m.z + b.z, m.w + b.w);
-                    y.x = y.x > 0.f ? y.x : 0.2f * y.x;
-                    y.y = y.y > 0.f ? y.y : 0.2f * y.y;
-                    y.z = y.z > 0.f ? y.z : 0.2f * y.z;
-                    y.w = y.w > 0.f ? y.w : 0.2f * y.w;
-                    if (dbg) {
-                        *reinterpret_cast<float4*>(dbg + (size_t)i * 64 + c4) = y;
-                        if (cout == 32)
-                            *reinterpret_cast<float4*>(dbg + (size_t)i * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int rstep = NW * rpw;
+            for (int ia = wave * rpw + sub; ia < NP; ia += 2 * rstep) {
+                const int ib = ia + rstep;
+                const bool hasb = ib < NP;                 // uniform per row group; all lanes of a row agree
+                const int ra = min(ia, N - 1), rb = min(hasb ? ib : ia, N - 1);   // padded rows: compute a real row, store 0
+                float4 ma, mb;
+                gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
+                            reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
+                const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * PX + c4), ia < N);
+                const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * PX + c4), ib < N);
+                if (dbg) {
+                    if (ia < N) {
+                        *reinterpret_cast<float4*>(dbg + (size_t)ia * 64 + c4) = ya;
+                        if (cout == 32) *reinterpret_cast<float4*>(dbg + (size_t)ia * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    if (hasb && ib < N) {
+                        *reinterpret_cast<float4*>(dbg + (size_t)ib * 64 + c4) = yb;
+                        if (cout == 32) *reinterpret_cast<float4*>(dbg + (size_t)ib * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-                *reinterpret_cast<float4*>(ydst + (size_t)i * ypitch + c4) = y;
-                if (want_norm) {                          // squared norm of the next layer's input row
-                    float s = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
-                    s += lane_xor(s, 1);
-                    s += lane_xor(s, 2);
-                    s += lane_xor(s, 4);
-                    s += lane_xor(s, 8);                 // cout == 64 here (16 lanes per row)
-                    if ((lane & 15) == 0) xx[i] = s;
+                *reinterpret_cast<float4*>(ydst + (size_t)ia * ypitch + c4) = ya;
+                if (hasb) *reinterpret_cast<float4*>(ydst + (size_t)ib * ypitch + c4) = yb;
+                if (want_norm) {                          // squared norms of the next layer's input rows (cout == 64: 16 lanes/row)
+                    float sa = fmaf(ya.x, ya.x, fmaf(ya.y, ya.y, fmaf(ya.z, ya.z, ya.w * ya.w)));
+                    float sb = fmaf(yb.x, yb.x, fmaf(yb.y, yb.y, fmaf(yb.z, yb.z, yb.w * yb.w)));
+                    sa += lane_xor(sa, 1);
+                    sb += lane_xor(sb, 1);
+                    sa += lane_xor(sa, 2);
+                    sb += lane_xor(sb, 2);
+                    sa += lane_xor(sa, 4);
+                    sb += lane_xor(sb, 4);
+                    sa += lane_xor(sa, 8);
+                    sb += lane_xor(sb, 8);
+                    if ((lane & 15) == 0) {
+                        xx[ia] = sa;
+                        if (hasb) xx[ib] = sb;
+                    }
                 }
             }
         }

@@ -174,7 +174,7 @@ class Engine:
     def lds_bytes(self, node_num, k):
         return int(self.lib.sgpr_embed_lds_bytes(self._h, node_num, k))
 
-    PHASES = ["stage", "norms", "gram", "select", "gemm", "gather", "conv_end", "attention"]
+    PHASES = ["stage", "select_only", "gram", "select||gemm", "gemm_only", "gather", "conv_end", "attention"]
 
     def phase_profile(self, centers, labels, k, reps=3):
         """Debug: fraction of workgroup cycles per phase of the embed kernel (thread-0 clocks)."""
@@ -187,7 +187,8 @@ class Engine:
         finally:
             self.lib.sgpr_debug_set_profile_buffer(None)
         c = buf.cpu().numpy().astype(np.float64)
-        return dict(zip(self.PHASES, c / max(c.sum(), 1.0))), c
+        tot = c.sum() - c[1] - c[4]   # slots 1 and 4 are sub-timers of slot 3
+        return dict(zip(self.PHASES, c / max(tot, 1.0))), c
 
     def check_status(self):
         self._check(self.lib.sgpr_check_status(self._h, self._stream()))

@@ -18,4 +18,4 @@ for name, (n, k, g) in {"kitti00": (100, 10, 4541), "pairs128": (64, 10, 256), "
     eng.embed(c, l, k)
     frac, cyc = eng.phase_profile(c, l, k)
     print(name, "N=%d k=%d G=%d" % (n, k, g), " ".join("%s=%.1f%%" % (p, 100 * f) for p, f in frac.items()),
-          "| cycles/graph=%.0f" % (cyc.sum() / 3 / g))
+          "| cycles/graph=%.0f" % ((cyc.sum() - cyc[1] - cyc[4]) / 3 / g))
