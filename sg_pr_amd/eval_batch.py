@@ -1,0 +1,105 @@
+"""Counterpart of the reference's eval_batch.py (eval_batch.py:14-91).
+
+    python -m sg_pr_amd.eval_batch [config.yml]
+
+Per sequence in `eva_batch.sequences`: reads `<pair_list_dir>/<seq>.txt`, scores every
+listed pair, and writes the same artefacts as the reference into `output_path`:
+`<seq>_gt_db.npy` (float64), `<seq>_DL_db.npy` (float32), `<seq>_DL_F1_max.txt`
+(plus ROC / PR PNGs when matplotlib is importable).
+
+Unlike the reference (which re-reads, re-pads and re-embeds both graphs of every pair,
+utils.py:27-28 / sg_net.py:503-520) each distinct graph is parsed and embedded ONCE on the
+GPU; only the NTN + head tail runs per listed pair (sgpr_score_pairs with index lists).
+Scores are identical because eval-mode batch elements are independent.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import metrics
+from .parser_sg import sgpr_args
+from .sg_net import SGTrainer
+from .utils import load_paires, pose_distance, tab_printer
+
+
+def score_pair_list(trainer, graph_pairs):
+    """[[path_a, path_b], ...] -> (pred float32 [P], gt float64 [P]); embeds each graph once."""
+    index, paths = {}, []
+    ia = np.empty(len(graph_pairs), dtype=np.int32)
+    ib = np.empty(len(graph_pairs), dtype=np.int32)
+    for p, (a, b) in enumerate(graph_pairs):
+        for path in (a, b):
+            if path not in index:
+                index[path] = len(paths)
+                paths.append(path)
+        ia[p], ib[p] = index[a], index[b]
+    n = int(trainer.args.node_num)
+    centers = np.empty((len(paths), n, 3), dtype=np.float32)
+    labels = np.empty((len(paths), n), dtype=np.int32)
+    poses = []
+    for g, path in enumerate(paths):
+        c, l, pose = trainer._load_graph(path)
+        centers[g], labels[g] = c, l
+        poses.append(pose)
+    gt = np.array([trainer.target_from_distance(pose_distance(poses[i], poses[j])) for i, j in zip(ia, ib)],
+                  dtype=np.float64)
+    model = trainer.model
+    chunk = max(1, int(trainer.args.batch_size)) * 64
+    pooled = torch.cat([model.embed(centers[s:s + chunk], labels[s:s + chunk])[0]
+                        for s in range(0, len(paths), chunk)]) if paths else torch.empty(0, 32)
+    pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib))
+    return pred.cpu().numpy().reshape(-1), gt
+
+
+def evaluate_sequence(trainer, sequence, args, plots=True):
+    graph_pairs = load_paires(os.path.join(args.pair_list_dir, sequence + ".txt"), args.graph_pairs_dir)
+    pred_db, gt_db = score_pair_list(trainer, graph_pairs)
+    assert len(pred_db) == len(gt_db)
+    assert np.sum(gt_db) > 0  # gt_db should have positive samples   (eval_batch.py:38)
+    np.save(os.path.join(args.output_path, sequence + "_gt_db.npy"), gt_db)
+    np.save(os.path.join(args.output_path, sequence + "_DL_db.npy"), pred_db)
+    roc_auc = metrics.roc_auc(gt_db, pred_db)
+    print("roc_auc: ", roc_auc)
+    precision, recall, pr_thresholds = metrics.precision_recall_curve(gt_db, pred_db)
+    if plots:
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            from matplotlib import pyplot as plt
+            plt.figure(1)
+            plt.plot(recall, precision, color='darkorange', lw=2, label='P-R curve')
+            plt.axis([0, 1, 0, 1])
+            plt.xlabel('Recall')
+            plt.ylabel('Precision')
+            plt.title('DL Precision-Recall Curve')
+            plt.legend(loc="lower right")
+            plt.savefig(os.path.join(args.output_path, sequence + "_DL_pr_curve.png"))
+            plt.close(1)
+        except ImportError:
+            pass
+    f1_max = metrics.f1_max(gt_db, pred_db)
+    print('F1 max score', f1_max)
+    with open(os.path.join(args.output_path, sequence + "_DL_F1_max.txt"), "w") as out:
+        out.write(str(f1_max))
+    return f1_max
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = sgpr_args()
+    args.load(argv[0] if argv else './config/config.yml')
+    tab_printer(args)
+    trainer = SGTrainer(args, False)
+    trainer.model.eval()
+    os.makedirs(args.output_path, exist_ok=True)
+    results = {}
+    for sequence in args.sequences:
+        print("sequence: ", sequence)
+        results[sequence] = evaluate_sequence(trainer, sequence, args)
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -233,3 +233,41 @@ def test_odd_sizes(eng, oracle, oracle_sd):
         rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
         assert (s - rs).abs().max().item() <= SCORE_TOL, (n, k)
         np.testing.assert_allclose(a.cpu().numpy(), ra.numpy(), rtol=0, atol=1e-4)
+
+
+def test_shard_invariance_bitwise(eng):
+    """Every score depends on its two graphs only: any split of the work gives bit-identical results
+    (the property the multi-GPU row sharding relies on)."""
+    from sg_pr_amd import synth
+    centers, labels, _, _ = synth.kitti_like_sequence(num_graphs=203, node_num=100, seed=9)
+    full, _, _ = eng.embed(centers, labels, 10)
+    parts = torch.cat([eng.embed(centers[a:b], labels[a:b], 10)[0] for a, b in ((0, 77), (77, 78), (78, 203))])
+    assert torch.equal(full, parts)
+    m = eng.score_all_pairs(full, full)
+    blocks = torch.cat([eng.score_all_pairs(full[a:b].contiguous(), full) for a, b in ((0, 26), (26, 102), (102, 203))])
+    assert torch.equal(m, blocks)
+
+
+def test_cli_counterparts(tmp_path, golden_dir, ckpt_path, capsys):
+    """eval_pair / eval_batch counterparts on the shipped graphs (BASELINE config 1 on the GPU engine)."""
+    from sg_pr_amd import eval_pair, eval_batch
+    data = os.path.join(golden_dir, "data")
+    (tmp_path / "00.txt").write_text("0.json 250.json\n0.json 3.json\n250.json 250.json\n3.json 0.json\n")
+    cfg = tmp_path / "config.yml"
+    cfg.write_text("""
+common: {model: "%s", cuda: "0", batch_size: 128, p_thresh: 3, graph_pairs_dir: "%s", pair_list_dir: '%s'}
+arch: {keep_node: 1, filters_1: 64, filters_2: 64, filters_3: 32, tensor_neurons: 16, bottle_neck_neurons: 16, K: 10}
+train: {epochs: 500, train_sequences: ['00'], eval_sequences: ["08"], dropout: 0, learning_rate: 0.001,
+        weight_decay: 0.0005, gpu: 0, logdir: "./logs_k10", node_num: 100}
+eva_batch: {sequences: ["00"], output_path: "%s", show: False}
+eva_pair: {pair_file: ["%s/0.json", "%s/250.json"]}
+""" % (ckpt_path, data, tmp_path, tmp_path / "eva", data, data))
+    score = eval_pair.main([str(cfg)])
+    out = capsys.readouterr().out
+    assert "Score:" in out and abs(float(score) - 1.3489922e-06) < 1e-6
+    res = eval_batch.main([str(cfg)])
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    pred = np.load(tmp_path / "eva" / "00_DL_db.npy")
+    np.testing.assert_allclose(pred, [g["scores"][2], g["scores"][1], g["scores"][8], g["scores"][3]], atol=SCORE_TOL)
+    np.testing.assert_array_equal(np.load(tmp_path / "eva" / "00_gt_db.npy"), [0, 1, 1, 1])
+    assert res["00"] == 1.0

@@ -1,0 +1,294 @@
+"""Host-side logic, C-ABI surface and the multi-process (gloo) sharding path.  CPU only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def test_library_exports_every_header_symbol():
+    from sg_pr_amd import engine
+    lib = engine.load_library()
+    header = open(os.path.join(REPO, "include", "sgpr.h")).read()
+    declared = set(re.findall(r"\b(sgpr_[a-z_]+)\s*\(", header))
+    assert declared == set(engine.ABI_SYMBOLS), declared ^ set(engine.ABI_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.sgpr_abi_version() == 1
+    assert lib.sgpr_weights_count(ctypes.byref(engine.default_dims())) == 48689   # 48 696 minus 7 int64 counters
+
+
+def test_create_rejects_bad_blobs_without_a_gpu():
+    from sg_pr_amd import engine
+    lib = engine.load_library()
+    h = ctypes.c_void_p()
+    blob = np.zeros(100, dtype=np.float32)
+    rc = lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(engine.default_dims()), 0,
+                         ctypes.byref(h))
+    assert rc == -8 and b"48689" in lib.sgpr_last_error()
+    odd = engine.SgprDims(12, 64, 64, 64, 16, 16)
+    rc = lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(odd), 0, ctypes.byref(h))
+    assert rc == -2
+    assert lib.sgpr_create(None, 0, ctypes.byref(odd), 0, ctypes.byref(h)) == -1
+
+
+def test_lds_plans():
+    from sg_pr_amd import engine
+    lib = engine.load_library()
+    h = ctypes.c_void_p(1)   # plan queries only need a non-NULL handle
+    for n, k in [(64, 10), (100, 10), (256, 20), (16, 10), (128, 32), (200, 32), (23, 5)]:
+        b = lib.sgpr_embed_lds_bytes(h, n, k)
+        assert 0 < b <= 160 * 1024, (n, k, b)
+    assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 0      # > SGPR_MAX_NODES
+    assert lib.sgpr_embed_lds_bytes(h, 8, 10) == 0        # K > node_num
+    assert lib.sgpr_embed_workspace_bytes(h, 10, 100, 10) == 0
+    assert lib.sgpr_embed_workspace_bytes(h, 10, 256, 20) == 10 * 256 * 32 * 4   # parked xyz3 block
+
+
+def test_engine_refuses_to_run_without_gpu(ckpt_path):
+    from sg_pr_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sd = torch.load(ckpt_path, map_location="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.Engine(sd)
+
+
+def test_blob_order_matches_checkpoint(ckpt_path):
+    from sg_pr_amd import engine
+    sd = torch.load(ckpt_path, map_location="cpu")
+    blob = engine.blob_from_state_dict(sd)
+    assert blob.dtype == np.float32 and blob.size == 48689
+    w = sd["module.dgcnn_s_conv1.0.weight"].reshape(-1).numpy()
+    np.testing.assert_array_equal(blob[: w.size], w)
+    np.testing.assert_array_equal(blob[-1:], sd["module.scoring_layer.bias"].numpy())
+    np.testing.assert_array_equal(blob[-17:-1], sd["module.scoring_layer.weight"].reshape(-1).numpy())
+
+
+# ------------------------------------------------------------------ reference-shaped host API
+def _write_config(tmp_path, **over):
+    cfg = """
+common:
+  model: "%(model)s"
+  cuda: "0"
+  batch_size: 128
+  p_thresh: 3
+  graph_pairs_dir: "%(graphs)s"
+  pair_list_dir: '%(lists)s'
+arch:
+  keep_node: 1
+  filters_1: 64
+  filters_2: 64
+  filters_3: 32
+  tensor_neurons: 16
+  bottle_neck_neurons: 16
+  K: 10
+train:
+  epochs: 500
+  train_sequences: ['00']
+  eval_sequences: ["08",]
+  dropout: 0
+  learning_rate: 0.001
+  weight_decay: 0.0005
+  gpu: 0
+  logdir: "./logs_k10"
+  node_num: 100
+eva_batch:
+  sequences: ["00",]
+  output_path: "%(out)s"
+  show: False
+eva_pair:
+  pair_file: ["%(graphs)s/0.json","%(graphs)s/250.json"]
+""" % over
+    path = tmp_path / "config.yml"
+    path.write_text(cfg)
+    return str(path)
+
+
+def test_parser_reads_reference_layout(tmp_path, golden_dir, ckpt_path):
+    from sg_pr_amd.parser_sg import sgpr_args
+    cfg = _write_config(tmp_path, model=ckpt_path, graphs=os.path.join(golden_dir, "data"), lists=str(tmp_path),
+                        out=str(tmp_path / "eva"))
+    a = sgpr_args()
+    assert a.node_num == 100 and a.K == 10 and a.batch_size == 128          # reference defaults
+    a.load(cfg)
+    assert a.cuda == "0" and a.gpu == 0 and a.p_thresh == 3 and a.sequences == ["00"]
+    assert isinstance(a.pair_file, list) and len(a.pair_file) == 2
+    with pytest.raises(KeyError):
+        bad = tmp_path / "bad.yml"
+        bad.write_text("common: {}\narch: {}\ntrain: {}\neva_batch: {}\neva_pair: {}\n")
+        sgpr_args().load(str(bad))
+
+
+def test_process_pair_and_pair_list(tmp_path, golden_dir):
+    from sg_pr_amd.utils import process_pair, load_paires
+    d = process_pair([os.path.join(golden_dir, "data", "0.json"), os.path.join(golden_dir, "data", "250.json")])
+    assert set(d) == {"centers_1", "nodes_1", "centers_2", "nodes_2", "distance"}
+    assert abs(d["distance"] - 133.12761323772054) < 1e-9 and len(d["nodes_1"]) == 38 and len(d["nodes_2"]) == 31
+    lst = tmp_path / "00.txt"
+    lst.write_text("0.json 3.json\n3.json 250.json\n")
+    assert load_paires(str(lst), "/g") == [["/g/0.json", "/g/3.json"], ["/g/3.json", "/g/250.json"]]
+
+
+def test_pack_graph_semantics():
+    from sg_pr_amd.sg_net import pack_graph
+    c, l = pack_graph([[1, 2, 3], [4, 5, 6]], [3, 11], 5)
+    assert c.dtype == np.float32 and l.dtype == np.int32
+    np.testing.assert_array_equal(l, [3, 11, -1, -1, -1])
+    np.testing.assert_array_equal(c[2:], 0)
+    with pytest.raises(KeyError):
+        pack_graph([[0, 0, 0]], [12], 5)          # reference: KeyError at global_labels[node]
+    with pytest.raises(ValueError):
+        pack_graph(np.zeros((6, 3)), [0] * 6, 5)  # reference subsamples randomly (unseeded)
+    c, l = pack_graph([], [], 4)
+    assert (l == -1).all()
+
+
+def test_sg_module_state_dict_and_transfer(golden_dir, ckpt_path):
+    from sg_pr_amd import sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    from sg_pr_amd.utils import process_pair
+    a = sgpr_args()
+    a.model = ckpt_path
+    t = sg_net.SGTrainer(a, False)
+    raw = torch.load(ckpt_path, map_location="cpu")
+    assert list(t.model.state_dict().keys()) == [k[7:] for k in raw.keys()]     # strict layout, same order
+    for k, v in raw.items():
+        assert torch.equal(t.model.state_dict()[k[7:]], v)
+    assert t.model.module is t.model and not t.model.training
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    d = process_pair([os.path.join(golden_dir, "data", "0.json"), os.path.join(golden_dir, "data", "250.json")])
+    x = t.transfer_to_torch(d, False)
+    assert x["features_1"].dtype == np.float64 and x["features_1"].shape == (15, 100) and x["target"] == 0.0
+    np.testing.assert_array_equal(x["features_1"].astype(np.float32), g["features"][0])
+    np.testing.assert_array_equal(x["features_2"].astype(np.float32), g["features"][2])
+    assert len(d["nodes_1"]) == 38                                             # input not mutated (reference mutates)
+    with pytest.raises(SystemExit):
+        t.target_from_distance(10.0)                                            # 3 m < d < 20 m: reference exit(-1)
+    with pytest.raises(NotImplementedError):
+        sg_net.SGTrainer(a, True)
+
+
+def test_metrics_golden(golden_dir):
+    from sg_pr_amd import metrics
+    g = np.load(os.path.join(golden_dir, "prf1.npz"))
+    for c in range(int(g["ncases"])):
+        p, r, _ = metrics.precision_recall_curve(g[f"gt{c}"], g[f"score{c}"])
+        np.testing.assert_allclose(p, g[f"precision{c}"], atol=1e-12)
+        np.testing.assert_allclose(r, g[f"recall{c}"], atol=1e-12)
+        assert abs(metrics.f1_max(g[f"gt{c}"], g[f"score{c}"]) - float(g[f"f1max{c}"])) < 1e-12
+        assert abs(metrics.roc_auc(g[f"gt{c}"], g[f"score{c}"]) - float(g[f"auc{c}"])) < 1e-9
+
+
+def test_synth_generators():
+    from sg_pr_amd import synth
+    c, l, n = synth.config2_pairs(seed=0)
+    assert c.shape == (256, 64, 3) and l.shape == (256, 64) and n.max() <= 54 and n.min() >= 20
+    c5, l5, n5 = synth.config5_pairs(seed=0, batch=4)
+    assert c5.shape == (8, 256, 3) and (256 - n5 >= 20).all()
+    ck, lk, nk, poses = synth.kitti_like_sequence(64, 100, 1)
+    assert poses.shape == (64, 12) and ((lk >= 0).sum(1) == nk).all()
+    d = synth.dense_features(c[:2], l[:2])
+    assert d.shape == (2, 15, 64) and set(np.unique(d[:, 3:].sum(1))) <= {0.0, 1.0}
+    c2, _, _ = synth.config2_pairs(seed=0)
+    np.testing.assert_array_equal(c, c2)
+
+
+# ------------------------------------------------------------------ all-pairs sharding (gloo, world_size 2)
+def test_shard_bounds():
+    from sg_pr_amd.allpairs import shard_bounds
+    for total in (0, 1, 7, 4541):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _allpairs_worker(rank, world, port, golden, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, REPO)
+    from oracle import sgpr_oracle as oracle
+    from sg_pr_amd import synth, allpairs
+    torch.set_num_threads(2)
+    sd = oracle.load_checkpoint(os.path.join(golden, "model.pth"))
+    centers, labels, _, _ = synth.kitti_like_sequence(11, 100, 3)     # 11 graphs: uneven shards
+
+    def embed_fn(c, l):
+        if c.shape[0] == 0:
+            return torch.empty(0, 32)
+        return oracle.embed(sd, torch.from_numpy(synth.dense_features(c, l)), 10)[0]
+
+    scorer = allpairs.AllPairsScorer(embed_fn=embed_fn, score_fn=lambda r, c: oracle.score_all_pairs(sd, r, c))
+    full = scorer.run(centers, labels)
+    if rank == 0:
+        torch.save(full, os.path.join(out_dir, "w%d.pt" % world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
+    """The gathered matrix of a 2-rank run is bit-identical to the single-process one."""
+    import torch.multiprocessing as mp
+    from oracle import sgpr_oracle as oracle
+    from sg_pr_amd import synth, allpairs
+    mp.spawn(_allpairs_worker, args=(2, 29611, golden_dir, str(tmp_path)), nprocs=2, join=True)
+    two = torch.load(os.path.join(str(tmp_path), "w2.pt"))
+    sd = oracle.load_checkpoint(os.path.join(golden_dir, "model.pth"))
+    centers, labels, _, poses = synth.kitti_like_sequence(11, 100, 3)
+    torch.set_num_threads(2)
+    # same shard shapes as the two ranks (torch-CPU matmuls are not bitwise batch-invariant; the HIP engine is,
+    # which tests/test_gpu_parity.py checks on the GPU)
+    def emb(lo, hi):
+        return oracle.embed(sd, torch.from_numpy(synth.dense_features(centers[lo:hi], labels[lo:hi])), 10)[0]
+
+    bounds = [allpairs.shard_bounds(11, 2, r) for r in range(2)]
+    pooled = torch.cat([emb(lo, hi) for lo, hi in bounds])
+    one = torch.cat([oracle.score_all_pairs(sd, pooled[lo:hi].contiguous(), pooled) for lo, hi in bounds])
+    assert two.shape == (11, 11)
+    assert torch.equal(one, two)
+    assert not torch.equal(two, two.t())                 # the NTN is asymmetric: full square needed
+    gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
+    assert gt.shape == (11, 11) and valid.diagonal().all() and gt.diagonal().all()
+
+
+def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, oracle_sd):
+    """eval_batch counterpart: graphs embedded once, index lists drive the tail; artefacts like the reference's."""
+    from sg_pr_amd import eval_batch, sg_net, synth
+    from sg_pr_amd.parser_sg import sgpr_args
+    data = os.path.join(golden_dir, "data")
+    (tmp_path / "00.txt").write_text("0.json 250.json\n0.json 3.json\n250.json 250.json\n3.json 0.json\n")
+    cfg = _write_config(tmp_path, model=ckpt_path, graphs=data, lists=str(tmp_path), out=str(tmp_path / "eva"))
+    args = sgpr_args()
+    args.load(cfg)
+    trainer = sg_net.SGTrainer(args, False)
+
+    class OracleModel:   # CPU stand-in for the two HIP entry points used by eval_batch
+        def embed(self, c, l):
+            return oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(np.asarray(c), np.asarray(l))), 10)
+
+        def score_pooled(self, p1, p2, i1, i2):
+            return oracle.score_from_pooled(oracle_sd, p1[i1.long()], p2[i2.long()])
+
+    trainer.model = OracleModel()
+    os.makedirs(args.output_path, exist_ok=True)
+    f1 = eval_batch.evaluate_sequence(trainer, "00", args, plots=False)
+    pred = np.load(os.path.join(args.output_path, "00_DL_db.npy"))
+    gt = np.load(os.path.join(args.output_path, "00_gt_db.npy"))
+    assert pred.dtype == np.float32 and gt.dtype == np.float64
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    want = [g["scores"][2], g["scores"][1], g["scores"][8], g["scores"][3]]
+    np.testing.assert_allclose(pred, want, atol=1e-6)
+    np.testing.assert_array_equal(gt, [0, 1, 1, 1])
+    assert f1 == 1.0 and float(open(os.path.join(args.output_path, "00_DL_F1_max.txt")).read()) == 1.0
