@@ -7,9 +7,9 @@
 //  * ntn_prep_kernel + score_all_pairs_kernel
 //                            dense R x M rectangle.  The bilinear form is hoisted per row
 //                            graph (A_r = e1^T W, 16x32) so a pair costs 512+256+16 FMA;
-//                            one thread owns one column graph (its pooled vector stays in
-//                            registers), rows are wave-uniform so A_r / FC weights arrive
-//                            through the scalar cache; the score row is written coalesced.
+//                            both dense layers run on the fp32 matrix cores (16x16x4 MFMA,
+//                            layer 2 chained off the accumulator layout of layer 1), column
+//                            operands stay in registers, score rows are written coalesced.
 #include <math.h>
 
 #include "sgpr_internal.hpp"
@@ -126,53 +126,80 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
     }
 }
 
-constexpr int AP_ROWS = 16;  // row graphs per workgroup (column vectors are reused from registers)
+constexpr int AP_ROWS = 32;   // row graphs per workgroup (column operands stay in registers)
+constexpr int AP_COLS = 256;  // column graphs per workgroup: 4 waves x 64
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    // D[4*(l>>4)+r][l&15] += sum_{q<4} A[row][q] * B[q][col];  lane l supplies A[l&15][l>>4], B[l>>4][l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// One wave owns 64 column graphs (4 blocks of 16) and walks AP_ROWS row graphs.  Per (row, block):
+//   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j])   8 MFMAs (16x16x4 f32, K = 32)
+//   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])              4 MFMAs: H is consumed straight from
+//            the accumulator layout (lane group g holds t = 4g..4g+3 and supplies t = 4g+s at step s;
+//            the A operand is permuted to match), so no data moves between the two layers
+//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs + 2 cross-lane adds), sigmoid once per 64 columns,
+//            one coalesced 256-B store per row.
 __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w, const float* __restrict__ cols,
                                                               int R, int M, const float* __restrict__ Ar,
                                                               const float* __restrict__ ur,
                                                               const float* __restrict__ vc,
                                                               float* __restrict__ score, int64_t ld) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const bool live = c < M;
-    const int cc = live ? c : M - 1;
-    float e2[F], v[T];
-    {
-        const float4* src = reinterpret_cast<const float4*>(cols + (size_t)cc * F);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.x * AP_COLS + wave * 64;
+    if (c0 >= M) return;
+    // column operands: e2 (two 16-wide k-blocks) and v_c for the 4 column blocks of this wave
+    float4 e2[4][2], v4[4];
 #pragma unroll
-        for (int j = 0; j < F / 4; ++j) {
-            const float4 x = src[j];
-            e2[4 * j] = x.x; e2[4 * j + 1] = x.y; e2[4 * j + 2] = x.z; e2[4 * j + 3] = x.w;
-        }
-        const float4* vs = reinterpret_cast<const float4*>(vc + (size_t)cc * T);
-#pragma unroll
-        for (int j = 0; j < T / 4; ++j) {
-            const float4 x = vs[j];
-            v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
-        }
+    for (int b = 0; b < 4; ++b) {
+        const int c = min(c0 + b * 16 + l15, M - 1);
+        e2[b][0] = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 4 * g);
+        e2[b][1] = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 16 + 4 * g);
+        v4[b] = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
     }
+    const float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);   // W1[o = l15][t = 4g..4g+3]
+    const float4 b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
+    const float4 w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
+    const float b2 = w.fc2_b[0];
     const int r0 = blockIdx.y * AP_ROWS;
     const int r1 = min(R, r0 + AP_ROWS);
-    for (int r = r0; r < r1; ++r) {                 // r is wave-uniform: A_r, u_r, FC weights -> scalar loads
-        const float* __restrict__ a = Ar + (size_t)r * (T * F);
-        const float* __restrict__ u = ur + (size_t)r * T;
-        float h[T];
+    const int cst = c0 + lane;                         // the column this lane stores
+    for (int r = r0; r < r1; ++r) {
+        const float* ap = Ar + (size_t)r * (T * F) + l15 * F + 4 * g;                 // A_r[t = l15][k-block + 4g..]
+        const float4 a0 = *reinterpret_cast<const float4*>(ap);
+        const float4 a1 = *reinterpret_cast<const float4*>(ap + 16);
+        const float4 u4 = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+        float zsel = 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            float s = u[t] + v[t];
-#pragma unroll
-            for (int j = 0; j < F; ++j) s = fmaf(a[t * F + j], e2[j], s);
-            h[t] = fmaxf(s, 0.f);
+        for (int b = 0; b < 4; ++b) {
+            f32x4 h = {u4.x + v4[b].x, u4.y + v4[b].y, u4.z + v4[b].z, u4.w + v4[b].w};
+            h = mfma4(a0.x, e2[b][0].x, h);
+            h = mfma4(a0.y, e2[b][0].y, h);
+            h = mfma4(a0.z, e2[b][0].z, h);
+            h = mfma4(a0.w, e2[b][0].w, h);
+            h = mfma4(a1.x, e2[b][1].x, h);
+            h = mfma4(a1.y, e2[b][1].y, h);
+            h = mfma4(a1.z, e2[b][1].z, h);
+            h = mfma4(a1.w, e2[b][1].w, h);
+            f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
+            q = mfma4(w1v.x, fmaxf(h[0], 0.f), q);
+            q = mfma4(w1v.y, fmaxf(h[1], 0.f), q);
+            q = mfma4(w1v.z, fmaxf(h[2], 0.f), q);
+            q = mfma4(w1v.w, fmaxf(h[3], 0.f), q);
+            float z = w2v.x * fmaxf(q[0], 0.f);
+            z = fmaf(w2v.y, fmaxf(q[1], 0.f), z);
+            z = fmaf(w2v.z, fmaxf(q[2], 0.f), z);
+            z = fmaf(w2v.w, fmaxf(q[3], 0.f), z);
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 32);                    // every lane group now holds z of column block b
+            zsel = (g == b) ? z : zsel;                // lane group g finishes block g
         }
-        float z = w.fc2_b[0];
-#pragma unroll
-        for (int o = 0; o < BN_; ++o) {
-            float gacc = w.fc1_b[o];
-#pragma unroll
-            for (int t = 0; t < T; ++t) gacc = fmaf(w.fc1_w[o * T + t], h[t], gacc);
-            z = fmaf(w.fc2_w[o], fmaxf(gacc, 0.f), z);
-        }
-        if (live) score[(size_t)r * ld + c] = 1.f / (1.f + expf(-z));
+        const float sc = 1.f / (1.f + expf(-(zsel + b2)));
+        if (cst < M) score[(size_t)r * ld + cst] = sc;
     }
 }
 
@@ -185,7 +212,7 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
     hipLaunchKernelGGL(ntn_prep_kernel, dim3((R + M + 3) / 4), dim3(256), 0, stream, h->w, rows, R, cols, M, Ar, ur, vc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
-    dim3 grid((M + 255) / 256, (R + AP_ROWS - 1) / AP_ROWS);
+    dim3 grid((M + AP_COLS - 1) / AP_COLS, (R + AP_ROWS - 1) / AP_ROWS);
     hipLaunchKernelGGL(score_all_pairs_kernel, grid, dim3(256), 0, stream, h->w, cols, R, M, Ar, ur, vc, score, ld);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
