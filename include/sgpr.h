@@ -136,10 +136,14 @@ int sgpr_check_status(const sgpr_handle* h, void* stream);
 /* LDS bytes / threads per workgroup the embed kernel uses for (N, k); 0 if unsupported. */
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 
-/* Debug: when set to a device array of 8 uint64 counters, sgpr_embed* adds the shader cycles
+/* Debug: when set to a device array of 16 uint64 counters (8..13 = sub-phases of the selection), sgpr_embed* adds the shader cycles
  * thread 0 of every workgroup spends in each phase (0 stage, 1 norms, 2 Gram, 3 select,
  * 4 GEMM, 5 gather-max, 6 conv_end, 7 attention).  NULL (default) disables it. */
 void sgpr_debug_set_profile_buffer(void* d_counters);
+
+/* Debug / ablation timing only (results become invalid): bit 0 skips the kNN selection, bit 1 the
+ * per-node GEMMs, bit 2 the Gram phase, bit 3 the gather-max of sgpr_embed*.  0 (default) = normal. */
+void sgpr_debug_set_skip_mask(int mask);
 
 const char* sgpr_last_error(void);
 int sgpr_abi_version(void);

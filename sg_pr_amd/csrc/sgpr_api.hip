@@ -12,6 +12,7 @@ namespace sgpr {
 
 static thread_local std::string g_last_error;
 static unsigned long long* g_prof_buffer = nullptr;  // debug: per-phase cycle counters
+static int g_skip_mask = 0;                           // debug: ablation (timing only, results invalid)
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 
@@ -247,6 +248,7 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, void* w
     a.park_ws = static_cast<float*>(ws);
     a.status = h->d_status;
     a.prof = g_prof_buffer;
+    a.skip = g_skip_mask;
     return launch_embed(h, plan, a, static_cast<hipStream_t>(stream));
 }
 
@@ -355,6 +357,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     a.park_ws = pooled + (size_t)2 * B * kF3;
     a.status = h->d_status;
     a.prof = g_prof_buffer;
+    a.skip = g_skip_mask;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d_att1 && d_att2 && d_att2 == d_att1 + (size_t)B * N) {
         a.att = d_att1;  // contiguous [2B, N] attention buffer
@@ -374,6 +377,8 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     if (rc != SGPR_OK) return rc;
     return launch_score_pairs(h, pooled, nullptr, pooled + (size_t)B * kF3, nullptr, B, d_score, s);
 }
+
+void sgpr_debug_set_skip_mask(int mask) { g_skip_mask = mask; }
 
 void sgpr_debug_set_profile_buffer(void* d_counters) { g_prof_buffer = static_cast<unsigned long long*>(d_counters); }
 

@@ -16,9 +16,10 @@
 //    -pairwise_distance up to the row constant |x_i|^2), then an exact k-smallest
 //    selection per row: register sorting networks + butterfly merges, deterministic
 //    lowest-index tie-break.
-//  * wave specialisation: the selection is pure VALU work and the per-node GEMMs pure
-//    MFMA work on the same input, so half the waves select while the other half run
-//    the GEMMs (the two pipes of a SIMD run concurrently).
+//  * fp32 MFMA and VALU instructions share one pipe per SIMD on gfx950 (measured:
+//    tools/probes/coexec_probe.hip) and a single wave issues at most one VALU op per ~9
+//    cycles, so the VALU phases (selection, gather) are spread over all 8 waves (2 per
+//    SIMD) while one wave per SIMD is enough to saturate the MFMA phases.
 //  * 512 threads (8 wave64) per workgroup; everything between the input read and the
 //    pooled vector lives in LDS/registers.
 #include <math.h>
@@ -62,15 +63,13 @@ bool make_embed_plan(int N, int k, EmbedPlan* p) {
     p->nt = NT;
     int rc = (kLdsLimit - off) / rowD / 16 * 16;
     if (rc > p->NP) rc = p->NP;
-    // overlapped mode: whole key matrix resident and the selection fits in half the waves
+    // resident mode: the whole key matrix fits in LDS -> upper-triangular Gram tiles, mirrored
     int P = 1;
     while ((N + P - 1) / P > CAP) P *= 2;
-    p->overlap = (rc == p->NP && p->NP * P <= NT / 2) ? 1 : 0;
-    const int lanes = p->overlap ? NT / 2 : NT;
-    if (!p->overlap && rc * P > lanes) rc = lanes / P / 16 * 16;
+    p->overlap = (rc == p->NP && p->NP * P <= NT) ? 1 : 0;
+    if (!p->overlap && rc * P > NT) rc = NT / P / 16 * 16;
     if (rc < 16) return false;
-    while (P * 2 * rc <= lanes && (N + 2 * P - 1) / (2 * P) >= 4) P *= 2;   // spread a row over more lanes
-    p->P = P;
+    p->P = P;                                   // lower bound; the kernel widens it per graph (select_parts)
     p->seg = round_up((N + P - 1) / P, 4);
     p->RC = rc;
     p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
@@ -170,17 +169,26 @@ __device__ __forceinline__ float lane_xor(float v, int m) {
     return __int_as_float(r);
 }
 
-// KP smallest (ascending) of the 32 candidates d[OFF..OFF+32): two sorted 16-lists, then a half-cleaner
+// KP smallest (ascending) of the first `cnt` (wave-uniform) of the 32 candidates d[OFF..OFF+32)
 template <int KP, int OFF>
-__device__ __forceinline__ void list_from_32(const float (&d)[CAP], bool need_hi, float (&L)[KP]) {
-    float lo[16], hi[16];
+__device__ __forceinline__ void list_from_32(const float (&d)[CAP], int cnt, float (&L)[KP]) {
+    if (cnt <= 8) {
+        float lo[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        lo[u] = d[OFF + u];
-        hi[u] = d[OFF + 16 + u];
+        for (int u = 0; u < 8; ++u) lo[u] = d[OFF + u];
+        bitonic_sort<8>(lo);
+#pragma unroll
+        for (int u = 0; u < KP; ++u) L[u] = u < 8 ? lo[u & 7] : INFINITY;
+        return;
     }
+    float lo[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) lo[u] = d[OFF + u];
     bitonic_sort<16>(lo);
-    if (need_hi) {
+    if (cnt > 16) {
+        float hi[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) hi[u] = d[OFF + 16 + u];
         bitonic_sort<16>(hi);
         if (KP == 16) {
 #pragma unroll
@@ -199,105 +207,192 @@ __device__ __forceinline__ void list_from_32(const float (&d)[CAP], bool need_hi
     }
 }
 
+// value of lane (l - sh) within the same 16-lane row (0 where that lane does not exist)
+template <int SH>
+__device__ __forceinline__ int row_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + SH, 0xF, 0xF, true);   // row_shr:SH, bound_ctrl: zero fill
+}
+
+// emit the candidates whose bits are set in `take` (32 candidate slots starting at index jbase)
+__device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, unsigned short* __restrict__ out,
+                                          int32_t* __restrict__ dbg_row, int& pos) {
+    while (take) {
+        const int u = __ffs(take) - 1;
+        take &= take - 1;
+        out[pos] = (unsigned short)((jbase + u) * pitchA);
+        if (dbg_row) dbg_row[pos] = jbase + u;
+        ++pos;
+    }
+}
+
 // Exact k-smallest selection for the rows of one key chunk.
 // P consecutive lanes share a row; lane `part` owns candidates [part*seg, (part+1)*seg), seg <= CAP.
 // Result: nbr[i][0..k) = (float offset of the A row of) the k nearest candidates of row i under the
 // total order (key ascending, index ascending) - written as an unordered set.
 template <int KP>
-__device__ __forceinline__ void select_phase(const EmbedPlan& p, int k, const float* __restrict__ D, int rc0,
-                                             int rows_chunk, unsigned short* __restrict__ nbr,
-                                             int32_t* __restrict__ dbg_knn) {
+__device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k,
+                                             const float* __restrict__ D, int rc0, int rows_chunk,
+                                             unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
+                                             unsigned long long* __restrict__ prof8) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int P = p.P;
+    unsigned long long ts = (prof8 && tid == 0) ? clock64() : 0ull;
+#define SEL_STAMP(i)                                                   \
+    if (prof8 && tid == 0) {                                           \
+        const unsigned long long tn_ = clock64();                      \
+        atomicAdd(&prof8[i], tn_ - ts);                                \
+        ts = tn_;                                                      \
+    }
     const int rl = tid >> (__ffs(P) - 1), part = tid & (P - 1);
     const int i = rc0 + rl;
-    const bool active = (rl < rows_chunk) && (i < p.N);
+    const bool active = (rl < rows_chunk) && (i < n);
     const float* drow = D + (active ? rl : 0) * p.pitchD;
-    const int j0 = part * p.seg;
+    const int j0 = part * seg;
+    // keys of candidates j >= n are +inf already (written so by the Gram phase); only the row end (np) needs a guard
+    const int nq = min(seg, max(np - j0, 0)) >> 2;   // 16-B groups this lane really owns
 
     float d[CAP];
 #pragma unroll
-    for (int q = 0; q < CAP / 4; ++q) {
-        float4 v = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-        if (4 * q < p.seg && j0 + 4 * q < p.NP) v = *reinterpret_cast<const float4*>(drow + j0 + 4 * q);
-        d[4 * q + 0] = (j0 + 4 * q + 0 < p.N) ? v.x : INFINITY;
-        d[4 * q + 1] = (j0 + 4 * q + 1 < p.N) ? v.y : INFINITY;
-        d[4 * q + 2] = (j0 + 4 * q + 2 < p.N) ? v.z : INFINITY;
-        d[4 * q + 3] = (j0 + 4 * q + 3 < p.N) ? v.w : INFINITY;
+    for (int c = 0; c < CAP / 16; ++c) {
+        if (16 * c < seg) {                          // wave-uniform
+#pragma unroll
+            for (int q = 4 * c; q < 4 * c + 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(drow + j0 + 4 * min(q, max(nq - 1, 0)));
+                const bool ok = q < nq;
+                d[4 * q + 0] = ok ? v.x : INFINITY;
+                d[4 * q + 1] = ok ? v.y : INFINITY;
+                d[4 * q + 2] = ok ? v.z : INFINITY;
+                d[4 * q + 3] = ok ? v.w : INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int u = 16 * c; u < 16 * c + 16; ++u) d[u] = INFINITY;
+        }
     }
+    SEL_STAMP(0)
     // this lane's KP smallest, ascending
     float L[KP];
-    list_from_32<KP, 0>(d, p.seg > 16, L);
-    if (p.seg > 32) {
+    list_from_32<KP, 0>(d, seg, L);
+    if (seg > 32) {
         float L2[KP];
-        list_from_32<KP, 32>(d, p.seg > 48, L2);
+        list_from_32<KP, 32>(d, seg - 32, L2);
 #pragma unroll
         for (int u = 0; u < KP; ++u) L[u] = kmin(L[u], L2[KP - 1 - u]);
         bitonic_merge<KP>(L);
     }
+    SEL_STAMP(1)
     // butterfly merge of the P sorted lists of a row: min(L[s], O[KP-1-s]) = the KP smallest of the union, bitonic
-    for (int m = 1; m < P; m <<= 1) {
-        float o[KP];
-#pragma unroll
-        for (int s = 0; s < KP; ++s) o[s] = lane_xor(L[s], m);
-#pragma unroll
-        for (int s = 0; s < KP; ++s) L[s] = kmin(L[s], o[KP - 1 - s]);
-        bitonic_merge<KP>(L);
+#define SGPR_MERGE_ROUND(M)                                              \
+    if (P > (M)) {                                                       \
+        float o[KP];                                                     \
+        _Pragma("unroll") for (int s = 0; s < KP; ++s) o[s] = lane_xor(L[s], (M)); \
+        _Pragma("unroll") for (int s = 0; s < KP; ++s) L[s] = kmin(L[s], o[KP - 1 - s]); \
+        bitonic_merge<KP>(L);                                            \
     }
-    float tau = L[0];
+    SGPR_MERGE_ROUND(1)
+    SGPR_MERGE_ROUND(2)
+    SGPR_MERGE_ROUND(4)
+    SGPR_MERGE_ROUND(8)
+    SGPR_MERGE_ROUND(16)
+    SGPR_MERGE_ROUND(32)
+#undef SGPR_MERGE_ROUND
+    SEL_STAMP(2)
+    float tau;                                       // the k-th smallest key of the row
+    if (k == 10) {
+        tau = L[9];
+    } else if (KP == 32 && k == 20) {
+        tau = L[KP == 32 ? 19 : 0];
+    } else {
+        tau = L[0];
 #pragma unroll
-    for (int s = 1; s < KP; ++s) tau = (s == k - 1) ? L[s] : tau;
-    int c_less = 0;
+        for (int s = 1; s < KP; ++s) tau = (s == k - 1) ? L[s] : tau;
+    }
+    // per-lane bit sets of the candidates below / at the threshold
+    unsigned lt0 = 0u, lt1 = 0u, eq0 = 0u, eq1 = 0u;
 #pragma unroll
-    for (int s = 0; s < KP; ++s) c_less += (s < k && L[s] < tau) ? 1 : 0;
-    const int T = k - c_less;  // ties at tau to accept, lowest index first
-
-    unsigned long long lt_mask = 0ull, eq_mask = 0ull;
-    {
-        unsigned lt0 = 0u, lt1 = 0u, eq0 = 0u, eq1 = 0u;
+    for (int c = 0; c < 2; ++c)
+        if (16 * c < seg) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            lt0 |= (d[u] < tau) ? (1u << u) : 0u;
-            eq0 |= (d[u] == tau) ? (1u << u) : 0u;
-            lt1 |= (d[32 + u] < tau) ? (1u << u) : 0u;
-            eq1 |= (d[32 + u] == tau) ? (1u << u) : 0u;
+            for (int u = 16 * c; u < 16 * c + 16; ++u) {
+                lt0 |= (d[u] < tau) ? (1u << u) : 0u;
+                eq0 |= (d[u] == tau) ? (1u << u) : 0u;
+            }
         }
-        lt_mask = ((unsigned long long)lt1 << 32) | lt0;
-        eq_mask = ((unsigned long long)eq1 << 32) | eq0;
-    }
-    const int n_less = __popcll(lt_mask), n_eq = __popcll(eq_mask);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (32 + 16 * c < seg) {
+#pragma unroll
+            for (int u = 16 * c; u < 16 * c + 16; ++u) {
+                lt1 |= (d[32 + u] < tau) ? (1u << u) : 0u;
+                eq1 |= (d[32 + u] == tau) ? (1u << u) : 0u;
+            }
+        }
+    SEL_STAMP(3)
+    const int n_less = __popc(lt0) + __popc(lt1), n_eq = __popc(eq0) + __popc(eq1);
     const int packed = n_less | (n_eq << 16);
-    int e_pack = 0;
-    const int base = lane & ~(P - 1);
-    for (int q = 0; q < P; ++q) {
-        const int v = __shfl(packed, base + q);
-        if (q < part) e_pack += v;
+    // inclusive prefix over the P lanes of the row (P <= 16: DPP row shifts; else ds_bpermute), and the row total
+    int incl = packed, total;
+    if (P <= 16) {
+        // (the DPP reads must execute with every lane enabled: keep them outside the per-lane selects)
+        if (P > 1) {
+            const int t = row_shr<1>(incl);
+            incl += (part >= 1) ? t : 0;
+        }
+        if (P > 2) {
+            const int t = row_shr<2>(incl);
+            incl += (part >= 2) ? t : 0;
+        }
+        if (P > 4) {
+            const int t = row_shr<4>(incl);
+            incl += (part >= 4) ? t : 0;
+        }
+        if (P > 8) {
+            const int t = row_shr<8>(incl);
+            incl += (part >= 8) ? t : 0;
+        }
+        total = __shfl(incl, (lane & ~(P - 1)) + P - 1);
+    } else {
+        int e = 0;
+        const int base = lane & ~(P - 1);
+        for (int q = 0; q < P; ++q) {
+            const int v = __shfl(packed, base + q);
+            if (q <= part) e += v;
+        }
+        incl = e;
+        total = __shfl(incl, (lane & ~(P - 1)) + P - 1);
     }
+    const int e_pack = incl - packed;                       // exclusive
     const int e_less = e_pack & 0xffff, e_eq = e_pack >> 16;
+    const int T = k - (total & 0xffff);                     // ties at tau to accept, lowest index first
+    SEL_STAMP(4)
     if (active) {
         int pos = e_less + min(e_eq, T);
-        const int my_ties = max(0, min(n_eq, T - e_eq));
-        // keep only the first my_ties tie bits
-        unsigned long long ties = eq_mask;
+        int my_ties = max(0, min(n_eq, T - e_eq));
+        // keep only the first my_ties tie bits (index order: low word first)
+        unsigned t0 = eq0, t1 = eq1;
         if (my_ties < n_eq) {
-            unsigned long long keep = 0ull;
-            for (int t = 0; t < my_ties; ++t) {
-                const unsigned long long low = ties & (0ull - ties);
-                keep |= low;
-                ties ^= low;
+            unsigned keep0 = 0u, keep1 = 0u;
+            while (my_ties > 0 && t0) {
+                const unsigned low = t0 & (0u - t0);
+                keep0 |= low;
+                t0 ^= low;
+                --my_ties;
             }
-            ties = keep;
+            while (my_ties > 0 && t1) {
+                const unsigned low = t1 & (0u - t1);
+                keep1 |= low;
+                t1 ^= low;
+                --my_ties;
+            }
+            t0 = keep0;
+            t1 = keep1;
         }
-        unsigned long long take = lt_mask | ties;
         unsigned short* out = nbr + i * p.kpitch;
-        while (take) {
-            const int u = __ffsll((long long)take) - 1;
-            take &= take - 1;
-            out[pos] = (unsigned short)((j0 + u) * p.pitchA);
-            if (dbg_knn) dbg_knn[(size_t)i * k + pos] = j0 + u;
-            ++pos;
-        }
+        int32_t* dbg_row = dbg_knn ? dbg_knn + (size_t)i * p.k : nullptr;
+        emit_bits(lt0 | t0, j0, p.pitchA, out, dbg_row, pos);
+        if (seg > 32) emit_bits(lt1 | t1, j0 + 32, p.pitchA, out, dbg_row, pos);
     }
+    SEL_STAMP(5)
+#undef SEL_STAMP
 }
 
 // ------------------------------------------------------------------ Gram tile -> ranking keys
@@ -507,9 +602,8 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int g = blockIdx.x;
-    const int N = p.N, NP = p.NP;
-    const int nrt = NP >> 4;
-    float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * NP * PP;
+    const int NS = p.N;                                   // slots per graph in global memory
+    float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * p.NP * PP;
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
     unsigned long long t_prev = 0;
     const bool prof = kp.a.prof != nullptr && tid == 0;
@@ -521,63 +615,102 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         t_prev = t_now;                                          \
     }
 
-    // packed input: one node per thread, fetched once (both branches)
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    int lab = -1;
-    if (!kp.a.dense && tid < N) {
-        const float* c = kp.a.centers + ((size_t)g * N + tid) * 3;
-        cx = c[0];
-        cy = c[1];
-        cz = c[2];
-        lab = kp.a.labels[(size_t)g * N + tid];
-        if (lab < -1 || lab >= kLabels) atomicOr(kp.a.status, 1);
+    // ---- one slot per thread, fetched once for both branches: xyz + 12 semantic channels
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    float sem[kLabels];
+#pragma unroll
+    for (int c = 0; c < kLabels; ++c) sem[c] = 0.f;
+    if (tid < NS) {
+        if (kp.a.dense) {
+            const bool second = kp.a.dense2 && g >= kp.a.g_split;
+            const float* dn = (second ? kp.a.dense2 : kp.a.dense) +
+                              (size_t)(second ? g - kp.a.g_split : g) * (3 + kLabels) * NS + tid;
+            fx = dn[0];
+            fy = dn[NS];
+            fz = dn[2 * NS];
+#pragma unroll
+            for (int c = 0; c < kLabels; ++c) sem[c] = dn[(size_t)(3 + c) * NS];
+        } else {
+            const float* c3 = kp.a.centers + ((size_t)g * NS + tid) * 3;
+            fx = c3[0];
+            fy = c3[1];
+            fz = c3[2];
+            const int lab = kp.a.labels[(size_t)g * NS + tid];
+            if (lab < -1 || lab >= kLabels) atomicOr(kp.a.status, 1);
+#pragma unroll
+            for (int c = 0; c < kLabels; ++c) sem[c] = (lab == c) ? 1.f : 0.f;
+        }
     }
+    // ---- trailing duplicate slots (zero padding: sg_net.py:258-272): slots identical to the last one keep
+    // identical features in every layer and any of them is an equally valid neighbour, so only min(m, k) of
+    // the m copies are processed; the attention pool re-weights them by m / min(m, k)  
+    int N, nd;            // slots processed; slots before the trailing run of duplicates
+    float wdup;           // weight of each kept duplicate in the attention pool
+    {
+        float* ref = red;                       // 16 floats: the last slot
+        int* wmax = reinterpret_cast<int*>(red + 16);
+        if (tid == NS - 1) {
+            ref[0] = fx;
+            ref[1] = fy;
+            ref[2] = fz;
+#pragma unroll
+            for (int c = 0; c < kLabels; ++c) ref[3 + c] = sem[c];
+        }
+        __syncthreads();
+        bool same = tid < NS && fx == ref[0] && fy == ref[1] && fz == ref[2];
+#pragma unroll
+        for (int c = 0; c < kLabels; ++c) same = same && (sem[c] == ref[3 + c]);
+        const unsigned long long differs = __ballot(tid < NS && !same);
+        if (lane == 0) wmax[wave] = differs ? wave * 64 + 63 - __clzll((long long)differs) : -1;
+        __syncthreads();
+        int last = -1;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) last = max(last, wmax[q]);
+        nd = last + 1;
+        const int m = NS - nd;
+        const int c = min(m, p.k);
+        N = nd + c;
+        wdup = (float)m / (float)c;
+        __syncthreads();                        // red / D region is reused below
+    }
+    const int NP = (N + 15) & ~15;
+    const int nrt = NP >> 4;
+    // lanes per row in the selection: as many as the workgroup has (two VALU waves per SIMD are needed
+    // to keep the vector pipe busy), but at least 8 candidates per lane
+    int P = p.P;
+    {
+        const int rows = p.overlap ? NP : p.RC;
+        while (2 * P * rows <= NT && (N + 2 * P - 1) / (2 * P) >= 8) P *= 2;
+    }
+    const int seg = (((N + P - 1) / P) + 3) & ~3;
 
     for (int L = 0; L < 6; ++L) {
-        // per-iteration opaque copies: keep the compiler from hoisting (and then spilling) dozens of
-        // k- / label-derived predicates out of the layer loop
+        // per-iteration opaque copy: keeps the compiler from hoisting (and then spilling) dozens of
+        // k-derived predicates out of the layer loop
         int k = p.k;
         asm volatile("" : "+s"(k));
         if (L == 0 || L == 3) {
             // ---- stage this branch's input features (zero padded to 16 channels / NP rows) + squared norms
-            const int br = L == 0 ? 0 : 1;
-            if (kp.a.dense) {
-                const bool second = kp.a.dense2 && g >= kp.a.g_split;
-                const float* dn = (second ? kp.a.dense2 : kp.a.dense) +
-                                  (size_t)(second ? g - kp.a.g_split : g) * (3 + kLabels) * N;
-                for (int e = tid; e < NP * 16; e += NT) {
-                    const int c = e / NP, i = e - c * NP;       // node index fastest: coalesced [ch][N] reads
-                    const bool ok = i < N && (br == 0 ? c < 3 : c < kLabels);
-                    X[i * PX + c] = ok ? dn[(size_t)(br == 0 ? c : 3 + c) * N + i] : 0.f;
-                }
-                __syncthreads();
-                for (int i = tid; i < NP; i += NT) {
-                    float s = 0.f;
-                    for (int c = 0; c < 16; ++c) s = fmaf(X[i * PX + c], X[i * PX + c], s);
-                    xx[i] = s;
-                }
-            } else if (tid < NP) {
-                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+            if (tid < NP) {
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
                 float s = 0.f;
-                if (br == 0) {
-                    r0 = make_float4(cx, cy, cz, 0.f);
-                    s = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
-                } else if (lab >= 0 && lab < kLabels) {
-                    int lb = lab;
-                    asm volatile("" : "+v"(lb));
-                    float oh[12];
+                if (tid < N) {
+                    if (L == 0) {
+                        r0 = make_float4(fx, fy, fz, 0.f);
+                        s = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                    } else {
+                        r0 = make_float4(sem[0], sem[1], sem[2], sem[3]);
+                        r1 = make_float4(sem[4], sem[5], sem[6], sem[7]);
+                        r2 = make_float4(sem[8], sem[9], sem[10], sem[11]);
 #pragma unroll
-                    for (int c = 0; c < 12; ++c) oh[c] = (lb == c) ? 1.f : 0.f;
-                    r0 = make_float4(oh[0], oh[1], oh[2], oh[3]);
-                    r1 = make_float4(oh[4], oh[5], oh[6], oh[7]);
-                    r2 = make_float4(oh[8], oh[9], oh[10], oh[11]);
-                    s = 1.f;
+                        for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
+                    }
                 }
                 float4* xr = reinterpret_cast<float4*>(X + tid * PX);
                 xr[0] = r0;
                 xr[1] = r1;
                 xr[2] = r2;
-                xr[3] = r3;
+                xr[3] = make_float4(0.f, 0.f, 0.f, 0.f);
                 xx[tid] = s;
             }
             __syncthreads();
@@ -585,27 +718,18 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         }
         const int Kp = kp.w.kp[L], cout = kp.w.cout[L];
         const bool k64 = Kp == 64;
-        int32_t* dbg_knn = kp.a.dbg_knn ? kp.a.dbg_knn + ((size_t)g * 6 + L) * N * p.k : nullptr;
-        if (p.overlap) {
-            // ---- Gram: whole key matrix resident: upper-triangular tiles, each also stores its transpose
-            if (k64)
-                gram_tiles_sym<4>(X, xx, D, p.pitchD, N, nrt, wave);
-            else
-                gram_tiles_sym<1>(X, xx, D, p.pitchD, N, nrt, wave);
-            __syncthreads();
-            SGPR_PROF(2)
-            // ---- first half of the waves: kNN selection (VALU); second half: per-node GEMMs (MFMA)
-            const unsigned long long t_gemm0 = (kp.a.prof && tid == NT / 2) ? clock64() : 0ull;
-            if (wave < NW / 2) {
-                select_phase<KP>(p, k, D, 0, NP, nbr, dbg_knn);
-                if (prof) atomicAdd(&kp.a.prof[1], (unsigned long long)(clock64() - t_prev));   // selection alone
+        int32_t* dbg_knn = kp.a.dbg_knn ? kp.a.dbg_knn + ((size_t)g * 6 + L) * NS * p.k : nullptr;
+        // ---- kNN keys (Gram on MFMA) -> selection, one chunk of rows at a time (a single chunk, upper-triangular
+        //      tiles mirrored, when the whole key matrix is resident)
+        for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
+            const int rows_chunk = min(p.RC, NP - rc0);
+            if (kp.a.skip & 4) {
+            } else if (p.overlap) {
+                if (k64)
+                    gram_tiles_sym<4>(X, xx, D, p.pitchD, N, nrt, wave);
+                else
+                    gram_tiles_sym<1>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
-                gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave - NW / 2, NW / 2);
-                if (kp.a.prof && tid == NT / 2) atomicAdd(&kp.a.prof[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
-            }
-        } else {
-            for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
-                const int rows_chunk = min(p.RC, NP - rc0);
                 const int nti = rows_chunk >> 4;
                 for (int tile = wave; tile < nti * nrt; tile += NW) {
                     const int ti = tile / nrt, tj = tile - ti * nrt;
@@ -614,13 +738,21 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
                     else
                         gram_tile<1>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
                 }
-                __syncthreads();
-                SGPR_PROF(2)
-                select_phase<KP>(p, k, D, rc0, rows_chunk, nbr, dbg_knn);
-                __syncthreads();
+            }
+            __syncthreads();
+            SGPR_PROF(2)
+            if (!(kp.a.skip & 1)) select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, kp.a.prof ? kp.a.prof + 8 : nullptr);
+            if (!p.overlap) {
+                __syncthreads();                      // the key chunk is reused
                 SGPR_PROF(3)
             }
+        }
+        if (prof && p.overlap) atomicAdd(&kp.a.prof[1], (unsigned long long)(clock64() - t_prev));   // selection alone
+        // per-node GEMMs (MFMA): no barrier needed after the selection - they only touch X rows owned by the wave and A
+        if (!(kp.a.skip & 2)) {
+            const unsigned long long t_gemm0 = prof ? clock64() : 0ull;
             gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
+            if (prof) atomicAdd(&kp.a.prof[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
         }
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
@@ -633,9 +765,9 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             const int rpw = 64 / lpr;                    // rows per wave-iteration: 4 or 8
             const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
             const bool want_norm = (L != 2 && L != 5);
-            float* dbg = kp.a.dbg_layers ? kp.a.dbg_layers + ((size_t)g * 6 + L) * N * 64 : nullptr;
+            float* dbg = kp.a.dbg_layers ? kp.a.dbg_layers + ((size_t)g * 6 + L) * NS * 64 : nullptr;
             const int rstep = NW * rpw;
-            for (int ia = wave * rpw + sub; ia < NP; ia += 2 * rstep) {
+            for (int ia = wave * rpw + sub; ia < ((kp.a.skip & 8) ? 0 : NP); ia += 2 * rstep) {
                 const int ib = ia + rstep;
                 const bool hasb = ib < NP;                 // uniform per row group; all lanes of a row agree
                 const int ra = min(ia, N - 1), rb = min(hasb ? ib : ia, N - 1);   // padded rows: compute a real row, store 0
@@ -701,15 +833,34 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             e4.y = e4.y > 0.f ? e4.y : 0.2f * e4.y;
             e4.z = e4.z > 0.f ? e4.z : 0.2f * e4.z;
             e4.w = e4.w > 0.f ? e4.w : 0.2f * e4.w;
-            const int node = rt * 16 + l15;
-            *reinterpret_cast<float4*>(E + node * PE + c4) = e4;
-            if (kp.a.emb && node < N) *reinterpret_cast<float4*>(kp.a.emb + ((size_t)g * N + node) * 32 + c4) = e4;
+            *reinterpret_cast<float4*>(E + (rt * 16 + l15) * PE + c4) = e4;
         }
     }
     __syncthreads();
     SGPR_PROF(6)
+    if (kp.a.emb)                                                  // dropped duplicates replicate the last kept row
+        for (int e = tid; e < NS * 8; e += NT) {
+            const int i = e >> 3, c4 = (e & 7) * 4;
+            *reinterpret_cast<float4*>(kp.a.emb + ((size_t)g * NS + i) * 32 + c4) =
+                *reinterpret_cast<const float4*>(E + min(i, N - 1) * PE + c4);
+        }
+    if (kp.a.dbg_layers)
+        for (int e = tid; e < 6 * (NS - N) * 16; e += NT) {
+            const int c4 = (e & 15) * 4, r = e >> 4;
+            const int Ld = r / (NS - N), i = N + r - Ld * (NS - N);
+            float* base = kp.a.dbg_layers + ((size_t)g * 6 + Ld) * NS * 64;
+            *reinterpret_cast<float4*>(base + (size_t)i * 64 + c4) = *reinterpret_cast<const float4*>(base + (size_t)(N - 1) * 64 + c4);
+        }
+    if (kp.a.dbg_knn)
+        for (int e = tid; e < 6 * (NS - N) * p.k; e += NT) {
+            const int q = e % p.k, r = e / p.k;
+            const int Ld = r / (NS - N), i = N + r - Ld * (NS - N);
+            int32_t* base = kp.a.dbg_knn + ((size_t)g * 6 + Ld) * NS * p.k;
+            base[(size_t)i * p.k + q] = base[(size_t)(N - 1) * p.k + q];
+        }
 
-    // ---- attention pooling over all N slots (padding is NOT masked, divisor N: layers_batch.py:34-38)
+    // ---- attention pooling over all NS slots (padding is NOT masked, divisor NS: layers_batch.py:34-38);
+    //      each kept duplicate row stands for wdup slots
     constexpr int NPART = NT / 32;   // partial sums per channel
     float* mean = red + NPART * 32;
     float* tg = mean + 32;
@@ -717,14 +868,14 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     const int c = tid & 31, prt = tid >> 5;
     {
         float s = 0.f;
-        for (int n = prt; n < N; n += NPART) s += E[n * PE + c];
+        for (int n = prt; n < N; n += NPART) s = fmaf(n >= nd ? wdup : 1.f, E[n * PE + c], s);
         red[prt * 32 + c] = s;
     }
     __syncthreads();
     if (tid < 32) {
         float s = 0.f;
         for (int q = 0; q < NPART; ++q) s += red[q * 32 + tid];
-        mean[tid] = s / (float)N;
+        mean[tid] = s / (float)NS;
     }
     __syncthreads();
     if (tid < 32) {
@@ -736,14 +887,14 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     for (int n = tid; n < N; n += NT) {
         float dsum = 0.f;
         for (int q = 0; q < 32; ++q) dsum = fmaf(E[n * PE + q], tg[q], dsum);
-        const float sg = 1.f / (1.f + expf(-dsum));
-        sig[n] = sg;
-        if (kp.a.att) kp.a.att[(size_t)g * N + n] = sg;
+        sig[n] = 1.f / (1.f + expf(-dsum));
     }
     __syncthreads();
+    if (kp.a.att)
+        for (int n = tid; n < NS; n += NT) kp.a.att[(size_t)g * NS + n] = sig[min(n, N - 1)];
     {
         float s = 0.f;
-        for (int n = prt; n < N; n += NPART) s = fmaf(sig[n], E[n * PE + c], s);
+        for (int n = prt; n < N; n += NPART) s = fmaf((n >= nd ? wdup : 1.f) * sig[n], E[n * PE + c], s);
         red[prt * 32 + c] = s;
     }
     __syncthreads();

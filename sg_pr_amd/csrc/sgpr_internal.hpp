@@ -82,6 +82,7 @@ struct EmbedArgs {
     float* park_ws;         // [G][NP][32] when !park_in_lds
     int32_t* status;
     unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
+    int skip;                   // debug/ablation only (sgpr_debug_set_profile_buffer's companion): phases to skip
 };
 
 void set_error(const std::string& msg);

@@ -33,7 +33,7 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
-               "sgpr_embed_lds_bytes", "sgpr_debug_set_profile_buffer", "sgpr_last_error", "sgpr_abi_version"]
+               "sgpr_embed_lds_bytes", "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
 
 
 class SgprError(RuntimeError):
@@ -90,6 +90,8 @@ def load_library():
     lib.sgpr_check_status.argtypes = [vp, vp]
     lib.sgpr_embed_lds_bytes.restype = sz
     lib.sgpr_embed_lds_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_debug_set_skip_mask.restype = None
+    lib.sgpr_debug_set_skip_mask.argtypes = [i32]
     lib.sgpr_debug_set_profile_buffer.restype = None
     lib.sgpr_debug_set_profile_buffer.argtypes = [vp]
     lib.sgpr_last_error.restype = ctypes.c_char_p
@@ -178,7 +180,7 @@ class Engine:
 
     def phase_profile(self, centers, labels, k, reps=3):
         """Debug: fraction of workgroup cycles per phase of the embed kernel (thread-0 clocks)."""
-        buf = torch.zeros(8, dtype=torch.int64, device=self.device)
+        buf = torch.zeros(16, dtype=torch.int64, device=self.device)
         self.lib.sgpr_debug_set_profile_buffer(_ptr(buf))
         try:
             for _ in range(reps):
@@ -186,7 +188,9 @@ class Engine:
             torch.cuda.synchronize(self.device)
         finally:
             self.lib.sgpr_debug_set_profile_buffer(None)
-        c = buf.cpu().numpy().astype(np.float64)
+        call = buf.cpu().numpy().astype(np.float64)
+        self.last_select_split = call[8:14]   # load, sort, merge, tau+masks, prefix, emit (thread-0 cycles)
+        c = call[:8]
         tot = c.sum() - c[1] - c[4]   # slots 1 and 4 are sub-timers of slot 3
         return dict(zip(self.PHASES, c / max(tot, 1.0))), c
 

@@ -88,3 +88,16 @@ def dense_features(centers, labels, num_labels=NUM_LABELS):
     gi, ni = np.nonzero(labels >= 0)
     out[gi, 3 + labels[gi, ni], ni] = 1.0
     return out
+
+
+def effective_nodes(centers, labels, k):
+    """Slots the engine actually processes per graph: trailing slots identical to the last one (zero
+    padding) are interchangeable, so only min(m, k) of the m copies are kept ("duplicate
+    slots").  Returns int32 [G]."""
+    g, n = labels.shape
+    same = (labels == labels[:, -1:]) & (centers == centers[:, -1:, :]).all(-1)     # [G, N]
+    differs = ~same
+    last = np.where(differs.any(1), n - 1 - np.argmax(differs[:, ::-1], axis=1), -1)
+    nd = last + 1
+    m = n - nd
+    return (nd + np.minimum(m, k)).astype(np.int32)

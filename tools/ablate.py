@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Ablation timing of the embed kernel: wall time per launch with phases skipped (GPU box only)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from sg_pr_amd import engine, synth  # noqa: E402
+
+sd = torch.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "model.pth"), map_location="cpu")
+eng = engine.Engine(sd)
+shapes = {"kitti00": (100, 10, 4541), "pairs128": (64, 10, 256)}
+for name, (n, k, g) in shapes.items():
+    if name == "kitti00":
+        c, l, _, _ = synth.kitti_like_sequence(g, n, 0)
+    else:
+        c, l, _ = synth.make_graphs(g, n, 20, n - k, 0)
+    c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
+    for mask, label in [(0, "full"), (1, "no select"), (2, "no gemm"), (3, "no select, no gemm"), (4, "no gram"),
+                        (8, "no gather"), (15, "skeleton (stage, barriers, conv_end, attention)")]:
+        eng.lib.sgpr_debug_set_skip_mask(mask)
+        for _ in range(3):
+            eng.embed(c, l, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            eng.embed(c, l, k)
+        torch.cuda.synchronize()
+        print("%-9s %-48s %.4f ms" % (name, label, (time.perf_counter() - t0) * 100))
+    eng.lib.sgpr_debug_set_skip_mask(0)

@@ -19,3 +19,5 @@ for name, (n, k, g) in {"kitti00": (100, 10, 4541), "pairs128": (64, 10, 256), "
     frac, cyc = eng.phase_profile(c, l, k)
     print(name, "N=%d k=%d G=%d" % (n, k, g), " ".join("%s=%.1f%%" % (p, 100 * f) for p, f in frac.items()),
           "| cycles/graph=%.0f" % ((cyc.sum() - cyc[1] - cyc[4]) / 3 / g))
+    ss = eng.last_select_split / 3 / g / 6
+    print("   select per layer (cycles): load %.0f sort %.0f merge %.0f tau+masks %.0f prefix %.0f emit %.0f" % tuple(ss))
