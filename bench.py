@@ -132,8 +132,11 @@ def main():
 
         scorer.embed_fn = embed_timed
 
+        full_out = (torch.empty(m, m, dtype=torch.float32, device=dev)
+                    if (world > 1 and rank == 0 and not a.no_gather) else None)
+
         def step():
-            return scorer.run(d_centers, d_labels, gather=not a.no_gather)
+            return scorer.run(d_centers, d_labels, gather=not a.no_gather, out=full_out)
     else:
         b = m // 2
         c1, l1 = d_centers[0::2].contiguous(), d_labels[0::2].contiguous()

@@ -9,7 +9,7 @@ Multi-GPU (one process per GPU, torch.distributed; backend "nccl" = RCCL over xG
     rank r embeds graphs [lo_r, hi_r)                      (no communication)
     all_gather of the pooled vectors   M x 32 fp32         (0.58 MB for KITTI-00)
     rank r scores rows [lo_r, hi_r) against all M columns  (no communication)
-    gather of the row blocks to rank 0                     (M*M*4 bytes in total)
+    row blocks sent point-to-point into rank 0's matrix   (M*M*4 bytes in total, 7 xGMI links in parallel)
 Every score depends on its two graphs only, so the matrix is bit-identical for any
 world size.
 """
@@ -70,32 +70,39 @@ class AllPairsScorer:
         lo, hi = shard_bounds(pooled.shape[0], world, rank)
         return self.score_fn(pooled[lo:hi].contiguous(), pooled)
 
-    def gather_matrix(self, block, m, dst=0):
-        """Gather the row blocks on rank `dst` -> [M, M] there, None elsewhere."""
+    def gather_matrix(self, block, m, dst=0, out=None):
+        """Collect the row blocks on rank `dst` -> [M, M] there (written in place into `out` when given:
+        every peer's block is received straight into its rows of the matrix - no padding, no extra copy),
+        None elsewhere."""
         world, rank = self._world()
         if world == 1:
             return block
-        cap = shard_bounds(m, world, 0)[1]
-        buf = block.new_zeros((cap, m))
-        buf[: block.shape[0]] = block
         if rank == dst:
-            recv = [torch.empty_like(buf) for _ in range(world)]
-            dist.gather(buf, recv, dst=dst, group=self.group)
-            parts = []
+            full = out if out is not None else block.new_empty((m, m))
+            lo, hi = shard_bounds(m, world, rank)
+            ops = []
             for r in range(world):
                 l, h = shard_bounds(m, world, r)
-                parts.append(recv[r][: h - l])
-            return torch.cat(parts, dim=0)
-        dist.gather(buf, None, dst=dst, group=self.group)
+                if r != rank and h > l:
+                    ops.append(dist.P2POp(dist.irecv, full[l:h], r, self.group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            full[lo:hi].copy_(block)
+            for q in reqs:
+                q.wait()
+            return full
+        if block.shape[0] > 0:
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, block.contiguous(), dst, self.group)]):
+                q.wait()
         return None
 
-    def run(self, centers, labels, gather=True):
-        """Whole job: returns the [M, M] matrix on rank 0 (row block elsewhere / if gather=False)."""
+    def run(self, centers, labels, gather=True, out=None):
+        """Whole job: returns the [M, M] matrix on rank 0 (row block elsewhere / if gather=False).
+        `out` (rank 0): preallocated [M, M] buffer that receives the matrix."""
         pooled = self.pooled_all(centers, labels)
         block = self.score_rows(pooled)
         if not gather:
             return block
-        full = self.gather_matrix(block, pooled.shape[0])
+        full = self.gather_matrix(block, pooled.shape[0], out=out)
         return full if full is not None else block
 
 

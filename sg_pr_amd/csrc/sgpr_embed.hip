@@ -395,6 +395,110 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
 #undef SEL_STAMP
 }
 
+// ------------------------------------------------------------------ selection by value bisection (wave per row)
+// order-preserving float -> uint32
+__device__ __forceinline__ unsigned ord_u32(float f) {
+    f += 0.0f;  // -0 -> +0
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+
+// wave64 min / max of a u32 (result uniform)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    // lane 15 of each row holds the row minimum; combine the four rows
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+    return min(min(r0, r1), min(r2, r3));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// One wave per row; lane l holds candidates l, l+64, ... (C of them).  The k-th smallest key is bracketed by
+// bisection on the key VALUE: one v_cmp (= a 64-lane ballot) + scalar popcount per candidate slot and step,
+// stopping as soon as exactly k keys lie below the pivot.  Ties at the k-th key (identical padding slots) run
+// the interval down to a single value and are then taken in candidate-index order.  Emission needs no loop:
+// a taken candidate's output position is the number of taken candidates before it (v_mbcnt).
+template <int C>
+__device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np, int k, const float* __restrict__ D,
+                                              int rc0, int rows_chunk, unsigned short* __restrict__ nbr,
+                                              int32_t* __restrict__ dbg_knn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int rl = wave; rl < rows_chunk; rl += NW) {
+        const int i = rc0 + rl;
+        if (i >= n) break;
+        const float* drow = D + rl * p.pitchD;
+        unsigned key[C];
+        unsigned kmin_ = 0xffffffffu, kmax_ = 0u;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int j = lane + 64 * c;
+            const bool valid = j < n;                       // keys of [n, np) are +inf, beyond np unwritten
+            const float v = drow[min(j, np - 1)];
+            key[c] = valid ? ord_u32(v) : 0xffffffffu;
+            kmin_ = min(kmin_, key[c]);
+            kmax_ = max(kmax_, valid ? key[c] : 0u);
+        }
+        unsigned lo = wave_min_u32(kmin_), hi = wave_max_u32(kmax_);
+        // invariant: #(key <= hi) >= k, #(key < lo) < k
+        unsigned pivot = hi;
+        bool exact = false;
+        while (lo < hi) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) cnt += __popcll(__ballot(key[c] <= mid));
+            if (cnt == k) {
+                pivot = mid;
+                exact = true;
+                break;
+            }
+            if (cnt > k)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        if (!exact) pivot = lo;                              // the k-th smallest key itself; ties possible
+        // taken = {key < pivot} (or <= pivot when exact) + the first T ties in candidate order
+        bool is_lt[C], is_eq[C];
+        unsigned long long eq[C];
+        int n_lt = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            is_lt[c] = exact ? key[c] <= pivot : key[c] < pivot;
+            is_eq[c] = !exact && key[c] == pivot;
+            eq[c] = __ballot(is_eq[c]);
+            n_lt += __popcll(__ballot(is_lt[c]));
+        }
+        int T = k - n_lt;                                    // ties still to accept (0 when exact)
+        int base = 0;
+        unsigned short* out = nbr + i * p.kpitch;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int tie_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(eq[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eq[c], 0));
+            const bool take = is_lt[c] || (is_eq[c] && tie_rank < T);
+            const unsigned long long tk = __ballot(take);
+            const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(tk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tk, 0));
+            if (take) {
+                out[pos] = (unsigned short)((lane + 64 * c) * p.pitchA);
+                if (dbg_knn) dbg_knn[(size_t)i * p.k + pos] = lane + 64 * c;
+            }
+            base += __popcll(tk);
+            T -= min(T, __popcll(eq[c]));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ Gram tile -> ranking keys
 template <int NKB>
 __device__ __forceinline__ void gram_tile(const float* __restrict__ X, const float* __restrict__ xx, float* __restrict__ D,
@@ -615,6 +719,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         t_prev = t_now;                                          \
     }
 
+    if (kp.a.skip & 16) return;   // ablation: pure dispatch cost
     // ---- one slot per thread, fetched once for both branches: xyz + 12 semantic channels
     float fx = 0.f, fy = 0.f, fz = 0.f;
     float sem[kLabels];
@@ -673,6 +778,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         wdup = (float)m / (float)c;
         __syncthreads();                        // red / D region is reused below
     }
+    if (kp.a.skip & 32) return;   // ablation: input fetch + duplicate detection only
     const int NP = (N + 15) & ~15;
     const int nrt = NP >> 4;
     // lanes per row in the selection: as many as the workgroup has (two VALU waves per SIMD are needed
@@ -741,7 +847,14 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             }
             __syncthreads();
             SGPR_PROF(2)
-            if (!(kp.a.skip & 1)) select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, kp.a.prof ? kp.a.prof + 8 : nullptr);
+            if (!(kp.a.skip & 1)) {
+                if (kp.a.skip & 64)   // A/B: sorting-network selection
+                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, kp.a.prof ? kp.a.prof + 8 : nullptr);
+                else if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
+                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, kp.a.prof ? kp.a.prof + 8 : nullptr);
+                else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
+                    select_bisect<4>(p, N, NP, k, D, rc0, rows_chunk, nbr, dbg_knn);
+            }
             if (!p.overlap) {
                 __syncthreads();                      // the key chunk is reused
                 SGPR_PROF(3)

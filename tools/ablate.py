@@ -17,8 +17,9 @@ for name, (n, k, g) in shapes.items():
     else:
         c, l, _ = synth.make_graphs(g, n, 20, n - k, 0)
     c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
-    for mask, label in [(0, "full"), (1, "no select"), (2, "no gemm"), (3, "no select, no gemm"), (4, "no gram"),
-                        (8, "no gather"), (15, "skeleton (stage, barriers, conv_end, attention)")]:
+    for mask, label in [(0, "full"), (64, "full, sorting-network selection"), (1, "no select"), (2, "no gemm"), (3, "no select, no gemm"), (4, "no gram"),
+                        (8, "no gather"), (15, "skeleton (stage, barriers, conv_end, attention)"),
+                        (32, "input fetch + duplicate detection only"), (16, "dispatch only")]:
         eng.lib.sgpr_debug_set_skip_mask(mask)
         for _ in range(3):
             eng.embed(c, l, k)
