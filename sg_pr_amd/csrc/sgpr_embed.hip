@@ -693,7 +693,9 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
     return live ? y : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int KP>
+// DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
+// production instance carries none of that code.
+template <int KP, bool DBG>
 __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const EmbedPlan& p = kp.p;
@@ -710,16 +712,20 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * p.NP * PP;
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
     unsigned long long t_prev = 0;
-    const bool prof = kp.a.prof != nullptr && tid == 0;
+    unsigned long long* const prof_buf = DBG ? kp.a.prof : nullptr;
+    const int skip = DBG ? skip : 0;
+    float* const dbg_layers = DBG ? kp.a.dbg_layers : nullptr;
+    int32_t* const dbg_knn_all = DBG ? kp.a.dbg_knn : nullptr;
+    const bool prof = prof_buf != nullptr && tid == 0;
     if (prof) t_prev = clock64();
 #define SGPR_PROF(ph)                                            \
     if (prof) {                                                  \
         const unsigned long long t_now = clock64();              \
-        atomicAdd(&kp.a.prof[ph], t_now - t_prev);               \
+        atomicAdd(&prof_buf[ph], t_now - t_prev);               \
         t_prev = t_now;                                          \
     }
 
-    if (kp.a.skip & 16) return;   // ablation: pure dispatch cost
+    if (skip & 16) return;   // ablation: pure dispatch cost
     // ---- one slot per thread, fetched once for both branches: xyz + 12 semantic channels
     float fx = 0.f, fy = 0.f, fz = 0.f;
     float sem[kLabels];
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         wdup = (float)m / (float)c;
         __syncthreads();                        // red / D region is reused below
     }
-    if (kp.a.skip & 32) return;   // ablation: input fetch + duplicate detection only
+    if (skip & 32) return;   // ablation: input fetch + duplicate detection only
     const int NP = (N + 15) & ~15;
     const int nrt = NP >> 4;
     // lanes per row in the selection: as many as the workgroup has (two VALU waves per SIMD are needed
@@ -824,12 +830,12 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         }
         const int Kp = kp.w.kp[L], cout = kp.w.cout[L];
         const bool k64 = Kp == 64;
-        int32_t* dbg_knn = kp.a.dbg_knn ? kp.a.dbg_knn + ((size_t)g * 6 + L) * NS * p.k : nullptr;
+        int32_t* dbg_knn = dbg_knn_all ? dbg_knn_all + ((size_t)g * 6 + L) * NS * p.k : nullptr;
         // ---- kNN keys (Gram on MFMA) -> selection, one chunk of rows at a time (a single chunk, upper-triangular
         //      tiles mirrored, when the whole key matrix is resident)
         for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
             const int rows_chunk = min(p.RC, NP - rc0);
-            if (kp.a.skip & 4) {
+            if (skip & 4) {
             } else if (p.overlap) {
                 if (k64)
                     gram_tiles_sym<4>(X, xx, D, p.pitchD, N, nrt, wave);
@@ -847,11 +853,11 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             }
             __syncthreads();
             SGPR_PROF(2)
-            if (!(kp.a.skip & 1)) {
-                if (kp.a.skip & 64)   // A/B: sorting-network selection
-                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, kp.a.prof ? kp.a.prof + 8 : nullptr);
+            if (!(skip & 1)) {
+                if (skip & 64)   // A/B: sorting-network selection
+                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
                 else if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, kp.a.prof ? kp.a.prof + 8 : nullptr);
+                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
                 else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, D, rc0, rows_chunk, nbr, dbg_knn);
             }
@@ -860,12 +866,12 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
                 SGPR_PROF(3)
             }
         }
-        if (prof && p.overlap) atomicAdd(&kp.a.prof[1], (unsigned long long)(clock64() - t_prev));   // selection alone
+        if (prof && p.overlap) atomicAdd(&prof_buf[1], (unsigned long long)(clock64() - t_prev));   // selection alone
         // per-node GEMMs (MFMA): no barrier needed after the selection - they only touch X rows owned by the wave and A
-        if (!(kp.a.skip & 2)) {
+        if (!(skip & 2)) {
             const unsigned long long t_gemm0 = prof ? clock64() : 0ull;
             gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
-            if (prof) atomicAdd(&kp.a.prof[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
+            if (prof) atomicAdd(&prof_buf[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
         }
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
@@ -878,9 +884,9 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             const int rpw = 64 / lpr;                    // rows per wave-iteration: 4 or 8
             const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
             const bool want_norm = (L != 2 && L != 5);
-            float* dbg = kp.a.dbg_layers ? kp.a.dbg_layers + ((size_t)g * 6 + L) * NS * 64 : nullptr;
+            float* dbg = dbg_layers ? dbg_layers + ((size_t)g * 6 + L) * NS * 64 : nullptr;
             const int rstep = NW * rpw;
-            for (int ia = wave * rpw + sub; ia < ((kp.a.skip & 8) ? 0 : NP); ia += 2 * rstep) {
+            for (int ia = wave * rpw + sub; ia < ((skip & 8) ? 0 : NP); ia += 2 * rstep) {
                 const int ib = ia + rstep;
                 const bool hasb = ib < NP;                 // uniform per row group; all lanes of a row agree
                 const int ra = min(ia, N - 1), rb = min(hasb ? ib : ia, N - 1);   // padded rows: compute a real row, store 0
@@ -957,18 +963,18 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             *reinterpret_cast<float4*>(kp.a.emb + ((size_t)g * NS + i) * 32 + c4) =
                 *reinterpret_cast<const float4*>(E + min(i, N - 1) * PE + c4);
         }
-    if (kp.a.dbg_layers)
+    if (dbg_layers)
         for (int e = tid; e < 6 * (NS - N) * 16; e += NT) {
             const int c4 = (e & 15) * 4, r = e >> 4;
             const int Ld = r / (NS - N), i = N + r - Ld * (NS - N);
-            float* base = kp.a.dbg_layers + ((size_t)g * 6 + Ld) * NS * 64;
+            float* base = dbg_layers + ((size_t)g * 6 + Ld) * NS * 64;
             *reinterpret_cast<float4*>(base + (size_t)i * 64 + c4) = *reinterpret_cast<const float4*>(base + (size_t)(N - 1) * 64 + c4);
         }
-    if (kp.a.dbg_knn)
+    if (dbg_knn_all)
         for (int e = tid; e < 6 * (NS - N) * p.k; e += NT) {
             const int q = e % p.k, r = e / p.k;
             const int Ld = r / (NS - N), i = N + r - Ld * (NS - N);
-            int32_t* base = kp.a.dbg_knn + ((size_t)g * 6 + Ld) * NS * p.k;
+            int32_t* base = dbg_knn_all + ((size_t)g * 6 + Ld) * NS * p.k;
             base[(size_t)i * p.k + q] = base[(size_t)(N - 1) * p.k + q];
         }
 
@@ -1020,16 +1026,16 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
 #undef SGPR_PROF
 }
 
-template <int KP>
+template <int KP, bool DBG>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_kernel<KP>), dim3(kp.a.G), dim3(NT), kp.p.lds_bytes, stream, kp);
+    hipLaunchKernelGGL((embed_kernel<KP, DBG>), dim3(kp.a.G), dim3(NT), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
@@ -1041,7 +1047,9 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.w = h->w;
     kp.p = plan;
     kp.a = a;
-    return plan.kp == 16 ? launch_t<16>(kp, stream) : launch_t<32>(kp, stream);
+    const bool dbg = a.prof || a.skip || a.dbg_layers || a.dbg_knn;
+    if (plan.kp == 16) return dbg ? launch_t<16, true>(kp, stream) : launch_t<16, false>(kp, stream);
+    return dbg ? launch_t<32, true>(kp, stream) : launch_t<32, false>(kp, stream);
 }
 
 }  // namespace sgpr
