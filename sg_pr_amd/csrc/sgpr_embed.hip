@@ -263,10 +263,7 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
                 d[4 * q + 2] = ok ? v.z : INFINITY;
                 d[4 * q + 3] = ok ? v.w : INFINITY;
             }
-        } else {
-#pragma unroll
-            for (int u = 16 * c; u < 16 * c + 16; ++u) d[u] = INFINITY;
-        }
+        }   // slots >= seg are never read: every later use is guarded by the same (wave-uniform) test
     }
     SEL_STAMP(0)
     // this lane's KP smallest, ascending
@@ -929,6 +926,10 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         SGPR_PROF(5)
     }
 
+    // conv_end weights of this wave's first tile: in flight while xyz3 is moved back
+    float4 wf_end[4];
+    load_frag<4>(kp.w.wf_end + (size_t)((wave & 1) * 16 + l15) * 64 + 4 * lq, wf_end);
+    const float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + (wave & 1) * 16 + 4 * lq);
     for (int e = tid; e < NP * 8; e += NT) {                      // xyz3 -> channels 0..31: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
         *reinterpret_cast<float4*>(X + i * PX + c4) = *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4);
@@ -940,20 +941,19 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     {
         const float* __restrict__ Wf = kp.w.wf_end;
         for (int task = wave; task < 2 * nrt; task += NW) {
-            const int ct = task & 1, rt = task >> 1;
-            float4 wf[4], xf[4];
-            load_frag<4>(Wf + (size_t)(ct * 16 + l15) * 64 + 4 * lq, wf);
+            const int ct = task & 1, rt = task >> 1;      // NW is even: ct == wave & 1 for every task of this wave
+            float4 xf[4];
             load_frag<4>(X + (rt * 16 + l15) * PX + 4 * lq, xf);
-            const f32x4 acc = tile16<4>(wf, xf);
+            const f32x4 acc = tile16<4>(wf_end, xf);
             const int c4 = ct * 16 + 4 * lq;
-            const float4 t4 = *reinterpret_cast<const float4*>(kp.w.tb_end + c4);
-            float4 e4 = make_float4(acc[0] + t4.x, acc[1] + t4.y, acc[2] + t4.z, acc[3] + t4.w);
+            float4 e4 = make_float4(acc[0] + t4_end.x, acc[1] + t4_end.y, acc[2] + t4_end.z, acc[3] + t4_end.w);
             e4.x = e4.x > 0.f ? e4.x : 0.2f * e4.x;
             e4.y = e4.y > 0.f ? e4.y : 0.2f * e4.y;
             e4.z = e4.z > 0.f ? e4.z : 0.2f * e4.z;
             e4.w = e4.w > 0.f ? e4.w : 0.2f * e4.w;
             *reinterpret_cast<float4*>(E + (rt * 16 + l15) * PE + c4) = e4;
         }
+        (void)Wf;
     }
     __syncthreads();
     SGPR_PROF(6)
