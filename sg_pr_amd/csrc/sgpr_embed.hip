@@ -710,7 +710,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
     unsigned long long t_prev = 0;
     unsigned long long* const prof_buf = DBG ? kp.a.prof : nullptr;
-    const int skip = DBG ? skip : 0;
+    const int skip = DBG ? kp.a.skip : 0;
     float* const dbg_layers = DBG ? kp.a.dbg_layers : nullptr;
     int32_t* const dbg_knn_all = DBG ? kp.a.dbg_knn : nullptr;
     const bool prof = prof_buf != nullptr && tid == 0;
