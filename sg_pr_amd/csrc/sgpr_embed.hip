@@ -230,7 +230,7 @@ __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, 
 // Result: nbr[i][0..k) = (float offset of the A row of) the k nearest candidates of row i under the
 // total order (key ascending, index ascending) - written as an unordered set.
 template <int KP>
-__device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k,
+__device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k, bool one_rep,
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
                                              unsigned long long* __restrict__ prof8) {
@@ -303,6 +303,24 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
 #pragma unroll
         for (int s = 1; s < KP; ++s) tau = (s == k - 1) ? L[s] : tau;
     }
+    // Last slot = representative of >= k identical slots (padding): if its key lies below the k-th key, every
+    // neighbour slot after the candidates at or below that key goes to copies of it, so the neighbour SET is
+    // {key <= key_rep}; the unused list entries are pre-filled with the representative itself.
+    bool dup_cut = false;
+    if (one_rep) {
+        const float krep = drow[n - 1];
+        if (krep < tau) {
+            tau = krep;
+            dup_cut = true;
+        }
+        if (active) {
+            unsigned short* out0 = nbr + i * p.kpitch;
+            const unsigned short rep = (unsigned short)((n - 1) * p.pitchA);
+            for (int q = part; q < k; q += P) out0[q] = rep;
+            if (dbg_knn)
+                for (int q = part; q < k; q += P) dbg_knn[(size_t)i * p.k + q] = n - 1;
+        }
+    }
     // per-lane bit sets of the candidates below / at the threshold
     unsigned lt0 = 0u, lt1 = 0u, eq0 = 0u, eq1 = 0u;
 #pragma unroll
@@ -323,6 +341,11 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
                 eq1 |= (d[32 + u] == tau) ? (1u << u) : 0u;
             }
         }
+    if (dup_cut) {           // take every candidate at or below the representative's key, no tie limit
+        lt0 |= eq0;
+        lt1 |= eq1;
+        eq0 = eq1 = 0u;
+    }
     SEL_STAMP(3)
     const int n_less = __popc(lt0) + __popc(lt1), n_eq = __popc(eq0) + __popc(eq1);
     const int packed = n_less | (n_eq << 16);
@@ -359,7 +382,7 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     }
     const int e_pack = incl - packed;                       // exclusive
     const int e_less = e_pack & 0xffff, e_eq = e_pack >> 16;
-    const int T = k - (total & 0xffff);                     // ties at tau to accept, lowest index first
+    const int T = dup_cut ? 0 : k - (total & 0xffff);       // ties at tau to accept, lowest index first
     SEL_STAMP(4)
     if (active) {
         int pos = e_less + min(e_eq, T);
@@ -427,8 +450,9 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // the interval down to a single value and are then taken in candidate-index order.  Emission needs no loop:
 // a taken candidate's output position is the number of taken candidates before it (v_mbcnt).
 template <int C>
-__device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np, int k, const float* __restrict__ D,
-                                              int rc0, int rows_chunk, unsigned short* __restrict__ nbr,
+__device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np, int k, bool one_rep,
+                                              const float* __restrict__ D, int rc0, int rows_chunk,
+                                              unsigned short* __restrict__ nbr,
                                               int32_t* __restrict__ dbg_knn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int rl = wave; rl < rows_chunk; rl += NW) {
@@ -466,6 +490,18 @@ __device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np,
                 lo = mid + 1;
         }
         if (!exact) pivot = lo;                              // the k-th smallest key itself; ties possible
+        unsigned short* out = nbr + i * p.kpitch;
+        if (one_rep) {       // see select_phase: the representative of >= k identical slots cuts the list
+            const unsigned krep = ord_u32(drow[n - 1]);
+            if (krep < pivot || (krep == pivot && exact)) {
+                pivot = krep;
+                exact = true;                                // take {key <= krep}
+            }
+            if (lane < k) {
+                out[lane] = (unsigned short)((n - 1) * p.pitchA);
+                if (dbg_knn) dbg_knn[(size_t)i * p.k + lane] = n - 1;
+            }
+        }
         // taken = {key < pivot} (or <= pivot when exact) + the first T ties in candidate order
         bool is_lt[C], is_eq[C];
         unsigned long long eq[C];
@@ -477,9 +513,8 @@ __device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np,
             eq[c] = __ballot(is_eq[c]);
             n_lt += __popcll(__ballot(is_lt[c]));
         }
-        int T = k - n_lt;                                    // ties still to accept (0 when exact)
+        int T = exact ? 0 : k - n_lt;                        // ties still to accept
         int base = 0;
-        unsigned short* out = nbr + i * p.kpitch;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int tie_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(eq[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eq[c], 0));
@@ -754,6 +789,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     // the m copies are processed; the attention pool re-weights them by m / min(m, k)  
     int N, nd;            // slots processed; slots before the trailing run of duplicates
     float wdup;           // weight of each kept duplicate in the attention pool
+    bool one_rep;         // the last processed slot stands for >= k identical slots
     {
         float* ref = red;                       // 16 floats: the last slot
         int* wmax = reinterpret_cast<int*>(red + 16);
@@ -776,7 +812,11 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         for (int q = 0; q < NW; ++q) last = max(last, wmax[q]);
         nd = last + 1;
         const int m = NS - nd;
-        const int c = min(m, p.k);
+        // m >= k copies: ONE representative slot is enough (a row can take at most k copies, and once a row
+        // reaches the duplicate key every remaining neighbour slot is filled by copies: see select_phase);
+        // fewer copies: keep them all as ordinary slots
+        one_rep = m >= p.k && m > 1;
+        const int c = one_rep ? 1 : m;
         N = nd + c;
         wdup = (float)m / (float)c;
         __syncthreads();                        // red / D region is reused below
@@ -852,11 +892,11 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
             SGPR_PROF(2)
             if (!(skip & 1)) {
                 if (skip & 64)   // A/B: sorting-network selection
-                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
+                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
                 else if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                    select_phase<KP>(p, N, NP, P, seg, k, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
+                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
                 else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
-                    select_bisect<4>(p, N, NP, k, D, rc0, rows_chunk, nbr, dbg_knn);
+                    select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
             }
             if (!p.overlap) {
                 __syncthreads();                      // the key chunk is reused

@@ -91,8 +91,8 @@ def dense_features(centers, labels, num_labels=NUM_LABELS):
 
 
 def effective_nodes(centers, labels, k):
-    """Slots the engine actually processes per graph: trailing slots identical to the last one (zero
-    padding) are interchangeable, so only min(m, k) of the m copies are kept ("duplicate
+    """Slots the engine actually processes per graph: of the m trailing slots identical to the last one
+    (zero padding) a single representative is kept when m >= k, all m otherwise ("duplicate
     slots").  Returns int32 [G]."""
     g, n = labels.shape
     same = (labels == labels[:, -1:]) & (centers == centers[:, -1:, :]).all(-1)     # [G, N]
@@ -100,4 +100,4 @@ def effective_nodes(centers, labels, k):
     last = np.where(differs.any(1), n - 1 - np.argmax(differs[:, ::-1], axis=1), -1)
     nd = last + 1
     m = n - nd
-    return (nd + np.minimum(m, k)).astype(np.int32)
+    return (nd + np.where((m >= k) & (m > 1), 1, m)).astype(np.int32)
