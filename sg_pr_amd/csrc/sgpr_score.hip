@@ -83,15 +83,30 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 }
 
 // ------------------------------------------------------------------ dense all-pairs
-// workspace layout (floats):  Ar [R][T][F] | ur [R][T] | vc [M][T]
+// workspace layout:  ur [R][T] f32 | vc [M][T] f32 | Ab [R][3][T][F] bf16  (A_r split into three bf16 planes:
+// a = hi + mid + lo exactly to 24 bits, so six bf16 MFMAs reproduce the fp32 product - see score_all_pairs_kernel)
 size_t score_all_pairs_ws_bytes(int R, int M) {
-    return ((size_t)R * (T * F + T) + (size_t)M * T) * sizeof(float);
+    return ((size_t)R * T + (size_t)M * T) * sizeof(float) + (size_t)R * 3 * T * F * sizeof(unsigned short);
+}
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {      // round-to-nearest-even fp32 -> bf16 (no NaNs here)
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void split3(float a, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = bf16_rne(a);
+    float r = a - bf16_f32(h);
+    m = bf16_rne(r);
+    r -= bf16_f32(m);
+    l = bf16_rne(r);
 }
 
 // one wave per graph: rows get A_r and u_r = Wb[:, :F] e1 + bias, columns get v_c = Wb[:, F:] e2
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
                                                        const float* __restrict__ cols, int M,
-                                                       float* __restrict__ Ar, float* __restrict__ ur,
+                                                       unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                        float* __restrict__ vc) {
     const int lane = threadIdx.x & 63;
     const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,7 +124,14 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
             for (int r = 0; r < 8; ++r) v[r] = fmaf(a, wr[64 * r], v[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) Ar[(size_t)gidx * (T * F) + t * F + (q + 4 * r)] = v[r];
+        for (int r = 0; r < 8; ++r) {
+            unsigned short h, m, l;
+            split3(v[r], h, m, l);
+            unsigned short* dst = Ab + (size_t)gidx * (3 * T * F) + t * F + (q + 4 * r);
+            dst[0] = h;
+            dst[T * F] = m;
+            dst[2 * T * F] = l;
+        }
         float s = 0.f;
         for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[t * 2 * F + q * 8 + m], e1[q * 8 + m], s);
         s += __shfl_xor(s, 16);
@@ -126,25 +148,33 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
     }
 }
 
-constexpr int AP_ROWS = 32;   // row graphs per workgroup (column operands stay in registers)
+constexpr int AP_ROWS = 64;   // row graphs per workgroup (column operands stay in registers)
 constexpr int AP_COLS = 256;  // column graphs per workgroup: 4 waves x 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     // D[4*(l>>4)+r][l&15] += sum_{q<4} A[row][q] * B[q][col];  lane l supplies A[l&15][l>>4], B[l>>4][l&15]
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    // 16x16x32: lane l supplies A[l&15][8*(l>>4) .. +7] and B[8*(l>>4) .. +7][l&15]; same D layout as above
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 // One wave owns 64 column graphs (4 blocks of 16) and walks AP_ROWS row graphs.  Per (row, block):
-//   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j])   8 MFMAs (16x16x4 f32, K = 32)
-//   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])              4 MFMAs: H is consumed straight from
-//            the accumulator layout (lane group g holds t = 4g..4g+3 and supplies t = 4g+s at step s;
-//            the A operand is permuted to match), so no data moves between the two layers
+//   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j]),  K = 32.  fp32 MFMA shares the vector pipe on
+//            gfx950, bf16 MFMA does not and is ~8x faster per product: both operands are split into three
+//            bf16 planes (x = hi + mid + lo, exact to 24 bits) and the six significant cross products
+//            hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are accumulated in fp32 -> fp32-class accuracy (error ~2^-24)
+//   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])   4 fp32 MFMAs: H is consumed straight from the
+//            accumulator layout (lane group g holds t = 4g..4g+3 and supplies t = 4g+s at step s; the A operand is
+//            permuted to match), so no data moves between the two layers
 //   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs + 2 cross-lane adds), sigmoid once per 64 columns,
 //            one coalesced 256-B store per row.
 __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w, const float* __restrict__ cols,
-                                                              int R, int M, const float* __restrict__ Ar,
+                                                              int R, int M, const unsigned short* __restrict__ Ab,
                                                               const float* __restrict__ ur,
                                                               const float* __restrict__ vc,
                                                               float* __restrict__ score, int64_t ld) {
@@ -152,13 +182,23 @@ __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w
     const int l15 = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.x * AP_COLS + wave * 64;
     if (c0 >= M) return;
-    // column operands: e2 (two 16-wide k-blocks) and v_c for the 4 column blocks of this wave
-    float4 e2[4][2], v4[4];
+    // column operands: e2_c[8g .. 8g+7] as three bf16 planes, and v_c, for the 4 column blocks of this wave
+    bf16x8 bh[4], bm[4], bl[4];
+    float4 v4[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int c = min(c0 + b * 16 + l15, M - 1);
-        e2[b][0] = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 4 * g);
-        e2[b][1] = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 16 + 4 * g);
+        const float4 x0 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g);
+        const float4 x1 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g + 4);
+        const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            unsigned short h, m, l;
+            split3(xs[q], h, m, l);
+            bh[b][q] = (short)h;
+            bm[b][q] = (short)m;
+            bl[b][q] = (short)l;
+        }
         v4[b] = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
     }
     const float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);   // W1[o = l15][t = 4g..4g+3]
@@ -169,27 +209,26 @@ __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w
     const int r1 = min(R, r0 + AP_ROWS);
     const int cst = c0 + lane;                         // the column this lane stores
     for (int r = r0; r < r1; ++r) {
-        const float* ap = Ar + (size_t)r * (T * F) + l15 * F + 4 * g;                 // A_r[t = l15][k-block + 4g..]
-        const float4 a0 = *reinterpret_cast<const float4*>(ap);
-        const float4 a1 = *reinterpret_cast<const float4*>(ap + 16);
+        const unsigned short* ap = Ab + (size_t)r * (3 * T * F) + l15 * F + 8 * g;   // A_r[t = l15][8g .. 8g+7]
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + T * F);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
         const float4 u4 = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
         float zsel = 0.f;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            f32x4 h = {u4.x + v4[b].x, u4.y + v4[b].y, u4.z + v4[b].z, u4.w + v4[b].w};
-            h = mfma4(a0.x, e2[b][0].x, h);
-            h = mfma4(a0.y, e2[b][0].y, h);
-            h = mfma4(a0.z, e2[b][0].z, h);
-            h = mfma4(a0.w, e2[b][0].w, h);
-            h = mfma4(a1.x, e2[b][1].x, h);
-            h = mfma4(a1.y, e2[b][1].y, h);
-            h = mfma4(a1.z, e2[b][1].z, h);
-            h = mfma4(a1.w, e2[b][1].w, h);
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+            h = mfma_bf16(al, bh[b], h);               // smallest terms first
+            h = mfma_bf16(ah, bl[b], h);
+            h = mfma_bf16(am, bm[b], h);
+            h = mfma_bf16(am, bh[b], h);
+            h = mfma_bf16(ah, bm[b], h);
+            h = mfma_bf16(ah, bh[b], h);
             f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
-            q = mfma4(w1v.x, fmaxf(h[0], 0.f), q);
-            q = mfma4(w1v.y, fmaxf(h[1], 0.f), q);
-            q = mfma4(w1v.z, fmaxf(h[2], 0.f), q);
-            q = mfma4(w1v.w, fmaxf(h[3], 0.f), q);
+            q = mfma4(w1v.x, fmaxf(h[0] + (u4.x + v4[b].x), 0.f), q);
+            q = mfma4(w1v.y, fmaxf(h[1] + (u4.y + v4[b].y), 0.f), q);
+            q = mfma4(w1v.z, fmaxf(h[2] + (u4.z + v4[b].z), 0.f), q);
+            q = mfma4(w1v.w, fmaxf(h[3] + (u4.w + v4[b].w), 0.f), q);
             float z = w2v.x * fmaxf(q[0], 0.f);
             z = fmaf(w2v.y, fmaxf(q[1], 0.f), z);
             z = fmaf(w2v.z, fmaxf(q[2], 0.f), z);
@@ -206,14 +245,14 @@ __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream) {
     if (R == 0 || M == 0) return SGPR_OK;
-    float* Ar = static_cast<float*>(ws);
-    float* ur = Ar + (size_t)R * T * F;
+    float* ur = static_cast<float*>(ws);
     float* vc = ur + (size_t)R * T;
-    hipLaunchKernelGGL(ntn_prep_kernel, dim3((R + M + 3) / 4), dim3(256), 0, stream, h->w, rows, R, cols, M, Ar, ur, vc);
+    unsigned short* Ab = reinterpret_cast<unsigned short*>(vc + (size_t)M * T);
+    hipLaunchKernelGGL(ntn_prep_kernel, dim3((R + M + 3) / 4), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
     dim3 grid((M + AP_COLS - 1) / AP_COLS, (R + AP_ROWS - 1) / AP_ROWS);
-    hipLaunchKernelGGL(score_all_pairs_kernel, grid, dim3(256), 0, stream, h->w, cols, R, M, Ar, ur, vc, score, ld);
+    hipLaunchKernelGGL(score_all_pairs_kernel, grid, dim3(256), 0, stream, h->w, cols, R, M, Ab, ur, vc, score, ld);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
     return SGPR_OK;
