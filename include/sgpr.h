@@ -34,7 +34,7 @@ enum {
     SGPR_OK = 0,
     SGPR_E_INVALID = -1,   /* NULL pointer / negative count                                   */
     SGPR_E_DIMS = -2,      /* architecture not supported by the kernels (see sgpr_dims)       */
-    SGPR_E_NODES = -3,     /* node_num outside [k, SGPR_MAX_NODES]                             */
+    SGPR_E_NODES = -3,     /* node_num outside [k, SGPR_MAX_NODES], or a graph exceeded node_cap      */
     SGPR_E_K = -4,         /* K outside [1, SGPR_MAX_K] or K > node_num                        */
     SGPR_E_LABEL = -5,     /* a label outside [-1, num_labels) was seen (sgpr_check_status)    */
     SGPR_E_HIP = -6,       /* HIP runtime error (message has hipGetErrorString)                */
@@ -94,7 +94,16 @@ int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_la
                float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
                void* stream);
 
-/* Same, taking the reference's dense tensor `features` [G, 3+L, N] f32
+/* sgpr_embed with a promise about the input: no graph of the batch needs more than `node_cap` PROCESSED slots
+ * (= slots before the trailing run of m identical padding slots, + 1 when m >= k, + m otherwise; 0 = no promise).
+ * The kernel sizes its LDS for node_cap instead of N, so padded graphs of a few dozen real nodes run as
+ * 256-thread workgroups, two or three per CU.  A graph that breaks the promise gets a NaN pooled vector and
+ * sgpr_check_status returns SGPR_E_NODES.  Results are otherwise identical to sgpr_embed. */
+int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
+                      int k, float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* Same as sgpr_embed, taking the reference's dense tensor `features` [G, 3+L, N] f32
  * (data["features_1"], sg_net.py:119) - the sem block may hold any values. */
 int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N, int k, float* d_pooled,
                      float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes, void* stream);

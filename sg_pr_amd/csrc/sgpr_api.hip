@@ -153,6 +153,11 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     memset(h, 0, sizeof(*h));
     h->device = device;
     h->dims = *dims;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        h->num_cus = cus;
+    }
     h->blob_floats = packed.size();
     e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), packed.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_status), sizeof(int32_t));
@@ -195,7 +200,7 @@ void sgpr_destroy(sgpr_handle* h) {
     delete h;
 }
 
-static int check_nk(int G, int N, int k, EmbedPlan* plan) {
+static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan) {
     if (G < 0) {
         set_error("negative graph count");
         return SGPR_E_INVALID;
@@ -208,7 +213,11 @@ static int check_nk(int G, int N, int k, EmbedPlan* plan) {
         set_error("K " + std::to_string(k) + " outside [1, min(node_num, " + std::to_string(SGPR_MAX_K) + ")]");
         return SGPR_E_K;
     }
-    if (!make_embed_plan(N, k, plan)) {
+    if (node_cap < 0 || (node_cap > 0 && node_cap < 1)) {
+        set_error("negative node_cap");
+        return SGPR_E_INVALID;
+    }
+    if (!make_embed_plan(N, node_cap, k, plan)) {
         set_error("no LDS plan for node_num " + std::to_string(N) + ", K " + std::to_string(k));
         return SGPR_E_NODES;
     }
@@ -221,24 +230,27 @@ static size_t embed_ws_bytes(const EmbedPlan& p, int G) {
 
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
     EmbedPlan p;
-    if (!h || G < 0 || !make_embed_plan(N, k, &p)) return 0;
+    if (!h || G < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
     return embed_ws_bytes(p, G);
 }
 
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
     EmbedPlan p;
-    if (!h || !make_embed_plan(N, k, &p)) return 0;
+    if (!h || !make_embed_plan(N, 0, k, &p)) return 0;
     return (size_t)p.lds_bytes;
 }
 
-static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, void* ws, size_t ws_bytes, void* stream) {
+static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int node_cap, void* ws, size_t ws_bytes,
+                        void* stream) {
     if (h && a.G == 0) return SGPR_OK;
     if (!h || !a.pooled || (!a.dense && (!a.centers || !a.labels))) {
         set_error("sgpr_embed: NULL argument");
         return SGPR_E_INVALID;
     }
+    // with at most one graph per CU there is nothing to overlap: keep the 512-thread workgroups (lower latency)
+    if (a.G <= h->num_cus) node_cap = 0;
     EmbedPlan plan;
-    int rc = check_nk(a.G, N, k, &plan);
+    int rc = check_nk(a.G, N, k, node_cap, &plan);
     if (rc != SGPR_OK) return rc;
     const size_t need = embed_ws_bytes(plan, a.G);
     if (need > 0 && (!ws || ws_bytes < need)) {
@@ -263,7 +275,21 @@ int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_la
     a.pooled = d_pooled;
     a.att = d_att;
     a.emb = d_emb;
-    return embed_common(h, a, N, k, d_workspace, workspace_bytes, stream);
+    return embed_common(h, a, N, k, 0, d_workspace, workspace_bytes, stream);
+}
+
+int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
+                      int k, float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
+                      void* stream) {
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.centers = d_centers;
+    a.labels = d_labels;
+    a.G = G;
+    a.pooled = d_pooled;
+    a.att = d_att;
+    a.emb = d_emb;
+    return embed_common(h, a, N, k, node_cap, d_workspace, workspace_bytes, stream);
 }
 
 int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N, int k, float* d_pooled,
@@ -275,7 +301,7 @@ int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N
     a.pooled = d_pooled;
     a.att = d_att;
     a.emb = d_emb;
-    return embed_common(h, a, N, k, d_workspace, workspace_bytes, stream);
+    return embed_common(h, a, N, k, 0, d_workspace, workspace_bytes, stream);
 }
 
 int sgpr_embed_debug(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int k,
@@ -291,7 +317,7 @@ int sgpr_embed_debug(const sgpr_handle* h, const float* d_centers, const int32_t
     a.emb = d_emb;
     a.dbg_layers = d_layers;
     a.dbg_knn = d_knn;
-    return embed_common(h, a, N, k, d_workspace, workspace_bytes, stream);
+    return embed_common(h, a, N, k, 0, d_workspace, workspace_bytes, stream);
 }
 
 int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t* d_idx1, const float* d_pooled2,
@@ -326,7 +352,7 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
 // workspace of sgpr_forward_dense: pooled [2B][32] | embed workspace for 2B graphs
 size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k) {
     EmbedPlan p;
-    if (!h || B < 0 || !make_embed_plan(N, k, &p)) return 0;
+    if (!h || B < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
     return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(p, 2 * B);
 }
 
@@ -338,7 +364,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
         return SGPR_E_INVALID;
     }
     EmbedPlan plan;
-    int rc = check_nk(2 * B, N, k, &plan);
+    int rc = check_nk(2 * B, N, k, 0, &plan);
     if (rc != SGPR_OK) return rc;
     const size_t need = sgpr_forward_workspace_bytes(h, B, N, k);
     if (!d_workspace || workspace_bytes < need) {
@@ -396,6 +422,10 @@ int sgpr_check_status(const sgpr_handle* h, void* stream) {
         e = hipMemsetAsync(h->d_status, 0, sizeof(flag), s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return hip_fail(e, "sgpr_check_status: reset");
+        if (flag & 2) {
+            set_error("a graph needed more slots than the node_cap passed to sgpr_embed_capped (its pooled vector is NaN)");
+            return SGPR_E_NODES;
+        }
         set_error("a node label outside [-1, num_labels) was seen by the embed kernel");
         return SGPR_E_LABEL;
     }

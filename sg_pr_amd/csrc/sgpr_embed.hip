@@ -31,8 +31,7 @@ namespace sgpr {
 constexpr int PX = 68;        // floats per row of X   (64 ch + 4: 16-B aligned, rows shift one 16-B slot)
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
 constexpr int PP = 32;        // floats per row of the parked xyz3 block
-constexpr int NT = 512;       // threads per workgroup (8 wave64; up to 256 VGPRs each)
-constexpr int NW = NT / 64;
+constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
 constexpr int CAP = 64;       // candidates per lane in the selection phase
 constexpr int kRedBytes = 4608;
 constexpr int kLdsLimit = 160 * 1024;
@@ -41,16 +40,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-bool make_embed_plan(int N, int k, EmbedPlan* p) {
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
     if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > SGPR_MAX_K || k > N) return false;
+    const int NC = (node_cap <= 0 || node_cap > N) ? N : node_cap;
     p->N = N;
-    p->NP = round_up(N, 16);
+    p->NC = NC;
+    p->NP = round_up(NC, 16);
     p->k = k;
     p->kp = k <= 16 ? 16 : 32;
     p->kpitch = round_up(k, 2);           // u16 entries per row of the neighbour list
     p->pitchD = p->NP + 4;
-    p->park_in_lds = N <= 128 ? 1 : 0;
-    p->pitchA = N <= 192 ? 68 : 64;       // 64 only when LDS is otherwise exhausted (bank-conflicted stores)
+    p->park_in_lds = NC <= 128 ? 1 : 0;
+    p->pitchA = NC <= 192 ? 68 : 64;      // 64 only when LDS is otherwise exhausted (bank-conflicted stores)
     int off = 0;
     p->offX = off;    off += p->NP * PX * 4;
     p->offA = off;    off += p->NP * p->pitchA * 4;
@@ -60,19 +61,24 @@ bool make_embed_plan(int N, int k, EmbedPlan* p) {
     p->offD = off;
     p->offRed = off;  // attention scratch aliases the key chunk (disjoint in time)
     const int rowD = p->pitchD * 4;
-    p->nt = NT;
     int rc = (kLdsLimit - off) / rowD / 16 * 16;
     if (rc > p->NP) rc = p->NP;
+    if (rc < 16) return false;
+    p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
+    // small graphs: 256-thread workgroups, two or three of them per CU, overlap each other's barriers
+    p->nt = (p->lds_bytes <= kLdsLimit / 2 && N <= 256) ? 256 : 512;
     // resident mode: the whole key matrix fits in LDS -> upper-triangular Gram tiles, mirrored
     int P = 1;
-    while ((N + P - 1) / P > CAP) P *= 2;
-    p->overlap = (rc == p->NP && p->NP * P <= NT) ? 1 : 0;
-    if (!p->overlap && rc * P > NT) rc = NT / P / 16 * 16;
-    if (rc < 16) return false;
-    p->P = P;                                   // lower bound; the kernel widens it per graph (select_parts)
-    p->seg = round_up((N + P - 1) / P, 4);
+    while ((NC + P - 1) / P > CAP) P *= 2;
+    p->overlap = (rc == p->NP && p->NP * P <= p->nt) ? 1 : 0;
+    if (!p->overlap && rc * P > p->nt) {
+        rc = p->nt / P / 16 * 16;
+        if (rc < 16) return false;
+        p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
+    }
+    p->P = P;                                   // lower bound; the kernel widens it per graph
+    p->seg = round_up((NC + P - 1) / P, 4);
     p->RC = rc;
-    p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
     return true;
 }
 
@@ -455,6 +461,7 @@ __device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np,
                                               unsigned short* __restrict__ nbr,
                                               int32_t* __restrict__ dbg_knn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
     for (int rl = wave; rl < rows_chunk; rl += NW) {
         const int i = rc0 + rl;
         if (i >= n) break;
@@ -650,7 +657,7 @@ __device__ __forceinline__ void gram_tiles_sym(const float* __restrict__ X, cons
     load_frag<NKB>(X + (ti * 16 + l15) * PX + 4 * lq, a);
     load_frag<NKB>(X + (tj * 16 + l15) * PX + 4 * lq, b);
     while (true) {
-        const int tn = t + NW;
+        const int tn = t + (int)(blockDim.x >> 6);
         const bool more = tn < ntiles;
         int tin = 0, tjn = 0;
         float4 an[4], bn[4];
@@ -728,8 +735,9 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
 template <int KP, bool DBG>
-__global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
+__global__ __launch_bounds__(NT_MAX) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NT = blockDim.x, NW = NT >> 6;          // 256 / 4 or 512 / 8
     const EmbedPlan& p = kp.p;
     float* X = reinterpret_cast<float*>(smem + p.offX);
     float* A = reinterpret_cast<float*>(smem + p.offA);
@@ -820,6 +828,11 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
         N = nd + c;
         wdup = (float)m / (float)c;
         __syncthreads();                        // red / D region is reused below
+    }
+    if (N > p.NC) {          // more slots to process than the caller's node_cap promised: fail loudly
+        if (tid == 0) atomicOr(kp.a.status, 2);
+        if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
+        return;
     }
     if (skip & 32) return;   // ablation: input fetch + duplicate detection only
     const int NP = (N + 15) & ~15;
@@ -1020,12 +1033,12 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
 
     // ---- attention pooling over all NS slots (padding is NOT masked, divisor NS: layers_batch.py:34-38);
     //      each kept duplicate row stands for wdup slots
-    constexpr int NPART = NT / 32;   // partial sums per channel
+    constexpr int NPART = 8;         // partial sums per channel: fixed, so results do not depend on the block size
     float* mean = red + NPART * 32;
     float* tg = mean + 32;
     float* sig = xx;
     const int c = tid & 31, prt = tid >> 5;
-    {
+    if (prt < NPART) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf(n >= nd ? wdup : 1.f, E[n * PE + c], s);
         red[prt * 32 + c] = s;
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(NT) void embed_kernel(const KParams kp) {
     __syncthreads();
     if (kp.a.att)
         for (int n = tid; n < NS; n += NT) kp.a.att[(size_t)g * NS + n] = sig[min(n, N - 1)];
-    {
+    if (prt < NPART) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf((n >= nd ? wdup : 1.f) * sig[n], E[n * PE + c], s);
         red[prt * 32 + c] = s;
@@ -1075,7 +1088,7 @@ static int launch_t(const KParams& kp, hipStream_t stream) {
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_kernel<KP, DBG>), dim3(kp.a.G), dim3(NT), kp.p.lds_bytes, stream, kp);
+    hipLaunchKernelGGL((embed_kernel<KP, DBG>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;

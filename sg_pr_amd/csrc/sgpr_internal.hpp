@@ -41,6 +41,7 @@ struct DevWeights {
 
 struct sgpr_handle {
     int device;
+    int num_cus;
     sgpr_dims dims;
     float* d_blob;       // owns the packed weights
     size_t blob_floats;
@@ -52,8 +53,10 @@ namespace sgpr {
 
 // LDS plan of the embed kernel for one (N, k); computed on the host, passed by value.
 struct EmbedPlan {
-    int N, NP, k, kp;
-    int nt;          // threads per workgroup: 512 (two workgroups per CU) or 1024 (one)
+    int N;           // slots per graph in global memory (node_num)
+    int NC;          // upper bound of the slots PROCESSED per graph (node_cap <= N): sizes every LDS buffer
+    int NP, k, kp;   // NP = NC rounded up to 16
+    int nt;          // threads per workgroup: 256 (LDS <= 80 KB: two or more workgroups per CU) or 512
     int pitchD;      // ints per row of the ranking-key chunk
     int RC;          // rows per key chunk (multiple of 16); RC == NP => symmetric Gram
     int P;           // lanes per row in the selection phase (power of two)
@@ -65,7 +68,7 @@ struct EmbedPlan {
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
 };
-bool make_embed_plan(int N, int k, EmbedPlan* plan);
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan);
 
 struct EmbedArgs {
     const float* centers;   // packed input, or

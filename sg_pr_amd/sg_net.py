@@ -96,9 +96,16 @@ class SG(torch.nn.Module):
         return score, att1.unsqueeze(-1), att2.unsqueeze(-1)
 
     # ------------------------------------------------------------------ packed fast paths (no one-hot tensors)
-    def embed(self, centers, labels, want_att=False, want_emb=False):
-        """Packed graphs (centers [G,N,3], labels [G,N], -1 = pad) -> pooled [G, filters_3] (+att, +emb)."""
-        return self.engine().embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb)
+    def embed(self, centers, labels, want_att=False, want_emb=False, node_cap=None):
+        """Packed graphs (centers [G,N,3], labels [G,N], -1 = pad) -> pooled [G, filters_3] (+att, +emb).
+        node_cap: promise on the slots processed per graph (engine.Engine.node_cap_of); host arrays get it
+        computed automatically, device tensors run without it unless given."""
+        if node_cap is None:
+            node_cap = 0
+            if not (isinstance(labels, torch.Tensor) and labels.is_cuda) and len(labels):
+                node_cap = _engine.Engine.node_cap_of(centers, labels, int(self.args.K))
+        return self.engine().embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb,
+                                   node_cap=node_cap)
 
     def score_pooled(self, pooled_1, pooled_2, idx_1=None, idx_2=None):
         """NTN + head on pooled vectors (optionally gathered through index lists)."""
