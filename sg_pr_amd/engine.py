@@ -181,13 +181,13 @@ class Engine:
 
     PHASES = ["stage", "select_only", "gram", "select||gemm", "gemm_only", "gather", "conv_end", "attention"]
 
-    def phase_profile(self, centers, labels, k, reps=3):
+    def phase_profile(self, centers, labels, k, reps=3, node_cap=0):
         """Debug: fraction of workgroup cycles per phase of the embed kernel (thread-0 clocks)."""
         buf = torch.zeros(16, dtype=torch.int64, device=self.device)
         self.lib.sgpr_debug_set_profile_buffer(_ptr(buf))
         try:
             for _ in range(reps):
-                self.embed(centers, labels, k)
+                self.embed(centers, labels, k, node_cap=node_cap)
             torch.cuda.synchronize(self.device)
         finally:
             self.lib.sgpr_debug_set_profile_buffer(None)

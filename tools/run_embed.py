@@ -16,9 +16,10 @@ if shape == "kitti00":
     c, l, _, _ = synth.kitti_like_sequence(g, n, 0)
 else:
     c, l, _ = synth.make_graphs(g, n, n // 3, n - k, 0)
+cap = eng.node_cap_of(c, l, k)
 c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
 for _ in range(reps):
-    p = eng.embed(c, l, k)[0]
+    p = eng.embed(c, l, k, node_cap=cap)[0]
     m = eng.score_all_pairs(p, p) if shape == "kitti00" else None
 torch.cuda.synchronize()
 print("ok", float(p.sum()))
