@@ -248,6 +248,7 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
         return SGPR_E_INVALID;
     }
     // with at most one graph per CU there is nothing to overlap: keep the 512-thread workgroups (lower latency)
+    a.promise = (node_cap > 0 && node_cap < N) ? node_cap : N;   // still enforced (a broken promise stays loud)
     if (a.G <= h->num_cus) node_cap = 0;
     EmbedPlan plan;
     int rc = check_nk(a.G, N, k, node_cap, &plan);

@@ -79,6 +79,18 @@ bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
     p->P = P;                                   // lower bound; the kernel widens it per graph
     p->seg = round_up((NC + P - 1) / P, 4);
     p->RC = rc;
+    // three workgroups per CU: the resident key matrix (dead once the neighbour lists exist) shares the A region
+    // (written by the GEMMs) at the price of one more barrier per layer
+    p->alias_da = 0;
+    if (p->overlap && p->nt == 256 && p->NP * rowD <= p->NP * p->pitchA * 4) {
+        const int lds3 = off + kRedBytes;
+        if (3 * lds3 <= kLdsLimit) {
+            p->alias_da = 1;
+            p->offD = p->offA;
+            p->offRed = off;
+            p->lds_bytes = lds3;
+        }
+    }
     return true;
 }
 
@@ -734,8 +746,9 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
-template <int KP, bool DBG>
-__global__ __launch_bounds__(NT_MAX) void embed_kernel(const KParams kp) {
+// LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
+template <int KP, bool DBG, bool LEAN>
+__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = blockDim.x, NW = NT >> 6;          // 256 / 4 or 512 / 8
     const EmbedPlan& p = kp.p;
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(NT_MAX) void embed_kernel(const KParams kp) {
         wdup = (float)m / (float)c;
         __syncthreads();                        // red / D region is reused below
     }
-    if (N > p.NC) {          // more slots to process than the caller's node_cap promised: fail loudly
+    if (N > p.NC || N > kp.a.promise) {          // more slots to process than the caller's node_cap promised: fail loudly
         if (tid == 0) atomicOr(kp.a.status, 2);
         if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
         return;
@@ -918,6 +931,8 @@ __global__ __launch_bounds__(NT_MAX) void embed_kernel(const KParams kp) {
         }
         if (prof && p.overlap) atomicAdd(&prof_buf[1], (unsigned long long)(clock64() - t_prev));   // selection alone
         // per-node GEMMs (MFMA): no barrier needed after the selection - they only touch X rows owned by the wave and A
+        // (unless A doubles as the key matrix)
+        if (p.alias_da) __syncthreads();
         if (!(skip & 2)) {
             const unsigned long long t_gemm0 = prof ? clock64() : 0ull;
             gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
@@ -1079,16 +1094,16 @@ __global__ __launch_bounds__(NT_MAX) void embed_kernel(const KParams kp) {
 #undef SGPR_PROF
 }
 
-template <int KP, bool DBG>
+template <int KP, bool DBG, bool LEAN>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, DBG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, DBG, LEAN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_kernel<KP, DBG>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
@@ -1100,9 +1115,11 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.w = h->w;
     kp.p = plan;
     kp.a = a;
+    if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
     const bool dbg = a.prof || a.skip || a.dbg_layers || a.dbg_knn;
-    if (plan.kp == 16) return dbg ? launch_t<16, true>(kp, stream) : launch_t<16, false>(kp, stream);
-    return dbg ? launch_t<32, true>(kp, stream) : launch_t<32, false>(kp, stream);
+    if (dbg) return plan.kp == 16 ? launch_t<16, true, false>(kp, stream) : launch_t<32, true, false>(kp, stream);
+    if (plan.alias_da) return plan.kp == 16 ? launch_t<16, false, true>(kp, stream) : launch_t<32, false, true>(kp, stream);
+    return plan.kp == 16 ? launch_t<16, false, false>(kp, stream) : launch_t<32, false, false>(kp, stream);
 }
 
 }  // namespace sgpr

@@ -65,6 +65,8 @@ struct EmbedPlan {
     int pitchA;      // floats per row of the gather target A
     int overlap;     // 1: key matrix resident, selection (half the waves) overlaps the GEMMs (other half)
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
+    int alias_da;    // 1: the key matrix D shares the A region (a barrier separates selection and GEMMs): three
+                     //    256-thread workgroups per CU, launched on the <= 168-VGPR kernel instance
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
 };
@@ -85,6 +87,7 @@ struct EmbedArgs {
     float* park_ws;         // [G][NP][32] when !park_in_lds
     int32_t* status;
     unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
+    int promise;                // the caller's node_cap (or N): checked even when the plan ignores it
     int skip;                   // debug/ablation only (sgpr_debug_set_profile_buffer's companion): phases to skip
 };
 

@@ -163,6 +163,19 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// v_permlane32_swap: lanes 32-63 of the first operand trade places with lanes 0-31 of the second; the sum of the two
+// results is, in the lower half, a[l] + a[l+32] and, in the upper half, b[l-32] + b[l]
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// v_permlane16_swap: odd 16-lane rows of the first operand trade places with even rows of the second; the sum is
+// a[l] + a[l+16] in even rows and b[l-16] + b[l] in odd rows
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // One wave owns 64 column graphs (4 blocks of 16) and walks AP_ROWS row graphs.  Per (row, block):
 //   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j]),  K = 32.  fp32 MFMA shares the vector pipe on
 //            gfx950, bf16 MFMA does not and is ~8x faster per product: both operands are split into three
@@ -171,7 +184,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 //   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])   4 fp32 MFMAs: H is consumed straight from the
 //            accumulator layout (lane group g holds t = 4g..4g+3 and supplies t = 4g+s at step s; the A operand is
 //            permuted to match), so no data moves between the two layers
-//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs + 2 cross-lane adds), sigmoid once per 64 columns,
+//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs, lane-swap transpose-reduce), sigmoid once per 64 columns,
 //            one coalesced 256-B store per row.
 __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w, const float* __restrict__ cols,
                                                               int R, int M, const unsigned short* __restrict__ Ab,
@@ -214,10 +227,10 @@ __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w
         const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + T * F);
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
         const float4 u4 = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
-        float zsel = 0.f;
+        float zb[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+            f32x4 h = {u4.x + v4[b].x, u4.y + v4[b].y, u4.z + v4[b].z, u4.w + v4[b].w};
             h = mfma_bf16(al, bh[b], h);               // smallest terms first
             h = mfma_bf16(ah, bl[b], h);
             h = mfma_bf16(am, bm[b], h);
@@ -225,18 +238,20 @@ __global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w
             h = mfma_bf16(ah, bm[b], h);
             h = mfma_bf16(ah, bh[b], h);
             f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
-            q = mfma4(w1v.x, fmaxf(h[0] + (u4.x + v4[b].x), 0.f), q);
-            q = mfma4(w1v.y, fmaxf(h[1] + (u4.y + v4[b].y), 0.f), q);
-            q = mfma4(w1v.z, fmaxf(h[2] + (u4.z + v4[b].z), 0.f), q);
-            q = mfma4(w1v.w, fmaxf(h[3] + (u4.w + v4[b].w), 0.f), q);
+            q = mfma4(w1v.x, fmaxf(h[0], 0.f), q);
+            q = mfma4(w1v.y, fmaxf(h[1], 0.f), q);
+            q = mfma4(w1v.z, fmaxf(h[2], 0.f), q);
+            q = mfma4(w1v.w, fmaxf(h[3], 0.f), q);
             float z = w2v.x * fmaxf(q[0], 0.f);
             z = fmaf(w2v.y, fmaxf(q[1], 0.f), z);
             z = fmaf(w2v.z, fmaxf(q[2], 0.f), z);
-            z = fmaf(w2v.w, fmaxf(q[3], 0.f), z);
-            z += __shfl_xor(z, 16);
-            z += __shfl_xor(z, 32);                    // every lane group now holds z of column block b
-            zsel = (g == b) ? z : zsel;                // lane group g finishes block g
+            zb[b] = fmaf(w2v.w, fmaxf(q[3], 0.f), z);   // partial over o = 4g..4g+3 of column block b
         }
+        // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the full
+        // sum of column block g (3 swaps + 3 adds instead of 8 bpermutes)
+        const float p02 = swap32_add(zb[0], zb[2]);    // lanes 0-31: block 0 over groups {g, g+2}; lanes 32-63: block 2
+        const float p13 = swap32_add(zb[1], zb[3]);    // likewise blocks 1 / 3
+        const float zsel = swap16_add(p02, p13);       // even 16-lane rows: block 0 / 2, odd rows: block 1 / 3
         const float sc = 1.f / (1.f + expf(-(zsel + b2)));
         if (cst < M) score[(size_t)r * ld + cst] = sc;
     }

@@ -277,15 +277,18 @@ def test_node_cap_is_bitwise_neutral_and_loud(eng):
     """sgpr_embed_capped: same bits as the uncapped launch; a broken promise yields NaN + SGPR_E_NODES."""
     from sg_pr_amd import synth
     from sg_pr_amd.engine import SgprError
-    centers, labels, _, _ = synth.kitti_like_sequence(num_graphs=150, node_num=100, seed=21)
-    cap = eng.node_cap_of(centers, labels, 10)
-    assert cap == int(synth.effective_nodes(centers, labels, 10).max()) <= 61
-    full, att0, _ = eng.embed(centers, labels, 10, want_att=True)
-    capped, att1, _ = eng.embed(centers, labels, 10, want_att=True, node_cap=cap)
-    assert torch.equal(full, capped) and torch.equal(att0, att1)
-    eng.check_status()
-    bad, _, _ = eng.embed(centers, labels, 10, node_cap=cap - 1)
-    assert torch.isnan(bad).any() and not torch.isnan(bad).all()
-    with pytest.raises(SgprError) as ei:
+    # 150 graphs: at most one per CU, the plan ignores the cap (the promise is still enforced);
+    # 600 graphs: the capped plan runs (256-thread workgroups, three per CU, key matrix sharing the A region)
+    for num_graphs in (150, 600):
+        centers, labels, _, _ = synth.kitti_like_sequence(num_graphs=num_graphs, node_num=100, seed=21)
+        cap = eng.node_cap_of(centers, labels, 10)
+        assert cap == int(synth.effective_nodes(centers, labels, 10).max()) <= 61
+        full, att0, _ = eng.embed(centers, labels, 10, want_att=True)
+        capped, att1, _ = eng.embed(centers, labels, 10, want_att=True, node_cap=cap)
+        assert torch.equal(full, capped) and torch.equal(att0, att1)
         eng.check_status()
-    assert ei.value.code == -3
+        bad, _, _ = eng.embed(centers, labels, 10, node_cap=cap - 1)
+        assert torch.isnan(bad).any() and not torch.isnan(bad).all()
+        with pytest.raises(SgprError) as ei:
+            eng.check_status()
+        assert ei.value.code == -3
