@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
     }
 }
 
-constexpr int AP_ROWS = 64;   // row graphs per workgroup (column operands stay in registers)
+constexpr int AP_ROWS = 16;   // row graphs per work item (column operands stay in registers across items)
 constexpr int AP_COLS = 256;  // column graphs per workgroup: 4 waves x 64
+constexpr int AP_OCC = 4;     // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -157,6 +158,10 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     // D[4*(l>>4)+r][l&15] += sum_{q<4} A[row][q] * B[q][col];  lane l supplies A[l&15][l>>4], B[l>>4][l&15]
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {   // same operand/result layout as mfma_bf16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     // 16x16x32: lane l supplies A[l&15][8*(l>>4) .. +7] and B[8*(l>>4) .. +7][l&15]; same D layout as above
@@ -176,6 +181,11 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// ReLU as ONE instruction: fmaxf (and fmed3 with an infinite bound, which the optimizer folds back into it) first
+// canonicalises the operand with a second v_max x, x.  A signed-integer max with 0 does the same job on the bit
+// pattern: every negative float (and -0) is a negative integer.
+__device__ __forceinline__ float relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 // One wave owns 64 column graphs (4 blocks of 16) and walks AP_ROWS row graphs.  Per (row, block):
 //   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j]),  K = 32.  fp32 MFMA shares the vector pipe on
 //            gfx950, bf16 MFMA does not and is ~8x faster per product: both operands are split into three
@@ -186,74 +196,96 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 //            permuted to match), so no data moves between the two layers
 //   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs, lane-swap transpose-reduce), sigmoid once per 64 columns,
 //            one coalesced 256-B store per row.
-__global__ __launch_bounds__(256) void score_all_pairs_kernel(const DevWeights w, const float* __restrict__ cols,
+__global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevWeights w, const float* __restrict__ cols,
                                                               int R, int M, const unsigned short* __restrict__ Ab,
                                                               const float* __restrict__ ur,
                                                               const float* __restrict__ vc,
                                                               float* __restrict__ score, int64_t ld) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int c0 = blockIdx.x * AP_COLS + wave * 64;
-    if (c0 >= M) return;
-    // column operands: e2_c[8g .. 8g+7] as three bf16 planes, and v_c, for the 4 column blocks of this wave
-    bf16x8 bh[4], bm[4], bl[4];
-    float4 v4[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int c = min(c0 + b * 16 + l15, M - 1);
-        const float4 x0 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g);
-        const float4 x1 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g + 4);
-        const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            unsigned short h, m, l;
-            split3(xs[q], h, m, l);
-            bh[b][q] = (short)h;
-            bm[b][q] = (short)m;
-            bl[b][q] = (short)l;
-        }
-        v4[b] = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
-    }
     const float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);   // W1[o = l15][t = 4g..4g+3]
+    const _Float16 wh0 = (_Float16)w1v.x, wh1 = (_Float16)w1v.y, wh2 = (_Float16)w1v.z, wh3 = (_Float16)w1v.w;
+    const _Float16 z16 = (_Float16)0.f;
+    const f16x8 w1hi = {wh0, wh1, wh2, wh3, wh0, wh1, wh2, wh3};                      // meets H's hi and lo planes
+    const f16x8 w1lo = {(_Float16)(w1v.x - (float)wh0), (_Float16)(w1v.y - (float)wh1), (_Float16)(w1v.z - (float)wh2),
+                        (_Float16)(w1v.w - (float)wh3), z16, z16, z16, z16};            // meets the hi plane only
     const float4 b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
     const float4 w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
     const float b2 = w.fc2_b[0];
-    const int r0 = blockIdx.y * AP_ROWS;
-    const int r1 = min(R, r0 + AP_ROWS);
-    const int cst = c0 + lane;                         // the column this lane stores
-    for (int r = r0; r < r1; ++r) {
-        const unsigned short* ap = Ab + (size_t)r * (3 * T * F) + l15 * F + 8 * g;   // A_r[t = l15][8g .. 8g+7]
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + T * F);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
-        const float4 u4 = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
-        float zb[4];
+    // work items = (column block of AP_COLS, row chunk of AP_ROWS), column-major; every workgroup takes a contiguous,
+    // equally long range (the grid is sized to one resident wave slot per workgroup, so there is no second,
+    // under-occupied round) and reloads its column operands only when the column block changes
+    const int nrc = (R + AP_ROWS - 1) / AP_ROWS;
+    const int64_t items = (int64_t)nrc * ((M + AP_COLS - 1) / AP_COLS);
+    const int it0 = (int)(items * blockIdx.x / gridDim.x), it1 = (int)(items * (blockIdx.x + 1) / gridDim.x);
+    bf16x8 bh[4], bm[4], bl[4];
+    float4 v4[4];
+    int cur_cb = -1, c0 = 0;
+    for (int it = it0; it < it1; ++it) {
+        const int cb = it / nrc, r0 = (it - cb * nrc) * AP_ROWS;
+        if (cb != cur_cb) {
+            cur_cb = cb;
+            c0 = cb * AP_COLS + wave * 64;
+            // column operands: e2_c[8g .. 8g+7] as three bf16 planes, and v_c, for the 4 column blocks of this wave
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            f32x4 h = {u4.x + v4[b].x, u4.y + v4[b].y, u4.z + v4[b].z, u4.w + v4[b].w};
-            h = mfma_bf16(al, bh[b], h);               // smallest terms first
-            h = mfma_bf16(ah, bl[b], h);
-            h = mfma_bf16(am, bm[b], h);
-            h = mfma_bf16(am, bh[b], h);
-            h = mfma_bf16(ah, bm[b], h);
-            h = mfma_bf16(ah, bh[b], h);
-            f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
-            q = mfma4(w1v.x, fmaxf(h[0], 0.f), q);
-            q = mfma4(w1v.y, fmaxf(h[1], 0.f), q);
-            q = mfma4(w1v.z, fmaxf(h[2], 0.f), q);
-            q = mfma4(w1v.w, fmaxf(h[3], 0.f), q);
-            float z = w2v.x * fmaxf(q[0], 0.f);
-            z = fmaf(w2v.y, fmaxf(q[1], 0.f), z);
-            z = fmaf(w2v.z, fmaxf(q[2], 0.f), z);
-            zb[b] = fmaf(w2v.w, fmaxf(q[3], 0.f), z);   // partial over o = 4g..4g+3 of column block b
+            for (int b = 0; b < 4; ++b) {
+                const int c = min(c0 + b * 16 + l15, M - 1);
+                const float4 x0 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g);
+                const float4 x1 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g + 4);
+                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    unsigned short h, m, l;
+                    split3(xs[q], h, m, l);
+                    bh[b][q] = (short)h;
+                    bm[b][q] = (short)m;
+                    bl[b][q] = (short)l;
+                }
+                v4[b] = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
+            }
         }
-        // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the full
-        // sum of column block g (3 swaps + 3 adds instead of 8 bpermutes)
-        const float p02 = swap32_add(zb[0], zb[2]);    // lanes 0-31: block 0 over groups {g, g+2}; lanes 32-63: block 2
-        const float p13 = swap32_add(zb[1], zb[3]);    // likewise blocks 1 / 3
-        const float zsel = swap16_add(p02, p13);       // even 16-lane rows: block 0 / 2, odd rows: block 1 / 3
-        const float sc = 1.f / (1.f + expf(-(zsel + b2)));
-        if (cst < M) score[(size_t)r * ld + cst] = sc;
+        if (c0 >= M) continue;                         // this wave's 64 columns lie past the matrix edge
+        const int r1 = min(R, r0 + AP_ROWS);
+        const int cst = c0 + lane;                     // the column this lane stores
+        for (int r = r0; r < r1; ++r) {
+            const unsigned short* ap = Ab + (size_t)r * (3 * T * F) + l15 * F + 8 * g;   // A_r[t = l15][8g .. 8g+7]
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + T * F);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
+            const float4 u4 = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+            float zb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                f32x4 h = {u4.x + v4[b].x, u4.y + v4[b].y, u4.z + v4[b].z, u4.w + v4[b].w};
+                h = mfma_bf16(al, bh[b], h);           // smallest terms first
+                h = mfma_bf16(ah, bl[b], h);
+                h = mfma_bf16(am, bm[b], h);
+                h = mfma_bf16(am, bh[b], h);
+                h = mfma_bf16(ah, bm[b], h);
+                h = mfma_bf16(ah, bh[b], h);
+                // layer 2 on the f16 matrix cores: H = hi + lo (two f16 planes, 22 bits); K slots 8g..8g+3 = hi,
+                // 8g+4..8g+7 = lo of t = 4g..4g+3 - exactly this lane's accumulators
+                const float h0 = relu(h[0]), h1 = relu(h[1]), h2 = relu(h[2]), h3 = relu(h[3]);
+                const _Float16 i0 = (_Float16)h0, i1 = (_Float16)h1, i2 = (_Float16)h2, i3 = (_Float16)h3;
+                const f16x8 hb = {i0, i1, i2, i3, (_Float16)(h0 - (float)i0), (_Float16)(h1 - (float)i1),
+                                  (_Float16)(h2 - (float)i2), (_Float16)(h3 - (float)i3)};
+                f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
+                q = mfma_f16(w1lo, hb, q);             // hi . W1lo
+                q = mfma_f16(w1hi, hb, q);             // (hi + lo) . W1hi
+                float z = w2v.x * relu(q[0]);
+                z = fmaf(w2v.y, relu(q[1]), z);
+                z = fmaf(w2v.z, relu(q[2]), z);
+                zb[b] = fmaf(w2v.w, relu(q[3]), z);   // partial over o = 4g..4g+3 of column block b
+            }
+            // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
+            // full sum of column block g (3 swaps + 3 adds instead of 8 bpermutes)
+            const float p02 = swap32_add(zb[0], zb[2]);    // lanes 0-31: block 0 over groups {g, g+2}; 32-63: block 2
+            const float p13 = swap32_add(zb[1], zb[3]);    // likewise blocks 1 / 3
+            const float zsel = swap16_add(p02, p13);       // even 16-lane rows: block 0 / 2, odd rows: block 1 / 3
+            // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
+            const float sc = __builtin_amdgcn_rcpf(1.f + __expf(-(zsel + b2)));
+            if (cst < M) score[(size_t)r * ld + cst] = sc;
+        }
     }
 }
 
@@ -266,8 +298,10 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
     hipLaunchKernelGGL(ntn_prep_kernel, dim3((R + M + 3) / 4), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
-    dim3 grid((M + AP_COLS - 1) / AP_COLS, (R + AP_ROWS - 1) / AP_ROWS);
-    hipLaunchKernelGGL(score_all_pairs_kernel, grid, dim3(256), 0, stream, h->w, cols, R, M, Ab, ur, vc, score, ld);
+    const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
+    const int64_t slots = (int64_t)h->num_cus * AP_OCC;   // one resident slot per workgroup: a single, full round
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL(score_all_pairs_kernel, dim3(grid), dim3(256), 0, stream, h->w, cols, R, M, Ab, ur, vc, score, ld);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
     return SGPR_OK;

@@ -57,7 +57,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("SGPR_HIP_LIB") or _build.LIB_PATH   # override: an alternative build of the same C-ABI
     if not os.path.exists(path):
         raise ImportError("HIP engine %s is not built; run `python -m sg_pr_amd._build` "
                           "(there is no CPU fallback)" % path)

@@ -1,0 +1,5 @@
+export TMPDIR=/tmp
+rm -rf gpurun_out/kt
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -o kt -- python bench.py --steps 30 --warmup 3 > gpurun_out/kt.log 2>&1 </dev/null
+python tools/kstats.py gpurun_out/kt/kt_kernel_stats.csv | head -3
+timeout 200 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
