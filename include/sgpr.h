@@ -97,11 +97,20 @@ int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_la
 /* sgpr_embed with a promise about the input: no graph of the batch needs more than `node_cap` PROCESSED slots
  * (= slots before the trailing run of m identical padding slots, + 1 when m >= k, + m otherwise; 0 = no promise).
  * The kernel sizes its LDS for node_cap instead of N, so padded graphs of a few dozen real nodes run as
- * 256-thread workgroups, two or three per CU.  A graph that breaks the promise gets a NaN pooled vector and
+ * one wave per 16 slots, 12 waves per CU.  A graph that breaks the promise gets a NaN pooled vector and
  * sgpr_check_status returns SGPR_E_NODES.  Results are otherwise identical to sgpr_embed. */
 int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
                       int k, float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
                       void* stream);
+
+/* sgpr_embed_capped over an explicit launch order: workgroup b embeds graph d_order[b] (device i32 [n_order],
+ * distinct indices in [0, G), n_order <= G).  A packed graph store lists its graphs largest-first (longest
+ * workgroups start first, the last round of the launch is filled by the smallest graphs - KITTI-00: -7 %), or lists
+ * only the graphs that changed.  Outputs are indexed by graph id exactly as in sgpr_embed and are bit-identical to
+ * it; a graph listed nowhere is not embedded and its output rows are left untouched. */
+int sgpr_embed_ordered(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
+                       int k, const int32_t* d_order, int n_order, float* d_pooled, float* d_att, float* d_emb,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Same as sgpr_embed, taking the reference's dense tensor `features` [G, 3+L, N] f32
  * (data["features_1"], sg_net.py:119) - the sem block may hold any values. */

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -241,7 +242,7 @@ size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
 }
 
 static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int node_cap, void* ws, size_t ws_bytes,
-                        void* stream) {
+                        void* stream, int total_graphs = -1) {   // total_graphs: G when a.ids lists a subset
     if (h && a.G == 0) return SGPR_OK;
     if (!h || !a.pooled || (!a.dense && (!a.centers || !a.labels))) {
         set_error("sgpr_embed: NULL argument");
@@ -253,7 +254,8 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     EmbedPlan plan;
     int rc = check_nk(a.G, N, k, node_cap, &plan);
     if (rc != SGPR_OK) return rc;
-    const size_t need = embed_ws_bytes(plan, a.G);
+    // graphs are addressed by their own index: an ordered launch needs rows for all of them
+    const size_t need = embed_ws_bytes(plan, total_graphs < 0 ? a.G : total_graphs);
     if (need > 0 && (!ws || ws_bytes < need)) {
         set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required");
         return SGPR_E_WORKSPACE;
@@ -291,6 +293,26 @@ int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_
     a.att = d_att;
     a.emb = d_emb;
     return embed_common(h, a, N, k, node_cap, d_workspace, workspace_bytes, stream);
+}
+
+int sgpr_embed_ordered(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
+                       int k, const int32_t* d_order, int n_order, float* d_pooled, float* d_att, float* d_emb,
+                       void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (G < 0 || n_order < 0 || n_order > G || (n_order > 0 && !d_order)) {
+        set_error("sgpr_embed_ordered: order list of " + std::to_string(n_order) + " entries for " + std::to_string(G) +
+                  " graphs");
+        return SGPR_E_INVALID;
+    }
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.centers = d_centers;
+    a.labels = d_labels;
+    a.ids = d_order;
+    a.G = n_order;
+    a.pooled = d_pooled;
+    a.att = d_att;
+    a.emb = d_emb;
+    return embed_common(h, a, N, k, node_cap, d_workspace, workspace_bytes, stream, G);
 }
 
 int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N, int k, float* d_pooled,

@@ -33,7 +33,7 @@ constexpr int PE = 36;        // floats per row of E   (final node embedding, 32
 constexpr int PP = 32;        // floats per row of the parked xyz3 block
 constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
 constexpr int CAP = 64;       // candidates per lane in the selection phase
-constexpr int kRedBytes = 4608;
+constexpr int kRedBytes = 1536;   // attention partial sums (8 x 32) + mean + tanh vector; duplicate-run scratch
 constexpr int kLdsLimit = 160 * 1024;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,15 +79,20 @@ bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
     p->P = P;                                   // lower bound; the kernel widens it per graph
     p->seg = round_up((NC + P - 1) / P, 4);
     p->RC = rc;
-    // three workgroups per CU: the resident key matrix (dead once the neighbour lists exist) shares the A region
-    // (written by the GEMMs) at the price of one more barrier per layer
+    // small graphs (NP <= 64): one wave per 16-row tile, 12 waves per CU.  The resident key matrix (dead once the
+    // neighbour lists exist) shares the A region (written by the GEMMs) at the price of one more barrier per layer,
+    // and the attention scratch shares X (dead after conv_end).
     p->alias_da = 0;
     if (p->overlap && p->nt == 256 && p->NP * rowD <= p->NP * p->pitchA * 4) {
-        const int lds3 = off + kRedBytes;
-        if (3 * lds3 <= kLdsLimit) {
+        int nt3 = 64 * (p->NP / 16);
+        if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
+        const bool red_in_x = p->NP * PX * 4 >= kRedBytes;
+        const int lds3 = off + (red_in_x ? 0 : kRedBytes);
+        if (nt3 <= 256 && (12 / (nt3 / 64)) * lds3 <= kLdsLimit) {
             p->alias_da = 1;
+            p->nt = nt3;
             p->offD = p->offA;
-            p->offRed = off;
+            p->offRed = red_in_x ? p->offX : off;
             p->lds_bytes = lds3;
         }
     }
@@ -750,7 +755,7 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 template <int KP, bool DBG, bool LEAN>
 __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int NT = blockDim.x, NW = NT >> 6;          // 256 / 4 or 512 / 8
+    const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
     const EmbedPlan& p = kp.p;
     float* X = reinterpret_cast<float*>(smem + p.offX);
     float* A = reinterpret_cast<float*>(smem + p.offA);
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     unsigned short* nbr = reinterpret_cast<unsigned short*>(smem + p.offIdx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int g = blockIdx.x;
+    const int g = kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x;
     const int NS = p.N;                                   // slots per graph in global memory
     float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * p.NP * PP;
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
@@ -996,8 +1001,9 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
 
     // conv_end weights of this wave's first tile: in flight while xyz3 is moved back
     float4 wf_end[4];
-    load_frag<4>(kp.w.wf_end + (size_t)((wave & 1) * 16 + l15) * 64 + 4 * lq, wf_end);
-    const float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + (wave & 1) * 16 + 4 * lq);
+    int ct_end = wave & 1;
+    load_frag<4>(kp.w.wf_end + (size_t)(ct_end * 16 + l15) * 64 + 4 * lq, wf_end);
+    float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct_end * 16 + 4 * lq);
     for (int e = tid; e < NP * 8; e += NT) {                      // xyz3 -> channels 0..31: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
         *reinterpret_cast<float4*>(X + i * PX + c4) = *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4);
@@ -1009,7 +1015,12 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     {
         const float* __restrict__ Wf = kp.w.wf_end;
         for (int task = wave; task < 2 * nrt; task += NW) {
-            const int ct = task & 1, rt = task >> 1;      // NW is even: ct == wave & 1 for every task of this wave
+            const int ct = task & 1, rt = task >> 1;      // NW even: ct == wave & 1 for every task of this wave
+            if (ct != ct_end) {                           // odd wave counts (192-thread workgroups) alternate
+                ct_end = ct;
+                load_frag<4>(Wf + (size_t)(ct * 16 + l15) * 64 + 4 * lq, wf_end);
+                t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct * 16 + 4 * lq);
+            }
             float4 xf[4];
             load_frag<4>(X + (rt * 16 + l15) * PX + 4 * lq, xf);
             const f32x4 acc = tile16<4>(wf_end, xf);
@@ -1021,7 +1032,6 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             e4.w = e4.w > 0.f ? e4.w : 0.2f * e4.w;
             *reinterpret_cast<float4*>(E + (rt * 16 + l15) * PE + c4) = e4;
         }
-        (void)Wf;
     }
     __syncthreads();
     SGPR_PROF(6)
@@ -1052,8 +1062,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     float* mean = red + NPART * 32;
     float* tg = mean + 32;
     float* sig = xx;
-    const int c = tid & 31, prt = tid >> 5;
-    if (prt < NPART) {
+    const int c = tid & 31;
+    for (int prt = tid >> 5; prt < NPART; prt += NT >> 5) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf(n >= nd ? wdup : 1.f, E[n * PE + c], s);
         red[prt * 32 + c] = s;
@@ -1079,7 +1089,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     __syncthreads();
     if (kp.a.att)
         for (int n = tid; n < NS; n += NT) kp.a.att[(size_t)g * NS + n] = sig[min(n, N - 1)];
-    if (prt < NPART) {
+    for (int prt = tid >> 5; prt < NPART; prt += NT >> 5) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf((n >= nd ? wdup : 1.f) * sig[n], E[n * PE + c], s);
         red[prt * 32 + c] = s;

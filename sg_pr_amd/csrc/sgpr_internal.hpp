@@ -65,8 +65,8 @@ struct EmbedPlan {
     int pitchA;      // floats per row of the gather target A
     int overlap;     // 1: key matrix resident, selection (half the waves) overlaps the GEMMs (other half)
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
-    int alias_da;    // 1: the key matrix D shares the A region (a barrier separates selection and GEMMs): three
-                     //    256-thread workgroups per CU, launched on the <= 168-VGPR kernel instance
+    int alias_da;    // 1: the key matrix D shares the A region (a barrier separates selection and GEMMs), one wave per
+                     //    16-row tile, 12 waves per CU, launched on the <= 168-VGPR kernel instance
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
 };
@@ -76,6 +76,7 @@ struct EmbedArgs {
     const float* centers;   // packed input, or
     const int32_t* labels;
     const float* dense;     // dense [G][3+L][N] input (centers/labels NULL)
+    const int32_t* ids;     // optional [G] graph indices: workgroup b embeds graph ids[b] (sgpr_embed_ordered)
     const float* dense2;    // optional second dense tensor: graphs g >= g_split read dense2[g - g_split]
     int g_split;
     int G;

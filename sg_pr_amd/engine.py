@@ -31,7 +31,7 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 
 # every symbol include/sgpr.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
-               "sgpr_embed_capped",
+               "sgpr_embed_capped", "sgpr_embed_ordered",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
                "sgpr_embed_lds_bytes", "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
@@ -75,6 +75,8 @@ def load_library():
     lib.sgpr_embed.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_capped.restype = i32
     lib.sgpr_embed_capped.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_embed_ordered.restype = i32
+    lib.sgpr_embed_ordered.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_dense.restype = i32
     lib.sgpr_embed_dense.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_debug.restype = i32
@@ -202,10 +204,9 @@ class Engine:
 
     # ------------------------------------------------------------------ per-graph half
     @staticmethod
-    def node_cap_of(centers, labels, k):
-        """Largest number of slots the kernel will process for any graph of the batch (see sgpr_embed_capped):
-        trailing slots identical to the last one collapse to one representative when there are >= k of them.
-        Works on numpy arrays or tensors; for device tensors this synchronises (do it once per dataset)."""
+    def processed_slots(centers, labels, k):
+        """Slots the kernel processes per graph, int64 [G] (see sgpr_embed_capped): trailing slots identical to the
+        last one collapse to one representative when there are >= k of them.  numpy arrays or tensors."""
         c = torch.as_tensor(centers)
         l = torch.as_tensor(labels)
         n = l.shape[1]
@@ -213,12 +214,29 @@ class Engine:
         idx = torch.arange(n, device=l.device).expand_as(l)
         nd = torch.where(~same, idx + 1, torch.zeros_like(idx)).amax(dim=1)          # slots before the trailing run
         m = n - nd
-        eff = nd + torch.where((m >= k) & (m > 1), torch.ones_like(m), m)
+        return nd + torch.where((m >= k) & (m > 1), torch.ones_like(m), m)
+
+    @staticmethod
+    def node_cap_of(centers, labels, k):
+        """Largest number of slots the kernel will process for any graph of the batch.
+        For device tensors this synchronises (do it once per dataset)."""
+        eff = Engine.processed_slots(centers, labels, k)
         return int(eff.max().item()) if eff.numel() else 0
 
-    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0):
+    def size_order(self, centers, labels, k):
+        """Launch order for sgpr_embed_ordered: graph indices sorted by processed slots, largest first, plus the
+        node_cap they justify -> (order i32 device tensor [G], node_cap).  A property of the packed data - build it
+        once per dataset (it synchronises for device inputs)."""
+        eff = self.processed_slots(centers, labels, k)
+        if eff.numel() == 0:
+            return torch.empty(0, dtype=torch.int32, device=self.device), 0
+        order = torch.argsort(eff, descending=True, stable=True).to(torch.int32).to(self.device)
+        return order, int(eff.max().item())
+
+    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None):
         """centers [G,N,3] f32, labels [G,N] i32 (-1 = pad) -> pooled [G,32] (+ att [G,N], emb [G,N,32]).
-        node_cap: optional promise on the processed slots per graph (node_cap_of); 0 = none."""
+        node_cap: optional promise on the processed slots per graph (node_cap_of); 0 = none.
+        order: optional i32 launch order (size_order) - graphs not listed keep uninitialised output rows."""
         centers = self._dev(centers, torch.float32, "centers")
         labels = self._dev(labels, torch.int32, "labels")
         g, n = labels.shape
@@ -236,6 +254,13 @@ class Engine:
             self._check(rc)
             return pooled, att, emb, layers, knn
         if g == 0:
+            return pooled, att, emb
+        if order is not None:
+            order = self._dev(order, torch.int32, "order")
+            rc = self.lib.sgpr_embed_ordered(self._h, _ptr(centers), _ptr(labels), g, n, int(node_cap), k, _ptr(order),
+                                             order.numel(), _ptr(pooled), _ptr(att), _ptr(emb), _ptr(ws), ws_bytes,
+                                             self._stream())
+            self._check(rc)
             return pooled, att, emb
         rc = self.lib.sgpr_embed_capped(self._h, _ptr(centers), _ptr(labels), g, n, int(node_cap), k, _ptr(pooled),
                                         _ptr(att), _ptr(emb), _ptr(ws), ws_bytes, self._stream())

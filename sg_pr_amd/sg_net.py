@@ -96,16 +96,17 @@ class SG(torch.nn.Module):
         return score, att1.unsqueeze(-1), att2.unsqueeze(-1)
 
     # ------------------------------------------------------------------ packed fast paths (no one-hot tensors)
-    def embed(self, centers, labels, want_att=False, want_emb=False, node_cap=None):
+    def embed(self, centers, labels, want_att=False, want_emb=False, node_cap=None, order=None):
         """Packed graphs (centers [G,N,3], labels [G,N], -1 = pad) -> pooled [G, filters_3] (+att, +emb).
-        node_cap: promise on the slots processed per graph (engine.Engine.node_cap_of); host arrays get it
-        computed automatically, device tensors run without it unless given."""
-        if node_cap is None:
-            node_cap = 0
+        node_cap: promise on the slots processed per graph; order: launch order, largest graphs first
+        (engine.Engine.size_order gives both).  Host arrays get them computed automatically; device tensors run
+        without unless given (computing them would synchronise)."""
+        eng = self.engine()
+        if node_cap is None and order is None:
             if not (isinstance(labels, torch.Tensor) and labels.is_cuda) and len(labels):
-                node_cap = _engine.Engine.node_cap_of(centers, labels, int(self.args.K))
-        return self.engine().embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb,
-                                   node_cap=node_cap)
+                order, node_cap = eng.size_order(centers, labels, int(self.args.K))
+        return eng.embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb,
+                         node_cap=node_cap or 0, order=order)
 
     def score_pooled(self, pooled_1, pooled_2, idx_1=None, idx_2=None):
         """NTN + head on pooled vectors (optionally gathered through index lists)."""

@@ -292,3 +292,33 @@ def test_node_cap_is_bitwise_neutral_and_loud(eng):
         with pytest.raises(SgprError) as ei:
             eng.check_status()
         assert ei.value.code == -3
+
+
+def test_ordered_embed_is_bitwise_equal_and_loud(eng):
+    """sgpr_embed_ordered: any launch order gives the same bits as the plain launch for every output; a subset
+    leaves the other rows untouched; a broken node_cap promise is NaN + SGPR_E_NODES."""
+    from sg_pr_amd import synth
+    from sg_pr_amd.engine import SgprError
+    centers, labels, _ = synth.make_graphs(700, 100, 3, 47, seed=5)          # node_cap <= 48: 192-thread workgroups
+    full, att0, emb0 = eng.embed(centers, labels, 10, want_att=True, want_emb=True)
+    order, cap = eng.size_order(centers, labels, 10)
+    assert cap == eng.node_cap_of(centers, labels, 10) <= 48 and sorted(order.tolist()) == list(range(700))
+    b, att1, emb1 = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
+    eng.check_status()
+    assert torch.equal(full, b) and torch.equal(att0, att1) and torch.equal(emb0, emb1)
+    # K = 20 > 16 (the other kernel instance), node_num = 256, generic plans
+    c2, l2, _ = synth.make_graphs(300, 256, 5, 230, seed=6)
+    f2 = eng.embed(c2, l2, 20)[0]
+    o2, cap2 = eng.size_order(c2, l2, 20)
+    assert torch.equal(f2, eng.embed(c2, l2, 20, node_cap=cap2, order=o2)[0])
+    eng.check_status()
+    # subset: only the listed graphs are written
+    sub = order[::7].contiguous()
+    part = eng.embed(centers, labels, 10, node_cap=cap, order=sub)[0]
+    assert torch.equal(part[sub.long()], full[sub.long()])
+    # broken promise
+    bad = eng.embed(centers, labels, 10, node_cap=cap - 1, order=order)[0]
+    assert torch.isnan(bad).any() and not torch.isnan(bad).all()
+    with pytest.raises(SgprError) as ei:
+        eng.check_status()
+    assert ei.value.code == -3
