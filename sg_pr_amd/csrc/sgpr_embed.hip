@@ -86,6 +86,7 @@ bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
     if (p->overlap && p->nt == 256 && p->NP * rowD <= p->NP * p->pitchA * 4) {
         int nt3 = 64 * (p->NP / 16);
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
+        if (nt3 < 128) nt3 = 128;                             // gemm_cols needs two waves
         const bool red_in_x = p->NP * PX * 4 >= kRedBytes;
         const int lds3 = off + (red_in_x ? 0 : kRedBytes);
         if (nt3 <= 256 && (12 / (nt3 / 64)) * lds3 <= kLdsLimit) {
@@ -638,8 +639,95 @@ __device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restri
     }
 }
 
+// ------------------------------------------------------------------ per-node GEMMs, weight-stationary (capped plans)
+// Small graphs (nrt <= 4 row tiles, 2..4 waves): a wave owns COLUMN tiles ct = wave, wave + NW, ... of [a | b], keeps
+// the weight fragment of the tile in registers and walks the row tiles, so the weights cross L2 -> CU once per
+// workgroup instead of once per row tile and the work divides evenly whatever nrt is.  a-tiles go straight to A;
+// the (at most two) b-tiles of a wave wait in registers until every wave has read its X operands, then replace X.
+template <int NKB, int COUT>
+__device__ __forceinline__ void gemm_cols(float* __restrict__ X, float* __restrict__ A, int pitchA,
+                                          const float* __restrict__ Wf, const float* __restrict__ tb, int nrt, int wave,
+                                          int NW) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int Kp = NKB * 16;
+    constexpr int NCA = COUT / 16, NCT = 2 * NCA;
+    const float* wp = Wf + (size_t)l15 * Kp + 4 * lq;
+    const float* xp = X + l15 * PX + 4 * lq;
+    // this wave's b-tiles: the first ct >= NCA congruent to wave (mod NW), and the one after it
+    int ctb0 = wave;
+    while (ctb0 < NCA) ctb0 += NW;
+    const int ctb1 = ctb0 + NW;
+    float4 w[4], wn[4], xf[4], xn[4];
+    f32x4 k0[4], k1[4];
+    // ---- a-tiles
+    int ct = wave;
+    if (ct < NCA) load_frag<NKB>(wp + (size_t)ct * 16 * Kp, w);
+    else if (ctb0 < NCT) load_frag<NKB>(wp + (size_t)ctb0 * 16 * Kp, w);
+    load_frag<NKB>(xp, xf);
+    for (; ct < NCA; ct += NW) {
+        const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
+        if (cn < NCT) load_frag<NKB>(wp + (size_t)cn * 16 * Kp, wn);
+        float* ap = A + l15 * pitchA + ct * 16 + 4 * lq;
+        for (int rt = 0; rt < nrt; ++rt) {
+            load_frag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PX, xn);   // next row tile (wraps to tile 0)
+            const f32x4 r = tile16<NKB>(w, xf);              // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
+            *reinterpret_cast<float4*>(ap + rt * 16 * pitchA) = make_float4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+            for (int q = 0; q < NKB; ++q) xf[q] = xn[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) w[q] = wn[q];
+    }
+    // ---- b-tiles: results stay in registers (row-tile loop unrolled: register arrays need static indices)
+    const bool has0 = ctb0 < NCT, has1 = ctb1 < NCT;
+    if (has0) {
+        if (has1) load_frag<NKB>(wp + (size_t)ctb1 * 16 * Kp, wn);
+        const float4 t4 = *reinterpret_cast<const float4*>(tb + (ctb0 - NCA) * 16 + 4 * lq);
+        const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+            if (rt < nrt) {
+                load_frag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PX, xn);
+                k0[rt] = tile16<NKB>(w, xf) + t;
+#pragma unroll
+                for (int q = 0; q < NKB; ++q) xf[q] = xn[q];
+            }
+    }
+    if (has1) {
+        const float4 t4 = *reinterpret_cast<const float4*>(tb + (ctb1 - NCA) * 16 + 4 * lq);
+        const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+            if (rt < nrt) {
+                load_frag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PX, xn);
+                k1[rt] = tile16<NKB>(wn, xf) + t;
+#pragma unroll
+                for (int q = 0; q < NKB; ++q) xf[q] = xn[q];
+            }
+    }
+    __syncthreads();                                             // every wave is done reading X
+    float* bp = X + l15 * PX + 4 * lq;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+        if (rt < nrt) {
+            if (has0) *reinterpret_cast<float4*>(bp + rt * 16 * PX + (ctb0 - NCA) * 16) = make_float4(k0[rt][0], k0[rt][1], k0[rt][2], k0[rt][3]);
+            if (has1) *reinterpret_cast<float4*>(bp + rt * 16 * PX + (ctb1 - NCA) * 16) = make_float4(k1[rt][0], k1[rt][1], k1[rt][2], k1[rt][3]);
+        }
+}
+
+template <bool COLS>
 __device__ __forceinline__ void gemm_layer(float* X, float* A, int pitchA, const float* Wf, const float* tb, int Kp,
                                            int cout, int nrt, int gw, int GW) {
+    if (COLS) {   // capped plans: nrt <= 4, GW >= 2 (make_embed_plan); contains a barrier - every wave calls it
+        if (Kp != 64)
+            gemm_cols<1, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+        else if (cout == 64)
+            gemm_cols<4, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+        else
+            gemm_cols<4, 32>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+        return;
+    }
     if (Kp != 64)
         gemm_rows<1, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);   // first layer of a branch: 3 / 12 -> 64 channels
     else if (cout == 64)
@@ -752,7 +840,7 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
 // LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
-template <int KP, bool DBG, bool LEAN>
+template <int KP, int DBG, bool LEAN>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
 __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
@@ -772,8 +860,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     unsigned long long t_prev = 0;
     unsigned long long* const prof_buf = DBG ? kp.a.prof : nullptr;
     const int skip = DBG ? kp.a.skip : 0;
-    float* const dbg_layers = DBG ? kp.a.dbg_layers : nullptr;
-    int32_t* const dbg_knn_all = DBG ? kp.a.dbg_knn : nullptr;
+    float* const dbg_layers = DBG == 2 ? kp.a.dbg_layers : nullptr;
+    int32_t* const dbg_knn_all = DBG == 2 ? kp.a.dbg_knn : nullptr;
     const bool prof = prof_buf != nullptr && tid == 0;
     if (prof) t_prev = clock64();
 #define SGPR_PROF(ph)                                            \
@@ -940,7 +1028,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         if (p.alias_da) __syncthreads();
         if (!(skip & 2)) {
             const unsigned long long t_gemm0 = prof ? clock64() : 0ull;
-            gemm_layer(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
+            gemm_layer<LEAN>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
             if (prof) atomicAdd(&prof_buf[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
         }
         __syncthreads();  // neighbour lists, A and b (in X) are complete
@@ -1104,7 +1192,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
 #undef SGPR_PROF
 }
 
-template <int KP, bool DBG, bool LEAN>
+template <int KP, int DBG, bool LEAN>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
@@ -1126,10 +1214,14 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.p = plan;
     kp.a = a;
     if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
-    const bool dbg = a.prof || a.skip || a.dbg_layers || a.dbg_knn;
-    if (dbg) return plan.kp == 16 ? launch_t<16, true, false>(kp, stream) : launch_t<32, true, false>(kp, stream);
-    if (plan.alias_da) return plan.kp == 16 ? launch_t<16, false, true>(kp, stream) : launch_t<32, false, true>(kp, stream);
-    return plan.kp == 16 ? launch_t<16, false, false>(kp, stream) : launch_t<32, false, false>(kp, stream);
+    const bool dump = a.dbg_layers || a.dbg_knn, prof = a.prof || a.skip;
+    if (dump) return plan.kp == 16 ? launch_t<16, 2, false>(kp, stream) : launch_t<32, 2, false>(kp, stream);
+    if (prof) {   // profiling / ablation keeps the production occupancy of capped plans
+        if (plan.alias_da) return plan.kp == 16 ? launch_t<16, 1, true>(kp, stream) : launch_t<32, 1, true>(kp, stream);
+        return plan.kp == 16 ? launch_t<16, 1, false>(kp, stream) : launch_t<32, 1, false>(kp, stream);
+    }
+    if (plan.alias_da) return plan.kp == 16 ? launch_t<16, 0, true>(kp, stream) : launch_t<32, 0, true>(kp, stream);
+    return plan.kp == 16 ? launch_t<16, 0, false>(kp, stream) : launch_t<32, 0, false>(kp, stream);
 }
 
 }  // namespace sgpr

@@ -16,18 +16,18 @@ for name, (n, k, g) in shapes.items():
         c, l, _, _ = synth.kitti_like_sequence(g, n, 0)
     else:
         c, l, _ = synth.make_graphs(g, n, 20, n - k, 0)
-    cap = eng.node_cap_of(c, l, k)
+    order, cap = eng.size_order(c, l, k)
     c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
-    for mask, label in [(0, "full"), (64, "full, sorting-network selection"), (1, "no select"), (2, "no gemm"), (3, "no select, no gemm"), (4, "no gram"),
+    for mask, label in [(0, "full"), (64, "full, profile instance"), (1, "no select"), (2, "no gemm"), (3, "no select, no gemm"), (4, "no gram"),
                         (8, "no gather"), (15, "skeleton (stage, barriers, conv_end, attention)"),
                         (32, "input fetch + duplicate detection only"), (16, "dispatch only")]:
         eng.lib.sgpr_debug_set_skip_mask(mask)
         for _ in range(3):
-            eng.embed(c, l, k, node_cap=cap)
+            eng.embed(c, l, k, node_cap=cap, order=order)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            eng.embed(c, l, k, node_cap=cap)
+            eng.embed(c, l, k, node_cap=cap, order=order)
         torch.cuda.synchronize()
         print("%-9s %-48s %.4f ms" % (name, label, (time.perf_counter() - t0) * 100))
     eng.lib.sgpr_debug_set_skip_mask(0)
