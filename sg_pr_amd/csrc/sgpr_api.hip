@@ -67,6 +67,27 @@ int sgpr_abi_version(void) { return SGPR_ABI_VERSION; }
 
 const char* sgpr_last_error(void) { return g_last_error.c_str(); }
 
+// w = hi + mid + lo with three round-to-nearest-even bf16 terms (exact to 24 bits)
+static unsigned short bf16_rne_host(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float bf16_to_float_host(unsigned short h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void split3_host(float w, unsigned short (&pl)[3]) {
+    pl[0] = bf16_rne_host(w);
+    float r = w - bf16_to_float_host(pl[0]);
+    pl[1] = bf16_rne_host(r);
+    r -= bf16_to_float_host(pl[1]);
+    pl[2] = bf16_rne_host(r);
+}
+
 int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, int device, sgpr_handle** out) {
     if (!weights || !dims || !out) {
         set_error("sgpr_create: NULL argument");
@@ -147,6 +168,29 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     const size_t o_fc2w = append(bn);
     const size_t o_fc2b = append(1);
     while (packed.size() % 4) packed.push_back(0.f);
+    // ---- bf16 three-plane copies of the seven folded weight matrices, in MFMA operand order (sgpr_internal.hpp)
+    size_t off_wb[7];
+    for (int b = 0; b < 7; ++b) {
+        const int rows = b < 6 ? 2 * bs[b].cout : bs[b].cout, kp = kp_of[b];
+        const int nks = kp == 64 ? 2 : 1, nct = rows / 16;
+        std::vector<unsigned short> wb((size_t)nct * nks * 3 * 512, 0);
+        const float* wf = packed.data() + off_wf[b];
+        for (int ct = 0; ct < nct; ++ct)
+            for (int st = 0; st < nks; ++st)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int l15 = lane & 15, lq = lane >> 4;
+                        int kk;
+                        if (nks == 2) kk = 32 * st + 8 * lq + j;
+                        else kk = j < 4 ? 4 * lq + j : -1;
+                        unsigned short pl[3] = {0, 0, 0};
+                        if (kk >= 0 && kk < kp) split3_host(wf[(size_t)(ct * 16 + l15) * kp + kk], pl);
+                        for (int q = 0; q < 3; ++q) wb[(((size_t)(ct * nks + st) * 3 + q) * 64 + lane) * 8 + j] = pl[q];
+                    }
+        off_wb[b] = packed.size();
+        packed.resize(packed.size() + wb.size() / 2);
+        memcpy(packed.data() + off_wb[b], wb.data(), wb.size() * sizeof(unsigned short));
+    }
 
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -176,11 +220,13 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         const int b = blob_of_layer[l];
         h->w.wf[l] = h->d_blob + off_wf[b];
         h->w.tb[l] = h->d_blob + off_tb[b];
+        h->w.wb[l] = reinterpret_cast<const unsigned short*>(h->d_blob + off_wb[b]);
         h->w.kp[l] = kp_of[b];
         h->w.cout[l] = bs[b].cout;
     }
     h->w.wf_end = h->d_blob + off_wf[6];
     h->w.tb_end = h->d_blob + off_tb[6];
+    h->w.wb_end = reinterpret_cast<const unsigned short*>(h->d_blob + off_wb[6]);
     h->w.att_w = h->d_blob + o_att;
     h->w.ntn_w = h->d_blob + o_ntw;
     h->w.ntn_wb = h->d_blob + o_ntb;

@@ -28,7 +28,10 @@
 
 namespace sgpr {
 
-constexpr int PX = 68;        // floats per row of X   (64 ch + 4: 16-B aligned, rows shift one 16-B slot)
+constexpr int PXB = 400;      // BYTES per row of X: three bf16 planes of 64 channels (128 B each; x = hi + mid + lo,
+                              // exact to 24 bits) + 16 B so that rows shift one 16-B slot; the per-node term b
+                              // (64 fp32 = 256 B) later overlays the row in place
+constexpr int PXF = 272;      // bytes per row of X in the fp32 layout (64 ch + 4 floats) of plans too large for the planes
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
 constexpr int PP = 32;        // floats per row of the parked xyz3 block
 constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
@@ -40,9 +43,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
-    if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > SGPR_MAX_K || k > N) return false;
-    const int NC = (node_cap <= 0 || node_cap > N) ? N : node_cap;
+// One layout attempt: X as bf16 planes (PXB bytes per row) or as fp32 rows (PXF, converted when loaded).
+// The key matrix / key chunk D always shares the A region: D is dead once the neighbour lists exist, A is written by
+// the GEMMs after them (a barrier separates the two); the attention scratch shares X (dead after conv_end).
+static bool plan_layout(int N, int NC, int k, bool planes, EmbedPlan* p) {
     p->N = N;
     p->NC = NC;
     p->NP = round_up(NC, 16);
@@ -52,52 +56,57 @@ bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
     p->pitchD = p->NP + 4;
     p->park_in_lds = NC <= 128 ? 1 : 0;
     p->pitchA = NC <= 192 ? 68 : 64;      // 64 only when LDS is otherwise exhausted (bank-conflicted stores)
+    p->xplanes = planes ? 1 : 0;
+    p->rowb = planes ? PXB : PXF;
     int off = 0;
-    p->offX = off;    off += p->NP * PX * 4;
-    p->offA = off;    off += p->NP * p->pitchA * 4;
+    p->offX = off;    off += p->NP * p->rowb;
+    p->offRed = p->offX;
     p->offPark = off; off += p->park_in_lds ? p->NP * PP * 4 : 0;
     p->offXX = off;   off += p->NP * 4;
     p->offIdx = off;  off += round_up(p->NP * p->kpitch * 2, 16);
+    p->offA = off;
     p->offD = off;
-    p->offRed = off;  // attention scratch aliases the key chunk (disjoint in time)
-    const int rowD = p->pitchD * 4;
-    int rc = (kLdsLimit - off) / rowD / 16 * 16;
+    p->alias_da = 1;
+    const int rowD = p->pitchD * 4, bytesA = p->NP * p->pitchA * 4;
+    const int region = kLdsLimit - off;
+    if (region < bytesA) return false;
+    int rc = region / rowD / 16 * 16;
     if (rc > p->NP) rc = p->NP;
     if (rc < 16) return false;
-    p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
-    // small graphs: 256-thread workgroups, two or three of them per CU, overlap each other's barriers
-    p->nt = (p->lds_bytes <= kLdsLimit / 2 && N <= 256) ? 256 : 512;
+    p->lds_bytes = off + (rc * rowD > bytesA ? rc * rowD : bytesA);
+    // small graphs: 256-thread workgroups, two of them per CU, overlap each other's barriers
+    p->nt = p->lds_bytes <= kLdsLimit / 2 ? 256 : 512;
     // resident mode: the whole key matrix fits in LDS -> upper-triangular Gram tiles, mirrored
     int P = 1;
     while ((NC + P - 1) / P > CAP) P *= 2;
-    p->overlap = (rc == p->NP && p->NP * P <= p->nt) ? 1 : 0;
+    p->overlap = (rc == p->NP && NC <= 128 && p->NP * P <= p->nt) ? 1 : 0;
     if (!p->overlap && rc * P > p->nt) {
         rc = p->nt / P / 16 * 16;
         if (rc < 16) return false;
-        p->lds_bytes = off + (rc * rowD > kRedBytes ? rc * rowD : kRedBytes);
+        p->lds_bytes = off + (rc * rowD > bytesA ? rc * rowD : bytesA);
     }
     p->P = P;                                   // lower bound; the kernel widens it per graph
     p->seg = round_up((NC + P - 1) / P, 4);
     p->RC = rc;
-    // small graphs (NP <= 64): one wave per 16-row tile, 12 waves per CU.  The resident key matrix (dead once the
-    // neighbour lists exist) shares the A region (written by the GEMMs) at the price of one more barrier per layer,
-    // and the attention scratch shares X (dead after conv_end).
-    p->alias_da = 0;
-    if (p->overlap && p->nt == 256 && p->NP * rowD <= p->NP * p->pitchA * 4) {
+    // lean plans (NP <= 64, bf16 planes): one wave per 16-row tile, 12 waves per CU on the <= 168-VGPR kernel instance
+    p->lean = 0;
+    if (planes && p->overlap && p->NP <= 64) {
         int nt3 = 64 * (p->NP / 16);
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
         if (nt3 < 128) nt3 = 128;                             // gemm_cols needs two waves
-        const bool red_in_x = p->NP * PX * 4 >= kRedBytes;
-        const int lds3 = off + (red_in_x ? 0 : kRedBytes);
-        if (nt3 <= 256 && (12 / (nt3 / 64)) * lds3 <= kLdsLimit) {
-            p->alias_da = 1;
+        if (nt3 <= 256 && (12 / (nt3 / 64)) * p->lds_bytes <= kLdsLimit) {
+            p->lean = 1;
             p->nt = nt3;
-            p->offD = p->offA;
-            p->offRed = red_in_x ? p->offX : off;
-            p->lds_bytes = lds3;
         }
     }
     return true;
+}
+
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
+    if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > SGPR_MAX_K || k > N) return false;
+    const int NC = (node_cap <= 0 || node_cap > N) ? N : node_cap;
+    // bf16 planes whenever they fit (every graph up to 208 processed slots); fp32 rows beyond
+    return plan_layout(N, NC, k, true, p) || plan_layout(N, NC, k, false, p);
 }
 
 struct KParams {
@@ -107,39 +116,147 @@ struct KParams {
 };
 
 // ------------------------------------------------------------------ MFMA helpers
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    // D[4*(l>>4)+r][l&15] += sum_{q<4} A[row][q] * B[q][col];  lane l supplies A[l&15][l>>4], B[l>>4][l&15]
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+// Every matrix product of the kernel (Gram, per-node GEMMs, conv_end) runs on v_mfma_f32_16x16x32_bf16 with both
+// operands split into three bf16 planes, x = hi + mid + lo (exact to 24 bits): the six significant cross products
+// are accumulated in fp32, smallest first, which reproduces the fp32 product to ~2^-24.  fp32 MFMA
+// (v_mfma_f32_16x16x4_f32) blocks the VALU of its SIMD for 32 cycles per instruction (tools/probes/coexec_probe.hip);
+// the bf16 instruction does not, and six of them cost 96 cycles per 16x16x32 block against 256 in fp32.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Frag {          // one 32-wide k-step of one operand: lane (l15, lq) holds k slots 8*lq .. 8*lq+7 of row l15
+    bf16x8 h, m, l;
+};
+
+__device__ __forceinline__ f32x4 mfma_b(bf16x8 a, bf16x8 b, f32x4 c) {
+    // D[4*(l>>4)+r][l&15] += sum_k A[row][k] * B[k][col];  lane l supplies A[l&15][8*(l>>4)..+7], B[8*(l>>4)..+7][l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// One 16-wide k-block: lane group q = l>>4 holds k = 4q..4q+3 of both operands (one
-// 16-B read each); MFMA step s contracts k = 4q+s over the four lane groups.  The
-// order of the k-sum is permuted, which a dot product does not care about.
-__device__ __forceinline__ f32x4 mfma_kblock(const float4 a, const float4 b, f32x4 acc) {
-    acc = mfma4(a.x, b.x, acc);
-    acc = mfma4(a.y, b.y, acc);
-    acc = mfma4(a.z, b.z, acc);
-    acc = mfma4(a.w, b.w, acc);
-    return acc;
+__device__ __forceinline__ f32x4 mfma6(const Frag& a, const Frag& b, f32x4 acc) {
+    acc = mfma_b(a.l, b.h, acc);
+    acc = mfma_b(a.h, b.l, acc);
+    acc = mfma_b(a.m, b.m, acc);
+    acc = mfma_b(a.m, b.h, acc);
+    acc = mfma_b(a.h, b.m, acc);
+    return mfma_b(a.h, b.h, acc);
 }
 
-// 16x16 output tile, K = 16*NKB: operands preloaded, two accumulators break the MFMA dependency chain
+// 16x16 output tile, K = 16*NKB (NKB = 4: two k-steps, two accumulators; NKB = 1: one half-filled k-step)
 template <int NKB>
-__device__ __forceinline__ f32x4 tile16(const float4 (&a)[4], const float4 (&b)[4]) {
+__device__ __forceinline__ f32x4 tile16(const Frag (&a)[2], const Frag (&b)[2]) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-    if (NKB == 1) return mfma_kblock(a[0], b[0], acc0);
+    acc0 = mfma6(a[0], b[0], acc0);
+    if (NKB == 1) return acc0;
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-    acc0 = mfma_kblock(a[0], b[0], acc0);
-    acc1 = mfma_kblock(a[1], b[1], acc1);
-    acc0 = mfma_kblock(a[2], b[2], acc0);
-    acc1 = mfma_kblock(a[3], b[3], acc1);
+    acc1 = mfma6(a[1], b[1], acc1);
     return acc0 + acc1;
 }
 
+// X operand of row `row` (byte pointer to the row): channels 32*step + 8*lq + 0..7 (NKB = 4), or channels
+// 4*lq + 0..3 followed by four zero slots (NKB = 1: 16 input channels)
 template <int NKB>
-__device__ __forceinline__ void load_frag(const float* p, float4 (&f)[4]) {
+__device__ __forceinline__ void load_xfrag(const unsigned char* row, int lq, Frag (&f)[2]) {
+    if (NKB == 1) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(row + 8 * lq);
+        const bf16x4 m = *reinterpret_cast<const bf16x4*>(row + 128 + 8 * lq);
+        const bf16x4 l = *reinterpret_cast<const bf16x4*>(row + 256 + 8 * lq);
+        f[0].h = bf16x8{h[0], h[1], h[2], h[3], 0, 0, 0, 0};
+        f[0].m = bf16x8{m[0], m[1], m[2], m[3], 0, 0, 0, 0};
+        f[0].l = bf16x8{l[0], l[1], l[2], l[3], 0, 0, 0, 0};
+    } else {
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) f[kb] = *reinterpret_cast<const float4*>(p + kb * 16);
+        for (int st = 0; st < 2; ++st) {
+            f[st].h = *reinterpret_cast<const bf16x8*>(row + 64 * st + 16 * lq);
+            f[st].m = *reinterpret_cast<const bf16x8*>(row + 128 + 64 * st + 16 * lq);
+            f[st].l = *reinterpret_cast<const bf16x8*>(row + 256 + 64 * st + 16 * lq);
+        }
+    }
+}
+
+// weight operand of one 16-row column tile (DevWeights::wb layout: [k-step][plane][lane][8]); tile = wb + ct * wtile<NKB>
+template <int NKB>
+__device__ __forceinline__ constexpr int wtile() { return (NKB == 1 ? 1 : 2) * 3 * 512; }
+template <int NKB>
+__device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, Frag (&f)[2]) {
+    const unsigned short* p = tile + (threadIdx.x & 63) * 8;
+#pragma unroll
+    for (int st = 0; st < (NKB == 1 ? 1 : 2); ++st) {
+        f[st].h = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 0) * 512);
+        f[st].m = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 1) * 512);
+        f[st].l = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 2) * 512);
+    }
+}
+
+template <int NKB>
+__device__ __forceinline__ void copy_frag(Frag (&d)[2], const Frag (&s)[2]) {
+    d[0] = s[0];
+    if (NKB != 1) d[1] = s[1];
+}
+
+// four consecutive fp32 values -> three bf16 planes, two packed values per dword (v_cvt_pk_bf16_f32, round to nearest
+// even; x - hi and (x - hi) - mid are exact in fp32)
+__device__ __forceinline__ void split4(float4 v, uint2& h, uint2& m, uint2& l) {
+    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    const bf16v2 ha = __builtin_convertvector(a, bf16v2), hb = __builtin_convertvector(b, bf16v2);
+    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+    const bf16v2 ma = __builtin_convertvector(ra, bf16v2), mb = __builtin_convertvector(rb, bf16v2);
+    const f32x2 sa = ra - __builtin_convertvector(ma, f32x2), sb = rb - __builtin_convertvector(mb, f32x2);
+    const bf16v2 la = __builtin_convertvector(sa, bf16v2), lb = __builtin_convertvector(sb, bf16v2);
+    h = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+    m = make_uint2(__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb));
+    l = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
+__device__ __forceinline__ bf16x8 pack8(uint2 a, uint2 b) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
+}
+
+// X layout policy.  XP = true: rows of three bf16 planes (PXB bytes), written once per layer by the gather epilogue.
+// XP = false: fp32 rows (PXF bytes) for plans whose LDS cannot hold the planes (N > 208), split when loaded.
+// Either way the per-node term b (fp32) overlays bytes 0..255 of the row in place.
+template <bool XP>
+__device__ __forceinline__ constexpr int xrow() { return XP ? PXB : PXF; }
+
+template <int NKB, bool XP>
+__device__ __forceinline__ void xload(const unsigned char* row, int lq, Frag (&f)[2]) {
+    if (XP) {
+        load_xfrag<NKB>(row, lq, f);
+    } else if (NKB == 1) {
+        uint2 h, m, l;
+        split4(*reinterpret_cast<const float4*>(row + 16 * lq), h, m, l);
+        const uint2 z = make_uint2(0u, 0u);
+        f[0].h = pack8(h, z);
+        f[0].m = pack8(m, z);
+        f[0].l = pack8(l, z);
+    } else {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uint2 h0, m0, l0, h1, m1, l1;
+            split4(*reinterpret_cast<const float4*>(row + 128 * st + 32 * lq), h0, m0, l0);
+            split4(*reinterpret_cast<const float4*>(row + 128 * st + 32 * lq + 16), h1, m1, l1);
+            f[st].h = pack8(h0, h1);
+            f[st].m = pack8(m0, m1);
+            f[st].l = pack8(l0, l1);
+        }
+    }
+}
+
+// four consecutive channels ch..ch+3 of one row
+template <bool XP>
+__device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v) {
+    if (XP) {
+        uint2 h, m, l;
+        split4(v, h, m, l);
+        *reinterpret_cast<uint2*>(row + 2 * ch) = h;
+        *reinterpret_cast<uint2*>(row + 128 + 2 * ch) = m;
+        *reinterpret_cast<uint2*>(row + 256 + 2 * ch) = l;
+    } else {
+        *reinterpret_cast<float4*>(row + 4 * ch) = v;
+    }
 }
 
 // ------------------------------------------------------------------ selection helpers
@@ -557,14 +674,14 @@ __device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np,
 }
 
 // ------------------------------------------------------------------ Gram tile -> ranking keys
-template <int NKB>
-__device__ __forceinline__ void gram_tile(const float* __restrict__ X, const float* __restrict__ xx, float* __restrict__ D,
+template <int NKB, bool XP>
+__device__ __forceinline__ void gram_tile(const unsigned char* __restrict__ X, const float* __restrict__ xx, float* __restrict__ D,
                                           int pitchD, int N, int rc0, int ti, int tj, bool mirror, int l15, int lq) {
     // ti indexes 16-row tiles inside the chunk starting at row rc0; tj indexes candidate tiles
     const int i0 = rc0 + ti * 16, j0 = tj * 16;
-    float4 a[4], b[4];
-    load_frag<NKB>(X + (i0 + l15) * PX + 4 * lq, a);
-    load_frag<NKB>(X + (j0 + l15) * PX + 4 * lq, b);
+    Frag a[2], b[2];
+    xload<NKB, XP>(X + (i0 + l15) * xrow<XP>(), lq, a);
+    xload<NKB, XP>(X + (j0 + l15) * xrow<XP>(), lq, b);
     const f32x4 g = tile16<NKB>(a, b);          // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
     const int j = j0 + l15;
     const float xj = j < N ? xx[j] : INFINITY;  // invalid candidates rank last
@@ -586,29 +703,26 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ X, const flo
 // ------------------------------------------------------------------ per-node GEMMs, gemm-wave gw of GW
 // A wave owns up to two 16-node row tiles (rt = gw, gw + GW) and computes every 16-channel column
 // tile of [a | b] for them:  a = x.W1'  -> A (LDS, the gather target);  b = x.(W2-W1)' + t replaces
-// the wave's own rows of X in place once all its column tiles are done (no other wave reads those
-// rows in this phase, so no barrier is needed).  Weight fragments stream from L1/L2.
-template <int NKB, int COUT>
-__device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restrict__ A, int pitchA,
-                                          const float* __restrict__ Wf, const float* __restrict__ tb, int nrt, int gw,
-                                          int GW) {
+// the wave's own rows of X in place (fp32, bytes 0..255 of the row) once all its column tiles are done (no other
+// wave reads those rows in this phase, so no barrier is needed).  Weight fragments stream from L1/L2.
+template <int NKB, int COUT, bool XP>
+__device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
+                                          const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
+                                          int gw, int GW) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
-    constexpr int Kp = NKB * 16;
     constexpr int NCA = COUT / 16;                   // a-type column tiles (= b-type column tiles)
     constexpr int NCT = 2 * NCA;
     const int rt0 = gw, rt1 = gw + GW;
     if (rt0 >= nrt) return;
     const bool two = rt1 < nrt;
-    float* x0 = X + (rt0 * 16 + l15) * PX;
-    float* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * PX;
-    const float* wp = Wf + (size_t)l15 * Kp + 4 * lq;
-    float4 w[3][4];                                  // weight fragments, fetched two column tiles ahead (L1/L2)
-    load_frag<NKB>(wp, w[0]);
-    load_frag<NKB>(wp + (size_t)16 * Kp, w[1]);
-    float4 xf0[4], xf1[4];
-    load_frag<NKB>(x0 + 4 * lq, xf0);
-    load_frag<NKB>(x1 + 4 * lq, xf1);
+    unsigned char* x0 = X + (rt0 * 16 + l15) * xrow<XP>();
+    unsigned char* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * xrow<XP>();
+    Frag w[2], wn[2];                                // weight fragments, fetched one column tile ahead (L1/L2)
+    load_wfrag<NKB>(Wb, w);
+    Frag xf0[2], xf1[2];
+    xload<NKB, XP>(x0, lq, xf0);
+    xload<NKB, XP>(x1, lq, xf1);
     float4 tv[NCA];
 #pragma unroll
     for (int cb = 0; cb < NCA; ++cb) tv[cb] = *reinterpret_cast<const float4*>(tb + cb * 16 + 4 * lq);
@@ -617,11 +731,11 @@ __device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restri
     f32x4 b0[NCA], b1[NCA];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        if (ct + 2 < NCT) load_frag<NKB>(wp + (size_t)(ct + 2) * 16 * Kp, w[(ct + 2) % 3]);
+        if (ct + 1 < NCT) load_wfrag<NKB>(Wb + (size_t)(ct + 1) * wtile<NKB>(), wn);
         // r[c] = out[channel ct*16 + 4lq + c][node rt*16 + l15]
-        const f32x4 r0 = tile16<NKB>(w[ct % 3], xf0);
+        const f32x4 r0 = tile16<NKB>(w, xf0);
         f32x4 r1 = r0;
-        if (two) r1 = tile16<NKB>(w[ct % 3], xf1);
+        if (two) r1 = tile16<NKB>(w, xf1);
         if (ct < NCA) {
             *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r0[0], r0[1], r0[2], r0[3]);
             if (two) *reinterpret_cast<float4*>(a1 + ct * 16) = make_float4(r1[0], r1[1], r1[2], r1[3]);
@@ -631,11 +745,12 @@ __device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restri
             b0[ct < NCA ? 0 : ct - NCA] = r0 + t;
             b1[ct < NCA ? 0 : ct - NCA] = r1 + t;
         }
+        if (ct + 1 < NCT) copy_frag<NKB>(w, wn);
     }
 #pragma unroll
     for (int cb = 0; cb < NCA; ++cb) {
-        *reinterpret_cast<float4*>(x0 + cb * 16 + 4 * lq) = make_float4(b0[cb][0], b0[cb][1], b0[cb][2], b0[cb][3]);
-        if (two) *reinterpret_cast<float4*>(x1 + cb * 16 + 4 * lq) = make_float4(b1[cb][0], b1[cb][1], b1[cb][2], b1[cb][3]);
+        *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * lq) * 4) = make_float4(b0[cb][0], b0[cb][1], b0[cb][2], b0[cb][3]);
+        if (two) *reinterpret_cast<float4*>(x1 + (cb * 16 + 4 * lq) * 4) = make_float4(b1[cb][0], b1[cb][1], b1[cb][2], b1[cb][3]);
     }
 }
 
@@ -645,53 +760,48 @@ __device__ __forceinline__ void gemm_rows(float* __restrict__ X, float* __restri
 // workgroup instead of once per row tile and the work divides evenly whatever nrt is.  a-tiles go straight to A;
 // the (at most two) b-tiles of a wave wait in registers until every wave has read its X operands, then replace X.
 template <int NKB, int COUT>
-__device__ __forceinline__ void gemm_cols(float* __restrict__ X, float* __restrict__ A, int pitchA,
-                                          const float* __restrict__ Wf, const float* __restrict__ tb, int nrt, int wave,
-                                          int NW) {
+__device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
+                                          const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
+                                          int wave, int NW) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
-    constexpr int Kp = NKB * 16;
     constexpr int NCA = COUT / 16, NCT = 2 * NCA;
-    const float* wp = Wf + (size_t)l15 * Kp + 4 * lq;
-    const float* xp = X + l15 * PX + 4 * lq;
+    const unsigned char* xp = X + l15 * PXB;
     // this wave's b-tiles: the first ct >= NCA congruent to wave (mod NW), and the one after it
     int ctb0 = wave;
     while (ctb0 < NCA) ctb0 += NW;
     const int ctb1 = ctb0 + NW;
-    float4 w[4], wn[4], xf[4], xn[4];
+    Frag w[2], wn[2], xf[2], xn[2];
     f32x4 k0[4], k1[4];
     // ---- a-tiles
     int ct = wave;
-    if (ct < NCA) load_frag<NKB>(wp + (size_t)ct * 16 * Kp, w);
-    else if (ctb0 < NCT) load_frag<NKB>(wp + (size_t)ctb0 * 16 * Kp, w);
-    load_frag<NKB>(xp, xf);
+    if (ct < NCA) load_wfrag<NKB>(Wb + (size_t)ct * wtile<NKB>(), w);
+    else if (ctb0 < NCT) load_wfrag<NKB>(Wb + (size_t)ctb0 * wtile<NKB>(), w);
+    load_xfrag<NKB>(xp, lq, xf);
     for (; ct < NCA; ct += NW) {
         const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
-        if (cn < NCT) load_frag<NKB>(wp + (size_t)cn * 16 * Kp, wn);
+        if (cn < NCT) load_wfrag<NKB>(Wb + (size_t)cn * wtile<NKB>(), wn);
         float* ap = A + l15 * pitchA + ct * 16 + 4 * lq;
         for (int rt = 0; rt < nrt; ++rt) {
-            load_frag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PX, xn);   // next row tile (wraps to tile 0)
+            load_xfrag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PXB, lq, xn);   // next row tile (wraps to tile 0)
             const f32x4 r = tile16<NKB>(w, xf);              // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
             *reinterpret_cast<float4*>(ap + rt * 16 * pitchA) = make_float4(r[0], r[1], r[2], r[3]);
-#pragma unroll
-            for (int q = 0; q < NKB; ++q) xf[q] = xn[q];
+            copy_frag<NKB>(xf, xn);
         }
-#pragma unroll
-        for (int q = 0; q < NKB; ++q) w[q] = wn[q];
+        copy_frag<NKB>(w, wn);
     }
     // ---- b-tiles: results stay in registers (row-tile loop unrolled: register arrays need static indices)
     const bool has0 = ctb0 < NCT, has1 = ctb1 < NCT;
     if (has0) {
-        if (has1) load_frag<NKB>(wp + (size_t)ctb1 * 16 * Kp, wn);
+        if (has1) load_wfrag<NKB>(Wb + (size_t)ctb1 * wtile<NKB>(), wn);
         const float4 t4 = *reinterpret_cast<const float4*>(tb + (ctb0 - NCA) * 16 + 4 * lq);
         const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
-                load_frag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PX, xn);
+                load_xfrag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PXB, lq, xn);
                 k0[rt] = tile16<NKB>(w, xf) + t;
-#pragma unroll
-                for (int q = 0; q < NKB; ++q) xf[q] = xn[q];
+                copy_frag<NKB>(xf, xn);
             }
     }
     if (has1) {
@@ -700,40 +810,39 @@ __device__ __forceinline__ void gemm_cols(float* __restrict__ X, float* __restri
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
-                load_frag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PX, xn);
+                load_xfrag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PXB, lq, xn);
                 k1[rt] = tile16<NKB>(wn, xf) + t;
-#pragma unroll
-                for (int q = 0; q < NKB; ++q) xf[q] = xn[q];
+                copy_frag<NKB>(xf, xn);
             }
     }
     __syncthreads();                                             // every wave is done reading X
-    float* bp = X + l15 * PX + 4 * lq;
+    unsigned char* bp = X + l15 * PXB + 16 * lq;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
         if (rt < nrt) {
-            if (has0) *reinterpret_cast<float4*>(bp + rt * 16 * PX + (ctb0 - NCA) * 16) = make_float4(k0[rt][0], k0[rt][1], k0[rt][2], k0[rt][3]);
-            if (has1) *reinterpret_cast<float4*>(bp + rt * 16 * PX + (ctb1 - NCA) * 16) = make_float4(k1[rt][0], k1[rt][1], k1[rt][2], k1[rt][3]);
+            if (has0) *reinterpret_cast<float4*>(bp + rt * 16 * PXB + (ctb0 - NCA) * 64) = make_float4(k0[rt][0], k0[rt][1], k0[rt][2], k0[rt][3]);
+            if (has1) *reinterpret_cast<float4*>(bp + rt * 16 * PXB + (ctb1 - NCA) * 64) = make_float4(k1[rt][0], k1[rt][1], k1[rt][2], k1[rt][3]);
         }
 }
 
-template <bool COLS>
-__device__ __forceinline__ void gemm_layer(float* X, float* A, int pitchA, const float* Wf, const float* tb, int Kp,
-                                           int cout, int nrt, int gw, int GW) {
+template <bool COLS, bool XP>
+__device__ __forceinline__ void gemm_layer(unsigned char* X, float* A, int pitchA, const unsigned short* Wb,
+                                           const float* tb, int Kp, int cout, int nrt, int gw, int GW) {
     if (COLS) {   // capped plans: nrt <= 4, GW >= 2 (make_embed_plan); contains a barrier - every wave calls it
         if (Kp != 64)
-            gemm_cols<1, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+            gemm_cols<1, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW);
         else if (cout == 64)
-            gemm_cols<4, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+            gemm_cols<4, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW);
         else
-            gemm_cols<4, 32>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+            gemm_cols<4, 32>(X, A, pitchA, Wb, tb, nrt, gw, GW);
         return;
     }
     if (Kp != 64)
-        gemm_rows<1, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);   // first layer of a branch: 3 / 12 -> 64 channels
+        gemm_rows<1, 64, XP>(X, A, pitchA, Wb, tb, nrt, gw, GW);   // first layer of a branch: 3 / 12 -> 64 channels
     else if (cout == 64)
-        gemm_rows<4, 64>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+        gemm_rows<4, 64, XP>(X, A, pitchA, Wb, tb, nrt, gw, GW);
     else
-        gemm_rows<4, 32>(X, A, pitchA, Wf, tb, nrt, gw, GW);
+        gemm_rows<4, 32, XP>(X, A, pitchA, Wb, tb, nrt, gw, GW);
 }
 
 // ------------------------------------------------------------------ Gram phase (whole key matrix resident)
@@ -748,8 +857,8 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
     tj = r + t;
 }
 
-template <int NKB>
-__device__ __forceinline__ void gram_tiles_sym(const float* __restrict__ X, const float* __restrict__ xx,
+template <int NKB, bool XP>
+__device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__ X, const float* __restrict__ xx,
                                                float* __restrict__ D, int pitchD, int N, int nrt, int wave) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -758,18 +867,18 @@ __device__ __forceinline__ void gram_tiles_sym(const float* __restrict__ X, cons
     if (t >= ntiles) return;
     int ti, tj;
     tri_decode(t, nrt, ti, tj);
-    float4 a[4], b[4];
-    load_frag<NKB>(X + (ti * 16 + l15) * PX + 4 * lq, a);
-    load_frag<NKB>(X + (tj * 16 + l15) * PX + 4 * lq, b);
+    Frag a[2], b[2];
+    xload<NKB, XP>(X + (ti * 16 + l15) * xrow<XP>(), lq, a);
+    xload<NKB, XP>(X + (tj * 16 + l15) * xrow<XP>(), lq, b);
     while (true) {
         const int tn = t + (int)(blockDim.x >> 6);
         const bool more = tn < ntiles;
         int tin = 0, tjn = 0;
-        float4 an[4], bn[4];
+        Frag an[2], bn[2];
         if (more) {                                   // operands of the next tile in flight during this tile's MFMAs
             tri_decode(tn, nrt, tin, tjn);
-            load_frag<NKB>(X + (tin * 16 + l15) * PX + 4 * lq, an);
-            load_frag<NKB>(X + (tjn * 16 + l15) * PX + 4 * lq, bn);
+            xload<NKB, XP>(X + (tin * 16 + l15) * xrow<XP>(), lq, an);
+            xload<NKB, XP>(X + (tjn * 16 + l15) * xrow<XP>(), lq, bn);
         }
         const f32x4 g = tile16<NKB>(a, b);            // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
         const int i0 = ti * 16, j = tj * 16 + l15;
@@ -788,11 +897,8 @@ __device__ __forceinline__ void gram_tiles_sym(const float* __restrict__ X, cons
                 fmaf(-2.f, g[0], xi.x), fmaf(-2.f, g[1], xi.y), fmaf(-2.f, g[2], xi.z), fmaf(-2.f, g[3], xi.w));
         }
         if (!more) break;
-#pragma unroll
-        for (int q = 0; q < NKB; ++q) {
-            a[q] = an[q];
-            b[q] = bn[q];
-        }
+        copy_frag<NKB>(a, an);
+        copy_frag<NKB>(b, bn);
         t = tn;
         ti = tin;
         tj = tjn;
@@ -840,12 +946,13 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
 // LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
-template <int KP, int DBG, bool LEAN>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
+template <int KP, int DBG, bool LEAN, bool XP>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
 __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
     const EmbedPlan& p = kp.p;
-    float* X = reinterpret_cast<float*>(smem + p.offX);
+    unsigned char* X = smem + p.offX;                    // [NP][XROW]: bf16 planes (or fp32 rows) / in-place fp32 b
+    constexpr int XROW = xrow<XP>();
     float* A = reinterpret_cast<float*>(smem + p.offA);
     float* D = reinterpret_cast<float*>(smem + p.offD);
     float* xx = reinterpret_cast<float*>(smem + p.offXX);
@@ -974,11 +1081,11 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                         for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
                     }
                 }
-                float4* xr = reinterpret_cast<float4*>(X + tid * PX);
-                xr[0] = r0;
-                xr[1] = r1;
-                xr[2] = r2;
-                xr[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned char* xr = X + tid * XROW;
+                xstore<XP>(xr, 0, r0);
+                xstore<XP>(xr, 4, r1);
+                xstore<XP>(xr, 8, r2);
+                xstore<XP>(xr, 12, make_float4(0.f, 0.f, 0.f, 0.f));
                 xx[tid] = s;
             }
             __syncthreads();
@@ -994,17 +1101,17 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             if (skip & 4) {
             } else if (p.overlap) {
                 if (k64)
-                    gram_tiles_sym<4>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<4, XP>(X, xx, D, p.pitchD, N, nrt, wave);
                 else
-                    gram_tiles_sym<1>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<1, XP>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
                 const int nti = rows_chunk >> 4;
                 for (int tile = wave; tile < nti * nrt; tile += NW) {
                     const int ti = tile / nrt, tj = tile - ti * nrt;
                     if (k64)
-                        gram_tile<4>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
+                        gram_tile<4, XP>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
                     else
-                        gram_tile<1>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
+                        gram_tile<1, XP>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
                 }
             }
             __syncthreads();
@@ -1025,10 +1132,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         if (prof && p.overlap) atomicAdd(&prof_buf[1], (unsigned long long)(clock64() - t_prev));   // selection alone
         // per-node GEMMs (MFMA): no barrier needed after the selection - they only touch X rows owned by the wave and A
         // (unless A doubles as the key matrix)
-        if (p.alias_da) __syncthreads();
+        if (p.overlap) __syncthreads();
         if (!(skip & 2)) {
             const unsigned long long t_gemm0 = prof ? clock64() : 0ull;
-            gemm_layer<LEAN>(X, A, p.pitchA, kp.w.wf[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
+            gemm_layer<LEAN, XP>(X, A, p.pitchA, kp.w.wb[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
             if (prof) atomicAdd(&prof_buf[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
         }
         __syncthreads();  // neighbour lists, A and b (in X) are complete
@@ -1036,8 +1143,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
 
         // ---- gather-max over the k neighbours: cout/4 lanes per row, 4 channels (16 B) per lane
         {
-            float* ydst = L == 2 ? park : (L == 5 ? X + 32 : X);
-            const int ypitch = L == 2 ? PP : PX;
+            const int ych = L == 5 ? 32 : 0;             // sem3 lands in channels 32..63 (xyz3 is un-parked below)
             const int lpr = cout >> 2;                   // lanes per row: 16 or 8
             const int rpw = 64 / lpr;                    // rows per wave-iteration: 4 or 8
             const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
@@ -1051,8 +1157,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                 float4 ma, mb;
                 gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
                             reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
-                const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * PX + c4), ia < N);
-                const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * PX + c4), ib < N);
+                const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * XROW + 4 * c4), ia < N);
+                const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * XROW + 4 * c4), ib < N);
                 if (dbg) {
                     if (ia < N) {
                         *reinterpret_cast<float4*>(dbg + (size_t)ia * 64 + c4) = ya;
@@ -1063,8 +1169,15 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                         if (cout == 32) *reinterpret_cast<float4*>(dbg + (size_t)ib * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-                *reinterpret_cast<float4*>(ydst + (size_t)ia * ypitch + c4) = ya;
-                if (hasb) *reinterpret_cast<float4*>(ydst + (size_t)ib * ypitch + c4) = yb;
+                // the next layer's operand: three bf16 planes over the row's own (already consumed) b; all lanes
+                // of a row sit in one wave, whose LDS reads above precede these writes
+                if (L == 2) {
+                    *reinterpret_cast<float4*>(park + (size_t)ia * PP + c4) = ya;
+                    if (hasb) *reinterpret_cast<float4*>(park + (size_t)ib * PP + c4) = yb;
+                } else {
+                    xstore<XP>(X + ia * XROW, ych + c4, ya);
+                    if (hasb) xstore<XP>(X + ib * XROW, ych + c4, yb);
+                }
                 if (want_norm) {                          // squared norms of the next layer's input rows (cout == 64: 16 lanes/row)
                     float sa = fmaf(ya.x, ya.x, fmaf(ya.y, ya.y, fmaf(ya.z, ya.z, ya.w * ya.w)));
                     float sb = fmaf(yb.x, yb.x, fmaf(yb.y, yb.y, fmaf(yb.z, yb.z, yb.w * yb.w)));
@@ -1088,29 +1201,28 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
 
     // conv_end weights of this wave's first tile: in flight while xyz3 is moved back
-    float4 wf_end[4];
+    Frag wf_end[2];
     int ct_end = wave & 1;
-    load_frag<4>(kp.w.wf_end + (size_t)(ct_end * 16 + l15) * 64 + 4 * lq, wf_end);
+    load_wfrag<4>(kp.w.wb_end + (size_t)ct_end * wtile<4>(), wf_end);
     float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct_end * 16 + 4 * lq);
     for (int e = tid; e < NP * 8; e += NT) {                      // xyz3 -> channels 0..31: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
-        *reinterpret_cast<float4*>(X + i * PX + c4) = *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4);
+        xstore<XP>(X + i * XROW, c4, *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4));
     }
     __syncthreads();
 
     // ---- conv_end: 64 -> 32, folded BN, LeakyReLU  -> E (in the A region)
     float* E = A;
     {
-        const float* __restrict__ Wf = kp.w.wf_end;
         for (int task = wave; task < 2 * nrt; task += NW) {
             const int ct = task & 1, rt = task >> 1;      // NW even: ct == wave & 1 for every task of this wave
             if (ct != ct_end) {                           // odd wave counts (192-thread workgroups) alternate
                 ct_end = ct;
-                load_frag<4>(Wf + (size_t)(ct * 16 + l15) * 64 + 4 * lq, wf_end);
+                load_wfrag<4>(kp.w.wb_end + (size_t)ct * wtile<4>(), wf_end);
                 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct * 16 + 4 * lq);
             }
-            float4 xf[4];
-            load_frag<4>(X + (rt * 16 + l15) * PX + 4 * lq, xf);
+            Frag xf[2];
+            xload<4, XP>(X + (rt * 16 + l15) * XROW, lq, xf);
             const f32x4 acc = tile16<4>(wf_end, xf);
             const int c4 = ct * 16 + 4 * lq;
             float4 e4 = make_float4(acc[0] + t4_end.x, acc[1] + t4_end.y, acc[2] + t4_end.z, acc[3] + t4_end.w);
@@ -1192,19 +1304,26 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
 #undef SGPR_PROF
 }
 
-template <int KP, int DBG, bool LEAN>
+template <int KP, int DBG, bool LEAN, bool XP>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, DBG, LEAN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, DBG, LEAN, XP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, XP>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
+}
+
+template <int KP, int DBG>
+static int launch_layout(const EmbedPlan& plan, const KParams& kp, hipStream_t stream) {
+    if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, true, true>(kp, stream);   // lean plans are planes-only
+    if (plan.xplanes) return launch_t<KP, DBG, false, true>(kp, stream);
+    return launch_t<KP, DBG, false, false>(kp, stream);
 }
 
 int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a, hipStream_t stream) {
@@ -1214,14 +1333,13 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.p = plan;
     kp.a = a;
     if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
-    const bool dump = a.dbg_layers || a.dbg_knn, prof = a.prof || a.skip;
-    if (dump) return plan.kp == 16 ? launch_t<16, 2, false>(kp, stream) : launch_t<32, 2, false>(kp, stream);
-    if (prof) {   // profiling / ablation keeps the production occupancy of capped plans
-        if (plan.alias_da) return plan.kp == 16 ? launch_t<16, 1, true>(kp, stream) : launch_t<32, 1, true>(kp, stream);
-        return plan.kp == 16 ? launch_t<16, 1, false>(kp, stream) : launch_t<32, 1, false>(kp, stream);
-    }
-    if (plan.alias_da) return plan.kp == 16 ? launch_t<16, 0, true>(kp, stream) : launch_t<32, 0, true>(kp, stream);
-    return plan.kp == 16 ? launch_t<16, 0, false>(kp, stream) : launch_t<32, 0, false>(kp, stream);
+    // layer / kNN dumps run on the roomy instance; timers and ablation keep the production occupancy
+    const int mode = (a.dbg_layers || a.dbg_knn) ? 2 : ((a.prof || a.skip) ? 1 : 0);
+    if (plan.kp == 16)
+        return mode == 2 ? launch_layout<16, 2>(plan, kp, stream)
+                         : (mode == 1 ? launch_layout<16, 1>(plan, kp, stream) : launch_layout<16, 0>(plan, kp, stream));
+    return mode == 2 ? launch_layout<32, 2>(plan, kp, stream)
+                     : (mode == 1 ? launch_layout<32, 1>(plan, kp, stream) : launch_layout<32, 0>(plan, kp, stream));
 }
 
 }  // namespace sgpr

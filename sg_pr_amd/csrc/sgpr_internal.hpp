@@ -21,11 +21,16 @@ constexpr int kKPad = 16;  // layer-1 inputs (3 / 12 channels) are zero-padded t
 //                                      rows [cout,2cout)  = s * (W[:, C:] - W[:, :C])  (acts on x_i)
 //     tb[l] : [cout] = beta - mean * s,  s = gamma / sqrt(var + 1e-5)   (eval BatchNorm folded)
 struct DevWeights {
-    const float* wf[6];
+    const float* wf[6];             // folded fp32 weights [2*cout][kp] (a rows, then b rows); host-side source of wb
+    // the same weights as three bf16 planes (w = hi + mid + lo, exact to 24 bits) in MFMA operand order:
+    // [column tile][k-step][plane][lane][8]  (lane = 16*lq + l15 holds row ct*16 + l15, k = 32*step + 8*lq + 0..7;
+    // first layers, K = 16: one step, k = 4*lq + 0..3 then four zeros)
+    const unsigned short* wb[6];
     const float* tb[6];
     int kp[6];
     int cout[6];
     const float* wf_end;  // [32][64] folded
+    const unsigned short* wb_end;   // conv_end in the wb layout (2 column tiles, 2 k-steps)
     const float* tb_end;  // [32]
     const float* att_w;   // [32][32]
     const float* ntn_w;   // [32][32*16]   (weight_matrix.view(F3,-1), col = j*16 + t)
@@ -65,8 +70,10 @@ struct EmbedPlan {
     int pitchA;      // floats per row of the gather target A
     int overlap;     // 1: key matrix resident, selection (half the waves) overlaps the GEMMs (other half)
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
-    int alias_da;    // 1: the key matrix D shares the A region (a barrier separates selection and GEMMs), one wave per
-                     //    16-row tile, 12 waves per CU, launched on the <= 168-VGPR kernel instance
+    int alias_da;    // 1: the key matrix / chunk D shares the A region (a barrier separates selection and GEMMs)
+    int lean;        // 1: NP <= 64 - one wave per 16-row tile, weight-stationary GEMMs, <= 168-VGPR kernel instance
+    int xplanes;     // 1: X rows are three bf16 planes (400 B); 0: fp32 rows (272 B) split when loaded (N > 208)
+    int rowb;        // bytes per X row
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
 };
