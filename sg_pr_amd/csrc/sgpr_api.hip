@@ -214,8 +214,9 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         delete h;
         return hip_fail(e, "sgpr_create: device allocation / upload");
     }
-    // blob order is s1,f1,s2,f2,s3,f3 ; kernel order is s1,s2,s3,f1,f2,f3
-    static const int blob_of_layer[6] = {0, 2, 4, 1, 3, 5};
+    // blob order is s1,f1,s2,f2,s3,f3 ; kernel order is f1,f2,f3,s1,s2,s3 (the semantic branch runs first: its 12
+    // input registers per thread die after the first staging, the 3 xyz registers wait for the second)
+    static const int blob_of_layer[6] = {1, 3, 5, 0, 2, 4};
     for (int l = 0; l < 6; ++l) {
         const int b = blob_of_layer[l];
         h->w.wf[l] = h->d_blob + off_wf[b];

@@ -33,7 +33,7 @@ constexpr int PXB = 400;      // BYTES per row of X: three bf16 planes of 64 cha
                               // (64 fp32 = 256 B) later overlays the row in place
 constexpr int PXF = 272;      // bytes per row of X in the fp32 layout (64 ch + 4 floats) of plans too large for the planes
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
-constexpr int PP = 32;        // floats per row of the parked xyz3 block
+constexpr int PP = 32;        // floats per row of the parked sem3 block (output of the first branch)
 constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
 constexpr int CAP = 64;       // candidates per lane in the selection phase
 constexpr int kRedBytes = 1536;   // attention partial sums (8 x 32) + mean + tanh vector; duplicate-run scratch
@@ -135,24 +135,30 @@ __device__ __forceinline__ f32x4 mfma_b(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ f32x4 mfma6(const Frag& a, const Frag& b, f32x4 acc) {
-    acc = mfma_b(a.l, b.h, acc);
-    acc = mfma_b(a.h, b.l, acc);
-    acc = mfma_b(a.m, b.m, acc);
-    acc = mfma_b(a.m, b.h, acc);
-    acc = mfma_b(a.h, b.m, acc);
-    return mfma_b(a.h, b.h, acc);
-}
-
-// 16x16 output tile, K = 16*NKB (NKB = 4: two k-steps, two accumulators; NKB = 1: one half-filled k-step)
+// 16x16 output tile, K = 16*NKB (NKB = 4: two k-steps; NKB = 1: one half-filled k-step).
+// The matrix core aligns the 32 products of an instruction and its C operand to the largest exponent and drops what
+// falls below fp32 precision, so the correction terms must never meet a large accumulator: they get a chain of their
+// own (2^-16 terms first, then the 2^-8 terms), the hi.hi products another, and the two sums meet in ONE fp32 add.
+// Error ~ 4 ulp of the result - tighter than a sequential fp32 dot product.  Dependent back-to-back MFMAs issue every
+// 18 cycles; more, shorter chains would be slower (tools/probes/mfma_chain_probe.hip).
 template <int NKB>
 __device__ __forceinline__ f32x4 tile16(const Frag (&a)[2], const Frag (&b)[2]) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-    acc0 = mfma6(a[0], b[0], acc0);
-    if (NKB == 1) return acc0;
-    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-    acc1 = mfma6(a[1], b[1], acc1);
-    return acc0 + acc1;
+    constexpr int NS = NKB == 1 ? 1 : 2;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        lo = mfma_b(a[st].l, b[st].h, lo);
+        lo = mfma_b(a[st].h, b[st].l, lo);
+        lo = mfma_b(a[st].m, b[st].m, lo);
+    }
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        lo = mfma_b(a[st].m, b[st].h, lo);
+        lo = mfma_b(a[st].h, b[st].m, lo);
+    }
+#pragma unroll
+    for (int st = 0; st < NS; ++st) hi = mfma_b(a[st].h, b[st].h, hi);
+    return hi + lo;
 }
 
 // X operand of row `row` (byte pointer to the row): channels 32*step + 8*lq + 0..7 (NKB = 4), or channels
@@ -771,22 +777,20 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     int ctb0 = wave;
     while (ctb0 < NCA) ctb0 += NW;
     const int ctb1 = ctb0 + NW;
-    Frag w[2], wn[2], xf[2], xn[2];
+    Frag w[2], wn[2], xf[2];      // no operand double-buffering for X: registers are the scarce resource here
     f32x4 k0[4], k1[4];
     // ---- a-tiles
     int ct = wave;
     if (ct < NCA) load_wfrag<NKB>(Wb + (size_t)ct * wtile<NKB>(), w);
     else if (ctb0 < NCT) load_wfrag<NKB>(Wb + (size_t)ctb0 * wtile<NKB>(), w);
-    load_xfrag<NKB>(xp, lq, xf);
     for (; ct < NCA; ct += NW) {
         const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
         if (cn < NCT) load_wfrag<NKB>(Wb + (size_t)cn * wtile<NKB>(), wn);
         float* ap = A + l15 * pitchA + ct * 16 + 4 * lq;
         for (int rt = 0; rt < nrt; ++rt) {
-            load_xfrag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PXB, lq, xn);   // next row tile (wraps to tile 0)
+            load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
             const f32x4 r = tile16<NKB>(w, xf);              // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
             *reinterpret_cast<float4*>(ap + rt * 16 * pitchA) = make_float4(r[0], r[1], r[2], r[3]);
-            copy_frag<NKB>(xf, xn);
         }
         copy_frag<NKB>(w, wn);
     }
@@ -799,9 +803,8 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
-                load_xfrag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PXB, lq, xn);
+                load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
                 k0[rt] = tile16<NKB>(w, xf) + t;
-                copy_frag<NKB>(xf, xn);
             }
     }
     if (has1) {
@@ -810,9 +813,8 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
-                load_xfrag<NKB>(xp + (rt + 1 < nrt ? rt + 1 : 0) * 16 * PXB, lq, xn);
+                load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
                 k1[rt] = tile16<NKB>(wn, xf) + t;
-                copy_frag<NKB>(xf, xn);
             }
     }
     __syncthreads();                                             // every wave is done reading X
@@ -857,7 +859,7 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
     tj = r + t;
 }
 
-template <int NKB, bool XP>
+template <int NKB, bool XP, bool PF>   // PF: fetch the next tile's operands during this tile's MFMAs (48 more VGPRs)
 __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__ X, const float* __restrict__ xx,
                                                float* __restrict__ D, int pitchD, int N, int nrt, int wave) {
     const int lane = threadIdx.x & 63;
@@ -877,8 +879,10 @@ __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__
         Frag an[2], bn[2];
         if (more) {                                   // operands of the next tile in flight during this tile's MFMAs
             tri_decode(tn, nrt, tin, tjn);
-            xload<NKB, XP>(X + (tin * 16 + l15) * xrow<XP>(), lq, an);
-            xload<NKB, XP>(X + (tjn * 16 + l15) * xrow<XP>(), lq, bn);
+            if (PF) {
+                xload<NKB, XP>(X + (tin * 16 + l15) * xrow<XP>(), lq, an);
+                xload<NKB, XP>(X + (tjn * 16 + l15) * xrow<XP>(), lq, bn);
+            }
         }
         const f32x4 g = tile16<NKB>(a, b);            // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
         const int i0 = ti * 16, j = tj * 16 + l15;
@@ -897,8 +901,13 @@ __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__
                 fmaf(-2.f, g[0], xi.x), fmaf(-2.f, g[1], xi.y), fmaf(-2.f, g[2], xi.z), fmaf(-2.f, g[3], xi.w));
         }
         if (!more) break;
-        copy_frag<NKB>(a, an);
-        copy_frag<NKB>(b, bn);
+        if (PF) {
+            copy_frag<NKB>(a, an);
+            copy_frag<NKB>(b, bn);
+        } else {
+            xload<NKB, XP>(X + (tin * 16 + l15) * xrow<XP>(), lq, a);
+            xload<NKB, XP>(X + (tjn * 16 + l15) * xrow<XP>(), lq, b);
+        }
         t = tn;
         ti = tin;
         tj = tjn;
@@ -969,12 +978,15 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     const int skip = DBG ? kp.a.skip : 0;
     float* const dbg_layers = DBG == 2 ? kp.a.dbg_layers : nullptr;
     int32_t* const dbg_knn_all = DBG == 2 ? kp.a.dbg_knn : nullptr;
-    const bool prof = prof_buf != nullptr && tid == 0;
+    // timers live in scalar registers of wave 0 and reach memory once, at the end of the kernel: per-phase global
+    // atomics from 4541 workgroups onto 8 addresses would triple the kernel time
+    const bool prof = prof_buf != nullptr && __builtin_amdgcn_readfirstlane(wave) == 0;
+    unsigned long long pacc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     if (prof) t_prev = clock64();
 #define SGPR_PROF(ph)                                            \
     if (prof) {                                                  \
         const unsigned long long t_now = clock64();              \
-        atomicAdd(&prof_buf[ph], t_now - t_prev);               \
+        pacc[ph] += t_now - t_prev;                              \
         t_prev = t_now;                                          \
     }
 
@@ -1070,7 +1082,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                 float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
                 float s = 0.f;
                 if (tid < N) {
-                    if (L == 0) {
+                    if (L == 3) {
                         r0 = make_float4(fx, fy, fz, 0.f);
                         s = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
                     } else {
@@ -1093,7 +1105,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         }
         const int Kp = kp.w.kp[L], cout = kp.w.cout[L];
         const bool k64 = Kp == 64;
-        int32_t* dbg_knn = dbg_knn_all ? dbg_knn_all + ((size_t)g * 6 + L) * NS * p.k : nullptr;
+        const int Ldump = L < 3 ? L + 3 : L - 3;     // dumps keep the reference's order: xyz1..3, sem1..3
+        int32_t* dbg_knn = dbg_knn_all ? dbg_knn_all + ((size_t)g * 6 + Ldump) * NS * p.k : nullptr;
         // ---- kNN keys (Gram on MFMA) -> selection, one chunk of rows at a time (a single chunk, upper-triangular
         //      tiles mirrored, when the whole key matrix is resident)
         for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
@@ -1101,9 +1114,9 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             if (skip & 4) {
             } else if (p.overlap) {
                 if (k64)
-                    gram_tiles_sym<4, XP>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<4, XP, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
                 else
-                    gram_tiles_sym<1, XP>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<1, XP, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
                 const int nti = rows_chunk >> 4;
                 for (int tile = wave; tile < nti * nrt; tile += NW) {
@@ -1118,37 +1131,27 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             SGPR_PROF(2)
             if (!(skip & 1)) {
                 if (skip & 64)   // A/B: sorting-network selection
-                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
+                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
                 else if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, prof_buf ? prof_buf + 8 : nullptr);
+                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
                 else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
             }
-            if (!p.overlap) {
-                __syncthreads();                      // the key chunk is reused
-                SGPR_PROF(3)
-            }
+            __syncthreads();                          // the key matrix / chunk is reused (next chunk, or A)
+            SGPR_PROF(1)
         }
-        if (prof && p.overlap) atomicAdd(&prof_buf[1], (unsigned long long)(clock64() - t_prev));   // selection alone
-        // per-node GEMMs (MFMA): no barrier needed after the selection - they only touch X rows owned by the wave and A
-        // (unless A doubles as the key matrix)
-        if (p.overlap) __syncthreads();
-        if (!(skip & 2)) {
-            const unsigned long long t_gemm0 = prof ? clock64() : 0ull;
-            gemm_layer<LEAN, XP>(X, A, p.pitchA, kp.w.wb[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
-            if (prof) atomicAdd(&prof_buf[4], (unsigned long long)(clock64() - t_gemm0));  // GEMMs alone
-        }
+        // per-node GEMMs (MFMA); A overwrites the key matrix
+        if (!(skip & 2)) gemm_layer<LEAN, XP>(X, A, p.pitchA, kp.w.wb[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
         // ---- gather-max over the k neighbours: cout/4 lanes per row, 4 channels (16 B) per lane
         {
-            const int ych = L == 5 ? 32 : 0;             // sem3 lands in channels 32..63 (xyz3 is un-parked below)
             const int lpr = cout >> 2;                   // lanes per row: 16 or 8
             const int rpw = 64 / lpr;                    // rows per wave-iteration: 4 or 8
             const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
             const bool want_norm = (L != 2 && L != 5);
-            float* dbg = dbg_layers ? dbg_layers + ((size_t)g * 6 + L) * NS * 64 : nullptr;
+            float* dbg = dbg_layers ? dbg_layers + ((size_t)g * 6 + Ldump) * NS * 64 : nullptr;
             const int rstep = NW * rpw;
             for (int ia = wave * rpw + sub; ia < ((skip & 8) ? 0 : NP); ia += 2 * rstep) {
                 const int ib = ia + rstep;
@@ -1175,8 +1178,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                     *reinterpret_cast<float4*>(park + (size_t)ia * PP + c4) = ya;
                     if (hasb) *reinterpret_cast<float4*>(park + (size_t)ib * PP + c4) = yb;
                 } else {
-                    xstore<XP>(X + ia * XROW, ych + c4, ya);
-                    if (hasb) xstore<XP>(X + ib * XROW, ych + c4, yb);
+                    xstore<XP>(X + ia * XROW, c4, ya);
+                    if (hasb) xstore<XP>(X + ib * XROW, c4, yb);
                 }
                 if (want_norm) {                          // squared norms of the next layer's input rows (cout == 64: 16 lanes/row)
                     float sa = fmaf(ya.x, ya.x, fmaf(ya.y, ya.y, fmaf(ya.z, ya.z, ya.w * ya.w)));
@@ -1200,14 +1203,14 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         SGPR_PROF(5)
     }
 
-    // conv_end weights of this wave's first tile: in flight while xyz3 is moved back
+    // conv_end weights of this wave's first tile: in flight while sem3 is moved back
     Frag wf_end[2];
     int ct_end = wave & 1;
     load_wfrag<4>(kp.w.wb_end + (size_t)ct_end * wtile<4>(), wf_end);
     float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct_end * 16 + 4 * lq);
-    for (int e = tid; e < NP * 8; e += NT) {                      // xyz3 -> channels 0..31: X = cat(xyz3, sem3)
+    for (int e = tid; e < NP * 8; e += NT) {                      // sem3 -> channels 32..63: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
-        xstore<XP>(X + i * XROW, c4, *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4));
+        xstore<XP>(X + i * XROW, 32 + c4, *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4));
     }
     __syncthreads();
 
@@ -1302,6 +1305,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
     SGPR_PROF(7)
 #undef SGPR_PROF
+    if (prof && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) atomicAdd(&prof_buf[q], pacc[q]);
+    }
 }
 
 template <int KP, int DBG, bool LEAN, bool XP>

@@ -181,23 +181,29 @@ class Engine:
     def lds_bytes(self, node_num, k):
         return int(self.lib.sgpr_embed_lds_bytes(self._h, node_num, k))
 
-    PHASES = ["stage", "select_only", "gram", "select||gemm", "gemm_only", "gather", "conv_end", "attention"]
+    PHASES = ["stage", "select", "gram", "gemm", "-", "gather", "conv_end", "attention"]
 
-    def phase_profile(self, centers, labels, k, reps=3, node_cap=0):
-        """Debug: fraction of workgroup cycles per phase of the embed kernel (thread-0 clocks)."""
+    def phase_profile(self, centers, labels, k, reps=3, node_cap=0, order=None, select_split=False):
+        """Debug: workgroup cycles per phase of the embed kernel (thread-0 clocks at the barriers, on the profile
+        instance of the kernel).  select_split adds timers inside the selection (they perturb it)."""
         buf = torch.zeros(16, dtype=torch.int64, device=self.device)
         self.lib.sgpr_debug_set_profile_buffer(_ptr(buf))
+        self.lib.sgpr_debug_set_skip_mask(128 if select_split else 0)
         try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             for _ in range(reps):
-                self.embed(centers, labels, k, node_cap=node_cap)
+                self.embed(centers, labels, k, node_cap=node_cap, order=order)
+            e1.record()
             torch.cuda.synchronize(self.device)
+            self.last_profile_ms = e0.elapsed_time(e1) / reps     # launch time WITH the timers running
         finally:
             self.lib.sgpr_debug_set_profile_buffer(None)
+            self.lib.sgpr_debug_set_skip_mask(0)
         call = buf.cpu().numpy().astype(np.float64)
         self.last_select_split = call[8:14]   # load, sort, merge, tau+masks, prefix, emit (thread-0 cycles)
         c = call[:8]
-        tot = c.sum() - c[1] - c[4]   # slots 1 and 4 are sub-timers of slot 3
-        return dict(zip(self.PHASES, c / max(tot, 1.0))), c
+        return dict(zip(self.PHASES, c / max(c.sum(), 1.0))), c
 
     def check_status(self):
         self._check(self.lib.sgpr_check_status(self._h, self._stream()))

@@ -14,11 +14,10 @@ for name, (n, k, g) in {"kitti00": (100, 10, 4541), "pairs128": (64, 10, 256), "
         c, l, _, _ = synth.kitti_like_sequence(g, n, 0)
     else:
         c, l, _ = synth.make_graphs(g, n, n // 3, n - k, 0)
-    cap = eng.node_cap_of(c, l, k)
+    order, cap = eng.size_order(c, l, k)
     c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
-    eng.embed(c, l, k, node_cap=cap)
-    frac, cyc = eng.phase_profile(c, l, k, node_cap=cap)
-    print(name, "N=%d k=%d G=%d" % (n, k, g), " ".join("%s=%.1f%%" % (p, 100 * f) for p, f in frac.items()),
-          "| cycles/graph=%.0f" % ((cyc.sum() - cyc[1] - cyc[4]) / 3 / g))
-    ss = eng.last_select_split / 3 / g / 6
-    print("   select per layer (cycles): load %.0f sort %.0f merge %.0f tau+masks %.0f prefix %.0f emit %.0f" % tuple(ss))
+    eng.embed(c, l, k, node_cap=cap, order=order)
+    frac, cyc = eng.phase_profile(c, l, k, node_cap=cap, order=order)
+    print(name, "N=%d k=%d G=%d" % (n, k, g), " ".join("%s=%.1f%%" % (p, 100 * f) for p, f in frac.items() if p != "-"),
+          "| cycles/graph=%.0f  launch %.3f ms with timers" % (cyc.sum() / 3 / g, eng.last_profile_ms))
+    print("   cycles per graph:", " ".join("%s=%.0f" % (p, v / 3 / g) for p, v in zip(eng.PHASES, cyc) if p != "-"))
