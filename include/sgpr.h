@@ -154,13 +154,16 @@ int sgpr_check_status(const sgpr_handle* h, void* stream);
 /* LDS bytes / threads per workgroup the embed kernel uses for (N, k); 0 if unsupported. */
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 
-/* Debug: when set to a device array of 16 uint64 counters (8..13 = sub-phases of the selection), sgpr_embed* adds the shader cycles
- * thread 0 of every workgroup spends in each phase (0 stage, 1 norms, 2 Gram, 3 select,
- * 4 GEMM, 5 gather-max, 6 conv_end, 7 attention).  NULL (default) disables it. */
+/* Debug: when set to a device array of 16 uint64 counters, sgpr_embed* runs its profiling instance and adds the
+ * shader cycles wave 0 of every workgroup spends in each phase, barrier to barrier (0 stage, 1 select, 2 Gram,
+ * 3 GEMM, 5 gather-max, 6 conv_end, 7 attention; 8..13 = sub-phases of the selection in sgpr_embed_debug with mask
+ * bit 7).  The timers perturb the kernel (~1.6x); use the ablation mask for magnitudes.  NULL (default) disables. */
 void sgpr_debug_set_profile_buffer(void* d_counters);
 
-/* Debug / ablation timing only (results become invalid): bit 0 skips the kNN selection, bit 1 the
- * per-node GEMMs, bit 2 the Gram phase, bit 3 the gather-max of sgpr_embed*.  0 (default) = normal. */
+/* Debug / ablation timing only (results become invalid): bit 0 skips the kNN selection, bit 1 the per-node GEMMs,
+ * bit 2 the Gram phase, bit 3 the gather-max; bit 4 returns right after dispatch, bit 5 after the input fetch;
+ * bit 8 = nothing skipped (just selects the profiling instance); bits 9/10/11 keep the GEMM phase but drop its weight
+ * loads / its MFMAs / its inner barrier.  0 (default) = normal. */
 void sgpr_debug_set_skip_mask(int mask);
 
 const char* sgpr_last_error(void);

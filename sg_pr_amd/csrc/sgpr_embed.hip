@@ -187,6 +187,10 @@ template <int NKB>
 __device__ __forceinline__ constexpr int wtile() { return (NKB == 1 ? 1 : 2) * 3 * 512; }
 template <int NKB>
 __device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, Frag (&f)[2]) {
+    if (tile == nullptr) {
+        for (int st = 0; st < 2; ++st) { f[st].h = bf16x8{1,2,3,4,5,6,7,8}; f[st].m = f[st].h; f[st].l = f[st].h; }
+        return;
+    }
     const unsigned short* p = tile + (threadIdx.x & 63) * 8;
 #pragma unroll
     for (int st = 0; st < (NKB == 1 ? 1 : 2); ++st) {
@@ -737,7 +741,7 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
     f32x4 b0[NCA], b1[NCA];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        if (ct + 1 < NCT) load_wfrag<NKB>(Wb + (size_t)(ct + 1) * wtile<NKB>(), wn);
+        if (ct + 1 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)(ct + 1) * wtile<NKB>() : nullptr, wn);
         // r[c] = out[channel ct*16 + 4lq + c][node rt*16 + l15]
         const f32x4 r0 = tile16<NKB>(w, xf0);
         f32x4 r1 = r0;
@@ -768,7 +772,7 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
 template <int NKB, int COUT>
 __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
-                                          int wave, int NW) {
+                                          int wave, int NW, int ex = 0) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int NCA = COUT / 16, NCT = 2 * NCA;
@@ -781,15 +785,15 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     f32x4 k0[4], k1[4];
     // ---- a-tiles
     int ct = wave;
-    if (ct < NCA) load_wfrag<NKB>(Wb + (size_t)ct * wtile<NKB>(), w);
-    else if (ctb0 < NCT) load_wfrag<NKB>(Wb + (size_t)ctb0 * wtile<NKB>(), w);
+    if (ct < NCA) load_wfrag<NKB>(Wb ? Wb + (size_t)ct * wtile<NKB>() : nullptr, w);
+    else if (ctb0 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb0 * wtile<NKB>() : nullptr, w);
     for (; ct < NCA; ct += NW) {
         const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
-        if (cn < NCT) load_wfrag<NKB>(Wb + (size_t)cn * wtile<NKB>(), wn);
+        if (cn < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)cn * wtile<NKB>() : nullptr, wn);
         float* ap = A + l15 * pitchA + ct * 16 + 4 * lq;
         for (int rt = 0; rt < nrt; ++rt) {
             load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
-            const f32x4 r = tile16<NKB>(w, xf);              // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
+            const f32x4 r = (ex & 1024) ? f32x4{1.f, 2.f, 3.f, 4.f} : tile16<NKB>(w, xf);              // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
             *reinterpret_cast<float4*>(ap + rt * 16 * pitchA) = make_float4(r[0], r[1], r[2], r[3]);
         }
         copy_frag<NKB>(w, wn);
@@ -797,14 +801,14 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     // ---- b-tiles: results stay in registers (row-tile loop unrolled: register arrays need static indices)
     const bool has0 = ctb0 < NCT, has1 = ctb1 < NCT;
     if (has0) {
-        if (has1) load_wfrag<NKB>(Wb + (size_t)ctb1 * wtile<NKB>(), wn);
+        if (has1) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb1 * wtile<NKB>() : nullptr, wn);
         const float4 t4 = *reinterpret_cast<const float4*>(tb + (ctb0 - NCA) * 16 + 4 * lq);
         const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
                 load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
-                k0[rt] = tile16<NKB>(w, xf) + t;
+                k0[rt] = ((ex & 1024) ? f32x4{1.f, 2.f, 3.f, 4.f} : tile16<NKB>(w, xf)) + t;
             }
     }
     if (has1) {
@@ -814,10 +818,10 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
                 load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
-                k1[rt] = tile16<NKB>(wn, xf) + t;
+                k1[rt] = ((ex & 1024) ? f32x4{1.f, 2.f, 3.f, 4.f} : tile16<NKB>(wn, xf)) + t;
             }
     }
-    __syncthreads();                                             // every wave is done reading X
+    if (!(ex & 2048)) __syncthreads();                                             // every wave is done reading X
     unsigned char* bp = X + l15 * PXB + 16 * lq;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -829,14 +833,14 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
 
 template <bool COLS, bool XP>
 __device__ __forceinline__ void gemm_layer(unsigned char* X, float* A, int pitchA, const unsigned short* Wb,
-                                           const float* tb, int Kp, int cout, int nrt, int gw, int GW) {
+                                           const float* tb, int Kp, int cout, int nrt, int gw, int GW, int ex = 0) {
     if (COLS) {   // capped plans: nrt <= 4, GW >= 2 (make_embed_plan); contains a barrier - every wave calls it
         if (Kp != 64)
-            gemm_cols<1, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW);
+            gemm_cols<1, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         else if (cout == 64)
-            gemm_cols<4, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW);
+            gemm_cols<4, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         else
-            gemm_cols<4, 32>(X, A, pitchA, Wb, tb, nrt, gw, GW);
+            gemm_cols<4, 32>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         return;
     }
     if (Kp != 64)
@@ -917,6 +921,14 @@ __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__
 // ------------------------------------------------------------------ gather-max over the k neighbours
 // cout/4 lanes own one row (4 channels each, 16-B LDS reads); nw = the row's u16 offsets, two per word.
 // Two rows per call so that twice as many independent LDS reads are in flight.
+// two maxima in one instruction; inline asm because fmaxf(fmaxf()) first canonicalises every LDS-loaded operand
+// (operands come from ds_read, never from an MFMA: no hazard the assembler-level scheduler would have to know about)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const uint32_t* __restrict__ nwa,
                                             const uint32_t* __restrict__ nwb, int k, float4& ma, float4& mb) {
     ma = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -932,14 +944,14 @@ __device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const 
         const float4 va1 = *reinterpret_cast<const float4*>(A4 + a1);
         const float4 vb0 = *reinterpret_cast<const float4*>(A4 + b0);
         const float4 vb1 = *reinterpret_cast<const float4*>(A4 + b1);
-        ma.x = kmax(ma.x, kmax(va0.x, va1.x));
-        ma.y = kmax(ma.y, kmax(va0.y, va1.y));
-        ma.z = kmax(ma.z, kmax(va0.z, va1.z));
-        ma.w = kmax(ma.w, kmax(va0.w, va1.w));
-        mb.x = kmax(mb.x, kmax(vb0.x, vb1.x));
-        mb.y = kmax(mb.y, kmax(vb0.y, vb1.y));
-        mb.z = kmax(mb.z, kmax(vb0.z, vb1.z));
-        mb.w = kmax(mb.w, kmax(vb0.w, vb1.w));
+        ma.x = max3(ma.x, va0.x, va1.x);
+        ma.y = max3(ma.y, va0.y, va1.y);
+        ma.z = max3(ma.z, va0.z, va1.z);
+        ma.w = max3(ma.w, va0.w, va1.w);
+        mb.x = max3(mb.x, vb0.x, vb1.x);
+        mb.y = max3(mb.y, vb0.y, vb1.y);
+        mb.z = max3(mb.z, vb0.z, vb1.z);
+        mb.w = max3(mb.w, vb0.w, vb1.w);
     }
 }
 
@@ -1130,10 +1142,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             __syncthreads();
             SGPR_PROF(2)
             if (!(skip & 1)) {
-                if (skip & 64)   // A/B: sorting-network selection
-                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
-                else if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
+                if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
+                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
                 else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
             }
@@ -1141,7 +1151,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<LEAN, XP>(X, A, p.pitchA, kp.w.wb[L], kp.w.tb[L], Kp, cout, nrt, wave, NW);
+        if (!(skip & 2)) gemm_layer<LEAN, XP>(X, A, p.pitchA, (skip & 512) ? nullptr : kp.w.wb[L], kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 

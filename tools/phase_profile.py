@@ -20,4 +20,5 @@ for name, (n, k, g) in {"kitti00": (100, 10, 4541), "pairs128": (64, 10, 256), "
     frac, cyc = eng.phase_profile(c, l, k, node_cap=cap, order=order)
     print(name, "N=%d k=%d G=%d" % (n, k, g), " ".join("%s=%.1f%%" % (p, 100 * f) for p, f in frac.items() if p != "-"),
           "| cycles/graph=%.0f  launch %.3f ms with timers" % (cyc.sum() / 3 / g, eng.last_profile_ms))
+    print("   gemm split (first weights, a-tiles, b-tiles, barrier):", (eng.last_select_split[:4] / 3 / g).round())
     print("   cycles per graph:", " ".join("%s=%.0f" % (p, v / 3 / g) for p, v in zip(eng.PHASES, cyc) if p != "-"))
