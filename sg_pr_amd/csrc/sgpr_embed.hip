@@ -41,6 +41,15 @@ constexpr int kLdsLimit = 160 * 1024;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// threadIdx.x behind an opaque copy: every lane-derived address is then computed inside the phase that uses it.
+// Without it the optimizer hoists dozens of them out of the six-layer loop, where they live in - and spill from -
+// registers across all phases (the scratch traffic showed up as 440 MB of HBM writes per launch).
+__device__ __forceinline__ int phase_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // One layout attempt: X as bf16 planes (PXB bytes per row) or as fp32 rows (PXF, converted when loaded).
@@ -188,10 +197,11 @@ __device__ __forceinline__ constexpr int wtile() { return (NKB == 1 ? 1 : 2) * 3
 template <int NKB>
 __device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, Frag (&f)[2]) {
     if (tile == nullptr) {
-        for (int st = 0; st < 2; ++st) { f[st].h = bf16x8{1,2,3,4,5,6,7,8}; f[st].m = f[st].h; f[st].l = f[st].h; }
+        // ablation (mask bit 9): constant weights, no loads
+        f[0].h = f[0].m = f[0].l = f[1].h = f[1].m = f[1].l = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
         return;
     }
-    const unsigned short* p = tile + (threadIdx.x & 63) * 8;
+    const unsigned short* p = tile + (phase_tid() & 63) * 8;
 #pragma unroll
     for (int st = 0; st < (NKB == 1 ? 1 : 2); ++st) {
         f[st].h = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 0) * 512);
@@ -385,7 +395,7 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
                                              unsigned long long* __restrict__ prof8) {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = phase_tid(), lane = tid & 63;
     unsigned long long ts = (prof8 && tid == 0) ? clock64() : 0ull;
 #define SEL_STAMP(i)                                                   \
     if (prof8 && tid == 0) {                                           \
@@ -605,7 +615,8 @@ __device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np,
                                               const float* __restrict__ D, int rc0, int rows_chunk,
                                               unsigned short* __restrict__ nbr,
                                               int32_t* __restrict__ dbg_knn) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid_ = phase_tid();
+    const int lane = tid_ & 63, wave = tid_ >> 6;
     const int NW = blockDim.x >> 6;
     for (int rl = wave; rl < rows_chunk; rl += NW) {
         const int i = rc0 + rl;
@@ -719,7 +730,7 @@ template <int NKB, int COUT, bool XP>
 __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
                                           int gw, int GW) {
-    const int lane = threadIdx.x & 63;
+    const int lane = phase_tid() & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int NCA = COUT / 16;                   // a-type column tiles (= b-type column tiles)
     constexpr int NCT = 2 * NCA;
@@ -773,7 +784,7 @@ template <int NKB, int COUT>
 __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
                                           int wave, int NW, int ex = 0) {
-    const int lane = threadIdx.x & 63;
+    const int lane = phase_tid() & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int NCA = COUT / 16, NCT = 2 * NCA;
     const unsigned char* xp = X + l15 * PXB;
@@ -866,7 +877,7 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
 template <int NKB, bool XP, bool PF>   // PF: fetch the next tile's operands during this tile's MFMAs (48 more VGPRs)
 __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__ X, const float* __restrict__ xx,
                                                float* __restrict__ D, int pitchD, int N, int nrt, int wave) {
-    const int lane = threadIdx.x & 63;
+    const int lane = phase_tid() & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     const int ntiles = nrt * (nrt + 1) / 2;
     int t = wave;
@@ -979,8 +990,9 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     float* xx = reinterpret_cast<float*>(smem + p.offXX);
     float* red = reinterpret_cast<float*>(smem + p.offRed);
     unsigned short* nbr = reinterpret_cast<unsigned short*>(smem + p.offIdx);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: wave-uniform task loops and branches
+    int tid = tid0, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int g = kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x;
     const int NS = p.N;                                   // slots per graph in global memory
     float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * p.NP * PP;
@@ -1088,6 +1100,13 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         // k-derived predicates out of the layer loop
         int k = p.k;
         asm volatile("" : "+s"(k));
+        // same for the lane-derived addresses: re-derived per layer (a few VALU ops) instead of living in - and
+        // spilling from - dozens of registers across all phases
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        l15 = lane & 15;
+        lq = lane >> 4;
         if (L == 0 || L == 3) {
             // ---- stage this branch's input features (zero padded to 16 channels / NP rows) + squared norms
             if (tid < NP) {
