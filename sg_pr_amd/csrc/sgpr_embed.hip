@@ -1095,6 +1095,24 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
     const int seg = (((N + P - 1) / P) + 3) & ~3;
 
+    // ---- stage the first branch's input (12 semantic channels, zero padded to 16 / NP rows) + squared norms; done
+    //      ahead of the layer loop so that the 12 input registers die here instead of living across it
+    if (tid < NP) {
+        const bool live = tid < N;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned char* xr = X + tid * XROW;
+        xstore<XP>(xr, 0, live ? make_float4(sem[0], sem[1], sem[2], sem[3]) : z4);
+        xstore<XP>(xr, 4, live ? make_float4(sem[4], sem[5], sem[6], sem[7]) : z4);
+        xstore<XP>(xr, 8, live ? make_float4(sem[8], sem[9], sem[10], sem[11]) : z4);
+        xstore<XP>(xr, 12, z4);
+        xx[tid] = live ? s : 0.f;
+    }
+    __syncthreads();
+    SGPR_PROF(0)
+
     for (int L = 0; L < 6; ++L) {
         // per-iteration opaque copy: keeps the compiler from hoisting (and then spilling) dozens of
         // k-derived predicates out of the layer loop
@@ -1107,29 +1125,16 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         lane = tid & 63;
         l15 = lane & 15;
         lq = lane >> 4;
-        if (L == 0 || L == 3) {
-            // ---- stage this branch's input features (zero padded to 16 channels / NP rows) + squared norms
+        if (L == 3) {
+            // ---- stage the second branch's input (xyz, zero padded to 16 channels / NP rows) + squared norms
             if (tid < NP) {
-                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-                float s = 0.f;
-                if (tid < N) {
-                    if (L == 3) {
-                        r0 = make_float4(fx, fy, fz, 0.f);
-                        s = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                    } else {
-                        r0 = make_float4(sem[0], sem[1], sem[2], sem[3]);
-                        r1 = make_float4(sem[4], sem[5], sem[6], sem[7]);
-                        r2 = make_float4(sem[8], sem[9], sem[10], sem[11]);
-#pragma unroll
-                        for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
-                    }
-                }
+                const bool live = tid < N;
                 unsigned char* xr = X + tid * XROW;
-                xstore<XP>(xr, 0, r0);
-                xstore<XP>(xr, 4, r1);
-                xstore<XP>(xr, 8, r2);
+                xstore<XP>(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+                xstore<XP>(xr, 4, make_float4(0.f, 0.f, 0.f, 0.f));
+                xstore<XP>(xr, 8, make_float4(0.f, 0.f, 0.f, 0.f));
                 xstore<XP>(xr, 12, make_float4(0.f, 0.f, 0.f, 0.f));
-                xx[tid] = s;
+                xx[tid] = live ? fmaf(fz, fz, fmaf(fy, fy, fx * fx)) : 0.f;
             }
             __syncthreads();
             SGPR_PROF(0)
