@@ -331,8 +331,8 @@ __device__ __forceinline__ float lane_xor(float v, int m) {
 }
 
 // KP smallest (ascending) of the first `cnt` (wave-uniform) of the 32 candidates d[OFF..OFF+32)
-template <int KP, int OFF>
-__device__ __forceinline__ void list_from_32(const float (&d)[CAP], int cnt, float (&L)[KP]) {
+template <int KP, int OFF, int CAPX>
+__device__ __forceinline__ void list_from_32(const float (&d)[CAPX], int cnt, float (&L)[KP]) {
     if (cnt <= 8) {
         float lo[8];
 #pragma unroll
@@ -346,10 +346,10 @@ __device__ __forceinline__ void list_from_32(const float (&d)[CAP], int cnt, flo
 #pragma unroll
     for (int u = 0; u < 16; ++u) lo[u] = d[OFF + u];
     bitonic_sort<16>(lo);
-    if (cnt > 16) {
+    if (CAPX >= OFF + 32 && cnt > 16) {
         float hi[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) hi[u] = d[OFF + 16 + u];
+        for (int u = 0; u < 16; ++u) hi[u] = d[CAPX >= OFF + 32 ? OFF + 16 + u : 0];
         bitonic_sort<16>(hi);
         if (KP == 16) {
 #pragma unroll
@@ -390,7 +390,9 @@ __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, 
 // P consecutive lanes share a row; lane `part` owns candidates [part*seg, (part+1)*seg), seg <= CAP.
 // Result: nbr[i][0..k) = (float offset of the A row of) the k nearest candidates of row i under the
 // total order (key ascending, index ascending) - written as an unordered set.
-template <int KP>
+// CAPX = candidates a lane may own: CAP in general, 16 in lean plans (NP <= 64 and >= 4 lanes per row whenever a row
+// has more than 16 candidates), which drops the 32- and 64-candidate paths and their registers from that instance.
+template <int KP, int CAPX>
 __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k, bool one_rep,
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
@@ -411,9 +413,9 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     // keys of candidates j >= n are +inf already (written so by the Gram phase); only the row end (np) needs a guard
     const int nq = min(seg, max(np - j0, 0)) >> 2;   // 16-B groups this lane really owns
 
-    float d[CAP];
+    float d[CAPX];
 #pragma unroll
-    for (int c = 0; c < CAP / 16; ++c) {
+    for (int c = 0; c < CAPX / 16; ++c) {
         if (16 * c < seg) {                          // wave-uniform
 #pragma unroll
             for (int q = 4 * c; q < 4 * c + 4; ++q) {
@@ -429,10 +431,10 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     SEL_STAMP(0)
     // this lane's KP smallest, ascending
     float L[KP];
-    list_from_32<KP, 0>(d, seg, L);
-    if (seg > 32) {
+    list_from_32<KP, 0, CAPX>(d, seg, L);
+    if (CAPX > 32 && seg > 32) {
         float L2[KP];
-        list_from_32<KP, 32>(d, seg - 32, L2);
+        list_from_32<KP, (CAPX > 32 ? 32 : 0), CAPX>(d, seg - 32, L2);
 #pragma unroll
         for (int u = 0; u < KP; ++u) L[u] = kmin(L[u], L2[KP - 1 - u]);
         bitonic_merge<KP>(L);
@@ -486,20 +488,20 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     unsigned lt0 = 0u, lt1 = 0u, eq0 = 0u, eq1 = 0u;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-        if (16 * c < seg) {
+        if (16 * c < CAPX && 16 * c < seg) {
 #pragma unroll
             for (int u = 16 * c; u < 16 * c + 16; ++u) {
-                lt0 |= (d[u] < tau) ? (1u << u) : 0u;
-                eq0 |= (d[u] == tau) ? (1u << u) : 0u;
+                lt0 |= (d[u < CAPX ? u : 0] < tau) ? (1u << u) : 0u;
+                eq0 |= (d[u < CAPX ? u : 0] == tau) ? (1u << u) : 0u;
             }
         }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-        if (32 + 16 * c < seg) {
+        if (32 + 16 * c < CAPX && 32 + 16 * c < seg) {
 #pragma unroll
             for (int u = 16 * c; u < 16 * c + 16; ++u) {
-                lt1 |= (d[32 + u] < tau) ? (1u << u) : 0u;
-                eq1 |= (d[32 + u] == tau) ? (1u << u) : 0u;
+                lt1 |= (d[32 + u < CAPX ? 32 + u : 0] < tau) ? (1u << u) : 0u;
+                eq1 |= (d[32 + u < CAPX ? 32 + u : 0] == tau) ? (1u << u) : 0u;
             }
         }
     if (dup_cut) {           // take every candidate at or below the representative's key, no tie limit
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             SGPR_PROF(2)
             if (!(skip & 1)) {
                 if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                    select_phase<KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
+                    select_phase<KP, LEAN ? 16 : CAP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
                 else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
             }
