@@ -168,6 +168,11 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     const size_t o_fc2w = append(bn);
     const size_t o_fc2b = append(1);
     while (packed.size() % 4) packed.push_back(0.f);
+    const size_t o_ntwt = packed.size();      // NTN weight re-ordered [i][t][j] for the all-pairs prep kernel
+    packed.resize(packed.size() + f * f * t);
+    for (size_t i = 0; i < f; ++i)
+        for (size_t tt = 0; tt < t; ++tt)
+            for (size_t j = 0; j < f; ++j) packed[o_ntwt + (i * t + tt) * f + j] = packed[o_ntw + i * (f * t) + j * t + tt];
     // ---- bf16 three-plane copies of the seven folded weight matrices, in MFMA operand order (sgpr_internal.hpp)
     size_t off_wb[7];
     for (int b = 0; b < 7; ++b) {
@@ -230,6 +235,7 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     h->w.wb_end = reinterpret_cast<const unsigned short*>(h->d_blob + off_wb[6]);
     h->w.att_w = h->d_blob + o_att;
     h->w.ntn_w = h->d_blob + o_ntw;
+    h->w.ntn_wt = h->d_blob + o_ntwt;
     h->w.ntn_wb = h->d_blob + o_ntb;
     h->w.ntn_bias = h->d_blob + o_ntbias;
     h->w.fc1_w = h->d_blob + o_fc1w;

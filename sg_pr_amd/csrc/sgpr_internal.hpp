@@ -34,6 +34,7 @@ struct DevWeights {
     const float* tb_end;  // [32]
     const float* att_w;   // [32][32]
     const float* ntn_w;   // [32][32*16]   (weight_matrix.view(F3,-1), col = j*16 + t)
+    const float* ntn_wt;  // the same tensor as [i][t][j] (ntn_prep_kernel reads 16 consecutive j per lane group)
     const float* ntn_wb;  // [16][64]
     const float* ntn_bias;  // [16]
     const float* fc1_w;   // [16][16]

@@ -103,48 +103,69 @@ __device__ __forceinline__ void split3(float a, unsigned short& h, unsigned shor
     l = bf16_rne(r);
 }
 
-// one wave per graph: rows get A_r and u_r = Wb[:, :F] e1 + bias, columns get v_c = Wb[:, F:] e2
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16 graphs per workgroup.  Row graphs get A_r = e1^T W (16 x 32 per graph) as ONE small GEMM per workgroup,
+// [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
+// instead of once per graph - split into three bf16 planes on the way out, plus u_r = Wb[:, :F] e1 + bias;
+// column graphs get v_c = Wb[:, F:] e2.
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
                                                        const float* __restrict__ cols, int M,
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                        float* __restrict__ vc) {
-    const int lane = threadIdx.x & 63;
-    const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gidx >= R + M) return;
-    const int t = lane & 15, q = lane >> 4;
-    if (gidx < R) {
-        const float* e1 = rows + (size_t)gidx * F;
-        float v[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int g0 = blockIdx.x * 16;
+    if (g0 < R) {
+        // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
+        const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
+        const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
+        for (int tile = wave * 8; tile < wave * 8 + 8; ++tile) {
+            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
+            const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wp[0 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wp[1 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wp[2 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wp[3 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wp[16 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wp[17 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wp[18 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wp[19 * T * F], acc, 0, 0, 0);
+            // acc[r] = A_{g0 + 4 lq + r}[t][j]
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = 0.f;
-        for (int i = 0; i < F; ++i) {
-            const float a = e1[i];
-            const float* wr = w.ntn_w + i * (F * T) + lane;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = fmaf(a, wr[64 * r], v[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int g = g0 + 4 * lq + r;
+                if (g < R) {
+                    unsigned short h, m, l;
+                    split3(acc[r], h, m, l);
+                    unsigned short* dst = Ab + (size_t)g * (3 * T * F) + t * F + j;
+                    dst[0] = h;
+                    dst[T * F] = m;
+                    dst[2 * T * F] = l;
+                }
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            unsigned short h, m, l;
-            split3(v[r], h, m, l);
-            unsigned short* dst = Ab + (size_t)gidx * (3 * T * F) + t * F + (q + 4 * r);
-            dst[0] = h;
-            dst[T * F] = m;
-            dst[2 * T * F] = l;
+    }
+    // block terms: one graph per wave pass, lane (t = l15, q = lq) sums 8 of the 32 products
+    for (int gi = wave * 4; gi < wave * 4 + 4; ++gi) {
+        const int g = g0 + gi;
+        if (g < R) {
+            const float* e1 = rows + (size_t)g * F;
+            float s = 0.f;
+            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lq == 0) ur[(size_t)g * T + l15] = s + w.ntn_bias[l15];
         }
-        float s = 0.f;
-        for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[t * 2 * F + q * 8 + m], e1[q * 8 + m], s);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (q == 0) ur[(size_t)gidx * T + t] = s + w.ntn_bias[t];
-    } else {
-        const int c = gidx - R;
-        const float* e2 = cols + (size_t)c * F;
-        float s = 0.f;
-        for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[t * 2 * F + F + q * 8 + m], e2[q * 8 + m], s);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (q == 0) vc[(size_t)c * T + t] = s;
+        if (g < M) {
+            const float* e2 = cols + (size_t)g * F;
+            float s = 0.f;
+            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + F + lq * 8 + m], e2[lq * 8 + m], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lq == 0) vc[(size_t)g * T + l15] = s;
+        }
     }
 }
 
@@ -152,7 +173,6 @@ constexpr int AP_ROWS = 16;   // row graphs per work item (column operands stay 
 constexpr int AP_COLS = 256;  // column graphs per workgroup: 4 waves x 64
 constexpr int AP_OCC = 4;     // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -295,7 +315,7 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
     float* ur = static_cast<float*>(ws);
     float* vc = ur + (size_t)R * T;
     unsigned short* Ab = reinterpret_cast<unsigned short*>(vc + (size_t)M * T);
-    hipLaunchKernelGGL(ntn_prep_kernel, dim3((R + M + 3) / 4), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc);
+    hipLaunchKernelGGL(ntn_prep_kernel, dim3(((R > M ? R : M) + 15) / 16), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
     const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
