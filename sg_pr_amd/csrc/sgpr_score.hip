@@ -83,10 +83,12 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 }
 
 // ------------------------------------------------------------------ dense all-pairs
-// workspace layout:  ur [R][T] f32 | vc [M][T] f32 | Ab [R][3][T][F] bf16  (A_r split into three bf16 planes:
-// a = hi + mid + lo exactly to 24 bits, so six bf16 MFMAs reproduce the fp32 product - see score_all_pairs_kernel)
+// workspace layout:  ur [R][T] f32 | vc [M][T] f32 | Ab [R][3][T][F] bf16 | Cb [M][3][F] bf16
+// (A_r and the column vectors e2 split into three bf16 planes: x = hi + mid + lo exactly to 24 bits, so six bf16
+// MFMAs reproduce the fp32 product - see score_all_pairs_kernel)
 size_t score_all_pairs_ws_bytes(int R, int M) {
-    return ((size_t)R * T + (size_t)M * T) * sizeof(float) + (size_t)R * 3 * T * F * sizeof(unsigned short);
+    return ((size_t)R * T + (size_t)M * T) * sizeof(float) +
+           ((size_t)R * 3 * T * F + (size_t)M * 3 * F) * sizeof(unsigned short);
 }
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) {      // round-to-nearest-even fp32 -> bf16 (no NaNs here)
@@ -108,11 +110,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 16 graphs per workgroup.  Row graphs get A_r = e1^T W (16 x 32 per graph) as ONE small GEMM per workgroup,
 // [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
 // instead of once per graph - split into three bf16 planes on the way out, plus u_r = Wb[:, :F] e1 + bias;
-// column graphs get v_c = Wb[:, F:] e2.
+// column graphs get v_c = Wb[:, F:] e2 and their own three-plane copy.
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
                                                        const float* __restrict__ cols, int M,
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
-                                                       float* __restrict__ vc) {
+                                                       float* __restrict__ vc, unsigned short* __restrict__ Cb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int g0 = blockIdx.x * 16;
@@ -165,13 +167,21 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             if (lq == 0) vc[(size_t)g * T + l15] = s;
+            if (lane < F) {                                 // the column operand itself, as three bf16 planes
+                unsigned short h, m, l;
+                split3(e2[lane], h, m, l);
+                Cb[(size_t)g * (3 * F) + lane] = h;
+                Cb[(size_t)g * (3 * F) + F + lane] = m;
+                Cb[(size_t)g * (3 * F) + 2 * F + lane] = l;
+            }
         }
     }
 }
 
-constexpr int AP_ROWS = 16;   // row graphs per work item (column operands stay in registers across items)
-constexpr int AP_COLS = 256;  // column graphs per workgroup: 4 waves x 64
-constexpr int AP_OCC = 4;     // resident workgroups per CU the kernel is compiled for (waves per SIMD)
+constexpr int AP_RW = 4;       // row graphs per wave: their A_r operands (3 planes) stay in registers
+constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
+constexpr int AP_COLS = 256;   // column graphs per work item (16 blocks of 16), streamed from L2
+constexpr int AP_OCC = 3;      // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -180,6 +190,8 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {   // same operand/result layout as mfma_bf16
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -206,18 +218,21 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 // pattern: every negative float (and -0) is a negative integer.
 __device__ __forceinline__ float relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
-// One wave owns 64 column graphs (4 blocks of 16) and walks AP_ROWS row graphs.  Per (row, block):
+// One wave owns AP_RW = 4 row graphs - their A_r operands, 14 MB in total and therefore MALL/HBM-resident, are fetched
+// once per work item and kept in registers - and streams blocks of 16 column graphs, whose three-plane operands
+// (0.9 MB in total) stay in L2 and are fetched one block ahead.  Per (row, block):
 //   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j]),  K = 32.  fp32 MFMA shares the vector pipe on
 //            gfx950, bf16 MFMA does not and is ~8x faster per product: both operands are split into three
 //            bf16 planes (x = hi + mid + lo, exact to 24 bits) and the six significant cross products
 //            hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are accumulated in fp32 -> fp32-class accuracy (error ~2^-24)
-//   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])   4 fp32 MFMAs: H is consumed straight from the
-//            accumulator layout (lane group g holds t = 4g..4g+3 and supplies t = 4g+s at step s; the A operand is
-//            permuted to match), so no data moves between the two layers
-//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs, lane-swap transpose-reduce), sigmoid once per 64 columns,
-//            one coalesced 256-B store per row.
-__global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevWeights w, const float* __restrict__ cols,
-                                                              int R, int M, const unsigned short* __restrict__ Ab,
+//   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])   two f16 MFMAs: H is consumed straight from the
+//            accumulator layout (lane group g holds t = 4g..4g+3), split into two f16 planes (22 bits); the K slots
+//            8g..8g+3 / 8g+4..8g+7 carry hi / lo, the A operand is W1 laid out to match
+//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs, lane-swap transpose-reduce over the 4 rows), sigmoid once per
+//            (4 rows x 16 columns), four 64-B row segments per store.
+__global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevWeights w, int R, int M,
+                                                              const unsigned short* __restrict__ Ab,
+                                                              const unsigned short* __restrict__ Cb,
                                                               const float* __restrict__ ur,
                                                               const float* __restrict__ vc,
                                                               float* __restrict__ score, int64_t ld) {
@@ -232,79 +247,86 @@ __global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevW
     const float4 b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
     const float4 w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
     const float b2 = w.fc2_b[0];
-    // work items = (column block of AP_COLS, row chunk of AP_ROWS), column-major; every workgroup takes a contiguous,
-    // equally long range (the grid is sized to one resident wave slot per workgroup, so there is no second,
-    // under-occupied round) and reloads its column operands only when the column block changes
-    const int nrc = (R + AP_ROWS - 1) / AP_ROWS;
-    const int64_t items = (int64_t)nrc * ((M + AP_COLS - 1) / AP_COLS);
+    // work items = (row group of AP_ROWS, column chunk of AP_COLS), row-major; every workgroup takes a contiguous,
+    // equally long range (the grid is sized to one resident slot per workgroup, so there is no second,
+    // under-occupied round) and reloads its row operands only when the row group changes
+    const int ncc = (M + AP_COLS - 1) / AP_COLS;
+    const int64_t items = (int64_t)ncc * ((R + AP_ROWS - 1) / AP_ROWS);
     const int it0 = (int)(items * blockIdx.x / gridDim.x), it1 = (int)(items * (blockIdx.x + 1) / gridDim.x);
-    bf16x8 bh[4], bm[4], bl[4];
-    float4 v4[4];
-    int cur_cb = -1, c0 = 0;
+    bf16x8 ah[AP_RW], am[AP_RW], al[AP_RW];
+    float4 u4[AP_RW];
+    int cur_rg = -1, rbase = 0;
+    const int nblk = (M + 15) >> 4;
     for (int it = it0; it < it1; ++it) {
-        const int cb = it / nrc, r0 = (it - cb * nrc) * AP_ROWS;
-        if (cb != cur_cb) {
-            cur_cb = cb;
-            c0 = cb * AP_COLS + wave * 64;
-            // column operands: e2_c[8g .. 8g+7] as three bf16 planes, and v_c, for the 4 column blocks of this wave
+        const int rg = it / ncc, cc = it - rg * ncc;
+        if (rg != cur_rg) {
+            cur_rg = rg;
+            rbase = rg * AP_ROWS + wave * AP_RW;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int c = min(c0 + b * 16 + l15, M - 1);
-                const float4 x0 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g);
-                const float4 x1 = *reinterpret_cast<const float4*>(cols + (size_t)c * F + 8 * g + 4);
-                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    unsigned short h, m, l;
-                    split3(xs[q], h, m, l);
-                    bh[b][q] = (short)h;
-                    bm[b][q] = (short)m;
-                    bl[b][q] = (short)l;
-                }
-                v4[b] = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
+            for (int rr = 0; rr < AP_RW; ++rr) {
+                const int r = min(rbase + rr, R - 1);
+                const unsigned short* ap = Ab + (size_t)r * (3 * T * F) + l15 * F + 8 * g;   // A_r[t = l15][8g .. 8g+7]
+                ah[rr] = *reinterpret_cast<const bf16x8*>(ap);
+                am[rr] = *reinterpret_cast<const bf16x8*>(ap + T * F);
+                al[rr] = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
+                u4[rr] = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
             }
         }
-        if (c0 >= M) continue;                         // this wave's 64 columns lie past the matrix edge
-        const int r1 = min(R, r0 + AP_ROWS);
-        const int cst = c0 + lane;                     // the column this lane stores
-        for (int r = r0; r < r1; ++r) {
-            const unsigned short* ap = Ab + (size_t)r * (3 * T * F) + l15 * F + 8 * g;   // A_r[t = l15][8g .. 8g+7]
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + T * F);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
-            const float4 u4 = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
-            float zb[4];
+        if (rbase >= R) continue;                          // this wave's rows lie past the matrix edge
+        const int blk0 = cc * (AP_COLS / 16), blk1 = min(nblk, blk0 + AP_COLS / 16);
+        // column operands e2_c[8g .. 8g+7] (three planes) and v_c of block blk, fetched one block ahead
+        int c = min(blk0 * 16 + l15, M - 1);
+        const unsigned short* cp = Cb + (size_t)c * (3 * F) + 8 * g;
+        bf16x8 bh = *reinterpret_cast<const bf16x8*>(cp);
+        bf16x8 bm = *reinterpret_cast<const bf16x8*>(cp + F);
+        bf16x8 bl = *reinterpret_cast<const bf16x8*>(cp + 2 * F);
+        float4 v4 = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
+        for (int blk = blk0; blk < blk1; ++blk) {
+            c = min(min(blk + 1, blk1 - 1) * 16 + l15, M - 1);   // the last block re-reads itself (no branch)
+            cp = Cb + (size_t)c * (3 * F) + 8 * g;
+            const bf16x8 nbh = *reinterpret_cast<const bf16x8*>(cp);
+            const bf16x8 nbm = *reinterpret_cast<const bf16x8*>(cp + F);
+            const bf16x8 nbl = *reinterpret_cast<const bf16x8*>(cp + 2 * F);
+            const float4 nv4 = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
+            float zb[AP_RW];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                f32x4 h = {u4.x + v4[b].x, u4.y + v4[b].y, u4.z + v4[b].z, u4.w + v4[b].w};
-                h = mfma_bf16(al, bh[b], h);           // smallest terms first
-                h = mfma_bf16(ah, bl[b], h);
-                h = mfma_bf16(am, bm[b], h);
-                h = mfma_bf16(am, bh[b], h);
-                h = mfma_bf16(ah, bm[b], h);
-                h = mfma_bf16(ah, bh[b], h);
+            for (int rr = 0; rr < AP_RW; ++rr) {
+                f32x4 h = {u4[rr].x + v4.x, u4[rr].y + v4.y, u4[rr].z + v4.z, u4[rr].w + v4.w};
+                h = mfma_bf16(al[rr], bh, h);              // smallest terms first
+                h = mfma_bf16(ah[rr], bl, h);
+                h = mfma_bf16(am[rr], bm, h);
+                h = mfma_bf16(am[rr], bh, h);
+                h = mfma_bf16(ah[rr], bm, h);
+                h = mfma_bf16(ah[rr], bh, h);
                 // layer 2 on the f16 matrix cores: H = hi + lo (two f16 planes, 22 bits); K slots 8g..8g+3 = hi,
                 // 8g+4..8g+7 = lo of t = 4g..4g+3 - exactly this lane's accumulators
-                const float h0 = relu(h[0]), h1 = relu(h[1]), h2 = relu(h[2]), h3 = relu(h[3]);
-                const _Float16 i0 = (_Float16)h0, i1 = (_Float16)h1, i2 = (_Float16)h2, i3 = (_Float16)h3;
-                const f16x8 hb = {i0, i1, i2, i3, (_Float16)(h0 - (float)i0), (_Float16)(h1 - (float)i1),
-                                  (_Float16)(h2 - (float)i2), (_Float16)(h3 - (float)i3)};
+                // (packed conversions: v_cvt_pk_f16_f32 for both planes, v_pk_add_f32 for the remainders)
+                const f32x2 ha = {relu(h[0]), relu(h[1])}, hc = {relu(h[2]), relu(h[3])};
+                const f16x2 ia = __builtin_convertvector(ha, f16x2), ic = __builtin_convertvector(hc, f16x2);
+                const f16x2 la = __builtin_convertvector(ha - __builtin_convertvector(ia, f32x2), f16x2);
+                const f16x2 lc = __builtin_convertvector(hc - __builtin_convertvector(ic, f32x2), f16x2);
+                const f16x8 hb = {ia[0], ia[1], ic[0], ic[1], la[0], la[1], lc[0], lc[1]};
                 f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
-                q = mfma_f16(w1lo, hb, q);             // hi . W1lo
-                q = mfma_f16(w1hi, hb, q);             // (hi + lo) . W1hi
+                q = mfma_f16(w1lo, hb, q);                 // hi . W1lo
+                q = mfma_f16(w1hi, hb, q);                 // (hi + lo) . W1hi
                 float z = w2v.x * relu(q[0]);
                 z = fmaf(w2v.y, relu(q[1]), z);
                 z = fmaf(w2v.z, relu(q[2]), z);
-                zb[b] = fmaf(w2v.w, relu(q[3]), z);   // partial over o = 4g..4g+3 of column block b
+                zb[rr] = fmaf(w2v.w, relu(q[3]), z);       // partial over o = 4g..4g+3 of row rr, column l15
             }
             // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
-            // full sum of column block g (3 swaps + 3 adds instead of 8 bpermutes)
-            const float p02 = swap32_add(zb[0], zb[2]);    // lanes 0-31: block 0 over groups {g, g+2}; 32-63: block 2
-            const float p13 = swap32_add(zb[1], zb[3]);    // likewise blocks 1 / 3
-            const float zsel = swap16_add(p02, p13);       // even 16-lane rows: block 0 / 2, odd rows: block 1 / 3
+            // full sum of row g (3 swaps + 3 adds instead of 8 bpermutes)
+            const float p02 = swap32_add(zb[0], zb[2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
+            const float p13 = swap32_add(zb[1], zb[3]);    // likewise rows 1 / 3
+            const float zsel = swap16_add(p02, p13);       // even 16-lane rows: row 0 / 2, odd: row 1 / 3
             // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
             const float sc = __builtin_amdgcn_rcpf(1.f + __expf(-(zsel + b2)));
-            if (cst < M) score[(size_t)r * ld + cst] = sc;
+            const int r = rbase + g, cst = blk * 16 + l15;
+            if (r < R && cst < M) score[(size_t)r * ld + cst] = sc;
+            bh = nbh;
+            bm = nbm;
+            bl = nbl;
+            v4 = nv4;
         }
     }
 }
@@ -315,13 +337,14 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
     float* ur = static_cast<float*>(ws);
     float* vc = ur + (size_t)R * T;
     unsigned short* Ab = reinterpret_cast<unsigned short*>(vc + (size_t)M * T);
-    hipLaunchKernelGGL(ntn_prep_kernel, dim3(((R > M ? R : M) + 15) / 16), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc);
+    unsigned short* Cb = Ab + (size_t)R * 3 * T * F;
+    hipLaunchKernelGGL(ntn_prep_kernel, dim3(((R > M ? R : M) + 15) / 16), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc, Cb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
     const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
     const int64_t slots = (int64_t)h->num_cus * AP_OCC;   // one resident slot per workgroup: a single, full round
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    hipLaunchKernelGGL(score_all_pairs_kernel, dim3(grid), dim3(256), 0, stream, h->w, cols, R, M, Ab, ur, vc, score, ld);
+    hipLaunchKernelGGL(score_all_pairs_kernel, dim3(grid), dim3(256), 0, stream, h->w, R, M, Ab, Cb, ur, vc, score, ld);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
     return SGPR_OK;

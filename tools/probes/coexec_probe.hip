@@ -38,6 +38,17 @@ __global__ __launch_bounds__(512) void probe(int mode, int iters, float* sink, u
                 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, c1, 0, 0, 0);
             }
             acc = c0[0] + c1[1];
+        } else if (KIND == 2) {   // ONE dependent chain of bf16 MFMAs (the pattern of the production kernels)
+            f32x4 c0 = {0, 0, 0, 0};
+            bf16x8 x, y;
+            for (int q = 0; q < 8; ++q) { x[q] = (short)(threadIdx.x + q); y[q] = (short)(threadIdx.x * 3 + q); }
+            for (int i = 0; i < iters; ++i) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, x, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, x, c0, 0, 0, 0);
+            }
+            acc = c0[0];
         } else {
             f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
             bf16x8 x, y;
@@ -69,4 +80,4 @@ void run(const char* name) {
                mode & 1 ? "on" : "off", mode & 2 ? "on" : "off", h[0] / (double)(nb * 4) / iters, h[1] / (double)(nb * 4) / iters);
     }
 }
-int main() { run<0>("f32 16x16x4 "); run<1>("bf16 16x16x32"); return 0; }
+int main() { run<0>("f32 16x16x4 "); run<1>("bf16 16x16x32, 2 chains"); run<2>("bf16 16x16x32, 1 chain "); return 0; }
