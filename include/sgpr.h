@@ -151,6 +151,33 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
  * raises KeyError at sg_net.py:277), else SGPR_OK.  Clears the flag. */
 int sgpr_check_status(const sgpr_handle* h, void* stream);
 
+/* ---- consumers of the score matrix that keep it on the device ----------------------------------------
+ *
+ * sgpr_pair_histogram: the counting half of eval_batch.py:69-87 (sklearn precision_recall_curve -> F1 max).  One pass
+ * over the R x M score rectangle (rows row0 .. row0+R-1 of the square matrix) builds class-wise radix histograms of the
+ * scores: the key of a score is its fp32 bit pattern (scores are >= 0, so the order is the numeric one); a pass looks
+ * only at elements whose top `prefix_bits` key bits equal one of the `n_prefix` (<= 4) host-given prefixes and counts
+ * them by the next `bits` (<= 12) bits:  d_hist[p][bin][cls] (uint64), cls 1 = positive pair, 0 = negative.
+ * Ground truth comes from the planar poses d_pose_xz [.][2] (x, z of the KITTI pose, utils.py:36): distance <= d_pos
+ * positive, >= d_neg negative, in between ignored (the pairs the reference refuses, sg_net.py:302-309) - or, when
+ * d_pose_xz is NULL, from explicit labels d_gt [R][ldg] (1 / 0 / negative = ignore).  prefix_bits = 0 is the first pass
+ * (prefixes may be NULL).  The host walks the cumulative counts, keeps the bins that can still contain the F1 maximum
+ * and refines them with further passes down to single fp32 values (sg_pr_amd/metrics.py:f1_max_device) - exact, no sort,
+ * the matrix never leaves the GPU.  d_hist holds (n_prefix << bits) * 2 + 1 words: the last one counts the scores that
+ * were negative or NaN (no defined rank) and were skipped. */
+size_t sgpr_pair_histogram_workspace_bytes(const sgpr_handle* h, int n_prefix, int bits);
+int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
+                        const float* d_pose_xz, float d_pos, float d_neg, const signed char* d_gt, int64_t ldg,
+                        int n_prefix, int prefix_bits, int bits, const uint32_t* prefixes,
+                        unsigned long long* d_hist, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Loop-closure candidates (the use the reference makes of a sequence's similarity matrix, README.md:92-97): for every
+ * row r the k (1, 4, 8 or 16) best-scoring columns c with |c - (row0 + r)| > window (window = -1 keeps every column),
+ * ordered by (score descending, column ascending); d_values / d_indices [R][k], index -1 where fewer than k columns
+ * qualify.  One wave per row, one pass over the row. */
+int sgpr_topk_rows(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0, int window, int k,
+                   float* d_values, int32_t* d_indices, void* stream);
+
 /* LDS bytes / threads per workgroup the embed kernel uses for (N, k); 0 if unsupported. */
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 

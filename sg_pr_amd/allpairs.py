@@ -12,6 +12,9 @@ Multi-GPU (one process per GPU, torch.distributed; backend "nccl" = RCCL over xG
     row blocks sent point-to-point into rank 0's matrix   (M*M*4 bytes in total, 7 xGMI links in parallel)
 Every score depends on its two graphs only, so the matrix is bit-identical for any
 world size.
+
+Consumers that never move the matrix: `f1_max` (eval_batch.py:69-87 from class-wise score histograms,
+per-rank counts summed with one small all_reduce per pass) and `loop_closures` (best matches per query row).
 """
 import torch
 import torch.distributed as dist
@@ -31,9 +34,11 @@ class AllPairsScorer:
     stand-ins to exercise the sharding / collective logic under gloo."""
 
     def __init__(self, model=None, embed_fn=None, score_fn=None, group=None):
+        self._engine = None
         if model is not None:
             embed_fn = lambda c, l: model.embed(c, l)[0]   # noqa: E731
             score_fn = model.score_all_pairs
+            self._engine = model.engine()
         if embed_fn is None or score_fn is None:
             raise ValueError("need a model or both embed_fn and score_fn")
         self.embed_fn = embed_fn
@@ -95,6 +100,40 @@ class AllPairsScorer:
                 q.wait()
         return None
 
+    def f1_max(self, block, poses, p_thresh=3.0, n_thresh=20.0, hist_fn=None):
+        """F1-max (eval_batch.py:85-87) over this job's matrix WITHOUT gathering it: `block` is this rank's row block
+        (score_rows), ground truth comes from the poses ([M,12] KITTI rows or [M,2] x/z).  Every rank returns the
+        same value.  hist_fn(block, row0, pose_xz, prefix_bits, bits, prefixes) -> uint64 counts overrides the
+        engine pass (CPU tests)."""
+        from . import metrics
+        world, rank = self._world()
+        xz = pose_xz(poses)
+        lo, _ = shard_bounds(xz.shape[0], world, rank)
+        if hist_fn is None:
+            eng = self._engine
+            xz_dev = xz.to(block.device)
+
+            def hist_fn(blk, row0, _xz, prefix_bits, bits, prefixes):   # noqa: E306
+                return eng.pair_histogram(blk, row0=row0, pose_xz=xz_dev, d_pos=p_thresh, d_neg=n_thresh,
+                                          prefixes=prefixes, prefix_bits=prefix_bits, bits=bits)[0]
+
+        def summed(prefix_bits, bits, prefixes):
+            import numpy as np
+            h = np.asarray(hist_fn(block, lo, xz, prefix_bits, bits, prefixes)).astype(np.int64)
+            if world > 1:
+                t = torch.from_numpy(h).to(block.device if block.is_cuda else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                h = t.cpu().numpy()
+            return h.astype(np.uint64)
+        return metrics.f1_max_from_histograms(summed)[0]
+
+    def loop_closures(self, block, k=1, window=50):
+        """Per query row of this rank's block: the k best-scoring frames at least `window` frames away
+        -> (scores [R,k], frame indices [R,k]) on the device."""
+        world, rank = self._world()
+        lo, _ = shard_bounds(block.shape[1], world, rank)
+        return self._engine.topk_rows(block, k=k, row0=lo, window=window)
+
     def run(self, centers, labels, gather=True, out=None):
         """Whole job: returns the [M, M] matrix on rank 0 (row block elsewhere / if gather=False).
         `out` (rank 0): preallocated [M, M] buffer that receives the matrix."""
@@ -104,6 +143,14 @@ class AllPairsScorer:
             return block
         full = self.gather_matrix(block, pooled.shape[0], out=out)
         return full if full is not None else block
+
+
+def pose_xz(poses):
+    """[M,12] KITTI pose rows (or [M,2]) -> float32 [M,2] planar position (x, z): the two numbers utils.py:36 uses."""
+    p = torch.as_tensor(poses)
+    if p.shape[1] != 2:
+        p = torch.stack((p[:, 3], p[:, 11]), dim=1)
+    return p.to(torch.float32).contiguous()
 
 
 def pose_distance_matrix(poses):

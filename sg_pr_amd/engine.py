@@ -34,6 +34,7 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_embed_capped", "sgpr_embed_ordered",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
+               "sgpr_pair_histogram_workspace_bytes", "sgpr_pair_histogram", "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
 
 
@@ -93,6 +94,13 @@ def load_library():
     lib.sgpr_forward_dense.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_check_status.restype = i32
     lib.sgpr_check_status.argtypes = [vp, vp]
+    lib.sgpr_pair_histogram_workspace_bytes.restype = sz
+    lib.sgpr_pair_histogram_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_pair_histogram.restype = i32
+    lib.sgpr_pair_histogram.argtypes = [vp, vp, i32, i32, i64, i32, vp, ctypes.c_float, ctypes.c_float, vp, i64, i32, i32, i32,
+                                        vp, vp, vp, sz, vp]
+    lib.sgpr_topk_rows.restype = i32
+    lib.sgpr_topk_rows.argtypes = [vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp]
     lib.sgpr_embed_lds_bytes.restype = sz
     lib.sgpr_embed_lds_bytes.argtypes = [vp, i32, i32]
     lib.sgpr_debug_set_skip_mask.restype = None
@@ -319,6 +327,47 @@ class Engine:
                                            _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
         return score
+
+    # ------------------------------------------------------------------ consumers of the score matrix
+    def pair_histogram(self, score, row0=0, pose_xz=None, d_pos=3.0, d_neg=20.0, gt=None, prefixes=(0,),
+                       prefix_bits=0, bits=12):
+        """One counting pass of the device-side PR/F1 (sgpr_pair_histogram): uint64 [n_prefix, 2^bits, 2] counts of
+        (negative, positive) pairs by score-key bits, plus the number of skipped (negative / NaN) scores."""
+        score = self._dev(score, torch.float32, "score")
+        r, m = score.shape
+        assert score.stride(1) == 1
+        if pose_xz is not None:
+            pose_xz = self._dev(pose_xz, torch.float32, "pose_xz")
+            assert pose_xz.shape[1] == 2 and pose_xz.shape[0] >= max(m, row0 + r)
+        elif gt is not None:
+            gt = self._dev(gt, torch.int8, "gt")
+            assert gt.shape == (r, m)
+        else:
+            raise ValueError("pair_histogram needs poses or explicit labels")
+        npre = len(prefixes)
+        nb = (npre << bits) * 2
+        hist = torch.empty(nb + 1, dtype=torch.int64, device=self.device)
+        ws_bytes = self.lib.sgpr_pair_histogram_workspace_bytes(self._h, npre, bits)
+        ws = self._ws(ws_bytes)
+        pre = (ctypes.c_uint32 * npre)(*[int(p) for p in prefixes])
+        rc = self.lib.sgpr_pair_histogram(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz),
+                                          float(d_pos), float(d_neg), _ptr(gt), m, npre, int(prefix_bits), int(bits),
+                                          pre, _ptr(hist), _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        h = hist.cpu().numpy().astype(np.uint64)
+        return h[:nb].reshape(npre, 1 << bits, 2), int(h[nb])
+
+    def topk_rows(self, score, k=1, row0=0, window=-1):
+        """Best k columns per row outside |col - (row0 + row)| <= window -> (values f32 [R,k], indices i32 [R,k])."""
+        score = self._dev(score, torch.float32, "score")
+        r, m = score.shape
+        assert score.stride(1) == 1
+        vals = torch.empty(r, k, dtype=torch.float32, device=self.device)
+        idx = torch.empty(r, k, dtype=torch.int32, device=self.device)
+        rc = self.lib.sgpr_topk_rows(self._h, _ptr(score), r, m, score.stride(0), int(row0), int(window), int(k),
+                                     _ptr(vals), _ptr(idx), self._stream())
+        self._check(rc)
+        return vals, idx
 
     def forward_dense(self, features_1, features_2, k, want_att=True):
         """Drop-in SG.forward on dense [B,3+L,N] inputs -> (score [B], att1 [B,N], att2 [B,N])."""

@@ -45,3 +45,101 @@ def roc_auc(gt, score):
         return float("nan")
     trapezoid = getattr(np, "trapezoid", None) or np.trapz
     return float(trapezoid(tps / tps[-1], fps / fps[-1]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device-side F1-max: exact, sort-free.  The engine counts (negative, positive) pairs by radix bins of
+# the score's fp32 key (sgpr_pair_histogram); this module walks the cumulative counts and asks for finer passes only
+# on the bins that can still contain the maximum.  `hist_fn(prefix_bits, bits, prefixes)` -> uint64 [n, 2^bits, 2].
+_LEVEL_BITS = (12, 12, 8)
+
+
+def _f1(tp, fp, pos):
+    tp = np.asarray(tp, dtype=np.float64)
+    fp = np.asarray(fp, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p = np.where(tp + fp > 0, tp / (tp + fp), 0.0)
+        r = tp / pos if pos > 0 else np.ones_like(tp)
+        f = 2 * p * r / (p + r)
+    return np.nan_to_num(f)
+
+
+def f1_max_from_histograms(hist_fn, max_prefixes=4, max_pending=256):
+    """F1-max of eval_batch.py:85-87 from class-wise score histograms; returns (f1_max, passes).
+    Raises RuntimeError if more than `max_pending` bins stay undecided (use a sorted path then)."""
+    h = np.asarray(hist_fn(0, _LEVEL_BITS[0], (0,)), dtype=np.uint64)[0].astype(np.float64)
+    pos = float(h[:, 1].sum())
+    best = 0.0
+    passes = 1
+    # pending: (prefix value, prefix_bits, TP above the bin, FP above the bin, upper bound of F1 inside the bin)
+    pending = []
+
+    def walk(hb, prefix, pbits, tp0, fp0, last):
+        nonlocal best
+        # bins in descending key order: cumulative counts ABOVE each bin, then including it
+        p_desc, n_desc = hb[::-1, 1], hb[::-1, 0]
+        tp_above = tp0 + np.concatenate(([0.0], np.cumsum(p_desc)[:-1]))
+        fp_above = fp0 + np.concatenate(([0.0], np.cumsum(n_desc)[:-1]))
+        occupied = (p_desc + n_desc) > 0
+        if not occupied.any():
+            return
+        edge = _f1(tp_above + p_desc, fp_above + n_desc, pos)          # threshold = smallest score of the bin
+        best = max(best, float(edge[occupied].max()))
+        if last:
+            return
+        ub = _f1(tp_above + p_desc, fp_above, pos)                     # all its positives, none of its negatives
+        nb = hb.shape[0]
+        for i in np.nonzero(occupied & (p_desc > 0) & (n_desc > 0))[0]:
+            b = nb - 1 - int(i)
+            pending.append(((prefix << int(np.log2(nb))) | b, pbits + int(np.log2(nb)), tp_above[i], fp_above[i], ub[i]))
+
+    walk(h, 0, 0, 0.0, 0.0, False)
+    level = 1
+    while pending and level < len(_LEVEL_BITS):
+        todo = [c for c in pending if c[4] > best]
+        pending = []
+        if len(todo) > max_pending:
+            raise RuntimeError("f1_max_from_histograms: %d undecided bins" % len(todo))
+        bits = _LEVEL_BITS[level]
+        last = level == len(_LEVEL_BITS) - 1
+        todo.sort(key=lambda c: -c[4])                                  # most promising first: raises `best` early
+        for s in range(0, len(todo), max_prefixes):
+            group = [c for c in todo[s:s + max_prefixes] if c[4] > best]
+            if not group:
+                continue
+            hg = np.asarray(hist_fn(group[0][1], bits, tuple(c[0] for c in group)), dtype=np.uint64).astype(np.float64)
+            passes += 1
+            for c, hb in zip(group, hg):
+                walk(hb, c[0], c[1], c[2], c[3], last)
+        level += 1
+    return best, passes
+
+
+def f1_max_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0):
+    """F1-max of a score rectangle that stays on the device.  Ground truth from planar poses [M,2] (distance <=
+    p_thresh positive, >= n_thresh negative, in between ignored) or explicit int8 labels (1 / 0 / -1)."""
+    def hist_fn(prefix_bits, bits, prefixes):
+        h, bad = engine.pair_histogram(score, row0=row0, pose_xz=pose_xz, d_pos=p_thresh, d_neg=n_thresh, gt=gt,
+                                       prefixes=prefixes, prefix_bits=prefix_bits, bits=bits)
+        if bad:
+            raise ValueError("%d scores are negative or NaN" % bad)
+        return h
+    return f1_max_from_histograms(hist_fn)
+
+
+def histograms_of(score, gt):
+    """numpy stand-in for sgpr_pair_histogram (tests, small inputs): gt 1 / 0 / negative = ignored."""
+    key = np.ascontiguousarray(score, dtype=np.float32).ravel().view(np.uint32).astype(np.uint64)
+    cls = np.asarray(gt).ravel().astype(np.int64)
+    keep = cls >= 0
+    key, cls = key[keep], (cls[keep] != 0).astype(np.int64)
+
+    def hist_fn(prefix_bits, bits, prefixes):
+        out = np.zeros((len(prefixes), 1 << bits, 2), dtype=np.uint64)
+        pre = key >> np.uint64(32 - prefix_bits) if prefix_bits else np.zeros_like(key)
+        b = (key >> np.uint64(32 - prefix_bits - bits)) & np.uint64((1 << bits) - 1)
+        for i, p in enumerate(prefixes):
+            sel = pre == np.uint64(p)
+            np.add.at(out[i], (b[sel].astype(np.int64), cls[sel]), 1)
+        return out
+    return hist_fn

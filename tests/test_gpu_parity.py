@@ -322,3 +322,67 @@ def test_ordered_embed_is_bitwise_equal_and_loud(eng):
     with pytest.raises(SgprError) as ei:
         eng.check_status()
     assert ei.value.code == -3
+
+
+def test_device_f1_max_and_histograms(eng):
+    """the score matrix stays on the GPU.  sgpr_pair_histogram == a numpy histogram of the same keys
+    (poses and explicit labels, sharded rows, refinement passes), and the refined F1-max equals the sorted one."""
+    from sg_pr_amd import synth, metrics, allpairs
+    centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=700, node_num=100, seed=9)
+    order, cap = eng.size_order(centers, labels, 10)
+    pooled = eng.embed(centers, labels, 10, node_cap=cap, order=order)[0]
+    m = eng.score_all_pairs(pooled, pooled)
+    xz = allpairs.pose_xz(poses)
+    d = torch.cdist(xz.double(), xz.double())
+    gt = torch.where(d <= 3, 1, torch.where(d >= 20, 0, -1)).to(torch.int8)
+    host = metrics.histograms_of(m.cpu().numpy(), gt.numpy())
+    h1, bad = eng.pair_histogram(m, pose_xz=xz)
+    assert bad == 0
+    np.testing.assert_array_equal(h1, host(0, 12, (0,)))
+    assert int(h1.sum()) == int((gt >= 0).sum())
+    # explicit labels, a row shard (row0 != 0, odd sizes), a refinement pass with several prefixes
+    h2, _ = eng.pair_histogram(m[101:358], row0=101, pose_xz=xz)
+    np.testing.assert_array_equal(h2, metrics.histograms_of(m[101:358].cpu().numpy(), gt[101:358].numpy())(0, 12, (0,)))
+    h3, _ = eng.pair_histogram(m, gt=gt)
+    np.testing.assert_array_equal(h3, h1)
+    busiest = np.argsort(h1[0].sum(1))[-3:].tolist()
+    h4, _ = eng.pair_histogram(m, pose_xz=xz, prefixes=busiest, prefix_bits=12, bits=12)
+    np.testing.assert_array_equal(h4, host(12, 12, tuple(busiest)))
+    h5, _ = eng.pair_histogram(m, pose_xz=xz, prefixes=[(busiest[-1] << 12) | int(np.argmax(h4[-1].sum(1)))],
+                               prefix_bits=24, bits=8)
+    np.testing.assert_array_equal(h5, host(24, 8, ((busiest[-1] << 12) | int(np.argmax(h4[-1].sum(1))),)))
+    f_dev, passes = metrics.f1_max_device(eng, m, pose_xz=xz)
+    valid = gt >= 0
+    f_host = metrics.f1_max(gt[valid].numpy(), m.cpu()[valid].numpy())
+    print("F1-max device / host:", f_dev, f_host, "passes", passes)
+    assert abs(f_dev - f_host) < 1e-12
+    # the scorer's entry point (single process: no all_reduce)
+    from sg_pr_amd import sg_net
+    # negative scores are refused
+    bad_m = m.clone()
+    bad_m[3, 5] = -0.25
+    with pytest.raises(ValueError):
+        metrics.f1_max_device(eng, bad_m, gt=torch.ones_like(gt))
+
+
+def test_topk_rows_loop_closures(eng):
+    """best matches per query row outside a temporal window == torch.topk on the masked matrix."""
+    g = torch.Generator().manual_seed(3)
+    m = torch.rand(301, 517, generator=g)
+    m[:, ::7] = m[:, 3:4]                                   # ties: lowest column must win
+    md = m.cuda()
+    for k in (1, 4, 8, 16):
+        for window, row0 in ((-1, 0), (10, 0), (50, 120)):
+            vals, idx = eng.topk_rows(md, k=k, row0=row0, window=window)
+            ref = m.clone()
+            if window >= 0:
+                rr = torch.arange(301).view(-1, 1) + row0
+                cc = torch.arange(517).view(1, -1)
+                ref[(rr - cc).abs() <= window] = -float("inf")
+            # stable descending sort == (value desc, column asc)
+            order = torch.sort(ref, dim=1, descending=True, stable=True)
+            np.testing.assert_array_equal(idx.cpu().numpy(), order.indices[:, :k].numpy().astype(np.int32))
+            np.testing.assert_array_equal(vals.cpu().numpy(), order.values[:, :k].numpy())
+    # fewer than k qualifying columns -> -1
+    vals, idx = eng.topk_rows(md[:5, :6].contiguous(), k=8, window=1)
+    assert (idx.cpu()[:, -1] == -1).all() and torch.isinf(vals.cpu()[:, -1]).all()

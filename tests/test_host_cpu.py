@@ -233,6 +233,19 @@ def _allpairs_worker(rank, world, port, golden, out_dir):
     full = scorer.run(centers, labels)
     if rank == 0:
         torch.save(full, os.path.join(out_dir, "w%d.pt" % world))
+    # sharded F1-max without gathering: per-rank histograms (numpy stand-in for the HIP pass), one all_reduce per pass
+    from sg_pr_amd import metrics
+    _, _, _, poses = synth.kitti_like_sequence(11, 100, 3)
+    block = scorer.score_rows(scorer.pooled_all(centers, labels))
+
+    def hist_fn(blk, row0, xz, prefix_bits, bits, prefixes):
+        d = torch.cdist(xz[row0:row0 + blk.shape[0]].double(), xz.double())
+        gt = torch.where(d <= 3, 1, torch.where(d >= 20, 0, -1)).numpy()
+        return metrics.histograms_of(blk.numpy(), gt)(prefix_bits, bits, prefixes)
+
+    f1 = scorer.f1_max(block, poses, hist_fn=hist_fn)
+    with open(os.path.join(out_dir, "f1_w%d_r%d.txt" % (world, rank)), "w") as f:
+        f.write(repr(f1))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -261,6 +274,11 @@ def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
     assert not torch.equal(two, two.t())                 # the NTN is asymmetric: full square needed
     gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
     assert gt.shape == (11, 11) and valid.diagonal().all() and gt.diagonal().all()
+    # both ranks computed the same F1-max from their own row blocks, equal to the gathered-matrix value
+    from sg_pr_amd import metrics
+    want = metrics.f1_max(gt[valid].numpy(), two[valid].numpy())
+    for r in range(2):
+        assert abs(float(open(os.path.join(str(tmp_path), "f1_w2_r%d.txt" % r)).read()) - want) < 1e-12
 
 
 def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, oracle_sd):
@@ -292,3 +310,30 @@ def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, ora
     np.testing.assert_allclose(pred, want, atol=1e-6)
     np.testing.assert_array_equal(gt, [0, 1, 1, 1])
     assert f1 == 1.0 and float(open(os.path.join(args.output_path, "00_DL_F1_max.txt")).read()) == 1.0
+
+
+def test_f1_max_from_histograms_is_exact(golden_dir):
+    """Host half of the device-side F1-max: radix-bin refinement == sklearn-style sort, incl. ties and ignored pairs."""
+    from sg_pr_amd import metrics
+    g = np.load(os.path.join(golden_dir, "prf1.npz"))
+    for c in range(3):
+        if f"gt{c}" not in g:
+            break
+        got, _ = metrics.f1_max_from_histograms(metrics.histograms_of(g[f"score{c}"], g[f"gt{c}"]))
+        assert abs(got - float(g[f"f1max{c}"])) < 1e-12
+    rng = np.random.default_rng(7)
+    for trial in range(5):
+        n = 60000
+        gt = (rng.random(n) < 0.03).astype(np.int64)
+        sc = (1.0 / (1.0 + np.exp(-(rng.normal(0, 3, n) + 4 * gt)))).astype(np.float32)
+        if trial == 1:
+            sc = np.round(sc, 2).astype(np.float32)            # massive ties
+        if trial == 2:
+            sc[:] = 0.25                                        # one distinct value
+        if trial == 3:
+            gt[:] = 0                                           # no positives
+        if trial == 4:
+            sc = np.where(rng.random(n) < 0.5, np.float32(1.0), sc).astype(np.float32)   # saturated scores
+        ign = rng.random(n) < 0.2
+        got, passes = metrics.f1_max_from_histograms(metrics.histograms_of(sc, np.where(ign, -1, gt)))
+        assert abs(got - metrics.f1_max(gt[~ign], sc[~ign])) < 1e-12 and passes <= 12
