@@ -158,7 +158,8 @@ int sgpr_check_status(const sgpr_handle* h, void* stream);
  * scores: the key of a score is its fp32 bit pattern (scores are >= 0, so the order is the numeric one); a pass looks
  * only at elements whose top `prefix_bits` key bits equal one of the `n_prefix` (<= 4) host-given prefixes and counts
  * them by the next `bits` (<= 12) bits:  d_hist[p][bin][cls] (uint64), cls 1 = positive pair, 0 = negative.
- * Ground truth comes from the planar poses d_pose_xz [.][2] (x, z of the KITTI pose, utils.py:36): distance <= d_pos
+ * Ground truth comes from the planar poses d_pose_xz [.][2] (float64 x, z of the KITTI pose; the distance is evaluated
+ * in float64 operation by operation like utils.py:36): distance <= d_pos
  * positive, >= d_neg negative, in between ignored (the pairs the reference refuses, sg_net.py:302-309) - or, when
  * d_pose_xz is NULL, from explicit labels d_gt [R][ldg] (1 / 0 / negative = ignore).  prefix_bits = 0 is the first pass
  * (prefixes may be NULL).  The host walks the cumulative counts, keeps the bins that can still contain the F1 maximum
@@ -167,7 +168,7 @@ int sgpr_check_status(const sgpr_handle* h, void* stream);
  * were negative or NaN (no defined rank) and were skipped. */
 size_t sgpr_pair_histogram_workspace_bytes(const sgpr_handle* h, int n_prefix, int bits);
 int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
-                        const float* d_pose_xz, float d_pos, float d_neg, const signed char* d_gt, int64_t ldg,
+                        const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt, int64_t ldg,
                         int n_prefix, int prefix_bits, int bits, const uint32_t* prefixes,
                         unsigned long long* d_hist, void* d_workspace, size_t workspace_bytes, void* stream);
 

@@ -146,11 +146,11 @@ class AllPairsScorer:
 
 
 def pose_xz(poses):
-    """[M,12] KITTI pose rows (or [M,2]) -> float32 [M,2] planar position (x, z): the two numbers utils.py:36 uses."""
+    """[M,12] KITTI pose rows (or [M,2]) -> float64 [M,2] planar position (x, z): the two numbers utils.py:36 uses."""
     p = torch.as_tensor(poses)
     if p.shape[1] != 2:
         p = torch.stack((p[:, 3], p[:, 11]), dim=1)
-    return p.to(torch.float32).contiguous()
+    return p.to(torch.float64).contiguous()
 
 
 def pose_distance_matrix(poses):

@@ -27,8 +27,8 @@ struct HistArgs {
     int R, M;
     int64_t ld;
     int row0;                 // global index of row 0 (rows are a shard of the square matrix)
-    const float* pose;        // [>= row0 + R and >= M][2] planar pose (x, z) or NULL
-    float d_pos, d_neg;       // positive if distance <= d_pos, negative if >= d_neg, ignored in between
+    const double* pose;       // [>= row0 + R and >= M][2] planar pose (x, z) or NULL; float64 like the reference
+    double d_pos, d_neg;      // positive if distance <= d_pos, negative if >= d_neg, ignored in between
     const signed char* gt;    // optional explicit labels [R][ldg]: 1 / 0 / negative = ignore (used when pose == NULL)
     int64_t ldg;
     int n_prefix, prefix_bits, bits;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] = c0 + q < a.M ? sp[q] : 0.f;
         }
-        float px = 0.f, pz = 0.f;
+        double px = 0.0, pz = 0.0;
         if (a.pose) {
             px = a.pose[2 * (a.row0 + r)];
             pz = a.pose[2 * (a.row0 + r) + 1];
@@ -72,8 +72,9 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
             if (c >= a.M) break;
             int cls;                                   // 1 positive, 0 negative, -1 ignored
             if (a.pose) {
-                const float dx = px - a.pose[2 * c], dz = pz - a.pose[2 * c + 1];
-                const float d = sqrtf(dx * dx + dz * dz);
+                // utils.py:36 in float64, operation by operation (no fused multiply-add)
+                const double dx = px - a.pose[2 * c], dz = pz - a.pose[2 * c + 1];
+                const double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz)));
                 cls = d <= a.d_pos ? 1 : (d >= a.d_neg ? 0 : -1);
             } else {
                 const int g = a.gt[(int64_t)r * a.ldg + c];
@@ -190,7 +191,7 @@ size_t sgpr_pair_histogram_workspace_bytes(const sgpr_handle* h, int n_prefix, i
 }
 
 int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
-                        const float* d_pose_xz, float d_pos, float d_neg, const signed char* d_gt, int64_t ldg,
+                        const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt, int64_t ldg,
                         int n_prefix, int prefix_bits, int bits, const uint32_t* prefixes,
                         unsigned long long* d_hist, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!h || !d_score || !d_hist || R < 0 || M < 0 || ld < M || (!d_pose_xz && !d_gt) || (d_gt && !d_pose_xz && ldg < M)) {

@@ -97,7 +97,7 @@ def load_library():
     lib.sgpr_pair_histogram_workspace_bytes.restype = sz
     lib.sgpr_pair_histogram_workspace_bytes.argtypes = [vp, i32, i32]
     lib.sgpr_pair_histogram.restype = i32
-    lib.sgpr_pair_histogram.argtypes = [vp, vp, i32, i32, i64, i32, vp, ctypes.c_float, ctypes.c_float, vp, i64, i32, i32, i32,
+    lib.sgpr_pair_histogram.argtypes = [vp, vp, i32, i32, i64, i32, vp, ctypes.c_double, ctypes.c_double, vp, i64, i32, i32, i32,
                                         vp, vp, vp, sz, vp]
     lib.sgpr_topk_rows.restype = i32
     lib.sgpr_topk_rows.argtypes = [vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp]
@@ -337,7 +337,7 @@ class Engine:
         r, m = score.shape
         assert score.stride(1) == 1
         if pose_xz is not None:
-            pose_xz = self._dev(pose_xz, torch.float32, "pose_xz")
+            pose_xz = self._dev(pose_xz, torch.float64, "pose_xz")
             assert pose_xz.shape[1] == 2 and pose_xz.shape[0] >= max(m, row0 + r)
         elif gt is not None:
             gt = self._dev(gt, torch.int8, "gt")

@@ -89,9 +89,10 @@ def f1_max_from_histograms(hist_fn, max_prefixes=4, max_pending=256):
             return
         ub = _f1(tp_above + p_desc, fp_above, pos)                     # all its positives, none of its negatives
         nb = hb.shape[0]
-        for i in np.nonzero(occupied & (p_desc > 0) & (n_desc > 0))[0]:
+        lg = nb.bit_length() - 1
+        for i in np.nonzero(occupied & (p_desc > 0) & (n_desc > 0) & (ub > best))[0]:
             b = nb - 1 - int(i)
-            pending.append(((prefix << int(np.log2(nb))) | b, pbits + int(np.log2(nb)), tp_above[i], fp_above[i], ub[i]))
+            pending.append(((prefix << lg) | b, pbits + lg, tp_above[i], fp_above[i], ub[i]))
 
     walk(h, 0, 0, 0.0, 0.0, False)
     level = 1
