@@ -148,7 +148,10 @@ class Engine:
                                "there is no CPU fallback")
         self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
         self.dims = dims if dims is not None else default_dims()
-        blob = blob_from_state_dict(state_dict)
+        if isinstance(state_dict, (np.ndarray, torch.Tensor)):          # already the flat fp32 blob (sg_pr_amd.ops)
+            blob = np.ascontiguousarray(torch.as_tensor(state_dict).detach().cpu().numpy(), dtype=np.float32).ravel()
+        else:
+            blob = blob_from_state_dict(state_dict)
         want = self.lib.sgpr_weights_count(ctypes.byref(self.dims))
         h = ctypes.c_void_p()
         rc = self.lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(self.dims),

@@ -386,3 +386,22 @@ def test_topk_rows_loop_closures(eng):
     # fewer than k qualifying columns -> -1
     vals, idx = eng.topk_rows(md[:5, :6].contiguous(), k=8, window=1)
     assert (idx.cpu()[:, -1] == -1).all() and torch.isinf(vals.cpu()[:, -1]).all()
+
+
+def test_custom_ops_match_engine(eng, ckpt_path):
+    """torch.ops.sgpr.* == the Engine methods they wrap (same C-ABI calls), bit for bit."""
+    from sg_pr_amd import ops, synth, engine  # noqa: F401
+    sd = torch.load(ckpt_path, map_location="cpu")
+    blob = torch.from_numpy(engine.blob_from_state_dict(sd)).cuda()
+    centers, labels, _ = synth.config2_pairs(seed=1, batch=8)
+    c, l = torch.from_numpy(centers).cuda(), torch.from_numpy(labels).cuda()
+    pooled, att = torch.ops.sgpr.embed(c, l, blob, 10)
+    p0, a0, _ = eng.embed(c, l, 10, want_att=True)
+    assert torch.equal(pooled, p0) and torch.equal(att, a0)
+    assert torch.equal(torch.ops.sgpr.score_all_pairs(pooled, pooled, blob), eng.score_all_pairs(p0, p0))
+    assert torch.equal(torch.ops.sgpr.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous(), blob),
+                       eng.score_pairs(p0[0::2].contiguous(), p0[1::2].contiguous()))
+    dense = torch.from_numpy(synth.dense_features(centers, labels)).cuda()
+    s1, x1, y1 = torch.ops.sgpr.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), blob, 10)
+    s0, x0, y0 = eng.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), 10)
+    assert torch.equal(s1, s0) and torch.equal(x1, x0) and torch.equal(y1, y0)

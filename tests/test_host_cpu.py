@@ -337,3 +337,22 @@ def test_f1_max_from_histograms_is_exact(golden_dir):
         ign = rng.random(n) < 0.2
         got, passes = metrics.f1_max_from_histograms(metrics.histograms_of(sc, np.where(ign, -1, gt)))
         assert abs(got - metrics.f1_max(gt[~ign], sc[~ign])) < 1e-12 and passes <= 12
+
+
+def test_custom_ops_registered_and_refuse_cpu():
+    """SURVEY §8b custom ops: registered with the dispatcher, shape-traceable, and GPU-only."""
+    from sg_pr_amd import ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ("embed", "score_pairs", "score_all_pairs", "forward_dense"):
+        assert hasattr(torch.ops.sgpr, name)
+    with FakeTensorMode():
+        c, l, w = torch.empty(5, 100, 3), torch.empty(5, 100, dtype=torch.int32), torch.empty(48689)
+        p, a = torch.ops.sgpr.embed(c, l, w, 10)
+        assert p.shape == (5, 32) and a.shape == (5, 100)
+        assert torch.ops.sgpr.score_all_pairs(p, p, w).shape == (5, 5)
+        assert torch.ops.sgpr.score_pairs(p, p, w).shape == (5,)
+        f = torch.empty(4, 15, 64)
+        s_, a1, a2 = torch.ops.sgpr.forward_dense(f, f, w, 10)
+        assert s_.shape == (4,) and a1.shape == (4, 64) and a2.shape == (4, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.sgpr.score_pairs(torch.zeros(2, 32), torch.zeros(2, 32), torch.zeros(48689))
