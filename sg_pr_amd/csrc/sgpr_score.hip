@@ -218,6 +218,18 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 // pattern: every negative float (and -0) is a negative integer.
 __device__ __forceinline__ float relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
+// layer 1 of one (row graph, 16 column graphs) block: six bf16 products, smallest terms first
+__device__ __forceinline__ f32x4 layer1(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, float4 u4,
+                                        float4 v4) {
+    f32x4 h = {u4.x + v4.x, u4.y + v4.y, u4.z + v4.z, u4.w + v4.w};
+    h = mfma_bf16(al, bh, h);
+    h = mfma_bf16(ah, bl, h);
+    h = mfma_bf16(am, bm, h);
+    h = mfma_bf16(am, bh, h);
+    h = mfma_bf16(ah, bm, h);
+    return mfma_bf16(ah, bh, h);
+}
+
 // One wave owns AP_RW = 4 row graphs - their A_r operands, 14 MB in total and therefore MALL/HBM-resident, are fetched
 // once per work item and kept in registers - and streams blocks of 16 column graphs, whose three-plane operands
 // (0.9 MB in total) stay in L2 and are fetched one block ahead.  Per (row, block):
@@ -289,15 +301,14 @@ __global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevW
             const bf16x8 nbl = *reinterpret_cast<const bf16x8*>(cp + 2 * F);
             const float4 nv4 = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
             float zb[AP_RW];
+            // software pipeline over the four rows: the layer-1 MFMA chain of row rr+1 is issued before the VALU
+            // epilogue of row rr, so that the matrix pipe works while this wave issues vector instructions
+            f32x4 hcur = layer1(ah[0], am[0], al[0], bh, bm, bl, u4[0], v4);
 #pragma unroll
             for (int rr = 0; rr < AP_RW; ++rr) {
-                f32x4 h = {u4[rr].x + v4.x, u4[rr].y + v4.y, u4[rr].z + v4.z, u4[rr].w + v4.w};
-                h = mfma_bf16(al[rr], bh, h);              // smallest terms first
-                h = mfma_bf16(ah[rr], bl, h);
-                h = mfma_bf16(am[rr], bm, h);
-                h = mfma_bf16(am[rr], bh, h);
-                h = mfma_bf16(ah[rr], bm, h);
-                h = mfma_bf16(ah[rr], bh, h);
+                f32x4 hnext = hcur;
+                if (rr + 1 < AP_RW) hnext = layer1(ah[rr + 1], am[rr + 1], al[rr + 1], bh, bm, bl, u4[rr + 1], v4);
+                const f32x4 h = hcur;
                 // layer 2 on the f16 matrix cores: H = hi + lo (two f16 planes, 22 bits); K slots 8g..8g+3 = hi,
                 // 8g+4..8g+7 = lo of t = 4g..4g+3 - exactly this lane's accumulators
                 // (packed conversions: v_cvt_pk_f16_f32 for both planes, v_pk_add_f32 for the remainders)
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevW
                 z = fmaf(w2v.y, relu(q[1]), z);
                 z = fmaf(w2v.z, relu(q[2]), z);
                 zb[rr] = fmaf(w2v.w, relu(q[3]), z);       // partial over o = 4g..4g+3 of row rr, column l15
+                hcur = hnext;
             }
             // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
             // full sum of row g (3 swaps + 3 adds instead of 8 bpermutes)
