@@ -79,8 +79,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # SGPR_BENCH_BACKEND=gloo: debugging aid - exercises the N > 1 code path with several ranks on ONE GPU
+        backend = os.environ.get("SGPR_BENCH_BACKEND", "nccl")
+        local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -200,6 +206,25 @@ def main():
         dt = float(t.item())
     embed_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_pairs])) if ev_pairs else float("nan")
     del out
+    # N > 1, extra information (not `value`): the same K steps with the matrix left sharded by rows - what the
+    # device-side consumers (F1-max histograms, top-k retrieval) work on; isolates the cost of the gather to rank 0
+    sharded = None
+    if world > 1 and a.workload == "kitti00" and not a.no_gather:
+        for _ in range(a.warmup):
+            scorer.run(d_centers, d_labels, gather=False)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            blk = scorer.run(d_centers, d_labels, gather=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sharded = {"ms_per_step": float(t.item()) / a.steps * 1e3, "value": units * a.steps / float(t.item()),
+                   "note": "matrix left sharded by rows (no gather to rank 0)"}
+        del blk
 
     if rank == 0:
         value = units * a.steps / dt
@@ -235,6 +260,7 @@ def main():
                        "parallelism": "row-sharded x%d" % world,
                        "gather_to_rank0": (not a.no_gather) if a.workload == "kitti00" else None,
                        "checkpoint": "tests/golden/model.pth"},
+            "sharded_output": sharded,
             "roofline": {"kernel": "sgpr::embed_kernel", "bound": "mfma", "achieved": ach_tflops,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP32_PEAK_TFLOPS,
                          "traffic": traffic, "launch_ms": embed_ms, "graphs_per_launch": int(g),

@@ -134,15 +134,53 @@ class AllPairsScorer:
         lo, _ = shard_bounds(block.shape[1], world, rank)
         return self._engine.topk_rows(block, k=k, row0=lo, window=window)
 
-    def run(self, centers, labels, gather=True, out=None):
+    def run(self, centers, labels, gather=True, out=None, chunks=4):
         """Whole job: returns the [M, M] matrix on rank 0 (row block elsewhere / if gather=False).
-        `out` (rank 0): preallocated [M, M] buffer that receives the matrix."""
+        `out` (rank 0): preallocated [M, M] buffer that receives the matrix.
+        chunks > 1 (multi-rank gather): every rank scores its row block in `chunks` pieces and ships each piece to
+        rank 0 as soon as it is computed, so the xGMI transfer of piece i overlaps the scoring of piece i+1; rank 0
+        posts all its receives up front, straight into the rows of the matrix."""
         pooled = self.pooled_all(centers, labels)
-        block = self.score_rows(pooled)
-        if not gather:
-            return block
-        full = self.gather_matrix(block, pooled.shape[0], out=out)
-        return full if full is not None else block
+        world, rank = self._world()
+        if not gather or world == 1 or chunks <= 1:
+            block = self.score_rows(pooled)
+            if not gather:
+                return block
+            full = self.gather_matrix(block, pooled.shape[0], out=out)
+            return full if full is not None else block
+        m = pooled.shape[0]
+        dst = 0
+
+        def pieces(lo, hi):
+            n = max(1, min(chunks, hi - lo))
+            return [(lo + (hi - lo) * i // n, lo + (hi - lo) * (i + 1) // n) for i in range(n)] if hi > lo else []
+
+        lo, hi = shard_bounds(m, world, rank)
+        if rank == dst:
+            full = out if out is not None else pooled.new_empty((m, m))
+            ops = []
+            for r in range(world):
+                if r == rank:
+                    continue
+                l, h = shard_bounds(m, world, r)
+                ops += [dist.P2POp(dist.irecv, full[a:b], r, self.group) for a, b in pieces(l, h)]
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            for a, b in pieces(lo, hi):                      # own rows: scored straight into the matrix
+                if self._engine is not None:
+                    self.score_fn(pooled[a:b].contiguous(), pooled, out=full[a:b])
+                else:
+                    full[a:b].copy_(self.score_fn(pooled[a:b].contiguous(), pooled))
+            for q in reqs:
+                q.wait()
+            return full
+        reqs, keep = [], []
+        for a, b in pieces(lo, hi):
+            blk = self.score_fn(pooled[a:b].contiguous(), pooled)
+            keep.append(blk)                                 # the buffer must outlive the asynchronous send
+            reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, blk, dst, self.group)])
+        for q in reqs:
+            q.wait()
+        return torch.cat(keep, dim=0) if keep else pooled.new_empty((0, m))
 
 
 def pose_xz(poses):

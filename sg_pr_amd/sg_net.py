@@ -112,8 +112,8 @@ class SG(torch.nn.Module):
         """NTN + head on pooled vectors (optionally gathered through index lists)."""
         return self.engine().score_pairs(pooled_1, pooled_2, idx_1, idx_2)
 
-    def score_all_pairs(self, pooled_rows, pooled_cols):
-        return self.engine().score_all_pairs(pooled_rows, pooled_cols)
+    def score_all_pairs(self, pooled_rows, pooled_cols, out=None):
+        return self.engine().score_all_pairs(pooled_rows, pooled_cols, out=out)
 
     def forward_packed(self, centers_1, labels_1, centers_2, labels_2):
         """Faithful per-pair scoring of packed graphs: both sides embedded, then the tail."""
