@@ -405,3 +405,23 @@ def test_custom_ops_match_engine(eng, ckpt_path):
     s1, x1, y1 = torch.ops.sgpr.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), blob, 10)
     s0, x0, y0 = eng.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), 10)
     assert torch.equal(s1, s0) and torch.equal(x1, x0) and torch.equal(y1, y0)
+
+
+def test_lean_plans_of_every_shape(eng, oracle, oracle_sd):
+    """Capped plans with 128 / 192 / 256 threads, K <= 16 and K > 16 instances: bit-identical to the uncapped
+    launch (which test_odd_sizes & co. hold against the oracle), plus one direct oracle check per shape."""
+    from sg_pr_amd import synth
+    for n, k, lo, hi in ((100, 10, 3, 14), (40, 10, 5, 28), (100, 10, 33, 47), (64, 20, 10, 40), (64, 5, 40, 59),
+                         (100, 32, 20, 60), (24, 3, 2, 20)):
+        centers, labels, _ = synth.make_graphs(300, n, lo, hi, 1000 + n + k)
+        order, cap = eng.size_order(centers, labels, k)
+        assert cap <= 64
+        full, att0, _ = eng.embed(centers, labels, k, want_att=True)
+        lean, att1, _ = eng.embed(centers, labels, k, want_att=True, node_cap=cap, order=order)
+        eng.check_status()
+        assert torch.equal(full, lean) and torch.equal(att0, att1), (n, k, lo, hi)
+        sub = slice(0, 12)
+        rp, _, _ = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(centers[sub], labels[sub])), k)
+        s = eng.score_pairs(lean[sub][0::2].contiguous(), lean[sub][1::2].contiguous()).cpu()
+        rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
+        assert (s - rs).abs().max().item() <= SCORE_TOL, (n, k)
