@@ -425,3 +425,35 @@ def test_lean_plans_of_every_shape(eng, oracle, oracle_sd):
         s = eng.score_pairs(lean[sub][0::2].contiguous(), lean[sub][1::2].contiguous()).cpu()
         rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
         assert (s - rs).abs().max().item() <= SCORE_TOL, (n, k)
+
+
+def test_sequence_evaluation_end_to_end(tmp_path, golden_dir, ckpt_path):
+    """Packed store -> embed once -> dense matrix -> device F1-max + loop closures, through the module CLI."""
+    from sg_pr_amd import graph_store, metrics
+    data = os.path.join(golden_dir, "data")
+    os.makedirs(tmp_path / "graphs" / "00")
+    for f in os.listdir(data):
+        with open(os.path.join(data, f)) as src, open(tmp_path / "graphs" / "00" / f, "w") as dst:
+            dst.write(src.read())
+    cfg = tmp_path / "config.yml"
+    cfg.write_text("""
+common: {model: "%s", cuda: "0", batch_size: 128, p_thresh: 3, graph_pairs_dir: "%s", pair_list_dir: '%s'}
+arch: {keep_node: 1, filters_1: 64, filters_2: 64, filters_3: 32, tensor_neurons: 16, bottle_neck_neurons: 16, K: 10}
+train: {epochs: 500, train_sequences: ['00'], eval_sequences: ["08"], dropout: 0, learning_rate: 0.001,
+        weight_decay: 0.0005, gpu: 0, logdir: "./logs_k10", node_num: 100}
+eva_batch: {sequences: ["00"], output_path: "%s", show: False}
+eva_pair: {pair_file: ["%s/0.json", "%s/250.json"]}
+""" % (ckpt_path, tmp_path / "graphs", tmp_path, tmp_path / "eva", data, data))
+    res = graph_store.main([str(cfg)])
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    # frames in natural order 0, 3, 250 == the golden's graph order; 9 ordered pairs row-major
+    seq = graph_store.PackedSequence.load(str(tmp_path / "eva" / "00_packed.npz"))
+    assert seq.names == ["0.json", "3.json", "250.json"]
+    lc = np.load(tmp_path / "eva" / "00_loop_closures.npy")
+    assert lc.shape == (3, 3)
+    # reference values: golden scores + float64 pose distances
+    scores = g["scores"].reshape(3, 3)
+    d = np.sqrt((seq.poses[:, None, 3] - seq.poses[None, :, 3]) ** 2 + (seq.poses[:, None, 11] - seq.poses[None, :, 11]) ** 2)
+    valid = (d <= 3) | (d >= 20)
+    want = metrics.f1_max((d <= 3)[valid].astype(np.float64), scores[valid])
+    assert abs(res["00"] - want) < 1e-9

@@ -356,3 +356,26 @@ def test_custom_ops_registered_and_refuse_cpu():
         assert s_.shape == (4,) and a1.shape == (4, 64) and a2.shape == (4, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         torch.ops.sgpr.score_pairs(torch.zeros(2, 32), torch.zeros(2, 32), torch.zeros(48689))
+
+
+def test_graph_store_roundtrip(tmp_path, golden_dir):
+    """a sequence directory is parsed once into the packed wire format (same bytes as pack_graph per
+    graph, frames in natural order) and survives the .npz round trip."""
+    from sg_pr_amd import graph_store, sg_net, utils
+    data = os.path.join(golden_dir, "data")
+    seq = graph_store.pack_directory(data, 100)
+    assert seq.names == ["0.json", "3.json", "250.json"] and len(seq) == 3 and seq.node_num == 100
+    for g, name in enumerate(seq.names):
+        d = utils.read_graph(os.path.join(data, name))
+        c, l = sg_net.pack_graph(d["centers"], d["nodes"], 100)
+        np.testing.assert_array_equal(seq.centers[g], c)
+        np.testing.assert_array_equal(seq.labels[g], l)
+        np.testing.assert_array_equal(seq.poses[g], np.asarray(d["pose"], dtype=np.float64))
+    seq.save(str(tmp_path / "s.npz"))
+    back = graph_store.PackedSequence.load(str(tmp_path / "s.npz"))
+    assert back.names == seq.names
+    for a, b in ((seq.centers, back.centers), (seq.labels, back.labels), (seq.poses, back.poses)):
+        np.testing.assert_array_equal(a, b)
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    if "centers" in g and g["centers"].shape[0] == 3:
+        pass
