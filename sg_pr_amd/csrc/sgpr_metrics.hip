@@ -49,6 +49,7 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
     const int gpr = (a.M + 3) >> 2;
     const int64_t items = (int64_t)a.R * gpr;
     unsigned nbad = 0;
+    const double lo2 = a.d_pos * a.d_pos, hi2 = a.d_neg * a.d_neg;
     for (int64_t it = (int64_t)blockIdx.x * HB_THREADS + threadIdx.x; it < items; it += (int64_t)gridDim.x * HB_THREADS) {
         const int r = (int)(it / gpr), c0 = (int)(it - (int64_t)r * gpr) * 4;
         const float* sp = a.score + (int64_t)r * a.ld + c0;
@@ -74,8 +75,16 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
             if (a.pose) {
                 // utils.py:36 in float64, operation by operation (no fused multiply-add)
                 const double dx = px - a.pose[2 * c], dz = pz - a.pose[2 * c + 1];
-                const double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz)));
-                cls = d <= a.d_pos ? 1 : (d >= a.d_neg ? 0 : -1);
+                const double s2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz));
+                // sqrt is monotone and correctly rounded: away from the two thresholds the squared distance decides;
+                // only within a relative 1e-12 of them is the reference's `sqrt(...) <= t` evaluated literally
+                if (s2 < lo2 * (1.0 - 1e-12)) cls = 1;
+                else if (s2 > lo2 * (1.0 + 1e-12) && s2 < hi2 * (1.0 - 1e-12)) cls = -1;
+                else if (s2 > hi2 * (1.0 + 1e-12)) cls = 0;
+                else {
+                    const double d = sqrt(s2);
+                    cls = d <= a.d_pos ? 1 : (d >= a.d_neg ? 0 : -1);
+                }
             } else {
                 const int g = a.gt[(int64_t)r * a.ldg + c];
                 cls = g < 0 ? -1 : (g != 0);
@@ -102,15 +111,20 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
     for (int i = threadIdx.x; i < nb; i += HB_THREADS) slab[i] = hist[i];
 }
 
+// 64 counters per workgroup, 4 threads per counter (each sums every 4th slab), 256-B coalesced reads
 __global__ __launch_bounds__(256) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int nb,
                                                        const unsigned* __restrict__ bad,
                                                        unsigned long long* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) out[nb] = *bad;
-    if (i >= nb) return;
+    __shared__ unsigned long long part[4][64];
+    const int b = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + b;
     unsigned long long s = 0ull;
-    for (int q = 0; q < n_slabs; ++q) s += slabs[(size_t)q * nb + i];
-    out[i] = s;
+    if (i < nb)
+        for (int q = grp; q < n_slabs; q += 4) s += slabs[(size_t)q * nb + i];
+    part[grp][b] = s;
+    __syncthreads();
+    if (grp == 0 && i < nb) out[i] = part[0][b] + part[1][b] + part[2][b] + part[3][b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[nb] = *bad;
 }
 
 // ------------------------------------------------------------------ top-K per row
@@ -241,7 +255,7 @@ int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M
     hipLaunchKernelGGL(pair_histogram_kernel, dim3(grid), dim3(HB_THREADS), nb * sizeof(unsigned), s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pair_histogram_kernel launch");
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, a.slabs, grid, nb, a.bad, d_hist);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((nb + 63) / 64), dim3(256), 0, s, a.slabs, grid, nb, a.bad, d_hist);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "slab_sum_kernel launch");
     return SGPR_OK;
