@@ -191,7 +191,8 @@ void sgpr_debug_set_profile_buffer(void* d_counters);
 /* Debug / ablation timing only (results become invalid): bit 0 skips the kNN selection, bit 1 the per-node GEMMs,
  * bit 2 the Gram phase, bit 3 the gather-max; bit 4 returns right after dispatch, bit 5 after the input fetch;
  * bit 8 = nothing skipped (just selects the profiling instance); bits 9/10/11 keep the GEMM phase but drop its weight
- * loads / its MFMAs / its inner barrier.  0 (default) = normal. */
+ * loads / its MFMAs / its inner barrier; bit 12 runs the generic first semantic layer instead of the label lookup (valid
+ * results).  0 (default) = normal. */
 void sgpr_debug_set_skip_mask(int mask);
 
 const char* sgpr_last_error(void);

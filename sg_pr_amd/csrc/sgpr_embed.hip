@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     if (skip & 16) return;   // ablation: pure dispatch cost
     // ---- one slot per thread, fetched once for both branches: xyz + 12 semantic channels
     float fx = 0.f, fy = 0.f, fz = 0.f;
+    int mylab = -2;                                       // packed input: this slot's label (-1 = pad)
     float sem[kLabels];
 #pragma unroll
     for (int c = 0; c < kLabels; ++c) sem[c] = 0.f;
@@ -1039,6 +1040,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             fz = c3[2];
             const int lab = kp.a.labels[(size_t)g * NS + tid];
             if (lab < -1 || lab >= kLabels) atomicOr(kp.a.status, 1);
+            mylab = lab;
 #pragma unroll
             for (int c = 0; c < kLabels; ++c) sem[c] = (lab == c) ? 1.f : 0.f;
         }
@@ -1097,25 +1099,96 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
     const int seg = (((N + P - 1) / P) + 3) & ~3;
 
-    // ---- stage the first branch's input (12 semantic channels, zero padded to 16 / NP rows) + squared norms; done
-    //      ahead of the layer loop so that the 12 input registers die here instead of living across it
-    if (tid < NP) {
-        const bool live = tid < N;
-        float s = 0.f;
+    // ---- first semantic layer by label lookup.  Packed input = one-hot rows: the ranking key of candidate j for row
+    //      i is 1 - 2[l_i == l_j] (0 for the zero-feature padding representative), so a row's neighbour set is "its
+    //      label-mates, lowest indices first, plus the representative when there are fewer than k of them", its
+    //      a / b terms are columns of the folded weights, and the layer's output depends on the label alone
+    //      (13 distinct rows: 12 labels + the representative).  The table is built with the very instructions of the
+    //      generic gather epilogue, so the result is bit-identical to the generic layer (which still runs for dense
+    //      input, debug dumps, graphs without >= k padding slots, stray -1 labels, or fewer than 17 slots).
+    int L0 = 0;
+    {
+        const int k0 = p.k;
+        const bool bad = (tid < nd && mylab < 0) || (tid == nd && mylab != -1);
+        // (__syncthreads_or would add static LDS on top of the 160 KB dynamic allocation)
+        int* flag = reinterpret_cast<int*>(red);
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        const unsigned long long bm = __ballot(bad);
+        if (lane == 0 && bm) atomicOr(flag, 1);
+        __syncthreads();
+        const bool any_bad = *flag != 0;
+        __syncthreads();                                    // red shares X, which is written next
+        const bool fast = !kp.a.dense && DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
+        if (fast) {
+            unsigned char* T = reinterpret_cast<unsigned char*>(A);               // [13][XROW] table rows
+            float* xxT = reinterpret_cast<float*>(T + 13 * XROW);                  // [16] squared norms
+            int* cnt = reinterpret_cast<int*>(xxT + 16);                           // [16] nodes per label
+            signed char* rowlab = reinterpret_cast<signed char*>(cnt + 16);        // [NP] table row of every slot
+            if (tid < 16) cnt[tid] = 0;
+            __syncthreads();
 #pragma unroll
-        for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned char* xr = X + tid * XROW;
-        xstore<XP>(xr, 0, live ? make_float4(sem[0], sem[1], sem[2], sem[3]) : z4);
-        xstore<XP>(xr, 4, live ? make_float4(sem[4], sem[5], sem[6], sem[7]) : z4);
-        xstore<XP>(xr, 8, live ? make_float4(sem[8], sem[9], sem[10], sem[11]) : z4);
-        xstore<XP>(xr, 12, z4);
-        xx[tid] = live ? s : 0.f;
+            for (int c = 0; c < kLabels; ++c) {
+                const unsigned long long mk = __ballot(tid < nd && mylab == c);
+                if (lane == 0 && mk) atomicAdd(&cnt[c], __popcll(mk));
+            }
+            if (tid < N) rowlab[tid] = (signed char)(tid == nd ? kLabels : mylab);
+            __syncthreads();
+            const float* wf0 = kp.w.wf[0];                                         // [2 * 64][16] folded fp32 weights
+            const float* tb0 = kp.w.tb[0];
+            for (int t = tid; t < 13 * 16; t += NT) {
+                const int v = t >> 4, c4 = (t & 15) * 4;
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
+                bool with_rep = true;
+                if (v < kLabels) {
+                    a4 = make_float4(wf0[(c4 + 0) * 16 + v], wf0[(c4 + 1) * 16 + v], wf0[(c4 + 2) * 16 + v],
+                                     wf0[(c4 + 3) * 16 + v]);
+                    b4 = make_float4(wf0[(64 + c4 + 0) * 16 + v] + b4.x, wf0[(64 + c4 + 1) * 16 + v] + b4.y,
+                                     wf0[(64 + c4 + 2) * 16 + v] + b4.z, wf0[(64 + c4 + 3) * 16 + v] + b4.w);
+                    with_rep = cnt[v] < k0;
+                }
+                const float z = with_rep ? 0.f : -INFINITY;                        // the representative's a is 0
+                const float4 m4 = make_float4(max3(-INFINITY, a4.x, z), max3(-INFINITY, a4.y, z),
+                                              max3(-INFINITY, a4.z, z), max3(-INFINITY, a4.w, z));
+                const float4 y = add_lrelu(m4, b4, true);
+                xstore<XP>(T + v * XROW, c4, y);
+                float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+                sa += lane_xor(sa, 1);
+                sa += lane_xor(sa, 2);
+                sa += lane_xor(sa, 4);
+                sa += lane_xor(sa, 8);
+                if ((t & 15) == 0) xxT[v] = sa;
+            }
+            __syncthreads();
+            constexpr int CH = XROW / 16;                                          // 16-byte chunks per row
+            for (int e = tid; e < NP * CH; e += NT) {
+                const int row = e / CH, ch = e - row * CH;
+                uint4 val = make_uint4(0u, 0u, 0u, 0u);
+                if (row < N) val = *reinterpret_cast<const uint4*>(T + (int)rowlab[row] * XROW + ch * 16);
+                *reinterpret_cast<uint4*>(X + row * XROW + ch * 16) = val;
+            }
+            if (tid < NP) xx[tid] = tid < N ? xxT[(int)rowlab[tid]] : 0.f;
+            L0 = 1;
+        } else if (tid < NP) {
+            // ---- generic: stage the first branch's input (12 semantic channels, zero padded to 16 / NP rows) +
+            //      squared norms, ahead of the layer loop so that the 12 input registers die here
+            const bool live = tid < N;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned char* xr = X + tid * XROW;
+            xstore<XP>(xr, 0, live ? make_float4(sem[0], sem[1], sem[2], sem[3]) : z4);
+            xstore<XP>(xr, 4, live ? make_float4(sem[4], sem[5], sem[6], sem[7]) : z4);
+            xstore<XP>(xr, 8, live ? make_float4(sem[8], sem[9], sem[10], sem[11]) : z4);
+            xstore<XP>(xr, 12, z4);
+            xx[tid] = live ? s : 0.f;
+        }
     }
     __syncthreads();
     SGPR_PROF(0)
 
-    for (int L = 0; L < 6; ++L) {
+    for (int L = L0; L < 6; ++L) {
         // per-iteration opaque copy: keeps the compiler from hoisting (and then spilling) dozens of
         // k-derived predicates out of the layer loop
         int k = p.k;

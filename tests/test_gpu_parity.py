@@ -457,3 +457,17 @@ eva_pair: {pair_file: ["%s/0.json", "%s/250.json"]}
     valid = (d <= 3) | (d >= 20)
     want = metrics.f1_max((d <= 3)[valid].astype(np.float64), scores[valid])
     assert abs(res["00"] - want) < 1e-9
+
+
+def test_label_lookup_layer_is_bitwise_generic(eng):
+    """The label-lookup first semantic layer (packed input) gives the bits of the generic kNN/EdgeConv layer, which
+    the debug-dump instance still runs - on KITTI-like graphs, on graphs with fewer label-mates than K, with every
+    label present, and in the lean and the latency plans."""
+    from sg_pr_amd import synth
+    for num, n, lo, hi, kitti in ((40, 100, 25, 60, True), (300, 100, 25, 60, True), (300, 64, 17, 50, False),
+                                  (300, 100, 40, 85, False)):
+        centers, labels, _ = synth.make_graphs(num, n, lo, hi, 77 + num + n, kitti_like=kitti)
+        order, cap = eng.size_order(centers, labels, 10)
+        prod, att, emb = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
+        dbg = eng.embed(centers, labels, 10, debug=True)
+        assert torch.equal(prod, dbg[0]) and torch.equal(att, dbg[1]) and torch.equal(emb, dbg[2]), (num, n)

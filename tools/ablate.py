@@ -18,7 +18,7 @@ for name, (n, k, g) in shapes.items():
         c, l, _ = synth.make_graphs(g, n, 20, n - k, 0)
     order, cap = eng.size_order(c, l, k)
     c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
-    for mask, label in [(0, "full"), (256, "full, profile instance"), (1, "no select"), (2, "no gemm"), (512, "gemm without weight loads"), (1024, "gemm without MFMAs"), (2048, "gemm without its inner barrier"), (1024+512, "gemm: no weights, no MFMAs"), (3, "no select, no gemm"), (4, "no gram"),
+    for mask, label in [(0, "full"), (256, "full, profile instance"), (256 + 4096, "full, generic first semantic layer"), (1, "no select"), (2, "no gemm"), (512, "gemm without weight loads"), (1024, "gemm without MFMAs"), (2048, "gemm without its inner barrier"), (1024+512, "gemm: no weights, no MFMAs"), (3, "no select, no gemm"), (4, "no gram"),
                         (8, "no gather"), (15, "skeleton (stage, barriers, conv_end, attention)"),
                         (32, "input fetch + duplicate detection only"), (16, "dispatch only")]:
         eng.lib.sgpr_debug_set_skip_mask(mask)
