@@ -1099,14 +1099,19 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
     const int seg = (((N + P - 1) / P) + 3) & ~3;
 
-    // ---- first semantic layer by label lookup.  Packed input = one-hot rows: the ranking key of candidate j for row
-    //      i is 1 - 2[l_i == l_j] (0 for the zero-feature padding representative), so a row's neighbour set is "its
-    //      label-mates, lowest indices first, plus the representative when there are fewer than k of them", its
-    //      a / b terms are columns of the folded weights, and the layer's output depends on the label alone
-    //      (13 distinct rows: 12 labels + the representative).  The table is built with the very instructions of the
-    //      generic gather epilogue, so the result is bit-identical to the generic layer (which still runs for dense
-    //      input, debug dumps, graphs without >= k padding slots, stray -1 labels, or fewer than 17 slots).
+    // ---- the semantic branch on label super-nodes.  Packed input = one-hot rows, so nodes with the same label have
+    //      identical features - and, by the argument that lets duplicate slots be dropped, identical
+    //      features in EVERY layer of this branch: its whole output is a function of the label (12 labels + the
+    //      zero-feature padding representative = 13 distinct rows) and of how many nodes carry each label.
+    //      Layer 1: the ranking key of candidate j for row i is 1 - 2[l_i == l_j] (0 for the representative): the
+    //      neighbour set is "label-mates, plus the representative when there are fewer than K of them", the a / b
+    //      terms are columns of the folded weights -> a 13-row table.  Layers 2 and 3 run on those 13 rows: one Gram
+    //      tile, a counting selection (labels in key order, each standing for its node count, the representative for
+    //      >= K copies), one row tile of GEMMs, a 13-row gather.  Every value is produced by the instructions of the
+    //      generic path on the same operands, so the result is bit-identical to it (tests); the generic path still
+    //      runs for dense input, debug dumps, graphs without >= K padding slots, stray -1 labels, < 17 slots.
     int L0 = 0;
+    const signed char* rowlab = nullptr;                     // fast path: table row of every slot (13 = zero row)
     {
         const int k0 = p.k;
         const bool bad = (tid < nd && mylab < 0) || (tid == nd && mylab != -1);
@@ -1119,24 +1124,26 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         __syncthreads();
         const bool any_bad = *flag != 0;
         __syncthreads();                                    // red shares X, which is written next
-        const bool fast = !kp.a.dense && DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
+        const bool fast = !kp.a.dense && DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32 && p.park_in_lds;
         if (fast) {
-            unsigned char* T = reinterpret_cast<unsigned char*>(A);               // [13][XROW] table rows
-            float* xxT = reinterpret_cast<float*>(T + 13 * XROW);                  // [16] squared norms
-            int* cnt = reinterpret_cast<int*>(xxT + 16);                           // [16] nodes per label
-            signed char* rowlab = reinterpret_cast<signed char*>(cnt + 16);        // [NP] table row of every slot
-            if (tid < 16) cnt[tid] = 0;
+            // scratch that must survive the branch sits behind the 16 virtual rows of the parked block
+            int* cnt = reinterpret_cast<int*>(park + 16 * PP);                     // [16] nodes per label, [12] = K
+            signed char* rl = reinterpret_cast<signed char*>(cnt + 16);            // [NP]
+            int* vmask = reinterpret_cast<int*>(nbr);                              // [16] neighbour label sets
+            rowlab = rl;
+            if (tid < 16) cnt[tid] = tid == kLabels ? k0 : 0;
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < kLabels; ++c) {
                 const unsigned long long mk = __ballot(tid < nd && mylab == c);
                 if (lane == 0 && mk) atomicAdd(&cnt[c], __popcll(mk));
             }
-            if (tid < N) rowlab[tid] = (signed char)(tid == nd ? kLabels : mylab);
+            if (tid < NP) rl[tid] = (signed char)(tid < N ? (tid == nd ? kLabels : mylab) : kLabels + 1);
             __syncthreads();
+            // layer 1: the table, straight into X rows 0..15 (rows 13..15 zero)
             const float* wf0 = kp.w.wf[0];                                         // [2 * 64][16] folded fp32 weights
             const float* tb0 = kp.w.tb[0];
-            for (int t = tid; t < 13 * 16; t += NT) {
+            for (int t = tid; t < 16 * 16; t += NT) {
                 const int v = t >> 4, c4 = (t & 15) * 4;
                 float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
                 bool with_rep = true;
@@ -1150,25 +1157,69 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                 const float z = with_rep ? 0.f : -INFINITY;                        // the representative's a is 0
                 const float4 m4 = make_float4(max3(-INFINITY, a4.x, z), max3(-INFINITY, a4.y, z),
                                               max3(-INFINITY, a4.z, z), max3(-INFINITY, a4.w, z));
-                const float4 y = add_lrelu(m4, b4, true);
-                xstore<XP>(T + v * XROW, c4, y);
+                const float4 y = add_lrelu(m4, b4, v <= kLabels);
+                xstore<XP>(X + v * XROW, c4, y);
                 float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
                 sa += lane_xor(sa, 1);
                 sa += lane_xor(sa, 2);
                 sa += lane_xor(sa, 4);
                 sa += lane_xor(sa, 8);
-                if ((t & 15) == 0) xxT[v] = sa;
+                if ((t & 15) == 0) xx[v] = sa;
             }
             __syncthreads();
-            constexpr int CH = XROW / 16;                                          // 16-byte chunks per row
-            for (int e = tid; e < NP * CH; e += NT) {
-                const int row = e / CH, ch = e - row * CH;
-                uint4 val = make_uint4(0u, 0u, 0u, 0u);
-                if (row < N) val = *reinterpret_cast<const uint4*>(T + (int)rowlab[row] * XROW + ch * 16);
-                *reinterpret_cast<uint4*>(X + row * XROW + ch * 16) = val;
+            // layers 2 and 3 on the 13 virtual rows
+            for (int Lv = 1; Lv < 3; ++Lv) {
+                const int cout = kp.w.cout[Lv];
+                gram_tiles_sym<4, XP, false>(X, xx, D, p.pitchD, kLabels + 1, 1, wave);
+                __syncthreads();
+                for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
+                    const int l = t >> 4, j = t & 15;
+                    const int cj = j <= kLabels ? cnt[j] : 0;
+                    const float key = cj > 0 ? D[l * p.pitchD + j] : INFINITY;
+                    int before = 0;                                                // nodes ranked ahead of label j
+#pragma unroll
+                    for (int sft = 1; sft < 16; ++sft) {
+                        const int jj = (j + sft) & 15, src = (lane & ~15) | jj;
+                        const float ko = __shfl(key, src);
+                        const int co = __shfl(cj, src);
+                        before += (ko < key || (ko == key && jj < j)) ? co : 0;
+                    }
+                    const unsigned long long inc = __ballot(cj > 0 && before < k0);
+                    if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
+                }
+                __syncthreads();                                                   // keys consumed: A may overwrite D
+                gemm_layer<LEAN, XP>(X, A, p.pitchA, kp.w.wb[Lv], kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
+                __syncthreads();
+                const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
+                for (int t = tid; t < 16 * lpr; t += NT) {
+                    const int l = t / lpr, c4 = (t & (lpr - 1)) * 4;
+                    const int mask = vmask[l];
+                    float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+                    for (int j = 0; j <= kLabels; ++j) {
+                        const float4 v = *reinterpret_cast<const float4*>(A + j * p.pitchA + c4);
+                        const bool in = (mask >> j) & 1;
+                        m4.x = kmax(m4.x, in ? v.x : -INFINITY);
+                        m4.y = kmax(m4.y, in ? v.y : -INFINITY);
+                        m4.z = kmax(m4.z, in ? v.z : -INFINITY);
+                        m4.w = kmax(m4.w, in ? v.w : -INFINITY);
+                    }
+                    const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(X + l * XROW + 4 * c4), l <= kLabels);
+                    if (Lv == 1) {
+                        xstore<XP>(X + l * XROW, c4, y);
+                        float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+                        sa += lane_xor(sa, 1);
+                        sa += lane_xor(sa, 2);
+                        sa += lane_xor(sa, 4);
+                        sa += lane_xor(sa, 8);
+                        if ((t & 15) == 0) xx[l] = sa;
+                    } else {
+                        *reinterpret_cast<float4*>(park + (size_t)l * PP + c4) = y;
+                    }
+                }
+                __syncthreads();
             }
-            if (tid < NP) xx[tid] = tid < N ? xxT[(int)rowlab[tid]] : 0.f;
-            L0 = 1;
+            L0 = 3;
         } else if (tid < NP) {
             // ---- generic: stage the first branch's input (12 semantic channels, zero padded to 16 / NP rows) +
             //      squared norms, ahead of the layer loop so that the 12 input registers die here
@@ -1319,7 +1370,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct_end * 16 + 4 * lq);
     for (int e = tid; e < NP * 8; e += NT) {                      // sem3 -> channels 32..63: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
-        xstore<XP>(X + i * XROW, 32 + c4, *reinterpret_cast<const float4*>(park + (size_t)i * PP + c4));
+        const int pr = rowlab ? (int)rowlab[i] : i;              // fast path: the row of slot i's label
+        xstore<XP>(X + i * XROW, 32 + c4, *reinterpret_cast<const float4*>(park + (size_t)pr * PP + c4));
     }
     __syncthreads();
 
