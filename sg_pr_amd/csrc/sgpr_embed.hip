@@ -1124,9 +1124,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         __syncthreads();
         const bool any_bad = *flag != 0;
         __syncthreads();                                    // red shares X, which is written next
-        const bool fast = !kp.a.dense && DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32 && p.park_in_lds;
+        const bool fast = !kp.a.dense && DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
         if (fast) {
-            // scratch that must survive the branch sits behind the 16 virtual rows of the parked block
+            // scratch that must survive the branch sits behind the 16 virtual rows of the parked block (LDS, or the
+            // global workspace of the large plans: same-workgroup visibility across the barriers either way)
             int* cnt = reinterpret_cast<int*>(park + 16 * PP);                     // [16] nodes per label, [12] = K
             signed char* rl = reinterpret_cast<signed char*>(cnt + 16);            // [NP]
             int* vmask = reinterpret_cast<int*>(nbr);                              // [16] neighbour label sets

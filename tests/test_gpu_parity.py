@@ -465,9 +465,10 @@ def test_label_lookup_layer_is_bitwise_generic(eng):
     label present, and in the lean and the latency plans."""
     from sg_pr_amd import synth
     for num, n, lo, hi, kitti in ((40, 100, 25, 60, True), (300, 100, 25, 60, True), (300, 64, 17, 50, False),
-                                  (300, 100, 40, 85, False)):
+                                  (300, 100, 40, 85, False), (24, 160, 60, 140, False), (24, 256, 100, 236, False)):
         centers, labels, _ = synth.make_graphs(num, n, lo, hi, 77 + num + n, kitti_like=kitti)
-        order, cap = eng.size_order(centers, labels, 10)
-        prod, att, emb = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
-        dbg = eng.embed(centers, labels, 10, debug=True)
+        k = 20 if n == 256 else 10
+        order, cap = eng.size_order(centers, labels, k)
+        prod, att, emb = eng.embed(centers, labels, k, want_att=True, want_emb=True, node_cap=cap, order=order)
+        dbg = eng.embed(centers, labels, k, debug=True)
         assert torch.equal(prod, dbg[0]) and torch.equal(att, dbg[1]) and torch.equal(emb, dbg[2]), (num, n)
