@@ -117,12 +117,13 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
                                                        float* __restrict__ vc, unsigned short* __restrict__ Cb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int g0 = blockIdx.x * 16;
+    // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
+    const int g0 = (blockIdx.x >> 1) * 16, half = blockIdx.x & 1;
     if (g0 < R) {
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
         const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
         const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
-        for (int tile = wave * 8; tile < wave * 8 + 8; ++tile) {
+        for (int tile = half * 16 + wave * 4; tile < half * 16 + wave * 4 + 4; ++tile) {
             const int t = tile >> 1, j = (tile & 1) * 16 + l15;
             const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
         }
     }
     // block terms: one graph per wave pass, lane (t = l15, q = lq) sums 8 of the 32 products
-    for (int gi = wave * 4; gi < wave * 4 + 4; ++gi) {
+    for (int gi = half * 8 + wave * 2; gi < half * 8 + wave * 2 + 2; ++gi) {
         const int g = g0 + gi;
         if (g < R) {
             const float* e1 = rows + (size_t)g * F;
@@ -350,7 +351,7 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
     float* vc = ur + (size_t)R * T;
     unsigned short* Ab = reinterpret_cast<unsigned short*>(vc + (size_t)M * T);
     unsigned short* Cb = Ab + (size_t)R * 3 * T * F;
-    hipLaunchKernelGGL(ntn_prep_kernel, dim3(((R > M ? R : M) + 15) / 16), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc, Cb);
+    hipLaunchKernelGGL(ntn_prep_kernel, dim3(2 * (((R > M ? R : M) + 15) / 16)), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc, Cb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
     const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
