@@ -472,3 +472,50 @@ def test_label_lookup_layer_is_bitwise_generic(eng):
         prod, att, emb = eng.embed(centers, labels, k, want_att=True, want_emb=True, node_cap=cap, order=order)
         dbg = eng.embed(centers, labels, k, debug=True)
         assert torch.equal(prod, dbg[0]) and torch.equal(att, dbg[1]) and torch.equal(emb, dbg[2]), (num, n)
+
+
+def test_full_size_kitti00_properties(eng, oracle, oracle_sd):
+    """BASELINE config 3 at full size (M = 4541, node_num 100, K 10): properties that do not need the oracle on 20 M
+    pairs - a random sample of pairs against the oracle's faithful per-pair forward, pair-list == matrix entries,
+    row shards bit-identical, device F1-max == sorted host F1-max on a row block, closures consistent."""
+    from sg_pr_amd import synth, metrics, allpairs
+    centers, labels, _, poses = synth.kitti_like_sequence(4541, 100, 0)
+    order, cap = eng.size_order(centers, labels, 10)
+    pooled = eng.embed(centers, labels, 10, node_cap=cap, order=order)[0]
+    eng.check_status()
+    m = eng.score_all_pairs(pooled, pooled)
+    assert m.shape == (4541, 4541) and bool(torch.isfinite(m).all()) and float(m.min()) >= 0 and float(m.max()) <= 1
+    rng = np.random.default_rng(5)
+    # (1) oracle on 48 random ordered pairs
+    ii, jj = rng.integers(0, 4541, 48), rng.integers(0, 4541, 48)
+    f1 = torch.from_numpy(synth.dense_features(centers[ii], labels[ii]))
+    f2 = torch.from_numpy(synth.dense_features(centers[jj], labels[jj]))
+    ref = oracle.forward(oracle_sd, f1, f2, 10)[0]
+    got = m[torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()].cpu()
+    assert (got - ref).abs().max().item() <= SCORE_TOL
+    # (2) pair-list kernel == matrix entries
+    pi = torch.from_numpy(rng.integers(0, 4541, 8192).astype(np.int32))
+    pj = torch.from_numpy(rng.integers(0, 4541, 8192).astype(np.int32))
+    lst = eng.score_pairs(pooled, pooled, pi, pj).cpu()
+    np.testing.assert_allclose(lst.numpy(), m[pi.long().cuda(), pj.long().cuda()].cpu().numpy(), rtol=0, atol=2e-5)
+    # (3) any row shard reproduces its rows bit for bit; embedding a shard alone reproduces its pooled rows
+    for lo, hi in ((0, 568), (1703, 2271), (4000, 4541)):
+        assert torch.equal(eng.score_all_pairs(pooled[lo:hi].contiguous(), pooled), m[lo:hi])
+        o2, c2 = eng.size_order(centers[lo:hi], labels[lo:hi], 10)
+        assert torch.equal(eng.embed(centers[lo:hi], labels[lo:hi], 10, node_cap=c2, order=o2)[0], pooled[lo:hi])
+    # (4) F1-max: device histograms over the whole matrix == sum-consistent with a sorted host computation on a block
+    xz = allpairs.pose_xz(poses)
+    blk = m[1000:1600]
+    f_dev, _ = metrics.f1_max_device(eng, blk, pose_xz=xz, row0=1000)
+    d = torch.cdist(xz[1000:1600], xz)
+    valid = (d <= 3) | (d >= 20)
+    f_host = metrics.f1_max((d <= 3)[valid].numpy(), blk.cpu()[valid].numpy())
+    assert abs(f_dev - f_host) < 1e-12
+    f_all, passes = metrics.f1_max_device(eng, m, pose_xz=xz)
+    assert 0.0 <= f_all <= 1.0 and passes <= 16
+    # (5) loop closures: top-1 outside a 50-frame window really is the row maximum there
+    vals, idx = eng.topk_rows(m, k=1, window=50)
+    r = 2345
+    row = m[r].clone()
+    row[max(0, r - 50):r + 51] = -1
+    assert int(idx[r, 0]) == int(torch.argmax(row)) and float(vals[r, 0]) == float(row.max())
