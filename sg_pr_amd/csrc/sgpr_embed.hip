@@ -9,19 +9,18 @@
 //  * the [B,2C,N,k] edge tensor of dgcnn.get_graph_feature is never built:
 //      W.[x_j - x_i ; x_i] = W1.x_j + (W2-W1).x_i,  BN(eval) folded into W, and since
 //      LeakyReLU is monotone   max_m lrelu(a_j + b_i) = lrelu(max_m a_j + b_i)
-//    => two per-node GEMMs (a = W1'x, b = (W2-W1)'x + t) on the fp32 matrix cores
-//       (v_mfma_f32_16x16x4_f32, exact fp32) and a gather-max over the k neighbours.
-//  * kNN: Gram matrix X.X^T on the same MFMA path (upper triangle only when the whole
-//    key matrix fits in LDS), ranking key |x_j|^2 - 2 x_i.x_j (= the reference's
-//    -pairwise_distance up to the row constant |x_i|^2), then an exact k-smallest
-//    selection per row: register sorting networks + butterfly merges, deterministic
-//    lowest-index tie-break.
-//  * fp32 MFMA and VALU instructions share one pipe per SIMD on gfx950 (measured:
-//    tools/probes/coexec_probe.hip) and a single wave issues at most one VALU op per ~9
-//    cycles, so the VALU phases (selection, gather) are spread over all 8 waves (2 per
-//    SIMD) while one wave per SIMD is enough to saturate the MFMA phases.
-//  * 512 threads (8 wave64) per workgroup; everything between the input read and the
-//    pooled vector lives in LDS/registers.
+//    => two per-node GEMMs (a = W1'x, b = (W2-W1)'x + t) and a gather-max over the k neighbours.
+//  * every matrix product (Gram, per-node GEMMs, conv_end) runs on v_mfma_f32_16x16x32_bf16 with both operands split
+//    into three bf16 planes (x = hi + mid + lo, exact to 24 bits; fp32-class results, see tile16): the fp32 MFMA
+//    blocks the VALU of its SIMD for 32 cycles per instruction and is 2.7x slower per product.
+//  * kNN: Gram matrix X.X^T (upper triangle only when the whole key matrix fits in LDS), ranking key
+//    |x_j|^2 - 2 x_i.x_j (= the reference's -pairwise_distance up to the row constant |x_i|^2), then an exact
+//    k-smallest selection per row: register sorting networks + butterfly merges, deterministic lowest-index tie-break.
+//  * trailing duplicate (padding) slots collapse to one representative; with packed input the whole semantic branch
+//    runs on 13 label super-nodes (embed_kernel, "semantic branch on label super-nodes").
+//  * one workgroup per graph, 128..512 threads chosen by the host plan (make_embed_plan): graphs of <= 64 processed
+//    slots run as three 4-wave workgroups per CU on an instance that needs <= 168 VGPRs and no scratch; everything
+//    between the input read and the pooled vector lives in LDS / registers.
 #include <math.h>
 
 #include "sgpr_internal.hpp"
