@@ -1032,6 +1032,16 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             fz = dn[2 * NS];
 #pragma unroll
             for (int c = 0; c < kLabels; ++c) sem[c] = dn[(size_t)(3 + c) * NS];
+            // the reference's own tensors (transfer_to_torch, sg_net.py:274-298) are one-hot rows / all-zero padding:
+            // recover the label so that the super-node branch below applies; anything else runs the generic branch
+            int ones = 0, zeros = 0, which = -1;
+#pragma unroll
+            for (int c = 0; c < kLabels; ++c) {
+                ones += sem[c] == 1.f;
+                zeros += sem[c] == 0.f;
+                which = sem[c] == 1.f ? c : which;
+            }
+            mylab = (ones == 1 && zeros == kLabels - 1) ? which : (zeros == kLabels ? -1 : -3);
         } else {
             const float* c3 = kp.a.centers + ((size_t)g * NS + tid) * 3;
             fx = c3[0];
@@ -1108,7 +1118,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     //      tile, a counting selection (labels in key order, each standing for its node count, the representative for
     //      >= K copies), one row tile of GEMMs, a 13-row gather.  Every value is produced by the instructions of the
     //      generic path on the same operands, so the result is bit-identical to it (tests); the generic path still
-    //      runs for dense input, debug dumps, graphs without >= K padding slots, stray -1 labels, < 17 slots.
+    //      runs for semantic rows that are not one-hot, debug dumps, graphs without >= K padding slots, stray
+    //      all-zero rows among the nodes, < 17 slots.
     int L0 = 0;
     const signed char* rowlab = nullptr;                     // fast path: table row of every slot (13 = zero row)
     {
@@ -1123,7 +1134,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         __syncthreads();
         const bool any_bad = *flag != 0;
         __syncthreads();                                    // red shares X, which is written next
-        const bool fast = !kp.a.dense && DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
+        const bool fast = DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
         if (fast) {
             // scratch that must survive the branch sits behind the 16 virtual rows of the parked block (LDS, or the
             // global workspace of the large plans: same-workgroup visibility across the barriers either way)

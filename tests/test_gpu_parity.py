@@ -459,6 +459,33 @@ eva_pair: {pair_file: ["%s/0.json", "%s/250.json"]}
     assert abs(res["00"] - want) < 1e-9
 
 
+def test_super_node_branch_equals_generic_on_every_entry_point(eng):
+    """Packed and dense (one-hot) inputs take the super-node semantic branch; ablation bit 12 forces the generic branch
+    on the same kernel: all three give the same bits, for embed, embed_dense and the drop-in forward_dense."""
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.config2_pairs(seed=11, batch=150)              # 300 graphs, N = 64
+    dense = torch.from_numpy(synth.dense_features(centers, labels)).cuda()
+    order, cap = eng.size_order(centers, labels, 10)
+    fast_p = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
+    fast_d = eng.embed_dense(dense, 10, want_att=True, want_emb=True)
+    fwd = eng.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), 10)
+    eng.lib.sgpr_debug_set_skip_mask(256 + 4096)
+    try:
+        gen_p = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
+        gen_d = eng.embed_dense(dense, 10, want_att=True, want_emb=True)
+        fwd_g = eng.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), 10)
+    finally:
+        eng.lib.sgpr_debug_set_skip_mask(0)
+    for a, b, c, d in zip(fast_p, fast_d, gen_p, gen_d):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    for a, b in zip(fwd, fwd_g):
+        assert torch.equal(a, b)
+    # general (not one-hot) semantic rows keep working: generic branch, different results from the one-hot ones
+    noisy = dense.clone()
+    noisy[:, 3:, :] += 0.25
+    assert not torch.equal(eng.embed_dense(noisy, 10)[0], fast_d[0])
+
+
 def test_label_lookup_layer_is_bitwise_generic(eng):
     """The label-lookup first semantic layer (packed input) gives the bits of the generic kNN/EdgeConv layer, which
     the debug-dump instance still runs - on KITTI-like graphs, on graphs with fewer label-mates than K, with every
