@@ -379,3 +379,21 @@ def test_graph_store_roundtrip(tmp_path, golden_dir):
     g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
     if "centers" in g and g["centers"].shape[0] == 3:
         pass
+
+
+def test_processed_slots_and_size_order_logic():
+    """Engine.processed_slots (torch) == synth.effective_nodes (numpy) - the promise behind node_cap / launch order."""
+    from sg_pr_amd import engine, synth
+    for n, k, lo, hi in ((100, 10, 25, 60), (64, 10, 20, 60), (40, 5, 1, 39), (256, 20, 100, 250)):
+        c, l, n_real = synth.make_graphs(50, n, lo, hi, 3 + n)
+        eff = engine.Engine.processed_slots(c, l, k).numpy()
+        np.testing.assert_array_equal(eff, synth.effective_nodes(c, l, k))
+        m = n - n_real
+        np.testing.assert_array_equal(eff, n_real + np.where((m >= k) & (m > 1), 1, m))
+        assert engine.Engine.node_cap_of(c, l, k) == int(eff.max())
+    # a graph whose trailing duplicates are REAL nodes (same centre and label) is compressed the same way
+    c = np.zeros((1, 12, 3), dtype=np.float32)
+    l = np.zeros((1, 12), dtype=np.int32)
+    c[0, :4] = np.arange(12, dtype=np.float32).reshape(4, 3)
+    assert int(engine.Engine.processed_slots(c, l, 5)[0]) == 4 + 1        # 8 identical trailing slots >= k -> one kept
+    assert int(engine.Engine.processed_slots(c, l, 9)[0]) == 12           # fewer than k copies: all kept
