@@ -969,10 +969,11 @@ __device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const 
 
 __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
     float4 y = make_float4(m.x + b.x, m.y + b.y, m.z + b.z, m.w + b.w);
-    y.x = y.x > 0.f ? y.x : 0.2f * y.x;
-    y.y = y.y > 0.f ? y.y : 0.2f * y.y;
-    y.z = y.z > 0.f ? y.z : 0.2f * y.z;
-    y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+    // LeakyReLU(0.2) = max(y, 0.2 y): two instructions per channel instead of compare / multiply / select
+    y.x = fmaxf(y.x, 0.2f * y.x);
+    y.y = fmaxf(y.y, 0.2f * y.y);
+    y.z = fmaxf(y.z, 0.2f * y.z);
+    y.w = fmaxf(y.w, 0.2f * y.w);
     return live ? y : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -1331,8 +1332,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                 float4 ma, mb;
                 gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
                             reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
-                const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * XROW + 4 * c4), ia < N);
-                const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * XROW + 4 * c4), ib < N);
+                // padded rows (>= N) simply keep a copy of row N-1: they are never candidates (their key is +inf) and
+                // nothing reads them as rows, so zero-filling them is not worth eight selects per iteration
+                const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * XROW + 4 * c4), true);
+                const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * XROW + 4 * c4), true);
                 if (dbg) {
                     if (ia < N) {
                         *reinterpret_cast<float4*>(dbg + (size_t)ia * 64 + c4) = ya;
