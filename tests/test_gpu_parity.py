@@ -546,3 +546,24 @@ def test_full_size_kitti00_properties(eng, oracle, oracle_sd):
     row = m[r].clone()
     row[max(0, r - 50):r + 51] = -1
     assert int(idx[r, 0]) == int(torch.argmax(row)) and float(vals[r, 0]) == float(row.max())
+
+
+def test_c_demo_matches_engine(tmp_path, eng, ckpt_path):
+    """examples/sgpr_demo.c (plain C, no Python / torch in the process) produces the Engine's score matrix bit for bit."""
+    import subprocess
+    from sg_pr_amd import engine, synth
+    from test_host_cpu import _build_c_demo
+    exe = _build_c_demo(tmp_path)
+    sd = torch.load(ckpt_path, map_location="cpu")
+    engine.blob_from_state_dict(sd).tofile(str(tmp_path / "w.f32"))
+    centers, labels, _, _ = synth.kitti_like_sequence(37, 100, 12)
+    with open(tmp_path / "g.bin", "wb") as f:
+        np.array([37, 100, 10], dtype=np.int32).tofile(f)
+        centers.astype(np.float32).tofile(f)
+        labels.astype(np.int32).tofile(f)
+    out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "g.bin"), str(tmp_path / "s.f32")],
+                         check=True, capture_output=True, text=True).stdout
+    assert "scored 37 x 37" in out
+    got = np.fromfile(tmp_path / "s.f32", dtype=np.float32).reshape(37, 37)
+    pooled = eng.embed(centers, labels, 10)[0]
+    np.testing.assert_array_equal(got, eng.score_all_pairs(pooled, pooled).cpu().numpy())

@@ -397,3 +397,22 @@ def test_processed_slots_and_size_order_logic():
     c[0, :4] = np.arange(12, dtype=np.float32).reshape(4, 3)
     assert int(engine.Engine.processed_slots(c, l, 5)[0]) == 4 + 1        # 8 identical trailing slots >= k -> one kept
     assert int(engine.Engine.processed_slots(c, l, 9)[0]) == 12           # fewer than k copies: all kept
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    from sg_pr_amd import _build
+    _build.build_library()
+    exe = str(tmp_path / "sgpr_demo")
+    cmd = ["gcc", "-O2", "-std=c11", "-D__HIP_PLATFORM_AMD__", os.path.join(REPO, "examples", "sgpr_demo.c"),
+           "-I" + os.path.join(REPO, "include"), "-I/opt/rocm/include", "-L" + _build.LIB_DIR, "-lsgpr_hip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + _build.LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def test_c_abi_links_from_plain_c(tmp_path):
+    """The boundary is a C ABI: a C11 translation unit including only sgpr.h + the HIP runtime API compiles with gcc
+    and links against libsgpr_hip.so (examples/sgpr_demo.c; it is RUN by the GPU suite)."""
+    exe = _build_c_demo(tmp_path)
+    assert os.path.exists(exe)
