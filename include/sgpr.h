@@ -16,7 +16,13 @@
  *   - return value 0 = SGPR_OK, negative = error; sgpr_last_error() gives the
  *     message of the last failing call on the calling thread.
  *   - a handle is immutable after create => safe to use from several
- *     streams/threads.  One process per GPU.
+ *     streams/threads (the sgpr_debug_* hooks are the one exception: they are
+ *     per handle, off by default and not meant for production).  One process
+ *     per GPU.
+ *   - every entry point that takes a handle runs on the handle's device and
+ *     restores the caller's current device before it returns; the handle-free
+ *     entry points (sgpr_knn, sgpr_graph_feature, sgpr_attention_pool,
+ *     sgpr_ntn) run on the caller's current device.
  */
 #ifndef SGPR_H
 #define SGPR_H
@@ -28,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 1
+#define SGPR_ABI_VERSION 2
 
 enum {
     SGPR_OK = 0,
@@ -182,18 +188,45 @@ int sgpr_topk_rows(const sgpr_handle* h, const float* d_score, int R, int M, int
 /* LDS bytes / threads per workgroup the embed kernel uses for (N, k); 0 if unsupported. */
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 
-/* Debug: when set to a device array of 16 uint64 counters, sgpr_embed* runs its profiling instance and adds the
+/* ---- stand-alone forms of the reference's building blocks (SURVEY.md 8b "signatures to keep") -------------------
+ * Inside sgpr_embed / sgpr_forward_dense these run fused and never materialise their outputs; the entry points below
+ * serve callers of the individual symbols.  They need no handle: a stand-alone module owns its own parameters, which
+ * are passed as device pointers.
+ *
+ * sgpr_knn replaces dgcnn.knn (dgcnn.py:14-20): d_x [B,C,N] f32 -> d_idx [B,N,k] int64 (torch.topk's index type), the
+ * k nearest candidates of every node under pd[i][j] = -|x_j|^2 + 2 x_i.x_j - |x_i|^2, best first; equal distances keep
+ * the lower candidate index first (torch.topk's tie order is implementation-defined).  N <= SGPR_MAX_NODES, k <= N,
+ * k <= SGPR_MAX_K. */
+int sgpr_knn(const float* d_x, int B, int C, int N, int k, int64_t* d_idx, void* stream);
+
+/* Replaces dgcnn.get_graph_feature (dgcnn.py:23-49) for given neighbour lists d_idx [B,N,k] (int64, from sgpr_knn or
+ * the caller): d_out [B,2C,N,k] f32 = cat(x_j - x_i, x_i) in the reference's channel order (dgcnn.py:47). */
+int sgpr_graph_feature(const float* d_x, const int64_t* d_idx, int B, int C, int N, int k, float* d_out, void* stream);
+
+/* Replaces AttentionModule.forward (layers_batch.py:28-39): d_weight [F3,F3] (attention.weight_matrix),
+ * d_emb [B,N,F3] -> d_rep [B,F3] (the graph-level representation) and d_att [B,N] (sigmoid scores; may be NULL).
+ * No padding mask, divisor N - exactly like the reference.  F3 = 32. */
+int sgpr_attention_pool(const float* d_weight, const float* d_emb, int B, int N, float* d_rep, float* d_att,
+                        void* stream);
+
+/* Replaces TenorNetworkModule.forward (layers_batch.py:70-83): d_weight [F3,F3,T], d_weight_block [T,2*F3],
+ * d_bias [T], d_e1 / d_e2 [B,F3] -> d_out [B,T] = relu(e1^T W e2 + Wb [e1;e2] + bias).  F3 = 32, T = 16. */
+int sgpr_ntn(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,
+             const float* d_e2, int64_t B, float* d_out, void* stream);
+
+/* Debug (per handle; not thread-safe; never set in production): a device array of 16 uint64 counters makes
+ * sgpr_embed* run its profiling instance and add the
  * shader cycles wave 0 of every workgroup spends in each phase, barrier to barrier (0 stage, 1 select, 2 Gram,
  * 3 GEMM, 5 gather-max, 6 conv_end, 7 attention; 8..13 = sub-phases of the selection in sgpr_embed_debug with mask
  * bit 7).  The timers perturb the kernel (~1.6x); use the ablation mask for magnitudes.  NULL (default) disables. */
-void sgpr_debug_set_profile_buffer(void* d_counters);
+void sgpr_debug_set_profile_buffer(sgpr_handle* h, void* d_counters);
 
 /* Debug / ablation timing only (results become invalid): bit 0 skips the kNN selection, bit 1 the per-node GEMMs,
  * bit 2 the Gram phase, bit 3 the gather-max; bit 4 returns right after dispatch, bit 5 after the input fetch;
  * bit 8 = nothing skipped (just selects the profiling instance); bits 9/10/11 keep the GEMM phase but drop its weight
  * loads / its MFMAs / its inner barrier; bit 12 runs the generic first semantic layer instead of the label lookup (valid
  * results).  0 (default) = normal. */
-void sgpr_debug_set_skip_mask(int mask);
+void sgpr_debug_set_skip_mask(sgpr_handle* h, int mask);
 
 const char* sgpr_last_error(void);
 int sgpr_abi_version(void);

@@ -12,8 +12,6 @@
 namespace sgpr {
 
 static thread_local std::string g_last_error;
-static unsigned long long* g_prof_buffer = nullptr;  // debug: per-phase cycle counters
-static int g_skip_mask = 0;                           // debug: ablation (timing only, results invalid)
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 
@@ -197,8 +195,14 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         memcpy(packed.data() + off_wb[b], wb.data(), wb.size() * sizeof(unsigned short));
     }
 
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+    if (device < 0 || device >= ndev) {
+        set_error("sgpr_create: device " + std::to_string(device) + " of " + std::to_string(ndev));
+        return SGPR_E_INVALID;
+    }
+    DeviceGuard guard(device);   // the caller's current device is restored on return
     sgpr_handle* h = new sgpr_handle();
     memset(h, 0, sizeof(*h));
     h->device = device;
@@ -248,7 +252,7 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
 
 void sgpr_destroy(sgpr_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_status) (void)hipFree(h->d_status);
     delete h;
@@ -315,8 +319,9 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     }
     a.park_ws = static_cast<float*>(ws);
     a.status = h->d_status;
-    a.prof = g_prof_buffer;
-    a.skip = g_skip_mask;
+    a.prof = h->dbg_prof;
+    a.skip = h->dbg_skip;
+    DeviceGuard guard(h->device);
     return launch_embed(h, plan, a, static_cast<hipStream_t>(stream));
 }
 
@@ -402,6 +407,7 @@ int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t
         set_error("sgpr_score_pairs: NULL argument or negative count");
         return SGPR_E_INVALID;
     }
+    DeviceGuard guard(h->device);
     return launch_score_pairs(h, d_pooled1, d_idx1, d_pooled2, d_idx2, P, d_score, static_cast<hipStream_t>(stream));
 }
 
@@ -421,6 +427,7 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
         set_error("sgpr_score_all_pairs: workspace of " + std::to_string(need) + " bytes required");
         return SGPR_E_WORKSPACE;
     }
+    DeviceGuard guard(h->device);
     return launch_score_all_pairs(h, d_pooled_rows, R, d_pooled_cols, M, d_score, ld, d_workspace,
                                   static_cast<hipStream_t>(stream));
 }
@@ -458,8 +465,9 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     a.pooled = pooled;
     a.park_ws = pooled + (size_t)2 * B * kF3;
     a.status = h->d_status;
-    a.prof = g_prof_buffer;
-    a.skip = g_skip_mask;
+    a.prof = h->dbg_prof;
+    a.skip = h->dbg_skip;
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d_att1 && d_att2 && d_att2 == d_att1 + (size_t)B * N) {
         a.att = d_att1;  // contiguous [2B, N] attention buffer
@@ -480,9 +488,59 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     return launch_score_pairs(h, pooled, nullptr, pooled + (size_t)B * kF3, nullptr, B, d_score, s);
 }
 
-void sgpr_debug_set_skip_mask(int mask) { g_skip_mask = mask; }
+int sgpr_knn(const float* d_x, int B, int C, int N, int k, int64_t* d_idx, void* stream) {
+    if (!d_x || !d_idx || B < 0 || C < 1) {
+        set_error("sgpr_knn: NULL argument, negative batch or no channels");
+        return SGPR_E_INVALID;
+    }
+    if (N < 1 || N > SGPR_MAX_NODES) {
+        set_error("sgpr_knn: N " + std::to_string(N) + " outside [1, " + std::to_string(SGPR_MAX_NODES) + "]");
+        return SGPR_E_NODES;
+    }
+    if (k < 1 || k > SGPR_MAX_K || k > N) {
+        set_error("sgpr_knn: K " + std::to_string(k) + " outside [1, min(N, " + std::to_string(SGPR_MAX_K) + ")]");
+        return SGPR_E_K;
+    }
+    return launch_knn(d_x, B, C, N, k, d_idx, static_cast<hipStream_t>(stream));
+}
 
-void sgpr_debug_set_profile_buffer(void* d_counters) { g_prof_buffer = static_cast<unsigned long long*>(d_counters); }
+int sgpr_graph_feature(const float* d_x, const int64_t* d_idx, int B, int C, int N, int k, float* d_out, void* stream) {
+    if (!d_x || !d_idx || !d_out || B < 0 || C < 1 || N < 1 || k < 1) {
+        set_error("sgpr_graph_feature: NULL argument or non-positive size");
+        return SGPR_E_INVALID;
+    }
+    return launch_graph_feature(d_x, d_idx, B, C, N, k, d_out, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_attention_pool(const float* d_weight, const float* d_emb, int B, int N, float* d_rep, float* d_att,
+                        void* stream) {
+    if (!d_weight || !d_emb || !d_rep || B < 0 || N < 1) {
+        set_error("sgpr_attention_pool: NULL argument, negative batch or no nodes");
+        return SGPR_E_INVALID;
+    }
+    if ((size_t)N * sizeof(float) > 48 * 1024) {
+        set_error("sgpr_attention_pool: more than 12288 nodes per graph");
+        return SGPR_E_NODES;
+    }
+    return launch_attention_pool(d_weight, d_emb, B, N, d_rep, d_att, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_ntn(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,
+             const float* d_e2, int64_t B, float* d_out, void* stream) {
+    if (!d_weight || !d_weight_block || !d_bias || !d_e1 || !d_e2 || !d_out || B < 0) {
+        set_error("sgpr_ntn: NULL argument or negative batch");
+        return SGPR_E_INVALID;
+    }
+    return launch_ntn(d_weight, d_weight_block, d_bias, d_e1, d_e2, B, d_out, static_cast<hipStream_t>(stream));
+}
+
+void sgpr_debug_set_skip_mask(sgpr_handle* h, int mask) {
+    if (h) h->dbg_skip = mask;
+}
+
+void sgpr_debug_set_profile_buffer(sgpr_handle* h, void* d_counters) {
+    if (h) h->dbg_prof = static_cast<unsigned long long*>(d_counters);
+}
 
 int sgpr_check_status(const sgpr_handle* h, void* stream) {
     if (!h) {
@@ -490,6 +548,7 @@ int sgpr_check_status(const sgpr_handle* h, void* stream) {
         return SGPR_E_INVALID;
     }
     int32_t flag = 0;
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemcpyAsync(&flag, h->d_status, sizeof(flag), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

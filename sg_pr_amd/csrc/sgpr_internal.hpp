@@ -53,6 +53,9 @@ struct sgpr_handle {
     size_t blob_floats;
     int32_t* d_status;   // label-error flag
     sgpr::DevWeights w;
+    // debug / ablation hooks (sgpr_debug_set_*): per handle, off by default; the only mutable state of a handle
+    int dbg_skip;
+    unsigned long long* dbg_prof;
 };
 
 namespace sgpr {
@@ -109,5 +112,22 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 size_t score_all_pairs_ws_bytes(int R, int M);
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream);
+int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,
+               float* out, hipStream_t stream);
+int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);
+int launch_graph_feature(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out, hipStream_t stream);
+int launch_attention_pool(const float* w, const float* emb, int B, int N, float* rep, float* att, hipStream_t stream);
+
+// makes `device` current for the lifetime of the object and restores the caller's device afterwards
+struct DeviceGuard {
+    int prev;
+    bool switched;
+    explicit DeviceGuard(int device) : prev(-1), switched(false) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 }  // namespace sgpr

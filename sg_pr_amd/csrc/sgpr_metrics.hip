@@ -222,6 +222,7 @@ int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M
         set_error("sgpr_pair_histogram: workspace of " + std::to_string(need) + " bytes required");
         return SGPR_E_WORKSPACE;
     }
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = (n_prefix << bits) * 2;
     HistArgs a;
@@ -272,6 +273,7 @@ int sgpr_topk_rows(const sgpr_handle* h, const float* d_score, int R, int M, int
         return SGPR_E_K;
     }
     if (R == 0) return SGPR_OK;
+    DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((R + 3) / 4), block(256);
     switch (k) {

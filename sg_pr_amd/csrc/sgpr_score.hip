@@ -21,27 +21,20 @@ constexpr int T = kT;    // 16 tensor neurons
 constexpr int BN_ = kB;  // 16 bottleneck neurons
 
 // ------------------------------------------------------------------ per-pair list
-__global__ __launch_bounds__(256) void score_pairs_kernel(const DevWeights w, const float* __restrict__ p1,
-                                                          const int32_t* __restrict__ i1,
-                                                          const float* __restrict__ p2,
-                                                          const int32_t* __restrict__ i2, int64_t P,
-                                                          float* __restrict__ score) {
-    const int lane = threadIdx.x & 63;
-    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= P) return;
-    const int64_t r1 = i1 ? i1[pair] : pair;
-    const int64_t r2 = i2 ? i2[pair] : pair;
-    const float* e1 = p1 + r1 * F;
-    const float* e2 = p2 + r2 * F;
+// TenorNetworkModule.forward for one pair on one wave64: lanes with equal t = lane & 15 return the same
+// relu(e1^T W[:, :, t] e2 + Wb[t, :] . [e1; e2] + bias[t])      (layers_batch.py:77-83)
+//   ntn_w [32][32*16] = weight_matrix.view(F3, -1) (col = j*16 + t),  ntn_wb [16][64],  bias [16]
+__device__ __forceinline__ float ntn_neuron(const float* __restrict__ ntn_w, const float* __restrict__ ntn_wb,
+                                            const float* __restrict__ bias, const float* __restrict__ e1,
+                                            const float* __restrict__ e2, int lane) {
     const int t = lane & 15, q = lane >> 4;
-
     // v[r] = sum_i e1[i] * W[i][col_r],  col_r = lane + 64 r  ->  j = q + 4r, same t for every r
     float v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = 0.f;
     for (int i = 0; i < F; ++i) {
         const float a = e1[i];
-        const float* wr = w.ntn_w + i * (F * T) + lane;
+        const float* wr = ntn_w + i * (F * T) + lane;
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = fmaf(a, wr[64 * r], v[r]);
     }
@@ -52,11 +45,25 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const DevWeights w, co
     for (int m = 0; m < 16; ++m) {
         const int mm = q * 16 + m;
         const float x = mm < F ? e1[mm] : e2[mm - F];
-        s = fmaf(w.ntn_wb[t * 2 * F + mm], x, s);
+        s = fmaf(ntn_wb[t * 2 * F + mm], x, s);
     }
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    const float h = fmaxf(s + w.ntn_bias[t], 0.f);   // lanes with equal t agree
+    return fmaxf(s + bias[t], 0.f);
+}
+
+__global__ __launch_bounds__(256) void score_pairs_kernel(const DevWeights w, const float* __restrict__ p1,
+                                                          const int32_t* __restrict__ i1,
+                                                          const float* __restrict__ p2,
+                                                          const int32_t* __restrict__ i2, int64_t P,
+                                                          float* __restrict__ score) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= P) return;
+    const int64_t r1 = i1 ? i1[pair] : pair;
+    const int64_t r2 = i2 ? i2[pair] : pair;
+    const int t = lane & 15;
+    const float h = ntn_neuron(w.ntn_w, w.ntn_wb, w.ntn_bias, p1 + r1 * F, p2 + r2 * F, lane);
     // fully_connected_first + ReLU: lane t computes output neuron t
     float gacc = w.fc1_b[t];
     for (int tt = 0; tt < T; ++tt) gacc = fmaf(w.fc1_w[t * T + tt], __shfl(h, tt), gacc);
@@ -66,6 +73,31 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const DevWeights w, co
     z += __shfl_xor(z, 4);
     z += __shfl_xor(z, 8);
     if (lane == 0) score[pair] = 1.f / (1.f + expf(-(z + w.fc2_b[0])));
+}
+
+// stand-alone TenorNetworkModule.forward: out [B][16] = the similarity vector before the FC head
+__global__ __launch_bounds__(256) void ntn_kernel(const float* __restrict__ ntn_w, const float* __restrict__ ntn_wb,
+                                                  const float* __restrict__ bias, const float* __restrict__ e1,
+                                                  const float* __restrict__ e2, int64_t B, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= B) return;
+    const float h = ntn_neuron(ntn_w, ntn_wb, bias, e1 + pair * F, e2 + pair * F, lane);
+    if (lane < T) out[pair * T + lane] = h;
+}
+
+int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,
+               float* out, hipStream_t stream) {
+    if (B == 0) return SGPR_OK;
+    const int64_t blocks = (B + 3) / 4;
+    if (blocks > 0x7fffffffLL) {
+        set_error("sgpr_ntn: too many pairs for one launch");
+        return SGPR_E_INVALID;
+    }
+    hipLaunchKernelGGL(ntn_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wb, bias, e1, e2, B, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "ntn_kernel launch");
+    return SGPR_OK;
 }
 
 int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,

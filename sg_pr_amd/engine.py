@@ -35,7 +35,8 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
                "sgpr_pair_histogram_workspace_bytes", "sgpr_pair_histogram", "sgpr_topk_rows",
-               "sgpr_embed_lds_bytes", "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
+               "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
+               "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
 
 
 class SgprError(RuntimeError):
@@ -103,10 +104,18 @@ def load_library():
     lib.sgpr_topk_rows.argtypes = [vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp]
     lib.sgpr_embed_lds_bytes.restype = sz
     lib.sgpr_embed_lds_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_knn.restype = i32
+    lib.sgpr_knn.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.sgpr_graph_feature.restype = i32
+    lib.sgpr_graph_feature.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.sgpr_attention_pool.restype = i32
+    lib.sgpr_attention_pool.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.sgpr_ntn.restype = i32
+    lib.sgpr_ntn.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sgpr_debug_set_skip_mask.restype = None
-    lib.sgpr_debug_set_skip_mask.argtypes = [i32]
+    lib.sgpr_debug_set_skip_mask.argtypes = [vp, i32]
     lib.sgpr_debug_set_profile_buffer.restype = None
-    lib.sgpr_debug_set_profile_buffer.argtypes = [vp]
+    lib.sgpr_debug_set_profile_buffer.argtypes = [vp, vp]
     lib.sgpr_last_error.restype = ctypes.c_char_p
     lib.sgpr_last_error.argtypes = []
     lib.sgpr_abi_version.restype = i32
@@ -198,8 +207,8 @@ class Engine:
         """Debug: workgroup cycles per phase of the embed kernel (thread-0 clocks at the barriers, on the profile
         instance of the kernel).  select_split adds timers inside the selection (they perturb it)."""
         buf = torch.zeros(16, dtype=torch.int64, device=self.device)
-        self.lib.sgpr_debug_set_profile_buffer(_ptr(buf))
-        self.lib.sgpr_debug_set_skip_mask(128 if select_split else 0)
+        self.lib.sgpr_debug_set_profile_buffer(self._h, _ptr(buf))
+        self.lib.sgpr_debug_set_skip_mask(self._h, 128 if select_split else 0)
         try:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -209,15 +218,21 @@ class Engine:
             torch.cuda.synchronize(self.device)
             self.last_profile_ms = e0.elapsed_time(e1) / reps     # launch time WITH the timers running
         finally:
-            self.lib.sgpr_debug_set_profile_buffer(None)
-            self.lib.sgpr_debug_set_skip_mask(0)
+            self.lib.sgpr_debug_set_profile_buffer(self._h, None)
+            self.lib.sgpr_debug_set_skip_mask(self._h, 0)
         call = buf.cpu().numpy().astype(np.float64)
         self.last_select_split = call[8:14]   # load, sort, merge, tau+masks, prefix, emit (thread-0 cycles)
         c = call[:8]
         return dict(zip(self.PHASES, c / max(c.sum(), 1.0))), c
 
     def check_status(self):
+        """Synchronises the stream and raises SgprError if a launch since the last check saw a label outside
+        [-1, num_labels) (the reference raises KeyError, sg_net.py:277) or a graph that broke its node_cap promise."""
         self._check(self.lib.sgpr_check_status(self._h, self._stream()))
+
+    def set_skip_mask(self, mask):
+        """Debug / ablation only (include/sgpr.h)."""
+        self.lib.sgpr_debug_set_skip_mask(self._h, int(mask))
 
     # ------------------------------------------------------------------ per-graph half
     @staticmethod
@@ -392,3 +407,77 @@ class Engine:
         if want_att:
             return score, att[0], att[1]
         return score, None, None
+
+
+# ---------------------------------------------------------------------- handle-free entry points (stand-alone modules)
+def _gpu_f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on the MI355X (there is no CPU fallback)" % name)
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _raise_if(lib, rc):
+    if rc != SGPR_OK:
+        raise SgprError(rc, lib.sgpr_last_error().decode())
+
+
+def _stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def knn(x, k):
+    """dgcnn.knn (dgcnn.py:14-20): x [B,C,N] on the GPU -> idx [B,N,k] int64."""
+    lib = load_library()
+    x = _gpu_f32(x, "x")
+    b, c, n = x.shape
+    idx = torch.empty(b, n, int(k), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _raise_if(lib, lib.sgpr_knn(_ptr(x), b, c, n, int(k), _ptr(idx), _stream_of(x)))
+    return idx
+
+
+def graph_feature(x, idx):
+    """dgcnn.get_graph_feature's gather (dgcnn.py:30-49): x [B,C,N], idx [B,N,k] int64 -> [B,2C,N,k]."""
+    lib = load_library()
+    x = _gpu_f32(x, "x")
+    b, c, n = x.shape
+    idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
+    if idx.shape[:2] != (b, n):
+        raise ValueError("idx must be [B, N, k], got %s" % (tuple(idx.shape),))
+    k = idx.shape[2]
+    out = torch.empty(b, 2 * c, n, k, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _raise_if(lib, lib.sgpr_graph_feature(_ptr(x), _ptr(idx), b, c, n, k, _ptr(out), _stream_of(x)))
+    return out
+
+
+def attention_pool(weight, emb):
+    """AttentionModule.forward (layers_batch.py:28-39): weight [32,32], emb [B,N,32] -> (rep [B,32], att [B,N])."""
+    lib = load_library()
+    emb = _gpu_f32(emb, "embedding")
+    weight = _gpu_f32(weight, "weight_matrix").to(emb.device)
+    b, n, f = emb.shape
+    if f != F3 or tuple(weight.shape) != (F3, F3):
+        raise ValueError("attention_pool is built for filters_3 = %d" % F3)
+    rep = torch.empty(b, F3, dtype=torch.float32, device=emb.device)
+    att = torch.empty(b, n, dtype=torch.float32, device=emb.device)
+    with torch.cuda.device(emb.device):
+        _raise_if(lib, lib.sgpr_attention_pool(_ptr(weight), _ptr(emb), b, n, _ptr(rep), _ptr(att), _stream_of(emb)))
+    return rep, att
+
+
+def ntn(weight, weight_block, bias, e1, e2):
+    """TenorNetworkModule.forward (layers_batch.py:70-83): e1, e2 [B,32] -> [B,16]."""
+    lib = load_library()
+    e1 = _gpu_f32(e1, "embedding_1")
+    e2 = _gpu_f32(e2, "embedding_2").to(e1.device)
+    w = _gpu_f32(weight, "weight_matrix").to(e1.device)
+    wb = _gpu_f32(weight_block, "weight_matrix_block").to(e1.device)
+    bs = _gpu_f32(bias, "bias").to(e1.device).view(-1)
+    b = e1.shape[0]
+    if e1.shape != (b, F3) or e2.shape != (b, F3) or tuple(w.shape) != (F3, F3, 16) or tuple(wb.shape) != (16, 2 * F3):
+        raise ValueError("ntn is built for filters_3 = 32, tensor_neurons = 16")
+    out = torch.empty(b, 16, dtype=torch.float32, device=e1.device)
+    with torch.cuda.device(e1.device):
+        _raise_if(lib, lib.sgpr_ntn(_ptr(w), _ptr(wb), _ptr(bs), _ptr(e1), _ptr(e2), b, _ptr(out), _stream_of(e1)))
+    return out

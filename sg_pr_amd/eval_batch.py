@@ -50,6 +50,7 @@ def score_pair_list(trainer, graph_pairs):
     pooled = torch.cat([model.embed(centers[s:s + chunk], labels[s:s + chunk])[0]
                         for s in range(0, len(paths), chunk)]) if paths else torch.empty(0, 32)
     pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib))
+    model.engine().check_status()          # bad labels / broken node_cap promises are errors, not silent NaNs
     return pred.cpu().numpy().reshape(-1), gt
 
 

@@ -1,8 +1,12 @@
-"""Parameter containers with the reference's names and state-dict keys
-(layers_batch.py:3-83).  Inside `sg_net.SG` their maths runs fused in the HIP
-engine; called stand-alone they run the same kernels on pooled / embedded inputs.
+"""`AttentionModule` / `TenorNetworkModule` with the reference's names, state-dict keys and forward contracts
+(layers_batch.py:3-83).  Inside `sg_net.SG` their maths runs fused in the HIP engine (attention in the tail of
+embed_kernel, the NTN in the score kernels); called stand-alone, `forward` runs the dedicated HIP kernels behind
+`sgpr_attention_pool` / `sgpr_ntn` (include/sgpr.h) with the module's own parameters.  Inference only, GPU tensors
+only: there is no CPU fallback and no autograd through the kernels.
 """
 import torch
+
+from . import engine as _engine
 
 
 class AttentionModule(torch.nn.Module):
@@ -15,9 +19,9 @@ class AttentionModule(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.weight_matrix)
 
     def forward(self, embedding):
-        raise NotImplementedError(
-            "AttentionModule runs fused inside the embed kernel (sg_pr_amd/csrc/sgpr_embed.hip); "
-            "call SG.forward / SG.embed, which return the attention scores and pooled vector")
+        """layers_batch.py:28-39 - embedding [B, N, F3] -> (representation [B, F3, 1], sigmoid_scores [B, N, 1])."""
+        rep, att = _engine.attention_pool(self.weight_matrix, embedding)
+        return rep.unsqueeze(-1), att.unsqueeze(-1)
 
 
 class TenorNetworkModule(torch.nn.Module):
@@ -35,6 +39,8 @@ class TenorNetworkModule(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.bias)
 
     def forward(self, embedding_1, embedding_2):
-        raise NotImplementedError(
-            "TenorNetworkModule runs fused with the scoring head (sg_pr_amd/csrc/sgpr_score.hip); "
-            "call SG.score_pooled / SG.forward")
+        """layers_batch.py:70-83 - embedding_1/2 [B, F3, 1] -> scores [B, T, 1]."""
+        b = embedding_1.shape[0]
+        out = _engine.ntn(self.weight_matrix, self.weight_matrix_block, self.bias,
+                          embedding_1.reshape(b, -1), embedding_2.reshape(b, -1))
+        return out.unsqueeze(-1)

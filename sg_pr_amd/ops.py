@@ -6,24 +6,45 @@
     torch.ops.sgpr.forward_dense(features_1 [B,15,N], features_2 [B,15,N], weights_blob, k) -> (score, att1, att2)
 
 `weights_blob` is the flat fp32 tensor of `engine.blob_from_state_dict` (order in include/sgpr.h); one engine handle is
-kept per (blob storage, device).  GPU tensors only: there is no CPU implementation - a CPU call raises.  Fake (meta)
+kept per (blob tensor, version, device) and released with the tensor.  GPU tensors only: there is no CPU implementation - a CPU call raises.  Fake (meta)
 kernels are registered so that the ops trace under torch.compile / FakeTensor.
 """
+import collections
+import weakref
+
 import torch
 
 from . import engine as _engine
 
-_ENGINES = {}
+_ENGINES = collections.OrderedDict()      # key -> Engine, least recently used first
+_MAX_ENGINES = 8
+
+
+def _drop(key):
+    eng = _ENGINES.pop(key, None)
+    if eng is not None:
+        eng.close()
 
 
 def _engine_for(blob, device):
+    """The engine handle for this weights tensor.  The entry is tied to the tensor OBJECT (its id is part of the key
+    and a weakref finaliser removes the entry - and frees the handle and its device copy - when the tensor dies), so
+    a later blob that happens to be allocated at the same address can never meet a stale handle; `_version` catches
+    in-place updates; the cache is bounded (least recently used handles are closed)."""
     if device.type != "cuda":
         raise RuntimeError("sgpr ops run on the MI355X only (got a %s tensor); there is no CPU fallback" % device.type)
-    key = (blob.data_ptr(), blob.numel(), blob._version, device.index)
+    key = (id(blob), blob.data_ptr(), blob.numel(), blob._version, device.index)
     eng = _ENGINES.get(key)
     if eng is None:
+        for stale in [k for k in _ENGINES if k[0] == key[0] and k[4] == key[4]]:   # same tensor, older version
+            _drop(stale)
         eng = _engine.Engine(blob, device=device.index or 0)
         _ENGINES[key] = eng
+        weakref.finalize(blob, _drop, key)
+        while len(_ENGINES) > _MAX_ENGINES:
+            _drop(next(iter(_ENGINES)))
+    else:
+        _ENGINES.move_to_end(key)
     return eng
 
 

@@ -6,6 +6,8 @@ must be in eval mode - BatchNorm running statistics are folded into the kernels'
 weights.  There is no CPU fallback.
 """
 import os
+import warnings
+import zlib
 from collections import OrderedDict
 
 import numpy as np
@@ -100,7 +102,11 @@ class SG(torch.nn.Module):
         """Packed graphs (centers [G,N,3], labels [G,N], -1 = pad) -> pooled [G, filters_3] (+att, +emb).
         node_cap: promise on the slots processed per graph; order: launch order, largest graphs first
         (engine.Engine.size_order gives both).  Host arrays get them computed automatically; device tensors run
-        without unless given (computing them would synchronise)."""
+        without unless given (computing them would synchronise).
+        Contract: the launch is asynchronous and does NOT report bad labels / a broken node_cap promise by itself
+        (affected graphs get all-zero semantic rows / a NaN pooled vector); call `engine().check_status()` once the
+        results are needed - the evaluation entry points (forward_packed, eval_batch_pair, eval_batch.score_pair_list,
+        graph_store.evaluate_all_pairs) do."""
         eng = self.engine()
         if node_cap is None and order is None:
             if not (isinstance(labels, torch.Tensor) and labels.is_cuda) and len(labels):
@@ -115,28 +121,58 @@ class SG(torch.nn.Module):
     def score_all_pairs(self, pooled_rows, pooled_cols, out=None):
         return self.engine().score_all_pairs(pooled_rows, pooled_cols, out=out)
 
-    def forward_packed(self, centers_1, labels_1, centers_2, labels_2):
-        """Faithful per-pair scoring of packed graphs: both sides embedded, then the tail."""
+    def forward_packed(self, centers_1, labels_1, centers_2, labels_2, validate=True):
+        """Faithful per-pair scoring of packed graphs: both sides embedded, then the tail.
+        validate (default): synchronise and raise SgprError if the kernel saw a label outside [-1, L) (the reference
+        raises KeyError, sg_net.py:277) or a broken node_cap promise; pass False on latency-critical paths whose
+        inputs were checked when they were packed."""
         b = labels_1.shape[0]
         c = torch.cat((torch.as_tensor(centers_1), torch.as_tensor(centers_2)), dim=0)
         l = torch.cat((torch.as_tensor(labels_1), torch.as_tensor(labels_2)), dim=0)
         pooled, att, _ = self.embed(c, l, want_att=True)
         score = self.score_pooled(pooled[:b], pooled[b:])
+        if validate:
+            self.engine().check_status()
         return score, att[:b].unsqueeze(-1), att[b:].unsqueeze(-1)
 
 
-def pack_graph(centers, nodes, node_num, number_of_labels=12):
+def subsample_indices(centers, nodes, node_num):
+    """The engine's documented, SEEDED rule for graphs with more than node_num nodes.
+
+    The reference draws `np.random.choice(n, node_num, replace=False)` from the global, unseeded NumPy state and sorts
+    the indices (sg_net.py:252-256), so two runs of the reference score such a graph differently.  Here the draw is
+    `np.random.default_rng(seed).choice(n, node_num, replace=False)`, sorted, with
+    `seed = crc32(float64 centres bytes + int64 label bytes)`: a function of the graph alone, hence the same subset in
+    every pair, batch, process and rank."""
+    c = np.ascontiguousarray(np.asarray(centers, dtype=np.float64).reshape(len(nodes), 3))
+    l = np.ascontiguousarray(np.asarray(nodes).astype(np.int64).reshape(-1))
+    seed = zlib.crc32(l.tobytes(), zlib.crc32(c.tobytes()))
+    idx = np.random.default_rng(seed).choice(len(nodes), int(node_num), replace=False)
+    idx.sort()
+    return idx
+
+
+def pack_graph(centers, nodes, node_num, number_of_labels=12, strict=False):
     """One side of transfer_to_torch (sg_net.py:250-272) in packed form.
 
     Returns (centers f32 [node_num,3], labels i32 [node_num]); padded slots have
     centre 0 / label -1.  A label outside [0, L) raises KeyError like
-    `self.global_labels[node]` (sg_net.py:277).  Graphs with more than node_num
-    nodes are rejected: the reference subsamples them with an *unseeded*
-    np.random.choice (sg_net.py:252-256), so no reproducible answer exists."""
+    `self.global_labels[node]` (sg_net.py:277).  A graph with more than node_num
+    nodes is subsampled like the reference does (sg_net.py:252-256) but with the
+    seeded rule of `subsample_indices` (a warning names the graph size);
+    strict=True rejects it instead.  Note that such a graph has no padded slot, so
+    its one-hot kNN ties are broken by the implementation: the
+    reference's own CPU and CUDA results already differ there."""
     n = len(nodes)
     if n > node_num:
-        raise ValueError("graph has %d nodes > node_num=%d; the reference subsamples such graphs randomly "
-                         "(unseeded) - raise node_num (<= 256) instead" % (n, node_num))
+        if strict:
+            raise ValueError("graph has %d nodes > node_num=%d (strict packing)" % (n, node_num))
+        warnings.warn("graph with %d nodes subsampled to node_num=%d (seeded rule, sg_pr_amd.sg_net.subsample_indices)"
+                      % (n, node_num), stacklevel=2)
+        keep = subsample_indices(centers, nodes, node_num)
+        centers = np.asarray(centers, dtype=np.float64).reshape(n, 3)[keep]
+        nodes = np.asarray(nodes).reshape(-1)[keep]
+        n = int(node_num)
     lab = np.asarray(nodes).astype(np.int64).reshape(-1)
     bad = (lab < 0) | (lab >= number_of_labels)
     if bad.any():
@@ -208,14 +244,18 @@ class SGTrainer(object):
             raise NotImplementedError("augmentation / training branch is out of scope")
         new_data = dict()
         for side in ("1", "2"):
-            c, l = pack_graph(data["centers_" + side], data["nodes_" + side], int(self.args.node_num),
-                              self.number_of_labels)
+            cen, nod = data["centers_" + side], data["nodes_" + side]
+            if len(nod) > int(self.args.node_num):                      # sg_net.py:252-256, seeded (subsample_indices)
+                keep = subsample_indices(cen, nod, int(self.args.node_num))
+                cen = np.asarray(cen, dtype=np.float64).reshape(len(nod), 3)[keep]
+                nod = np.asarray(nod).reshape(-1)[keep]
+            c, l = pack_graph(cen, nod, int(self.args.node_num), self.number_of_labels)
             onehot = np.zeros((l.shape[0], self.number_of_labels), dtype=np.float64)
             real = l >= 0
             onehot[np.nonzero(real)[0], l[real]] = 1.0
             centers64 = np.zeros((l.shape[0], 3), dtype=np.float64)
-            n = len(data["nodes_" + side])
-            centers64[:n] = np.asarray(data["centers_" + side], dtype=np.float64).reshape(n, 3)
+            n = len(nod)
+            centers64[:n] = np.asarray(cen, dtype=np.float64).reshape(n, 3)
             new_data["features_" + side] = np.concatenate((centers64, onehot), axis=1).T
         new_data["target"] = self.target_from_distance(data["distance"])
         return new_data

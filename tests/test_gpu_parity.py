@@ -469,13 +469,13 @@ def test_super_node_branch_equals_generic_on_every_entry_point(eng):
     fast_p = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
     fast_d = eng.embed_dense(dense, 10, want_att=True, want_emb=True)
     fwd = eng.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), 10)
-    eng.lib.sgpr_debug_set_skip_mask(256 + 4096)
+    eng.set_skip_mask(256 + 4096)
     try:
         gen_p = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap, order=order)
         gen_d = eng.embed_dense(dense, 10, want_att=True, want_emb=True)
         fwd_g = eng.forward_dense(dense[0::2].contiguous(), dense[1::2].contiguous(), 10)
     finally:
-        eng.lib.sgpr_debug_set_skip_mask(0)
+        eng.set_skip_mask(0)
     for a, b, c, d in zip(fast_p, fast_d, gen_p, gen_d):
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     for a, b in zip(fwd, fwd_g):

@@ -19,7 +19,7 @@ def test_library_exports_every_header_symbol():
     assert declared == set(engine.ABI_SYMBOLS), declared ^ set(engine.ABI_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.sgpr_abi_version() == 1
+    assert lib.sgpr_abi_version() == int(re.search(r"#define SGPR_ABI_VERSION (\d+)", header).group(1)) >= 2
     assert lib.sgpr_weights_count(ctypes.byref(engine.default_dims())) == 48689   # 48 696 minus 7 int64 counters
 
 
@@ -144,7 +144,23 @@ def test_pack_graph_semantics():
     with pytest.raises(KeyError):
         pack_graph([[0, 0, 0]], [12], 5)          # reference: KeyError at global_labels[node]
     with pytest.raises(ValueError):
-        pack_graph(np.zeros((6, 3)), [0] * 6, 5)  # reference subsamples randomly (unseeded)
+        pack_graph(np.zeros((6, 3)), [0] * 6, 5, strict=True)
+    # oversized graphs: the reference subsamples with the unseeded global RNG (sg_net.py:252-256); the engine's rule is
+    # seeded by the graph itself -> same sorted subset every time, whatever else was packed before
+    from sg_pr_amd.sg_net import subsample_indices
+    rng = np.random.default_rng(5)
+    cen, lab = rng.normal(size=(9, 3)), rng.integers(0, 12, size=9)
+    with pytest.warns(UserWarning):
+        c1, l1 = pack_graph(cen, lab, 5)
+    pack_graph(rng.normal(size=(7, 3)), [1] * 7, 5)
+    with pytest.warns(UserWarning):
+        c2, l2 = pack_graph(cen.tolist(), lab.tolist(), 5)
+    np.testing.assert_array_equal(c1, c2)
+    np.testing.assert_array_equal(l1, l2)
+    keep = subsample_indices(cen, lab, 5)
+    assert len(keep) == 5 and (np.diff(keep) > 0).all()
+    np.testing.assert_array_equal(l1, lab[keep])
+    np.testing.assert_array_equal(c1, cen[keep].astype(np.float32))
     c, l = pack_graph([], [], 4)
     assert (l == -1).all()
 

@@ -21,7 +21,7 @@ for name, (n, k, g) in shapes.items():
     for mask, label in [(0, "full"), (256, "full, profile instance"), (256 + 4096, "full, generic first semantic layer"), (1, "no select"), (2, "no gemm"), (512, "gemm without weight loads"), (1024, "gemm without MFMAs"), (2048, "gemm without its inner barrier"), (1024+512, "gemm: no weights, no MFMAs"), (3, "no select, no gemm"), (4, "no gram"),
                         (8, "no gather"), (15, "skeleton (stage, barriers, conv_end, attention)"),
                         (32, "input fetch + duplicate detection only"), (16, "dispatch only")]:
-        eng.lib.sgpr_debug_set_skip_mask(mask)
+        eng.set_skip_mask(mask)
         for _ in range(3):
             eng.embed(c, l, k, node_cap=cap, order=order)
         torch.cuda.synchronize()
@@ -30,4 +30,4 @@ for name, (n, k, g) in shapes.items():
             eng.embed(c, l, k, node_cap=cap, order=order)
         torch.cuda.synchronize()
         print("%-9s %-48s %.4f ms" % (name, label, (time.perf_counter() - t0) * 100))
-    eng.lib.sgpr_debug_set_skip_mask(0)
+    eng.set_skip_mask(0)

@@ -23,9 +23,9 @@ for trial in range(60):
             l[q, :(l[q] >= 0).sum()].sort()
     order, cap = eng.size_order(c, l, k)
     fast = eng.embed(c, l, k, want_att=True, node_cap=cap, order=order)
-    eng.lib.sgpr_debug_set_skip_mask(256 + 4096)
+    eng.set_skip_mask(256 + 4096)
     gen = eng.embed(c, l, k, want_att=True, node_cap=cap, order=order)
-    eng.lib.sgpr_debug_set_skip_mask(0)
+    eng.set_skip_mask(0)
     eng.check_status()
     ok = torch.equal(fast[0], gen[0]) and torch.equal(fast[1], gen[1])
     cases += 1

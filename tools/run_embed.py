@@ -18,7 +18,7 @@ if shape == "kitti00":
 else:
     c, l, _ = synth.make_graphs(g, n, n // 3, n - k, 0)
 order, cap = eng.size_order(c, l, k)
-eng.lib.sgpr_debug_set_skip_mask(mask)
+eng.set_skip_mask(mask)
 c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
 for _ in range(reps):
     p = eng.embed(c, l, k, node_cap=cap, order=order)[0]
