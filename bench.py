@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
 """bench.py - graph-pairs/sec of the SG_PR hot path on MI355X (BASELINE.json metric).
 
-Default workload (`--workload kitti00`): the KITTI-00 all-pairs similarity matrix -
-M = 4541 graphs (KITTI-00 frame count), node_num = 100, K = 10 -> 4541^2 = 20 620 681
-ordered pairs per step.  KITTI graphs are not in the reference tree (README.md:54), so the
-sequence is the seeded KITTI-like synthetic generator of sg_pr_amd.synth (`"data":
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kitti00|kitti5seq|pairs128|stress]
+
+`--gpus N` with N > 1 and no torch.distributed environment: this script re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU, backend
+nccl = RCCL) and rank 0 prints the line; under a launcher (RANK / WORLD_SIZE set, the driver's form) it joins as a
+rank.  Asking for more ranks than visible GPUs is an error, never a silent 1-GPU run
+(SGPR_BENCH_BACKEND=gloo is the debugging aid that lets several ranks share one GPU).
+
+Default workload (`kitti00`): the KITTI-00 all-pairs similarity matrix - M = 4541 graphs (KITTI-00 frame count),
+node_num = 100, K = 10 -> 4541^2 = 20 620 681 ordered pairs per step.  KITTI graphs are not in the reference tree
+(README.md:54), so the sequence is the seeded KITTI-like synthetic generator of sg_pr_amd.synth (`"data":
 "synthetic"`); weights are the shipped checkpoint tests/golden/model.pth.
+`kitti5seq` (BASELINE config 4): sequences 00+02+05+06+08 (M = 4541, 4661, 2761, 1101, 4071 -> 67.75 M pairs),
+evaluated one after another per step like the reference's loop over `eva_batch.sequences` (eval_batch.py:26-36).
 
-One step = one pass of the hot path over the whole job with inputs already resident in
-HBM: embed every graph of this rank's shard (fused kNN/EdgeConv/attention kernel), exchange
-the pooled vectors, score this rank's row block of the matrix (NTN + head), gather the
-matrix on rank 0.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL);
-the M graphs / M rows are sharded across ranks, weak-scaling in the driver's sense is
-not applicable to a fixed matrix, so `scaling` is "strong".
+One step = one pass of the hot path over the whole job with inputs already resident in HBM: embed every graph of
+this rank's shard (fused kNN/EdgeConv/attention kernel), exchange the pooled vectors, score this rank's row block of
+the matrix (NTN + head), gather the matrix on rank 0.  N > 1: the M graphs / M rows are sharded across ranks; the
+matrix is fixed, so `scaling` is "strong".  `end_to_end` adds what `value` excludes by contract: the H2D copy of the
+packed graphs and either the D2H copy of the matrix or its device-side consumer (F1-max from histograms).
 
-Other workloads (parity-test shapes, not the headline): `--workload pairs128` (config 2:
-128 pairs, N=64, k=10, faithful per-pair forward) and `--workload stress` (config 5).
+Other workloads (parity-test shapes, not the headline): `pairs128` (config 2: 128 pairs, N=64, k=10, faithful
+per-pair forward) and `stress` (config 5: 1024 pairs, N=256, k=20).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +38,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
-FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_16x16x4_f32) = vector peak
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak (= fp32 matrix peak)
+KITTI_FRAMES = {"00": 4541, "02": 4661, "05": 2761, "06": 1101, "08": 4071}
 
 
 def embed_flops_per_graph(n, k):
@@ -55,6 +63,16 @@ def embed_bytes_per_graph(n):
     return 16 * n + 32 * 4
 
 
+def source_hash():
+    """sha256 over the HIP sources: ties a committed PMC profile to the code it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "sg_pr_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,34 +80,61 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prewarm", type=float, default=1.5,
                     help="seconds of untimed steps before the warmup (GPU clock ramp), 0 disables")
-    ap.add_argument("--workload", default="kitti00", choices=["kitti00", "pairs128", "stress"])
+    ap.add_argument("--workload", default="kitti00", choices=["kitti00", "kitti5seq", "pairs128", "stress"])
     ap.add_argument("--graphs", type=int, default=4541, help="M for the kitti00 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--embed-mode", default="ordered", choices=["ordered", "capped"],
                     help="launch the graphs largest-first (default) or in storage order")
     ap.add_argument("--no-gather", action="store_true", help="leave the score matrix sharded (skip the gather)")
+    ap.add_argument("--chunks", type=int, default=4, help="pieces per rank of the overlapped gather (1 = plain gather)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the transfer-inclusive measurements")
     return ap.parse_args()
+
+
+def respawn_under_launcher(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_launcher(a))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1):
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("SGPR_BENCH_BACKEND", "nccl")   # gloo: debugging aid, several ranks on ONE GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # SGPR_BENCH_BACKEND=gloo: debugging aid - exercises the N > 1 code path with several ranks on ONE GPU
-        backend = os.environ.get("SGPR_BENCH_BACKEND", "nccl")
-        local_rank %= torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible (RCCL needs one GPU per rank)" % (world, ndev))
+        local_rank %= max(ndev, 1)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
     else:
+        local_rank = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank)
 
     from sg_pr_amd import sg_net, synth, allpairs
     from sg_pr_amd.parser_sg import sgpr_args
@@ -97,22 +142,21 @@ def main():
     args = sgpr_args()
     args.model = os.path.join(REPO, "tests", "golden", "model.pth")
     args.gpu = dev.index
+    allpairs_job = a.workload in ("kitti00", "kitti5seq")
     if a.workload == "kitti00":
-        n, k, m = 100, 10, a.graphs
-        centers, labels, _, _ = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=0)
-        units = m * m
-        wl_name = "KITTI-00-sized all-pairs matrix (synthetic KITTI-like graphs), M=%d, node_num=100, K=10" % m
+        n, k = 100, 10
+        seqs = [("00", a.graphs)]
+        wl_name = "KITTI-00-sized all-pairs matrix (synthetic KITTI-like graphs), M=%d, node_num=100, K=10" % a.graphs
+    elif a.workload == "kitti5seq":
+        n, k = 100, 10
+        seqs = list(KITTI_FRAMES.items())
+        wl_name = ("config 4: KITTI 00+02+05+06+08-sized all-pairs matrices back to back (synthetic KITTI-like graphs), "
+                   "M=" + "/".join(str(m) for _, m in seqs) + ", node_num=100, K=10")
     elif a.workload == "pairs128":
         n, k = 64, 10
-        centers, labels, _ = synth.config2_pairs(seed=0)
-        m = centers.shape[0]
-        units = (m // 2) * world
         wl_name = "config 2: 128 synthetic pairs per GPU, node_num=64, K=10, faithful per-pair forward"
     else:
         n, k = 256, 20
-        centers, labels, _ = synth.config5_pairs(seed=0)
-        m = centers.shape[0]
-        units = (m // 2) * world
         wl_name = "config 5: 1024 synthetic pairs per GPU, node_num=256, K=20, faithful per-pair forward"
     args.node_num, args.K = n, k
     import contextlib
@@ -120,67 +164,99 @@ def main():
         trainer = sg_net.SGTrainer(args, False)
     model = trainer.model
     eng = model.engine()
-    d_centers = torch.from_numpy(centers).to(dev)
-    d_labels = torch.from_numpy(labels).to(dev)
-    # dataset property, computed once outside the timed region (the graph store knows its node counts):
-    # no graph needs more than node_cap processed slots -> the kernel sizes its LDS for that, not for node_num
-    node_cap = eng.node_cap_of(centers, labels, k)
-    # ... and a launch order, largest graphs first (sgpr_embed_ordered)
-    order = None
 
-    ev_pairs = []          # (start, stop) events around the dominant (embed) kernel
-    graphs_per_launch = [0]
+    ev_embed, ev_tail = [], []      # (start, stop) events around the embed launch / the all-pairs tail launches
+    graphs_per_step = 0             # graphs this rank embeds per step
+    n_eff_all = []                  # processed slots of those graphs (algorithmic FLOPs)
+    host_inputs = []                # (centers, labels) numpy, for the transfer-inclusive runs and the CPU baseline
 
-    if a.workload == "kitti00":
-        scorer = allpairs.AllPairsScorer(model=model)
-        lo, hi = allpairs.shard_bounds(m, world, rank)
-        graphs_per_launch[0] = hi - lo
-        if a.embed_mode == "ordered":
-            order = eng.size_order(centers[lo:hi], labels[lo:hi], k)[0]
-
-        def embed_timed(c, l):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+    def timed(events, fn):
+        def wrapped(*x, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            p = eng.embed(c, l, k, node_cap=node_cap, order=order)[0]
+            r = fn(*x, **kw)
             e1.record()
-            ev_pairs.append((e0, e1))
-            return p
+            events.append((e0, e1))
+            return r
+        return wrapped
 
-        scorer.embed_fn = embed_timed
+    if allpairs_job:
+        jobs = []
+        units = 0
+        for si, (name, m) in enumerate(seqs):
+            centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=si)
+            host_inputs.append((centers, labels, poses))
+            lo, hi = allpairs.shard_bounds(m, world, rank)
+            node_cap = eng.node_cap_of(centers, labels, k)   # dataset property (the graph store knows its node counts)
+            order = eng.size_order(centers[lo:hi], labels[lo:hi], k)[0] if a.embed_mode == "ordered" else None
+            scorer = allpairs.AllPairsScorer(model=model)
+            scorer.embed_fn = timed(ev_embed, lambda c, l, cap=node_cap, o=order: eng.embed(c, l, k, node_cap=cap, order=o)[0])
+            scorer.score_fn = timed(ev_tail, model.score_all_pairs)
+            full_out = (torch.empty(m, m, dtype=torch.float32, device=dev)
+                        if (world > 1 and rank == 0 and not a.no_gather) else None)
+            jobs.append({"name": name, "m": m, "scorer": scorer, "out": full_out, "node_cap": node_cap,
+                         "d_centers": torch.from_numpy(centers).to(dev), "d_labels": torch.from_numpy(labels).to(dev)})
+            units += m * m
+            graphs_per_step += hi - lo
+            n_eff_all.append(synth.effective_nodes(centers[lo:hi], labels[lo:hi], k))
+        node_cap_report = max(j["node_cap"] for j in jobs)
 
-        full_out = (torch.empty(m, m, dtype=torch.float32, device=dev)
-                    if (world > 1 and rank == 0 and not a.no_gather) else None)
-
-        def step():
-            return scorer.run(d_centers, d_labels, gather=not a.no_gather, out=full_out)
+        def step(gather=not a.no_gather):
+            out = None
+            for j in jobs:
+                out = j["scorer"].run(j["d_centers"], j["d_labels"], gather=gather, out=j["out"], chunks=a.chunks)
+            return out
     else:
+        centers, labels, _ = (synth.config2_pairs(seed=0) if a.workload == "pairs128" else synth.config5_pairs(seed=0))
+        host_inputs.append((centers, labels, None))
+        m = centers.shape[0]
         b = m // 2
-        c1, l1 = d_centers[0::2].contiguous(), d_labels[0::2].contiguous()
-        c2, l2 = d_centers[1::2].contiguous(), d_labels[1::2].contiguous()
-        cc, ll = torch.cat((c1, c2)), torch.cat((l1, l2))
-        graphs_per_launch[0] = m
-        if a.embed_mode == "ordered":
-            order = eng.size_order(cc, ll, k)[0]
+        units = b * world
+        d_centers, d_labels = torch.from_numpy(centers).to(dev), torch.from_numpy(labels).to(dev)
+        cc = torch.cat((d_centers[0::2], d_centers[1::2])).contiguous()
+        ll = torch.cat((d_labels[0::2], d_labels[1::2])).contiguous()
+        node_cap_report = eng.node_cap_of(centers, labels, k)
+        order = eng.size_order(cc, ll, k)[0] if a.embed_mode == "ordered" else None
+        graphs_per_step = m
+        n_eff_all.append(synth.effective_nodes(centers, labels, k))
+        embed_t = timed(ev_embed, lambda: eng.embed(cc, ll, k, node_cap=node_cap_report, order=order)[0])
 
-        def step():
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            pooled = eng.embed(cc, ll, k, node_cap=node_cap, order=order)[0]
-            e1.record()
-            ev_pairs.append((e0, e1))
+        def step(gather=True):
+            pooled = embed_t()
             return eng.score_pairs(pooled[:b], pooled[b:])
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed_steps(count, fn):
+        """Barrier + synchronize on both sides, MAX over ranks."""
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(count):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        del out
+        return dt
 
     # The GPU leaves its idle power state only after some tens of milliseconds of sustained work: a fresh process that
     # times 15 ms of kernels right away measures the clock ramp (observed: 7x slower kernels).  Run the same step,
     # untimed, until the device has been busy for --prewarm seconds; the W warmup steps of the contract follow.
     t_pre = time.perf_counter()
     while a.prewarm > 0:
-        for _ in range(50):
+        for _ in range(20 if a.workload == "kitti5seq" else 50):
             step()
         torch.cuda.synchronize()
-        ev_pairs.clear()
         more = torch.tensor([1 if time.perf_counter() - t_pre < a.prewarm else 0], device=dev)
         if world > 1:
             dist.broadcast(more, src=0)          # every rank runs the same number of (collective) steps
@@ -188,102 +264,152 @@ def main():
             break
     for _ in range(a.warmup):
         step()
-    ev_pairs.clear()
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    embed_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_pairs])) if ev_pairs else float("nan")
-    del out
+    ev_embed.clear()
+    ev_tail.clear()
+    dt = timed_steps(a.steps, step)
+    launches_per_step = len(host_inputs)
+    embed_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in ev_embed])) / max(len(ev_embed), 1)
+    tail_ms = (float(np.sum([e0.elapsed_time(e1) for e0, e1 in ev_tail])) / max(len(ev_tail), 1)) if ev_tail else None
+    tail_calls_per_step = len(ev_tail) / max(a.steps, 1)
+
     # N > 1, extra information (not `value`): the same K steps with the matrix left sharded by rows - what the
     # device-side consumers (F1-max histograms, top-k retrieval) work on; isolates the cost of the gather to rank 0
     sharded = None
-    if world > 1 and a.workload == "kitti00" and not a.no_gather:
+    if world > 1 and allpairs_job and not a.no_gather:
         for _ in range(a.warmup):
-            scorer.run(d_centers, d_labels, gather=False)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            blk = scorer.run(d_centers, d_labels, gather=False)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sharded = {"ms_per_step": float(t.item()) / a.steps * 1e3, "value": units * a.steps / float(t.item()),
+            step(gather=False)
+        ts = timed_steps(a.steps, lambda: step(gather=False))
+        sharded = {"ms_per_step": ts / a.steps * 1e3, "value": units * a.steps / ts,
                    "note": "matrix left sharded by rows (no gather to rank 0)"}
-        del blk
+
+    # what `value` excludes by contract: host <-> device transfers (SURVEY.md 8d counts them in its metric)
+    end_to_end = None
+    if allpairs_job and world == 1 and not a.no_end_to_end:
+        pinned = [(torch.from_numpy(c).pin_memory(), torch.from_numpy(l).pin_memory()) for c, l, _ in host_inputs]
+        host_out = [torch.empty(j["m"], j["m"], dtype=torch.float32).pin_memory() for j in jobs]
+        xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
+        reps = max(3, min(20, a.steps))
+
+        def e2e(consumer):
+            for j, (pc, pl), ho, pz in zip(jobs, pinned, host_out, xz):
+                dc, dl = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True)
+                mat = j["scorer"].run(dc, dl)
+                if consumer == "d2h":
+                    ho.copy_(mat, non_blocking=True)
+                else:
+                    from sg_pr_amd import metrics
+                    metrics.f1_max_device(eng, mat, pose_xz=pz)
+            torch.cuda.synchronize()
+
+        end_to_end = {}
+        for consumer in ("d2h", "device_f1"):
+            e2e(consumer)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                e2e(consumer)
+            te = (time.perf_counter() - t0) / reps
+            end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
+        end_to_end["note"] = ("per step: H2D of the packed graphs from pinned host memory (%.1f MB) + the step + either "
+                              "the D2H copy of the score matrices into pinned memory (%.1f MB; `d2h`) or the device-side "
+                              "F1-max over them with only the histograms crossing PCIe (`device_f1`); %d repetitions"
+                              % (sum(c.nbytes + l.nbytes for c, l, _ in host_inputs) / 1e6, units * 4 / 1e6, reps))
+        ev_embed.clear()
+        ev_tail.clear()
 
     if rank == 0:
         value = units * a.steps / dt
-        g = graphs_per_launch[0]
-        # ALGORITHMIC FLOPs of the launch: the factored formulation evaluated at each graph's processed
-        # slot count (surplus padding slots are dropped).  The kernel executes fewer still: the semantic branch runs on
-        # 13 label super-nodes instead of the graph's nodes.
-        n_eff = synth.effective_nodes(centers, labels, k)
-        if a.workload == "kitti00":
-            lo_, hi_ = allpairs.shard_bounds(m, world, 0)
-            n_eff = n_eff[lo_:hi_]
-        flops = float(sum(embed_flops_per_graph(int(v), k) for v in n_eff))
-        flops_dense = embed_flops_per_graph(n, k) * g
-        bytes_ = embed_bytes_per_graph(n) * g
+        g = graphs_per_step
+        # ALGORITHMIC FLOPs of the embed launches of one step: the factored formulation evaluated at each
+        # graph's processed slot count (surplus padding slots are dropped).  The kernel executes fewer still: the
+        # semantic branch runs on 13 label super-nodes instead of the graph's nodes.
+        n_eff = np.concatenate(n_eff_all)
+        flops = float(sum(embed_flops_per_graph(int(v), k) for v in n_eff)) / launches_per_step   # per launch
+        flops_dense = embed_flops_per_graph(n, k) * g / launches_per_step
+        bytes_ = embed_bytes_per_graph(n) * g / launches_per_step
         ach_tflops = flops / (embed_ms * 1e-3) / 1e12
         ach_gbs = bytes_ / (embed_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value
-        # comes from the committed rocprofv3 --pmc passes of the same workload (profiles/pmc_hbm_latest.json)
-        traffic = None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value comes from
+        # the committed rocprofv3 --pmc passes of the same workload (profiles/pmc_hbm_latest.json) and is reported only
+        # while that profile was taken from exactly these kernel sources
+        traffic, traffic_tail = None, None
         try:
             with open(os.path.join(REPO, "profiles", "pmc_hbm_latest.json")) as f:
-                pmc = json.load(f)["sgpr::embed_kernel"]
-            if a.workload == "kitti00" and pmc["graphs_per_launch"] == g and pmc["node_num"] == n:
-                traffic = (2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0   # gfx950 FETCH_SIZE correction
+                pmc = json.load(f)
+            if pmc.get("source_hash") == source_hash() and a.workload == "kitti00" and world == 1:
+                pe = pmc["sgpr::embed_kernel"]
+                if pe["graphs_per_launch"] == g and pe["node_num"] == n:
+                    traffic = (2 * pe["FETCH_SIZE_KiB"] + pe["WRITE_SIZE_KiB"]) * 1024.0   # gfx950 FETCH_SIZE correction
+                pt = pmc.get("sgpr::score_all_pairs_kernel")
+                if pt and a.graphs == 4541:
+                    traffic_tail = (2 * pt["FETCH_SIZE_KiB"] + pt["WRITE_SIZE_KiB"]) * 1024.0
         except (OSError, KeyError, ValueError):
             pass
         res = {
             "metric": "graph-pairs/sec", "value": value, "unit": "graph-pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if a.workload == "kitti00" else "weak",
+            "higher_is_better": True, "scaling": "strong" if allpairs_job else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_name, "graphs": int(m), "node_num": n, "K": k,
-                       "pairs_per_step": int(units), "node_cap": int(node_cap),
-                       "embed_launch_order": "largest graph first" if order is not None else "as stored",
-                       "parallelism": "row-sharded x%d" % world,
-                       "gather_to_rank0": (not a.no_gather) if a.workload == "kitti00" else None,
+            "config": {"workload": wl_name, "graphs": int(sum(mm for _, mm in seqs)) if allpairs_job else int(m),
+                       "node_num": n, "K": k, "pairs_per_step": int(units), "node_cap": int(node_cap_report),
+                       "embed_launch_order": "largest graph first" if a.embed_mode == "ordered" else "as stored",
+                       "parallelism": "row-sharded x%d" % world, "backend": backend if world > 1 else None,
+                       "gather_to_rank0": (not a.no_gather) if allpairs_job else None,
+                       "gather_chunks": a.chunks if (allpairs_job and world > 1) else None,
                        "checkpoint": "tests/golden/model.pth"},
             "sharded_output": sharded,
-            "roofline": {"kernel": "sgpr::embed_kernel", "bound": "mfma", "achieved": ach_tflops,
-                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP32_PEAK_TFLOPS,
-                         "traffic": traffic, "launch_ms": embed_ms, "graphs_per_launch": int(g),
+            "end_to_end": end_to_end,
+            "roofline": {"kernel": "sgpr::embed_kernel", "bound": "valu",
+                         "bound_note": "VALU issue + dependent latency (selection networks, gather-max, epilogues); the "
+                                       "matrix pipe is ~10 % busy and HBM ~0.3 % - priced against the fp32 vector peak",
+                         "achieved": ach_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tflops / FP32_PEAK_TFLOPS, "traffic": traffic, "launch_ms": embed_ms,
+                         "graphs_per_launch": g / launches_per_step, "launches_per_step": launches_per_step,
                          "flops_per_launch_algorithmic": flops, "mean_nodes_processed": float(np.mean(n_eff)),
                          "dense_equivalent_tflops": flops_dense / (embed_ms * 1e-3) / 1e12,
                          "flops_per_graph_dense": embed_flops_per_graph(n, k),
                          "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_graph": embed_bytes_per_graph(n)}},
         }
+        if tail_ms is not None:
+            # all-pairs tail (ntn_prep + score_all_pairs kernels of one call): the HBM-write-bound piece -
+            # algorithmic bytes = the scores written + the pooled vectors read
+            rows_per_call = sum(allpairs.shard_bounds(mm, world, 0)[1] for _, mm in seqs) / max(tail_calls_per_step, 1)
+            cols = float(np.mean([mm for _, mm in seqs]))
+            tb = sum(allpairs.shard_bounds(mm, world, 0)[1] * mm * 4 + (allpairs.shard_bounds(mm, world, 0)[1] + mm) * 128
+                     for _, mm in seqs) / max(tail_calls_per_step, 1)
+            gbs = tb / (tail_ms * 1e-3) / 1e9
+            res["roofline_tail"] = {"kernel": "sgpr::ntn_prep_kernel + sgpr::score_all_pairs_kernel", "bound": "hbm",
+                                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                    "traffic": traffic_tail, "launch_ms": tail_ms, "rows_per_call": rows_per_call,
+                                    "mean_cols": cols, "bytes_per_call_algorithmic": tb,
+                                    "calls_per_step": tail_calls_per_step}
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.model, centers, labels, n, k, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(args.model, host_inputs[0][0], host_inputs[0][1], n, k, a.cpu_seconds,
+                                               allpairs_job)
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(ckpt, centers, labels, n, k, target_s):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job):
     """The oracle (faithful torch-CPU restatement of the reference forward: both graphs of
     every pair embedded, materialised edge tensors) timed on the host cores over a bounded
     sample of pairs drawn from the same workload."""
+    import numpy as np
+    import torch
     from oracle import sgpr_oracle as oracle   # checker / baseline only
     from sg_pr_amd import synth
     sd = oracle.load_checkpoint(ckpt)
@@ -318,10 +444,31 @@ def cpu_baseline(ckpt, centers, labels, n, k, target_s):
         f1, f2 = batch()
         oracle.forward(sd, f1, f2, k)
     dt = time.perf_counter() - t0
-    return {"value": reps * bsz / dt, "unit": "graph-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d random pairs of the same workload in batches of %d (node_num=%d, K=%d), "
-                      "faithful per-pair forward incl. dense feature assembly" % (reps * bsz, bsz, n, k),
-            "host_cpus": ncpu}
+    res = {"value": reps * bsz / dt, "unit": "graph-pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d random pairs of the same workload in batches of %d (node_num=%d, K=%d), faithful per-pair "
+                     "forward incl. dense feature assembly; SURVEY.md 8d asks for a 100 k-pair sample (~%d s at this "
+                     "rate) - bounded to ~%d s of CPU work by the bench contract"
+                     % (reps * bsz, bsz, n, k, int(100000 / (reps * bsz / dt)), int(target_s)),
+           "host_cpus": ncpu, "cpu_model": cpu_model()}
+    if allpairs_job:
+        # context, not the baseline: the SAME algorithm as the GPU path on the CPU (embed every graph once, then only
+        # the NTN + head per pair) - separates "better algorithm" from "faster hardware"
+        ge = min(m, 256)
+        fe = torch.from_numpy(synth.dense_features(centers[:ge], labels[:ge]))
+        oracle.embed(sd, fe[:32], k)
+        t0 = time.perf_counter()
+        pooled = oracle.embed(sd, fe, k)[0]
+        te = (time.perf_counter() - t0) / ge
+        rows = pooled[:64].contiguous()
+        oracle.score_all_pairs(sd, rows[:8], pooled)
+        t0 = time.perf_counter()
+        oracle.score_all_pairs(sd, rows, pooled)
+        tp = (time.perf_counter() - t0) / (rows.shape[0] * pooled.shape[0])
+        res["same_algorithm_cpu"] = {"value": (m * m) / (m * te + m * m * tp), "unit": "graph-pairs/s",
+                                     "embed_s_per_graph": te, "tail_s_per_pair": tp,
+                                     "sample": "%d graphs embedded once + a %d x %d tail block, extrapolated to the "
+                                               "%d x %d matrix" % (ge, rows.shape[0], pooled.shape[0], m, m)}
+    return res
 
 
 if __name__ == "__main__":

@@ -50,6 +50,27 @@ class AllPairsScorer:
             return dist.get_world_size(self.group), dist.get_rank(self.group)
         return 1, 0
 
+    def _host_staged(self, t):
+        """gloo (the CPU tests, and the debugging aid that runs several ranks on one GPU) moves host memory only:
+        device tensors are staged through the host for it.  RCCL takes the device buffers directly."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _irecv_ops(self, views, srcs):
+        """P2POps receiving into `views` (+ the copies to run after the wait when staged)."""
+        ops, after = [], []
+        for v, r in zip(views, srcs):
+            if self._host_staged(v):
+                h = torch.empty(v.shape, dtype=v.dtype)
+                ops.append(dist.P2POp(dist.irecv, h, r, self.group))
+                after.append((v, h))
+            else:
+                ops.append(dist.P2POp(dist.irecv, v, r, self.group))
+        return ops, after
+
+    def _isend(self, t, dst):
+        buf = t.cpu() if self._host_staged(t) else t.contiguous()
+        return buf, dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst, self.group)])
+
     def pooled_all(self, centers, labels):
         """Embed this rank's shard and all_gather: every rank returns pooled [M, F]."""
         world, rank = self._world()
@@ -61,13 +82,17 @@ class AllPairsScorer:
         cap = shard_bounds(m, world, 0)[1]               # largest shard
         buf = local.new_zeros((cap, local.shape[1]))
         buf[: hi - lo] = local
+        staged = self._host_staged(buf)
+        if staged:
+            buf = buf.cpu()
         gathered = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(gathered, buf, group=self.group)
         parts = []
         for r in range(world):
             l, h = shard_bounds(m, world, r)
             parts.append(gathered[r][: h - l])
-        return torch.cat(parts, dim=0)
+        out = torch.cat(parts, dim=0)
+        return out.to(local.device) if staged else out
 
     def score_rows(self, pooled):
         """This rank's row block of the score matrix: [hi-lo, M]."""
@@ -85,18 +110,19 @@ class AllPairsScorer:
         if rank == dst:
             full = out if out is not None else block.new_empty((m, m))
             lo, hi = shard_bounds(m, world, rank)
-            ops = []
-            for r in range(world):
-                l, h = shard_bounds(m, world, r)
-                if r != rank and h > l:
-                    ops.append(dist.P2POp(dist.irecv, full[l:h], r, self.group))
+            spans = [(r,) + shard_bounds(m, world, r) for r in range(world) if r != rank]
+            spans = [(r, l, h) for r, l, h in spans if h > l]
+            ops, after = self._irecv_ops([full[l:h] for _, l, h in spans], [r for r, _, _ in spans])
             reqs = dist.batch_isend_irecv(ops) if ops else []
             full[lo:hi].copy_(block)
             for q in reqs:
                 q.wait()
+            for v, h in after:
+                v.copy_(h)
             return full
         if block.shape[0] > 0:
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, block.contiguous(), dst, self.group)]):
+            _keep, reqs = self._isend(block, dst)
+            for q in reqs:
                 q.wait()
         return None
 
@@ -121,7 +147,9 @@ class AllPairsScorer:
             import numpy as np
             h = np.asarray(hist_fn(block, lo, xz, prefix_bits, bits, prefixes)).astype(np.int64)
             if world > 1:
-                t = torch.from_numpy(h).to(block.device if block.is_cuda else "cpu")
+                t = torch.from_numpy(h)
+                if block.is_cuda and not self._host_staged(block):
+                    t = t.to(block.device)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 h = t.cpu().numpy()
             return h.astype(np.uint64)
@@ -139,7 +167,8 @@ class AllPairsScorer:
         `out` (rank 0): preallocated [M, M] buffer that receives the matrix.
         chunks > 1 (multi-rank gather): every rank scores its row block in `chunks` pieces and ships each piece to
         rank 0 as soon as it is computed, so the xGMI transfer of piece i overlaps the scoring of piece i+1; rank 0
-        posts all its receives up front, straight into the rows of the matrix."""
+        posts all its receives up front (one group per piece index, one receive per peer in it), straight into the
+        rows of the matrix.  chunks = 1 is the plain form: score the block, then one gather (gather_matrix)."""
         pooled = self.pooled_all(centers, labels)
         world, rank = self._world()
         if not gather or world == 1 or chunks <= 1:
@@ -158,13 +187,17 @@ class AllPairsScorer:
         lo, hi = shard_bounds(m, world, rank)
         if rank == dst:
             full = out if out is not None else pooled.new_empty((m, m))
-            ops = []
-            for r in range(world):
-                if r == rank:
-                    continue
-                l, h = shard_bounds(m, world, r)
-                ops += [dist.P2POp(dist.irecv, full[a:b], r, self.group) for a, b in pieces(l, h)]
-            reqs = dist.batch_isend_irecv(ops) if ops else []
+            # one receive group PER PIECE INDEX, holding one receive from every peer (the shape of a plain gather:
+            # a root group of world-1 receives against one single-send group on each peer); peer r's c-th send group
+            # meets rank 0's c-th receive group, in order, so both sides agree on the sequence of groups per pair
+            peer_pieces = {r: pieces(*shard_bounds(m, world, r)) for r in range(world) if r != rank}
+            reqs, after = [], []
+            for c in range(chunks):
+                srcs = [r for r, pc in peer_pieces.items() if c < len(pc)]
+                ops, aft = self._irecv_ops([full[peer_pieces[r][c][0]:peer_pieces[r][c][1]] for r in srcs], srcs)
+                after += aft
+                if ops:
+                    reqs += dist.batch_isend_irecv(ops)
             for a, b in pieces(lo, hi):                      # own rows: scored straight into the matrix
                 if self._engine is not None:
                     self.score_fn(pooled[a:b].contiguous(), pooled, out=full[a:b])
@@ -172,12 +205,16 @@ class AllPairsScorer:
                     full[a:b].copy_(self.score_fn(pooled[a:b].contiguous(), pooled))
             for q in reqs:
                 q.wait()
+            for v, h in after:
+                v.copy_(h)
             return full
-        reqs, keep = [], []
+        reqs, keep, sent = [], [], []
         for a, b in pieces(lo, hi):
             blk = self.score_fn(pooled[a:b].contiguous(), pooled)
-            keep.append(blk)                                 # the buffer must outlive the asynchronous send
-            reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, blk, dst, self.group)])
+            keep.append(blk)
+            buf, rq = self._isend(blk, dst)
+            sent.append(buf)                                 # the buffer must outlive the asynchronous send
+            reqs += rq
         for q in reqs:
             q.wait()
         return torch.cat(keep, dim=0) if keep else pooled.new_empty((0, m))

@@ -5,7 +5,8 @@
 Per sequence in `eva_batch.sequences`: reads `<pair_list_dir>/<seq>.txt`, scores every
 listed pair, and writes the same artefacts as the reference into `output_path`:
 `<seq>_gt_db.npy` (float64), `<seq>_DL_db.npy` (float32), `<seq>_DL_F1_max.txt`
-(plus ROC / PR PNGs when matplotlib is importable).
+`<seq>_DL_roc_curve.png`, `<seq>_DL_pr_curve.png`, the fpr / tpr / thresholds / roc_auc prints, `plt.show()` when
+`eva_batch.show` is set.
 
 Unlike the reference (which re-reads, re-pads and re-embeds both graphs of every pair,
 utils.py:27-28 / sg_net.py:503-520) each distinct graph is parsed and embedded ONCE on the
@@ -54,6 +55,40 @@ def score_pair_list(trainer, graph_pairs):
     return pred.cpu().numpy().reshape(-1), gt
 
 
+def plot_curves(args, sequence, fpr, tpr, roc_auc, precision, recall):
+    """eval_batch.py:55-82: `<seq>_DL_roc_curve.png`, `<seq>_DL_pr_curve.png`, and `plt.show()` when `args.show`.
+    Headless unless `show` is set; skipped with a note when matplotlib is not installed."""
+    try:
+        import matplotlib
+        if not getattr(args, "show", False):
+            matplotlib.use("Agg")
+        from matplotlib import pyplot as plt
+    except ImportError:
+        print("matplotlib is not installed: ROC / P-R plots skipped")
+        return
+    lw = 2
+    plt.figure(0)
+    plt.plot(fpr, tpr, color='darkorange', lw=lw, label='ROC curve (area = %0.2f)' % roc_auc)
+    plt.plot([0, 1], [0, 1], color='navy', lw=lw, linestyle='--')
+    plt.xlabel('False Positive Rate')
+    plt.ylabel('True Positive Rate')
+    plt.title('DL ROC Curve')
+    plt.legend(loc="lower right")
+    plt.savefig(os.path.join(args.output_path, sequence + "_DL_roc_curve.png"))
+    plt.figure(1)
+    plt.plot(recall, precision, color='darkorange', lw=lw, label='P-R curve')
+    plt.axis([0, 1, 0, 1])
+    plt.xlabel('Recall')
+    plt.ylabel('Precision')
+    plt.title('DL Precision-Recall Curve')
+    plt.legend(loc="lower right")
+    plt.savefig(os.path.join(args.output_path, sequence + "_DL_pr_curve.png"))
+    if getattr(args, "show", False):
+        plt.show()
+    plt.close(0)
+    plt.close(1)
+
+
 def evaluate_sequence(trainer, sequence, args, plots=True):
     graph_pairs = load_paires(os.path.join(args.pair_list_dir, sequence + ".txt"), args.graph_pairs_dir)
     pred_db, gt_db = score_pair_list(trainer, graph_pairs)
@@ -61,25 +96,16 @@ def evaluate_sequence(trainer, sequence, args, plots=True):
     assert np.sum(gt_db) > 0  # gt_db should have positive samples   (eval_batch.py:38)
     np.save(os.path.join(args.output_path, sequence + "_gt_db.npy"), gt_db)
     np.save(os.path.join(args.output_path, sequence + "_DL_db.npy"), pred_db)
-    roc_auc = metrics.roc_auc(gt_db, pred_db)
+    # ROC (eval_batch.py:48-53)
+    fpr, tpr, roc_thresholds = metrics.roc_curve(gt_db, pred_db)
+    roc_auc = metrics.auc(fpr, tpr)
+    print("fpr: ", fpr)
+    print("tpr: ", tpr)
+    print("thresholds: ", roc_thresholds)
     print("roc_auc: ", roc_auc)
     precision, recall, pr_thresholds = metrics.precision_recall_curve(gt_db, pred_db)
     if plots:
-        try:
-            import matplotlib
-            matplotlib.use("Agg")
-            from matplotlib import pyplot as plt
-            plt.figure(1)
-            plt.plot(recall, precision, color='darkorange', lw=2, label='P-R curve')
-            plt.axis([0, 1, 0, 1])
-            plt.xlabel('Recall')
-            plt.ylabel('Precision')
-            plt.title('DL Precision-Recall Curve')
-            plt.legend(loc="lower right")
-            plt.savefig(os.path.join(args.output_path, sequence + "_DL_pr_curve.png"))
-            plt.close(1)
-        except ImportError:
-            pass
+        plot_curves(args, sequence, fpr, tpr, roc_auc, precision, recall)
     f1_max = metrics.f1_max(gt_db, pred_db)
     print('F1 max score', f1_max)
     with open(os.path.join(args.output_path, sequence + "_DL_F1_max.txt"), "w") as out:

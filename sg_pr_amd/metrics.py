@@ -36,15 +36,33 @@ def f1_max(gt, score):
     return float(np.max(np.nan_to_num(f1)))
 
 
-def roc_auc(gt, score):
-    """eval_batch.py:48-49 (roc_curve without drop_intermediate does not change the area)."""
-    fps, tps, _ = _binary_clf_curve(gt, score)
+def roc_curve(gt, score, drop_intermediate=True):
+    """eval_batch.py:48: sklearn.metrics.roc_curve's definition -> (fpr, tpr, thresholds).  Collinear points are
+    dropped like sklearn's default does; the first point is (0, 0) at threshold +inf."""
+    fps, tps, thr = _binary_clf_curve(gt, score)
+    if drop_intermediate and fps.size > 2:
+        keep = np.where(np.r_[True, np.logical_or(np.diff(fps, 2), np.diff(tps, 2)), True])[0]
+        fps, tps, thr = fps[keep], tps[keep], thr[keep]
     fps = np.r_[0.0, fps]
     tps = np.r_[0.0, tps]
-    if fps[-1] <= 0 or tps[-1] <= 0:
-        return float("nan")
+    thr = np.r_[np.inf, thr]
+    fpr = fps / fps[-1] if fps[-1] > 0 else np.full(fps.shape, np.nan)
+    tpr = tps / tps[-1] if tps[-1] > 0 else np.full(tps.shape, np.nan)
+    return fpr, tpr, thr
+
+
+def auc(x, y):
+    """sklearn.metrics.auc for a monotone x: trapezoidal area (eval_batch.py:49)."""
     trapezoid = getattr(np, "trapezoid", None) or np.trapz
-    return float(trapezoid(tps / tps[-1], fps / fps[-1]))
+    return float(trapezoid(y, x))
+
+
+def roc_auc(gt, score):
+    """eval_batch.py:48-49: area under the ROC curve (dropping collinear points does not change it)."""
+    fpr, tpr, _ = roc_curve(gt, score, drop_intermediate=False)
+    if np.isnan(fpr).any() or np.isnan(tpr).any():
+        return float("nan")
+    return auc(fpr, tpr)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

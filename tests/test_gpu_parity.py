@@ -567,3 +567,50 @@ def test_c_demo_matches_engine(tmp_path, eng, ckpt_path):
     got = np.fromfile(tmp_path / "s.f32", dtype=np.float32).reshape(37, 37)
     pooled = eng.embed(centers, labels, 10)[0]
     np.testing.assert_array_equal(got, eng.score_all_pairs(pooled, pooled).cpu().numpy())
+
+
+# ------------------------------------------------------------------ N > 1 code path on ONE GPU (gloo ranks share cuda:0)
+def _two_rank_worker(rank, world, port, ckpt, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sg_pr_amd import synth, allpairs, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    args = sgpr_args()
+    args.model = ckpt
+    trainer = sg_net.SGTrainer(args, False)
+    centers, labels, _, poses = synth.kitti_like_sequence(203, 100, 6)          # 203 = 102 + 101 rows: uneven shards
+    dc, dl = torch.from_numpy(centers).cuda(), torch.from_numpy(labels).cuda()
+    scorer = allpairs.AllPairsScorer(model=trainer.model)
+    full = scorer.run(dc, dl, chunks=4)                                          # pieces overlapped with scoring
+    plain = scorer.run(dc, dl, chunks=1)                                         # plain gather
+    block = scorer.run(dc, dl, gather=False)
+    f1 = scorer.f1_max(block, poses)
+    if rank == 0:
+        assert torch.equal(full, plain)
+        torch.save({"full": full.cpu(), "f1": f1}, os.path.join(out_dir, "two.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_bitwise_equal_one_rank(tmp_path, ckpt_path):
+    """The real AllPairsScorer.run (HIP embed / all-pairs kernels, sharded rows, overlapped gather in 4 pieces and the
+    plain gather) with two ranks on cuda:0: the gathered matrix is bit-identical to the single-process one and the
+    sharded device F1-max equals the single-rank value.  (RCCL needs one GPU per rank; gloo ranks can share one.)"""
+    import torch.multiprocessing as mp
+    from sg_pr_amd import synth, allpairs, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    mp.spawn(_two_rank_worker, args=(2, 29641, ckpt_path, str(tmp_path)), nprocs=2, join=True)
+    two = torch.load(os.path.join(str(tmp_path), "two.pt"))
+    args = sgpr_args()
+    args.model = ckpt_path
+    trainer = sg_net.SGTrainer(args, False)
+    centers, labels, _, poses = synth.kitti_like_sequence(203, 100, 6)
+    scorer = allpairs.AllPairsScorer(model=trainer.model)
+    one = scorer.run(torch.from_numpy(centers).cuda(), torch.from_numpy(labels).cuda())
+    assert torch.equal(one.cpu(), two["full"])
+    assert scorer.f1_max(one, poses) == two["f1"]

@@ -246,8 +246,10 @@ def _allpairs_worker(rank, world, port, golden, out_dir):
         return oracle.embed(sd, torch.from_numpy(synth.dense_features(c, l)), 10)[0]
 
     scorer = allpairs.AllPairsScorer(embed_fn=embed_fn, score_fn=lambda r, c: oracle.score_all_pairs(sd, r, c))
-    full = scorer.run(centers, labels)
+    full = scorer.run(centers, labels)                       # chunks = 4: pieces shipped while the next one is scored
+    plain = scorer.run(centers, labels, chunks=1)            # the plain form: one block, one gather
     if rank == 0:
+        torch.testing.assert_close(full, plain, rtol=0, atol=2e-6)   # torch-CPU matmuls are not batch-invariant
         torch.save(full, os.path.join(out_dir, "w%d.pt" % world))
     # sharded F1-max without gathering: per-rank histograms (numpy stand-in for the HIP pass), one all_reduce per pass
     from sg_pr_amd import metrics
@@ -273,7 +275,9 @@ def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
     from oracle import sgpr_oracle as oracle
     from sg_pr_amd import synth, allpairs
     mp.spawn(_allpairs_worker, args=(2, 29611, golden_dir, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_allpairs_worker, args=(3, 29613, golden_dir, str(tmp_path)), nprocs=3, join=True)   # uneven: 4 + 4 + 3 rows
     two = torch.load(os.path.join(str(tmp_path), "w2.pt"))
+    three = torch.load(os.path.join(str(tmp_path), "w3.pt"))
     sd = oracle.load_checkpoint(os.path.join(golden_dir, "model.pth"))
     centers, labels, _, poses = synth.kitti_like_sequence(11, 100, 3)
     torch.set_num_threads(2)
@@ -287,6 +291,8 @@ def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
     one = torch.cat([oracle.score_all_pairs(sd, pooled[lo:hi].contiguous(), pooled) for lo, hi in bounds])
     assert two.shape == (11, 11)
     assert torch.equal(one, two)
+    # the oracle's torch-CPU embed is not bitwise batch-invariant (see above): 3 ranks embed other shard shapes
+    torch.testing.assert_close(three, two, rtol=0, atol=2e-6)
     assert not torch.equal(two, two.t())                 # the NTN is asymmetric: full square needed
     gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
     assert gt.shape == (11, 11) and valid.diagonal().all() and gt.diagonal().all()
