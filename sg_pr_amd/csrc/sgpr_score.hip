@@ -5,11 +5,12 @@
 //  * score_pairs_kernel      one wave64 per pair (pair-list mode: eval_batch.py:30-36,
 //                            SG.forward's per-pair tail).
 //  * ntn_prep_kernel + score_all_pairs_kernel
-//                            dense R x M rectangle.  The bilinear form is hoisted per row
-//                            graph (A_r = e1^T W, 16x32) so a pair costs 512+256+16 FMA;
-//                            both dense layers run on the fp32 matrix cores (16x16x4 MFMA,
-//                            layer 2 chained off the accumulator layout of layer 1), column
-//                            operands stay in registers, score rows are written coalesced.
+//                            dense R x M rectangle.  The bilinear form AND the column half of the block term are
+//                            hoisted per row graph (A'_r = e1^T W + Wb[:, F:], 16x32; u_r = Wb[:, :F] e1 + bias), so a
+//                            pair costs 512 + 256 + 16 FMA.  Both dense layers run on v_mfma_f32_16x16x32_f16 with
+//                            two-plane f16 operands (x = hi + lo, 22 bits; three cross products per layer), layer 2
+//                            chained off the accumulator layout of layer 1; a wave keeps 4 row graphs in registers and
+//                            walks 64-column super-blocks; every store instruction writes 4 rows x 256 contiguous bytes.
 #include <math.h>
 
 #include "sgpr_internal.hpp"
@@ -115,42 +116,68 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 }
 
 // ------------------------------------------------------------------ dense all-pairs
-// workspace layout:  ur [R][T] f32 | vc [M][T] f32 | Ab [R][3][T][F] bf16 | Cb [M][3][F] bf16
-// (A_r and the column vectors e2 split into three bf16 planes: x = hi + mid + lo exactly to 24 bits, so six bf16
-// MFMAs reproduce the fp32 product - see score_all_pairs_kernel)
-size_t score_all_pairs_ws_bytes(int R, int M) {
-    return ((size_t)R * T + (size_t)M * T) * sizeof(float) +
-           ((size_t)R * 3 * T * F + (size_t)M * 3 * F) * sizeof(unsigned short);
+// workspace layout:  ur [R][T] f32 | rng [NWG][4] f32 | Ab [R][2][64][8] f16 | Cb [NSB][2][4][64][8] f16
+//   ur   u_r[t] = Wb[t][:F] . e1_r + bias[t]
+//   Ab   A'_r[t][j] = sum_i e1_r[i] W[i][j][t] + Wb[t][F + j]  as two f16 planes (hi = RNE(a), lo = RNE(a - hi): 22 bits)
+//        in MFMA A-operand order: lane (g = j >> 3, l15 = t) holds j = 8g .. 8g+7 -> a wave's operand = 1 KB contiguous
+//   Cb   column vectors e2_c as two f16 planes in MFMA B-operand order, 64 columns per super-block: block b (0..3) of a
+//        super-block feeds MFMA column l15 with graph column 64 sb + 4 l15 + b, so that after the head a lane owns four
+//        CONSECUTIVE columns of one row (one 16-byte store); lane (g, l15) holds j = 8g .. 8g+7
+//   rng  per prep workgroup: max |A'|, max |u|, max |e2| - the main kernel derives a bound on every f16 it will form
+// f16 has 11 significant bits and a 65504 range: inputs whose bound reaches that range take the exact fp32 per-pair
+// path inside score_all_pairs_kernel (never on real data: |pooled| ~ 10); subnormal lo planes are honoured by the
+// matrix core (tools/probes/f16_split_probe.hip), so small values only lose what fp32 would lose as well.
+constexpr int AP_RW = 4;       // row graphs per wave: their A' operands (2 planes) stay in registers
+constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
+constexpr int AP_SB = 64;      // columns per super-block (4 MFMA column blocks)
+constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
+constexpr int AP_OCC = 4;      // resident workgroups per CU the kernel is compiled for (waves per SIMD)
+constexpr int AP_NI = 1;       // row graphs interleaved in program order (see score_all_pairs_kernel)
+constexpr float AP_F16_SAFE = 60000.f;
+
+static inline int ap_prep_groups(int R, int M) {
+    const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
+    return ((R > msb ? R : msb) + 15) / 16;
 }
 
-__device__ __forceinline__ unsigned short bf16_rne(float x) {      // round-to-nearest-even fp32 -> bf16 (no NaNs here)
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ void split3(float a, unsigned short& h, unsigned short& m, unsigned short& l) {
-    h = bf16_rne(a);
-    float r = a - bf16_f32(h);
-    m = bf16_rne(r);
-    r -= bf16_f32(m);
-    l = bf16_rne(r);
+size_t score_all_pairs_ws_bytes(int R, int M) {
+    const size_t nsb = (size_t)(M + AP_SB - 1) / AP_SB;
+    return (size_t)R * T * sizeof(float) + (size_t)2 * ap_prep_groups(R, M) * 4 * sizeof(float) +
+           (size_t)R * 2 * 64 * 8 * sizeof(unsigned short) + nsb * 2 * 4 * 64 * 8 * sizeof(unsigned short);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// 16 graphs per workgroup.  Row graphs get A_r = e1^T W (16 x 32 per graph) as ONE small GEMM per workgroup,
+__device__ __forceinline__ void split2_f16(float a, _Float16& h, _Float16& l) {
+    h = (_Float16)a;                       // round to nearest even
+    l = (_Float16)(a - (float)h);          // exact residual, rounded once: |a - (h + l)| <= 2^-23 |a| (or 2^-25 absolute)
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+
+// 16 graphs per pair of workgroups.  Row graphs get A' (16 x 32 per graph) as ONE small GEMM per workgroup,
 // [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
-// instead of once per graph - split into three bf16 planes on the way out, plus u_r = Wb[:, :F] e1 + bias;
-// column graphs get v_c = Wb[:, F:] e2 and their own three-plane copy.
+// instead of once per graph - plus the column half of the block term, split into two f16 planes on the way out, and
+// u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
                                                        const float* __restrict__ cols, int M,
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
-                                                       float* __restrict__ vc, unsigned short* __restrict__ Cb) {
+                                                       float* __restrict__ rng, unsigned short* __restrict__ Cb) {
+    __shared__ float red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
     const int g0 = (blockIdx.x >> 1) * 16, half = blockIdx.x & 1;
+    float amax = 0.f, umax = 0.f, emax = 0.f;
     if (g0 < R) {
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
         const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
@@ -167,22 +194,24 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wp[17 * T * F], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wp[18 * T * F], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wp[19 * T * F], acc, 0, 0, 0);
-            // acc[r] = A_{g0 + 4 lq + r}[t][j]
+            // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
+            const float wbc = w.ntn_wb[t * 2 * F + F + j];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = g0 + 4 * lq + r;
                 if (g < R) {
-                    unsigned short h, m, l;
-                    split3(acc[r], h, m, l);
-                    unsigned short* dst = Ab + (size_t)g * (3 * T * F) + t * F + j;
-                    dst[0] = h;
-                    dst[T * F] = m;
-                    dst[2 * T * F] = l;
+                    const float a = acc[r] + wbc;
+                    amax = fmaxf(amax, fabsf(a));
+                    _Float16 h, l;
+                    split2_f16(a, h, l);
+                    unsigned short* dst = Ab + ((size_t)g * 2 * 64 + (j >> 3) * 16 + t) * 8 + (j & 7);
+                    dst[0] = __builtin_bit_cast(unsigned short, h);
+                    dst[64 * 8] = __builtin_bit_cast(unsigned short, l);
                 }
             }
         }
     }
-    // block terms: one graph per wave pass, lane (t = l15, q = lq) sums 8 of the 32 products
+    // block term of the row graphs and the column operands: one graph per wave pass
     for (int gi = half * 8 + wave * 2; gi < half * 8 + wave * 2 + 2; ++gi) {
         const int g = g0 + gi;
         if (g < R) {
@@ -191,46 +220,43 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
             for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
-            if (lq == 0) ur[(size_t)g * T + l15] = s + w.ntn_bias[l15];
+            s += w.ntn_bias[l15];
+            umax = fmaxf(umax, fabsf(s));
+            if (lq == 0) ur[(size_t)g * T + l15] = s;
         }
-        if (g < M) {
-            const float* e2 = cols + (size_t)g * F;
-            float s = 0.f;
-            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + F + lq * 8 + m], e2[lq * 8 + m], s);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (lq == 0) vc[(size_t)g * T + l15] = s;
-            if (lane < F) {                                 // the column operand itself, as three bf16 planes
-                unsigned short h, m, l;
-                split3(e2[lane], h, m, l);
-                Cb[(size_t)g * (3 * F) + lane] = h;
-                Cb[(size_t)g * (3 * F) + F + lane] = m;
-                Cb[(size_t)g * (3 * F) + 2 * F + lane] = l;
-            }
+        const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
+        if (g < msb && lane < F) {                          // the column operand itself, two f16 planes (zeros past M)
+            const float x = g < M ? cols[(size_t)g * F + lane] : 0.f;
+            emax = fmaxf(emax, fabsf(x));
+            _Float16 h, l;
+            split2_f16(x, h, l);
+            const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
+            unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
+            dst[0] = __builtin_bit_cast(unsigned short, h);
+            dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
         }
     }
+    // NaN inputs: fmaxf drops them, so fold an explicit "not finite" marker in (infinity fails every bound)
+    amax = wave_max_f32(amax);
+    umax = wave_max_f32(umax);
+    emax = wave_max_f32(emax);
+    if (lane == 0) {
+        red[wave][0] = amax;
+        red[wave][1] = umax;
+        red[wave][2] = emax;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        rng[(size_t)blockIdx.x * 4 + q] = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
+    }
+    if (threadIdx.x == 3) rng[(size_t)blockIdx.x * 4 + 3] = 0.f;
 }
 
-constexpr int AP_RW = 4;       // row graphs per wave: their A_r operands (3 planes) stay in registers
-constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
-constexpr int AP_COLS = 256;   // column graphs per work item (16 blocks of 16), streamed from L2
-constexpr int AP_OCC = 3;      // resident workgroups per CU the kernel is compiled for (waves per SIMD)
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    // D[4*(l>>4)+r][l&15] += sum_{q<4} A[row][q] * B[q][col];  lane l supplies A[l&15][l>>4], B[l>>4][l&15]
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {   // same operand/result layout as mfma_bf16
+__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
+    // 16x16x32: D[4*(l>>4)+r][l&15] += sum_k A[row][k] B[k][col]; lane l supplies A[l&15][8*(l>>4) .. +7] and
+    // B[8*(l>>4) .. +7][l&15]
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
-    // 16x16x32: lane l supplies A[l&15][8*(l>>4) .. +7] and B[8*(l>>4) .. +7][l&15]; same D layout as above
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // v_permlane32_swap: lanes 32-63 of the first operand trade places with lanes 0-31 of the second; the sum of the two
@@ -251,38 +277,112 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
 // pattern: every negative float (and -0) is a negative integer.
 __device__ __forceinline__ float relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
-// layer 1 of one (row graph, 16 column graphs) block: six bf16 products, smallest terms first
-__device__ __forceinline__ f32x4 layer1(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, float4 u4,
-                                        float4 v4) {
-    f32x4 h = {u4.x + v4.x, u4.y + v4.y, u4.z + v4.z, u4.w + v4.w};
-    h = mfma_bf16(al, bh, h);
-    h = mfma_bf16(ah, bl, h);
-    h = mfma_bf16(am, bm, h);
-    h = mfma_bf16(am, bh, h);
-    h = mfma_bf16(ah, bm, h);
-    return mfma_bf16(ah, bh, h);
+// relu(h[0..3]) -> the layer-2 B operand {hi01, hi23, lo01, lo23} (packed f16 planes, hi + lo = relu(h) to 22 bits):
+//   hi = the values truncated to f16 (v_cvt_pkrtz_f16_f32: |hi| <= |h|, same sign)
+//   lo = f16(h - hi) straight out of one mixed-precision FMA per value (v_fma_mixlo/mixhi_f16: f16 * f32 + f32, the f16
+//        result written to one half of the destination)
+//   truncation makes both planes carry h's sign, so the ReLU is one packed SIGNED-INTEGER max with 0 per plane pair
+//   (v_pk_max_i16: a negative f16 is a negative int16; no canonicalising pre-pass like the float max gets).
+// Only the four mix instructions are inline asm (the compiler has no builtin for them): the conversions before and the
+// maxima after are visible instructions, so the wait states an MFMA result needs before a vector read and a vector
+// result needs before an MFMA read are inserted by the compiler - it does not look inside inline asm (a first version
+// with everything in asm read half-written accumulators).
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 split_relu4(f32x4 h) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l01), "=&v"(l23)
+        : "v"(h01), "v"(h23), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    const i16x2 z = {0, 0};
+    const unsigned a = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, h01), z));
+    const unsigned b = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, h23), z));
+    const unsigned c = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l01), z));
+    const unsigned d = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l23), z));
+    return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
 }
 
-// One wave owns AP_RW = 4 row graphs - their A_r operands, 14 MB in total and therefore MALL/HBM-resident, are fetched
-// once per work item and kept in registers - and streams blocks of 16 column graphs, whose three-plane operands
-// (0.9 MB in total) stay in L2 and are fetched one block ahead.  Per (row, block):
-//   layer 1  H[t][c] = relu(u_r[t] + v_c[t] + sum_j A_r[t][j] e2_c[j]),  K = 32.  fp32 MFMA shares the vector pipe on
-//            gfx950, bf16 MFMA does not and is ~8x faster per product: both operands are split into three
-//            bf16 planes (x = hi + mid + lo, exact to 24 bits) and the six significant cross products
-//            hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are accumulated in fp32 -> fp32-class accuracy (error ~2^-24)
+// Exact fp32 evaluation of the rectangle [r0, r1) x [c0, c1), one pair per wave iteration, for inputs outside the f16
+// range.  Deliberately rolled loops: it shares the kernel with the hot loop and must not cost it registers.
+__device__ __forceinline__ void slow_tile(const DevWeights& w, const float* __restrict__ prow,
+                                          const float* __restrict__ pcol, int r0, int r1, int c0, int c1,
+                                          float* __restrict__ score, int64_t ld) {
+    const int lane = threadIdx.x & 63, t = lane & 15, q = lane >> 4;
+#pragma unroll 1
+    for (int r = r0; r < r1; ++r)
+#pragma unroll 1
+        for (int c = c0; c < c1; ++c) {
+            const float* e1 = prow + (size_t)r * F;
+            const float* e2 = pcol + (size_t)c * F;
+            float s = 0.f;
+#pragma unroll 1
+            for (int j = 8 * q; j < 8 * q + 8; ++j) {                     // this lane group's quarter of the 32 j
+                float v = 0.f;
+#pragma unroll 1
+                for (int i = 0; i < F; ++i) v = fmaf(e1[i], w.ntn_w[i * (F * T) + j * T + t], v);
+                s = fmaf(v, e2[j], s);
+            }
+#pragma unroll 1
+            for (int m = 16 * q; m < 16 * q + 16; ++m) s = fmaf(w.ntn_wb[t * 2 * F + m], m < F ? e1[m] : e2[m - F], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float h = fmaxf(s + w.ntn_bias[t], 0.f);
+            float gacc = w.fc1_b[t];
+#pragma unroll 1
+            for (int tt = 0; tt < T; ++tt) gacc = fmaf(w.fc1_w[t * T + tt], __shfl(h, tt), gacc);
+            float z = fmaxf(gacc, 0.f) * w.fc2_w[t];
+            z += __shfl_xor(z, 1);
+            z += __shfl_xor(z, 2);
+            z += __shfl_xor(z, 4);
+            z += __shfl_xor(z, 8);
+            if (lane == 0) score[(size_t)r * ld + c] = 1.f / (1.f + expf(-(z + w.fc2_b[0])));
+        }
+}
+
+// One wave owns AP_RW = 4 row graphs - their A' operands (two f16 planes) are fetched once per work item and kept in
+// registers - and walks super-blocks of 64 column graphs, whose operands (0.6 MB in total: L2-resident) are fetched
+// one 16-column block ahead.  Per (row, block of 16 columns):
+//   layer 1  H[t][c] = relu(u_r[t] + sum_j A'_r[t][j] e2_c[j]),  K = 32: three f16 MFMAs (lo.hi, hi.lo, hi.hi) on the
+//            accumulator initialised with u_r - no vector instruction at all
 //   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])   two f16 MFMAs: H is consumed straight from the
-//            accumulator layout (lane group g holds t = 4g..4g+3), split into two f16 planes (22 bits); the K slots
+//            accumulator layout (lane group g holds t = 4g..4g+3), split into two f16 planes; the K slots
 //            8g..8g+3 / 8g+4..8g+7 carry hi / lo, the A operand is W1 laid out to match
-//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs, lane-swap transpose-reduce over the 4 rows), sigmoid once per
-//            (4 rows x 16 columns), four 64-B row segments per store.
-__global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevWeights w, int R, int M,
+//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs per lane), then per super-block a lane-swap transpose-reduce over
+//            the 4 lane groups leaves lane (g, l15) with row g, columns 4 l15 .. 4 l15 + 3: sigmoid, one 16-byte store.
+// OCC = resident workgroups per CU the instance is compiled for; NI = row graphs whose dependent MFMA -> vector ->
+// MFMA -> vector chains are interleaved in program order (1, 2 or 4); VAR = timing experiments only (tools/probes):
+// bit 1 drops the stores, bit 2 the operand loads of the next block
+template <int OCC, int NI, int VAR>
+__global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeights w, int R, int M,
                                                               const unsigned short* __restrict__ Ab,
                                                               const unsigned short* __restrict__ Cb,
                                                               const float* __restrict__ ur,
-                                                              const float* __restrict__ vc,
+                                                              const float* __restrict__ rng, int nrng,
+                                                              const float* __restrict__ prow,
+                                                              const float* __restrict__ pcol,
                                                               float* __restrict__ score, int64_t ld) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
+    // ---- can every f16 this launch forms be represented?  |A'|, |e2| and |H| <= |u| + 32 max|A'| max|e2|
+    bool fast;
+    {
+        float am = 0.f, um = 0.f, em = 0.f;
+        for (int i = lane; i < nrng; i += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(rng + (size_t)i * 4);
+            am = fmaxf(am, v.x);
+            um = fmaxf(um, v.y);
+            em = fmaxf(em, v.z);
+        }
+        am = wave_max_f32(am);
+        um = wave_max_f32(um);
+        em = wave_max_f32(em);
+        fast = (am < AP_F16_SAFE) && (em < AP_F16_SAFE) && (um + 32.f * am * em < AP_F16_SAFE);
+    }
     const float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);   // W1[o = l15][t = 4g..4g+3]
     const _Float16 wh0 = (_Float16)w1v.x, wh1 = (_Float16)w1v.y, wh2 = (_Float16)w1v.z, wh3 = (_Float16)w1v.w;
     const _Float16 z16 = (_Float16)0.f;
@@ -291,17 +391,18 @@ __global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevW
                         (_Float16)(w1v.w - (float)wh3), z16, z16, z16, z16};            // meets the hi plane only
     const float4 b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
     const float4 w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
-    const float b2 = w.fc2_b[0];
+    const float kL2E = 1.4426950408889634f;
+    const float nb2 = -w.fc2_b[0] * kL2E;
     // work items = (row group of AP_ROWS, column chunk of AP_COLS), row-major; every workgroup takes a contiguous,
     // equally long range (the grid is sized to one resident slot per workgroup, so there is no second,
     // under-occupied round) and reloads its row operands only when the row group changes
     const int ncc = (M + AP_COLS - 1) / AP_COLS;
     const int64_t items = (int64_t)ncc * ((R + AP_ROWS - 1) / AP_ROWS);
     const int it0 = (int)(items * blockIdx.x / gridDim.x), it1 = (int)(items * (blockIdx.x + 1) / gridDim.x);
-    bf16x8 ah[AP_RW], am[AP_RW], al[AP_RW];
-    float4 u4[AP_RW];
+    f16x8 ah[AP_RW], al[AP_RW];
+    f32x4 u4[AP_RW];
     int cur_rg = -1, rbase = 0;
-    const int nblk = (M + 15) >> 4;
+    const int nsb = (M + AP_SB - 1) / AP_SB;
     for (int it = it0; it < it1; ++it) {
         const int rg = it / ncc, cc = it - rg * ncc;
         if (rg != cur_rg) {
@@ -310,68 +411,90 @@ __global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevW
 #pragma unroll
             for (int rr = 0; rr < AP_RW; ++rr) {
                 const int r = min(rbase + rr, R - 1);
-                const unsigned short* ap = Ab + (size_t)r * (3 * T * F) + l15 * F + 8 * g;   // A_r[t = l15][8g .. 8g+7]
-                ah[rr] = *reinterpret_cast<const bf16x8*>(ap);
-                am[rr] = *reinterpret_cast<const bf16x8*>(ap + T * F);
-                al[rr] = *reinterpret_cast<const bf16x8*>(ap + 2 * T * F);
-                u4[rr] = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+                const unsigned short* ap = Ab + ((size_t)r * 2 * 64 + lane) * 8;      // A'_r[t = l15][8g .. 8g+7]
+                ah[rr] = *reinterpret_cast<const f16x8*>(ap);
+                al[rr] = *reinterpret_cast<const f16x8*>(ap + 64 * 8);
+                const float4 u = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+                u4[rr] = f32x4{u.x, u.y, u.z, u.w};
             }
         }
+        const int sb0 = cc * (AP_COLS / AP_SB), sb1 = min(nsb, sb0 + AP_COLS / AP_SB);
         if (rbase >= R) continue;                          // this wave's rows lie past the matrix edge
-        const int blk0 = cc * (AP_COLS / 16), blk1 = min(nblk, blk0 + AP_COLS / 16);
-        // column operands e2_c[8g .. 8g+7] (three planes) and v_c of block blk, fetched one block ahead
-        int c = min(blk0 * 16 + l15, M - 1);
-        const unsigned short* cp = Cb + (size_t)c * (3 * F) + 8 * g;
-        bf16x8 bh = *reinterpret_cast<const bf16x8*>(cp);
-        bf16x8 bm = *reinterpret_cast<const bf16x8*>(cp + F);
-        bf16x8 bl = *reinterpret_cast<const bf16x8*>(cp + 2 * F);
-        float4 v4 = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
-        for (int blk = blk0; blk < blk1; ++blk) {
-            c = min(min(blk + 1, blk1 - 1) * 16 + l15, M - 1);   // the last block re-reads itself (no branch)
-            cp = Cb + (size_t)c * (3 * F) + 8 * g;
-            const bf16x8 nbh = *reinterpret_cast<const bf16x8*>(cp);
-            const bf16x8 nbm = *reinterpret_cast<const bf16x8*>(cp + F);
-            const bf16x8 nbl = *reinterpret_cast<const bf16x8*>(cp + 2 * F);
-            const float4 nv4 = *reinterpret_cast<const float4*>(vc + (size_t)c * T + 4 * g);
-            float zb[AP_RW];
-            // software pipeline over the four rows: the layer-1 MFMA chain of row rr+1 is issued before the VALU
-            // epilogue of row rr, so that the matrix pipe works while this wave issues vector instructions
-            f32x4 hcur = layer1(ah[0], am[0], al[0], bh, bm, bl, u4[0], v4);
+        if (!fast) {      // inputs outside the f16 range: exact fp32 per-pair arithmetic
+            slow_tile(w, prow, pcol, rbase, min(R, rbase + AP_RW), sb0 * AP_SB, min(M, sb1 * AP_SB), score, ld);
+            continue;
+        }
+        // column operands of block (sb, b): e2_c[8g .. 8g+7], c = 64 sb + 4 l15 + b; 1 KB contiguous per wave and plane,
+        // straight from L2 / L1 (the four waves of a workgroup read the same blocks).  Staging them through LDS once per
+        // workgroup was measured and is no faster (112 vs 108 us): the kernel is bound by vector issue, not by operands.
+        const unsigned short* cp = Cb + (size_t)sb0 * (2 * 4 * 64 * 8) + (size_t)lane * 8;
+        f16x8 bh = *reinterpret_cast<const f16x8*>(cp);
+        f16x8 bl = *reinterpret_cast<const f16x8*>(cp + 4 * 64 * 8);
+        for (int sb = sb0; sb < sb1; ++sb) {
+            float zb[4][AP_RW];
 #pragma unroll
-            for (int rr = 0; rr < AP_RW; ++rr) {
-                f32x4 hnext = hcur;
-                if (rr + 1 < AP_RW) hnext = layer1(ah[rr + 1], am[rr + 1], al[rr + 1], bh, bm, bl, u4[rr + 1], v4);
-                const f32x4 h = hcur;
-                // layer 2 on the f16 matrix cores: H = hi + lo (two f16 planes, 22 bits); K slots 8g..8g+3 = hi,
-                // 8g+4..8g+7 = lo of t = 4g..4g+3 - exactly this lane's accumulators
-                // (packed conversions: v_cvt_pk_f16_f32 for both planes, v_pk_add_f32 for the remainders)
-                const f32x2 ha = {relu(h[0]), relu(h[1])}, hc = {relu(h[2]), relu(h[3])};
-                const f16x2 ia = __builtin_convertvector(ha, f16x2), ic = __builtin_convertvector(hc, f16x2);
-                const f16x2 la = __builtin_convertvector(ha - __builtin_convertvector(ia, f32x2), f16x2);
-                const f16x2 lc = __builtin_convertvector(hc - __builtin_convertvector(ic, f32x2), f16x2);
-                const f16x8 hb = {ia[0], ia[1], ic[0], ic[1], la[0], la[1], lc[0], lc[1]};
-                f32x4 q = {b1v.x, b1v.y, b1v.z, b1v.w};
-                q = mfma_f16(w1lo, hb, q);                 // hi . W1lo
-                q = mfma_f16(w1hi, hb, q);                 // (hi + lo) . W1hi
-                float z = w2v.x * relu(q[0]);
-                z = fmaf(w2v.y, relu(q[1]), z);
-                z = fmaf(w2v.z, relu(q[2]), z);
-                zb[rr] = fmaf(w2v.w, relu(q[3]), z);       // partial over o = 4g..4g+3 of row rr, column l15
-                hcur = hnext;
+            for (int b = 0; b < 4; ++b) {
+                // next block: b + 1 of this super-block, or block 0 of the next one (the last one re-reads itself)
+                const int nb = b + 1 < 4 ? b + 1 : 0;
+                const int nsbk = b + 1 < 4 ? sb : min(sb + 1, sb1 - 1);
+                const unsigned short* np = Cb + ((size_t)nsbk * 2 * 4 + nb) * (64 * 8) + (size_t)lane * 8;
+                const f16x8 nbh = (VAR & 4) ? bh : *reinterpret_cast<const f16x8*>(np);
+                const f16x8 nbl = (VAR & 4) ? bl : *reinterpret_cast<const f16x8*>(np + 4 * 64 * 8);
+#pragma unroll
+                for (int r0 = 0; r0 < AP_RW; r0 += NI) {
+                    f32x4 h[NI], q[NI];
+                    f16x8 hb[NI];
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) hb[i] = split_relu4(h[i]);
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        float z = w2v.x * relu(q[i][0]);
+                        z = fmaf(w2v.y, relu(q[i][1]), z);
+                        z = fmaf(w2v.z, relu(q[i][2]), z);
+                        zb[b][r0 + i] = fmaf(w2v.w, relu(q[i][3]), z);   // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
+                    }
+                }
+                bh = nbh;
+                bl = nbl;
             }
             // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
-            // full sum of row g (3 swaps + 3 adds instead of 8 bpermutes)
-            const float p02 = swap32_add(zb[0], zb[2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
-            const float p13 = swap32_add(zb[1], zb[3]);    // likewise rows 1 / 3
-            const float zsel = swap16_add(p02, p13);       // even 16-lane rows: row 0 / 2, odd: row 1 / 3
-            // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
-            const float sc = __builtin_amdgcn_rcpf(1.f + __expf(-(zsel + b2)));
-            const int r = rbase + g, cst = blk * 16 + l15;
-            if (r < R && cst < M) score[(size_t)r * ld + cst] = sc;
-            bh = nbh;
-            bm = nbm;
-            bl = nbl;
-            v4 = nv4;
+            // full sum of row g (3 swaps + 3 adds per column block instead of 8 bpermutes), for its 4 columns
+            float sc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float p02 = swap32_add(zb[b][0], zb[b][2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
+                const float p13 = swap32_add(zb[b][1], zb[b][3]);    // likewise rows 1 / 3
+                const float zsel = swap16_add(p02, p13);             // even 16-lane rows: row 0 / 2, odd: row 1 / 3
+                // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
+                sc[b] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
+            }
+            const int r = rbase + g, c0 = sb * AP_SB + 4 * l15;
+            if ((VAR & 2) && sc[0] + sc[1] + sc[2] + sc[3] != 12345.678f) continue;
+            if (r < R) {
+                float* dst = score + (size_t)r * ld + c0;
+                if (c0 + 3 < M) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (c0 + b < M) dst[b] = sc[b];
+                }
+            }
         }
     }
 }
@@ -379,17 +502,21 @@ __global__ __launch_bounds__(256, AP_OCC) void score_all_pairs_kernel(const DevW
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream) {
     if (R == 0 || M == 0) return SGPR_OK;
+    const int ngroups = ap_prep_groups(R, M), nrng = 2 * ngroups;
+    const size_t nsb = (size_t)(M + AP_SB - 1) / AP_SB;
     float* ur = static_cast<float*>(ws);
-    float* vc = ur + (size_t)R * T;
-    unsigned short* Ab = reinterpret_cast<unsigned short*>(vc + (size_t)M * T);
-    unsigned short* Cb = Ab + (size_t)R * 3 * T * F;
-    hipLaunchKernelGGL(ntn_prep_kernel, dim3(2 * (((R > M ? R : M) + 15) / 16)), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, vc, Cb);
+    float* rng = ur + (size_t)R * T;
+    unsigned short* Ab = reinterpret_cast<unsigned short*>(rng + (size_t)nrng * 4);
+    unsigned short* Cb = Ab + (size_t)R * 2 * 64 * 8;
+    (void)nsb;
+    hipLaunchKernelGGL(ntn_prep_kernel, dim3(nrng), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, rng, Cb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
     const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
     const int64_t slots = (int64_t)h->num_cus * AP_OCC;   // one resident slot per workgroup: a single, full round
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    hipLaunchKernelGGL(score_all_pairs_kernel, dim3(grid), dim3(256), 0, stream, h->w, R, M, Ab, Cb, ur, vc, score, ld);
+    hipLaunchKernelGGL((score_all_pairs_kernel<AP_OCC, AP_NI, 0>), dim3(grid), dim3(256), 0, stream, h->w, R, M, Ab, Cb, ur, rng, nrng, rows,
+                       cols, score, ld);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
     return SGPR_OK;

@@ -614,3 +614,46 @@ def test_two_ranks_on_one_gpu_bitwise_equal_one_rank(tmp_path, ckpt_path):
     one = scorer.run(torch.from_numpy(centers).cuda(), torch.from_numpy(labels).cuda())
     assert torch.equal(one.cpu(), two["full"])
     assert scorer.f1_max(one, poses) == two["f1"]
+
+
+def _tail_float64(sd, rows, cols):
+    """NTN + head (layers_batch.py:70-83, sg_net.py:131-136) for every (row, col) pair in float64 numpy."""
+    w = sd["tensor_network.weight_matrix"].double().numpy()             # [32, 32, 16]
+    wb = sd["tensor_network.weight_matrix_block"].double().numpy()      # [16, 64]
+    bias = sd["tensor_network.bias"].double().numpy().reshape(-1)
+    e1, e2 = rows.astype(np.float64), cols.astype(np.float64)
+    bil = np.einsum("ri,ijt,cj->rct", e1, w, e2)
+    blk = (e1 @ wb[:, :32].T)[:, None, :] + (e2 @ wb[:, 32:].T)[None, :, :]
+    h = np.maximum(bil + blk + bias, 0.0)
+    g = np.maximum(h @ sd["fully_connected_first.weight"].double().numpy().T + sd["fully_connected_first.bias"].double().numpy(), 0.0)
+    z = g @ sd["scoring_layer.weight"].double().numpy().reshape(-1) + float(sd["scoring_layer.bias"])
+    return 1.0 / (1.0 + np.exp(-z))
+
+
+def test_all_pairs_f16_range_guard(eng, oracle_sd):
+    """The dense tail forms f16 planes of A' = e1^T W + Wb, of the column vectors and of the hidden layer; inputs whose
+    bound leaves the f16 range must take the exact fp32 path inside the same kernel (sgpr_score.hip) - results equal the
+    pair-list kernel's (same arithmetic), including non-multiple-of-64 column counts and ragged row counts.  Accuracy
+    of both kernels is held against a float64 evaluation: the two-plane f16 path is as close to it as the fp32 one."""
+    rng = np.random.default_rng(11)
+    rows_np = rng.normal(0, 4, size=(37, 32)).astype(np.float32)
+    cols_np = rng.normal(0, 4, size=(131, 32)).astype(np.float32)
+    rows, cols = torch.from_numpy(rows_np).cuda(), torch.from_numpy(cols_np).cuda()
+    ii, jj = torch.meshgrid(torch.arange(37, dtype=torch.int32), torch.arange(131, dtype=torch.int32), indexing="ij")
+
+    def both(scale):
+        m = eng.score_all_pairs(rows * scale, cols * scale)
+        lst = eng.score_pairs(rows * scale, cols * scale, ii.reshape(-1), jj.reshape(-1)).view(37, 131)
+        return m.cpu().numpy(), lst.cpu().numpy()
+
+    m, lst = both(1.0)                      # in range: the f16 two-plane MFMA path (|pooled| up to ~15: beyond real data)
+    ref = _tail_float64(oracle_sd, rows_np, cols_np)
+    err_m, err_l = np.abs(m - ref).max(), np.abs(lst - ref).max()
+    print("tail vs float64: all-pairs (f16 planes) %.3g, pair list (fp32) %.3g" % (err_m, err_l))
+    assert err_m <= 3e-6 and err_l <= 3e-6
+    assert 0.02 < m.mean() < 0.98           # not saturated: the comparison means something
+    m, lst = both(400.0)                    # |A'| |e2| bound far beyond 65504: exact path, same arithmetic as the list
+    np.testing.assert_array_equal(m, lst)
+    m, lst = both(1e-4)                     # tiny inputs: subnormal lo planes
+    ref = _tail_float64(oracle_sd, rows_np * np.float32(1e-4), cols_np * np.float32(1e-4))
+    assert np.abs(m - ref).max() <= 1e-6 and np.abs(lst - ref).max() <= 1e-6

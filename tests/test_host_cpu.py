@@ -321,9 +321,17 @@ def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, ora
         def score_pooled(self, p1, p2, i1, i2):
             return oracle.score_from_pooled(oracle_sd, p1[i1.long()], p2[i2.long()])
 
+        def engine(self):
+            return self
+
+        def check_status(self):
+            pass
+
     trainer.model = OracleModel()
     os.makedirs(args.output_path, exist_ok=True)
-    f1 = eval_batch.evaluate_sequence(trainer, "00", args, plots=False)
+    f1 = eval_batch.evaluate_sequence(trainer, "00", args, plots=True)
+    for png in ("00_DL_roc_curve.png", "00_DL_pr_curve.png"):                    # eval_batch.py:66, 80
+        assert os.path.getsize(os.path.join(args.output_path, png)) > 1000
     pred = np.load(os.path.join(args.output_path, "00_DL_db.npy"))
     gt = np.load(os.path.join(args.output_path, "00_gt_db.npy"))
     assert pred.dtype == np.float32 and gt.dtype == np.float64
