@@ -32,3 +32,16 @@ def oracle():
 @pytest.fixture(scope="session")
 def oracle_sd(oracle, ckpt_path):
     return oracle.load_checkpoint(ckpt_path)
+
+
+@pytest.fixture(scope="session")
+def release_state_dicts(oracle):
+    """{"3_20/00": state dict, ...}: the 18 checkpoints of the reference's model/release_model.zip (copied as a data
+    fixture next to the goldens generated from it, tests/golden/make_golden.py)."""
+    import io
+    import zipfile
+    out = {}
+    with zipfile.ZipFile(os.path.join(GOLDEN, "release_model.zip")) as z:
+        for name in sorted(n for n in z.namelist() if n.endswith("model.pth")):
+            out[name.split("/", 1)[1].rsplit("/", 1)[0]] = oracle.load_checkpoint(io.BytesIO(z.read(name)))
+    return out

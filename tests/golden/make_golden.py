@@ -21,7 +21,15 @@ Fixtures written (all float32 unless noted):
                         seeded synthetic pairs (sg_pr_amd.synth) with pooled
                         vectors, attention and scores
   prf1.npz              random (score, gt) vectors with the F1-max computed the
-                        way eval_batch.py:69-87 does (sklearn PR curve)
+                        way eval_batch.py:69-87 does (sklearn PR curve), plus the
+                        ROC curve / AUC of eval_batch.py:48-49
+  edge_n100_k10.npz     graphs at the edges of the tie regime: k-1 and
+                        k padded slots, a single label, fewer than 17 nodes, no padding
+                        with >= k nodes per label, trailing duplicate real nodes
+  release_models.npz    scores of the reference under each of the 18 checkpoints of
+                        model/release_model.zip (the zip itself is copied beside it as
+                        a data fixture: it holds weights only): the 9 shipped pairs
+                        and one synthetic batch per checkpoint
 """
 import os
 import sys
@@ -217,6 +225,75 @@ def main():
     synth_case("synth_n100_k10.npz", 100, 10, 25, 60, 8, 1)
     synth_case("synth_n256_k20.npz", 256, 20, 100, 236, 4, 2)
 
+    # ---------------------------------------------------------------- edges of the tie regime
+    def edge_graphs(node_num=100, k=10):
+        rng = np.random.default_rng(17)
+        centers = np.zeros((12, node_num, 3), dtype=np.float32)
+        labels = -np.ones((12, node_num), dtype=np.int32)
+
+        def fill(g, n, lab):
+            centers[g, :n, :2] = rng.uniform(-50, 50, size=(n, 2))
+            centers[g, :n, 2] = rng.uniform(-2, 1, size=n)
+            labels[g, :n] = np.sort(np.asarray(lab))
+
+        fill(0, node_num - k + 1, rng.integers(0, 12, node_num - k + 1))     # k-1 pads: every copy kept as a slot
+        fill(1, node_num - k, rng.integers(0, 12, node_num - k))             # exactly k pads: one representative
+        fill(2, 40, np.full(40, 3))                                          # a single label
+        fill(3, 12, rng.integers(0, 12, 12))                                 # < 17 slots processed
+        fill(4, node_num, np.repeat([0, 5, 7, 9], node_num // 4))            # no padding, >= k nodes per label
+        fill(5, 60, rng.integers(0, 12, 60))                                 # trailing duplicate REAL nodes + pads
+        centers[5, 48:60] = centers[5, 59]
+        labels[5, 48:60] = labels[5, 59]
+        fill(6, node_num, np.repeat([1, 2, 3, 4], node_num // 4))            # no padding, last 12 real nodes identical
+        centers[6, 88:] = centers[6, 99]
+        fill(7, 1, [6])                                                      # one node
+        fill(8, node_num - k + 1, np.full(node_num - k + 1, 11))             # k-1 pads and a single label
+        fill(9, 17, rng.integers(0, 12, 17))                                 # 17 nodes + representative = 18 slots
+        fill(10, 50, np.repeat(np.arange(10), 5))                            # 5 nodes per label: every row needs pads
+        fill(11, 33, rng.integers(0, 3, 33))
+        return centers, labels
+
+    a = make_args(parser_sg, 100, 10, tmp)
+    tr = sg_net.SGTrainer(a, False)
+    tr.model.eval()
+    m = tr.model.module if hasattr(tr.model, "module") else tr.model
+    ec, el = edge_graphs()
+    dense = torch.from_numpy(synth.dense_features(ec, el))
+    with torch.no_grad():
+        e = m.dgcnn_conv_pass(dense)
+        pl, at = m.attention(e)
+        ii, jj = np.meshgrid(np.arange(12), np.arange(12), indexing="ij")
+        s, _, _ = tr.model({"features_1": dense[ii.reshape(-1)], "features_2": dense[jj.reshape(-1)]})
+    np.savez_compressed(os.path.join(HERE, "edge_n100_k10.npz"), centers=ec, labels=el, node_num=100, k=10,
+                        pooled=pl.numpy().reshape(12, -1), att=at.numpy().reshape(12, -1), emb=e.numpy(),
+                        scores=s.numpy().reshape(12, 12))
+    print("edge: score matrix diag", np.diag(s.numpy().reshape(12, 12)))
+
+    # ---------------------------------------------------------------- the 18 checkpoints of release_model.zip
+    import io
+    import shutil
+    import zipfile
+    zsrc = os.path.join(REF, "model", "release_model.zip")
+    shutil.copyfile(zsrc, os.path.join(HERE, "release_model.zip"))           # weights only: a data fixture
+    centers, labels, _ = synth.make_graphs(16, 100, 25, 60, 21, kitti_like=True)
+    dsyn = torch.from_numpy(synth.dense_features(centers, labels))
+    out = {"names": [], "pair_ij": np.array(pair_ij, dtype=np.int32), "syn_centers": centers, "syn_labels": labels}
+    with zipfile.ZipFile(zsrc) as z:
+        for name in sorted(n for n in z.namelist() if n.endswith("model.pth")):
+            sd = torch.load(io.BytesIO(z.read(name)), map_location="cpu")
+            m.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in sd.items()})
+            m.eval()
+            with torch.no_grad():
+                s9, _, _ = m(data)
+                ssyn, _, _ = m({"features_1": dsyn[0::2], "features_2": dsyn[1::2]})
+            key = name.split("/", 1)[1].rsplit("/", 1)[0]                     # e.g. 3_20/00
+            out["names"].append(key)
+            out["scores9/" + key] = s9.numpy()
+            out["scores_syn/" + key] = ssyn.numpy()
+            print("release", key, "scores9[:3]", s9.numpy()[:3])
+    out["names"] = np.array(out["names"])
+    np.savez_compressed(os.path.join(HERE, "release_models.npz"), **out)
+
     # ---------------------------------------------------------------- PR / F1-max (eval_batch.py:69-87)
     from sklearn import metrics
     rng = np.random.default_rng(3)
@@ -231,7 +308,10 @@ def main():
         with np.errstate(divide="ignore", invalid="ignore"):
             f1 = 2 * precision * recall / (precision + recall)
         f1 = np.nan_to_num(f1)
-        fpr, tpr, _ = metrics.roc_curve(gt, sc)
+        fpr, tpr, roc_thr = metrics.roc_curve(gt, sc)
+        cases[f"fpr{c}"] = fpr
+        cases[f"tpr{c}"] = tpr
+        cases[f"roc_thr{c}"] = roc_thr
         cases[f"gt{c}"] = gt
         cases[f"score{c}"] = sc
         cases[f"f1max{c}"] = np.float64(np.max(f1))

@@ -12,7 +12,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SCORE_TOL = 1e-4   # north_star: "Similarity scores match the reference within 1e-4"
-FEAT_TOL = 2e-4    # intermediates (values up to ~10): folded BN + reassociated dot products
+# Gates below sit just above what the kernels deliver today (tools/diag_tolerances.py prints the observed values: layer
+# outputs <= 7.2e-7, embeddings 2.4e-6, attention 7.3e-7, pooled 1.2e-5 (1.2e-4 at node_num 256), golden scores
+# 1.4e-6), so that a numerical regression shows long before the 1e-4 bar.
+FEAT_TOL = 5e-6    # EdgeConv layer outputs (values up to ~10): folded BN + reassociated dot products
+EMB_TOL = 2e-5     # conv_end output
+ATT_TOL = 5e-6
+GOLDEN_SCORE_TOL = 1e-5
 
 
 @pytest.fixture(scope="module")
@@ -58,17 +64,17 @@ def test_shipped_graphs_every_intermediate(eng, golden_dir):
         agree.append(np.mean(rows_ok))
     print("neighbour-set agreement per layer (xyz1..3, sem1..3):", np.round(agree, 4))
     assert (knn >= 0).all() and (knn < 100).all()
-    assert min(agree) >= 0.98 and agree[0] == 1.0 and agree[3] == 1.0
-    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=0, atol=FEAT_TOL)
-    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=1e-5, atol=5e-4)
+    assert min(agree) == 1.0                                    # every neighbour set of every row of every layer
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=0, atol=EMB_TOL)
+    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=ATT_TOL)
+    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=0, atol=5e-5)
     # nine ordered pairs: pair-list kernel and dense all-pairs kernel
     i1 = torch.tensor(g["pair_ij"][:, 0].astype(np.int32))
     i2 = torch.tensor(g["pair_ij"][:, 1].astype(np.int32))
     s = eng.score_pairs(pooled, pooled, i1, i2).cpu().numpy()
-    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
     m = eng.score_all_pairs(pooled, pooled).cpu().numpy()
-    np.testing.assert_allclose(m.reshape(-1), g["scores"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(m.reshape(-1), g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
     np.testing.assert_allclose(m.reshape(-1), s, rtol=0, atol=2e-6)
     assert abs(m[0, 2] - 1.3489922e-06) < 1e-6 and abs(m[2, 0] - 2.8918e-05) < 1e-6   # asymmetric NTN
 
@@ -78,10 +84,11 @@ def test_synthetic_golden(eng, golden_dir, fname):
     g = np.load(os.path.join(golden_dir, fname))
     k = int(g["k"])
     pooled, att, _ = eng.embed(g["centers"], g["labels"], k, want_att=True)
-    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(att.cpu().numpy(), g["att"], rtol=0, atol=ATT_TOL)
+    # pooled = a sum over up to 256 nodes of values up to ~25: the gate scales with node_num
+    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=0, atol=3e-4 if int(g["node_num"]) > 128 else 5e-5)
     s = eng.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous()).cpu().numpy()
-    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
 
 
 def test_forward_dense_matches_oracle_config2_full(eng, oracle, oracle_sd):
@@ -95,8 +102,8 @@ def test_forward_dense_matches_oracle_config2_full(eng, oracle, oracle_sd):
     err = (score.cpu() - ref).abs().max().item()
     print("config2 max|dscore| =", err)
     assert err <= SCORE_TOL
-    np.testing.assert_allclose(a1.cpu().numpy(), r1.numpy()[..., 0], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(a2.cpu().numpy(), r2.numpy()[..., 0], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(a1.cpu().numpy(), r1.numpy()[..., 0], rtol=0, atol=ATT_TOL)
+    np.testing.assert_allclose(a2.cpu().numpy(), r2.numpy()[..., 0], rtol=0, atol=ATT_TOL)
     # packed and dense entry points are the same computation
     p_packed, _, _ = eng.embed(centers, labels, 10)
     p_dense, _, _ = eng.embed_dense(dense, 10)
@@ -132,7 +139,7 @@ def test_stress_shape_subset_and_invariances(eng, oracle, oracle_sd):
     s = eng.score_pairs(pooled[0:16:2].contiguous(), pooled[1:16:2].contiguous()).cpu()
     print("N=256 max|dscore| =", (s - rs).abs().max().item())
     assert (s - rs).abs().max().item() <= SCORE_TOL
-    np.testing.assert_allclose(att[:16].cpu().numpy(), ra.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(att[:16].cpu().numpy(), ra.numpy(), rtol=0, atol=ATT_TOL)
     # batch invariance: reversed graph order gives bit-identical per-graph results
     p_rev, _, _ = eng.embed(centers[::-1].copy(), labels[::-1].copy(), 20)
     assert torch.equal(p_rev.flip(0), pooled)
@@ -161,7 +168,7 @@ def test_all_pairs_matrix_vs_oracle_and_f1(eng, oracle, oracle_sd):
     f_hip = metrics.f1_max(gt[valid].numpy(), m[valid].numpy())
     f_ref = oracle.f1_max(gt[valid].numpy(), rm[valid].numpy())
     print("F1-max hip/oracle:", f_hip, f_ref)
-    assert abs(f_hip - f_ref) <= 1e-3
+    assert abs(f_hip - f_ref) <= 1e-6          # |dF1| <= 1e-6 given score parity (observed: 0)
 
 
 def test_reference_api_drop_in(golden_dir, ckpt_path):
@@ -188,7 +195,7 @@ def test_reference_api_drop_in(golden_dir, ckpt_path):
     np.testing.assert_allclose(score.cpu().numpy(), g["scores"], rtol=0, atol=SCORE_TOL)
     e = trainer.model.dgcnn_conv_pass(feats)
     assert e.shape == (3, 100, 32)
-    np.testing.assert_allclose(e.cpu().numpy(), g["emb"], rtol=0, atol=FEAT_TOL)
+    np.testing.assert_allclose(e.cpu().numpy(), g["emb"], rtol=0, atol=EMB_TOL)
     from sg_pr_amd.utils import process_pair
     p, w1, w2 = trainer.eval_pair(process_pair(batch[2]))
     assert abs(p[0] - g["scores"][2]) <= SCORE_TOL and w1.shape == (100,)
@@ -232,7 +239,7 @@ def test_odd_sizes(eng, oracle, oracle_sd):
         s = eng.score_pairs(p[0::2].contiguous(), p[1::2].contiguous()).cpu()
         rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
         assert (s - rs).abs().max().item() <= SCORE_TOL, (n, k)
-        np.testing.assert_allclose(a.cpu().numpy(), ra.numpy(), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(a.cpu().numpy(), ra.numpy(), rtol=0, atol=ATT_TOL)
 
 
 def test_shard_invariance_bitwise(eng):
@@ -657,3 +664,57 @@ def test_all_pairs_f16_range_guard(eng, oracle_sd):
     m, lst = both(1e-4)                     # tiny inputs: subnormal lo planes
     ref = _tail_float64(oracle_sd, rows_np * np.float32(1e-4), cols_np * np.float32(1e-4))
     assert np.abs(m - ref).max() <= 1e-6 and np.abs(lst - ref).max() <= 1e-6
+
+
+
+def test_edges_of_the_tie_regime(eng, golden_dir):
+    """Reference goldens for the graphs at the switch points of the kernel's branches: exactly k padded slots (one
+    representative), a single label, < 17 processed slots (generic semantic branch), no padding with >= k nodes per
+    label, trailing duplicate REAL nodes with and without padding, a one-node graph, k-1 padded slots with one label.
+    Graph 0 (k-1 padded slots, mixed labels) is the counter-example: its padded rows have only k-1 zero-distance
+    candidates and must take ONE real node, all of which tie at distance 1 with different features - torch.topk's
+    choice there is implementation-defined, so it is held to determinism only."""
+    g = np.load(os.path.join(golden_dir, "edge_n100_k10.npz"))
+    pooled, att, emb = eng.embed(g["centers"], g["labels"], 10, want_att=True, want_emb=True)
+    eng.check_status()
+    defined = np.arange(1, 12)
+    d_emb = np.abs(emb.cpu().numpy() - g["emb"]).reshape(12, -1).max(1)
+    print("edge graphs: max|d emb| per graph", np.array2string(d_emb, precision=2))
+    np.testing.assert_allclose(emb.cpu().numpy()[defined], g["emb"][defined], rtol=0, atol=EMB_TOL)
+    np.testing.assert_allclose(att.cpu().numpy()[defined], g["att"][defined], rtol=0, atol=ATT_TOL)
+    np.testing.assert_allclose(pooled.cpu().numpy()[defined], g["pooled"][defined], rtol=0, atol=1e-4)
+    m = eng.score_all_pairs(pooled, pooled).cpu().numpy()
+    err = np.abs(m - g["scores"])[np.ix_(defined, defined)].max()
+    print("edge graphs: max|dscore| vs the reference =", err)
+    assert err <= 2e-5
+    # the same graphs through the capped / ordered launch and the dense entry point: bit-identical (graph 0 included)
+    order, cap = eng.size_order(g["centers"], g["labels"], 10)
+    p2, _, _ = eng.embed(g["centers"], g["labels"], 10, node_cap=cap, order=order)
+    assert torch.equal(p2, pooled)
+    from sg_pr_amd import synth
+    p3, _, _ = eng.embed_dense(torch.from_numpy(synth.dense_features(g["centers"], g["labels"])), 10)
+    assert torch.equal(p3, pooled)
+
+
+def test_all_release_checkpoints(release_state_dicts, golden_dir):
+    """Every checkpoint of the reference's release_model.zip through sgpr_create (BatchNorm fold in double, plane
+    splits) and the kernels: the nine shipped pairs (dense drop-in forward) and a synthetic batch (packed path)."""
+    from sg_pr_amd import engine
+    g = np.load(os.path.join(golden_dir, "release_models.npz"))
+    k3 = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    feats = torch.from_numpy(k3["features"])
+    i, j = g["pair_ij"][:, 0].astype(np.int64), g["pair_ij"][:, 1].astype(np.int64)
+    worst = 0.0
+    for name, sd in release_state_dicts.items():
+        e = engine.Engine(sd, device=0)
+        try:
+            s9, _, _ = e.forward_dense(feats[i], feats[j], 10)
+            pooled, _, _ = e.embed(g["syn_centers"], g["syn_labels"], 10)
+            ss = e.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous())
+            d = max(np.abs(s9.cpu().numpy() - g["scores9/" + name]).max(),
+                    np.abs(ss.cpu().numpy() - g["scores_syn/" + name]).max())
+            assert d <= 2e-5, (name, d)
+            worst = max(worst, d)
+        finally:
+            e.close()
+    print("18 release checkpoints: worst max|dscore| =", worst)

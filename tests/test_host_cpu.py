@@ -201,6 +201,37 @@ def test_metrics_golden(golden_dir):
         assert abs(metrics.roc_auc(g[f"gt{c}"], g[f"score{c}"]) - float(g[f"auc{c}"])) < 1e-9
 
 
+def test_roc_curve_golden(golden_dir):
+    """eval_batch.py:48-49 - roc_curve (collinear points dropped, +inf first threshold) and auc vs sklearn's."""
+    from sg_pr_amd import metrics
+    g = np.load(os.path.join(golden_dir, "prf1.npz"))
+    for c in range(int(g["ncases"])):
+        fpr, tpr, thr = metrics.roc_curve(g["gt%d" % c], g["score%d" % c])
+        np.testing.assert_allclose(fpr, g["fpr%d" % c], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(tpr, g["tpr%d" % c], rtol=0, atol=1e-15)
+        np.testing.assert_array_equal(thr, g["roc_thr%d" % c].astype(thr.dtype))
+        assert abs(metrics.auc(fpr, tpr) - float(g["auc%d" % c])) < 1e-12
+        assert abs(metrics.roc_auc(g["gt%d" % c], g["score%d" % c]) - float(g["auc%d" % c])) < 1e-12
+
+
+def test_every_shipped_checkpoint_loads_strictly(release_state_dicts, ckpt_path, oracle):
+    """`load_state_dict` of any of the 19 shipped checkpoints must succeed strictly, and each flattens
+    into the C-ABI blob."""
+    from sg_pr_amd import sg_net, engine
+    from sg_pr_amd.parser_sg import sgpr_args
+    model = sg_net.SG(sgpr_args(), 12)
+    sds = dict(release_state_dicts)
+    sds["model.pth"] = oracle.load_checkpoint(ckpt_path)
+    assert len(sds) == 19
+    blobs = []
+    for name, sd in sds.items():
+        model.load_state_dict(sd, strict=True)
+        blob = engine.blob_from_state_dict(model.state_dict())
+        assert blob.shape == (48689,) and np.isfinite(blob).all(), name
+        blobs.append(blob)
+    assert len({b.tobytes() for b in blobs}) == 19          # nineteen different models
+
+
 def test_synth_generators():
     from sg_pr_amd import synth
     c, l, n = synth.config2_pairs(seed=0)

@@ -133,3 +133,34 @@ def test_f1_max_vs_sklearn(oracle):
     with np.errstate(divide="ignore", invalid="ignore"):
         f1 = np.nan_to_num(2 * p * r / (p + r))
     assert abs(oracle.f1_max(gt, sc) - f1.max()) < 1e-12
+
+
+def test_edges_of_the_tie_regime(oracle, oracle_sd, golden_dir):
+    """k-1 / k padded slots, one label, < 17 nodes, no padding with >= k nodes per label, trailing duplicate real
+    nodes (every tie is between feature-identical nodes, so the reference itself is deterministic)."""
+    from sg_pr_amd import synth
+    g = _load(golden_dir, "edge_n100_k10.npz")
+    dense = torch.from_numpy(synth.dense_features(g["centers"], g["labels"]))
+    pooled, att, emb = oracle.embed(oracle_sd, dense, 10)
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(att.numpy().reshape(12, -1), g["att"], rtol=0, atol=2e-6)
+    s = oracle.score_all_pairs(oracle_sd, pooled, pooled).numpy()
+    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=5e-6)
+
+
+def test_all_release_checkpoints(oracle, release_state_dicts, golden_dir):
+    """The 18 checkpoints of model/release_model.zip: different BatchNorm statistics and weights through the same
+    restatement - the nine shipped pairs and a synthetic batch under each."""
+    from sg_pr_amd import synth
+    g = _load(golden_dir, "release_models.npz")
+    k3 = _load(golden_dir, "kitti3_n100_k10.npz")
+    feats = torch.from_numpy(k3["features"])
+    i, j = g["pair_ij"][:, 0].astype(np.int64), g["pair_ij"][:, 1].astype(np.int64)
+    dsyn = torch.from_numpy(synth.dense_features(g["syn_centers"], g["syn_labels"]))
+    assert sorted(release_state_dicts) == sorted(str(n) for n in g["names"]) and len(release_state_dicts) == 18
+    for name, sd in release_state_dicts.items():
+        assert len(sd) == 50                                                    # strict layout (SURVEY.md a-ckpt)
+        s9, _, _ = oracle.forward(sd, feats[i], feats[j], 10)
+        np.testing.assert_allclose(s9.numpy(), g["scores9/" + name], rtol=0, atol=5e-6, err_msg=name)
+        ss, _, _ = oracle.forward(sd, dsyn[0::2], dsyn[1::2], 10)
+        np.testing.assert_allclose(ss.numpy(), g["scores_syn/" + name], rtol=0, atol=5e-6, err_msg=name)
