@@ -214,6 +214,35 @@ int sgpr_attention_pool(const float* d_weight, const float* d_emb, int B, int N,
 int sgpr_ntn(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,
              const float* d_e2, int64_t B, float* d_out, void* stream);
 
+/* ---- upstream of the path: labelled LiDAR scan -> semantic-graph nodes -------------------------
+ * Replaces, for one scan, gen_labels + the node half of gen_graphs (data_process/gen_label_graph.py:196-365):
+ * raw SemanticKITTI labels are remapped (learning_map, :23-58); road / parking and the discarded classes produce no
+ * node; a class that carries instance ids is grouped by instance (groups of <= 20 points dropped, :274); every other
+ * class is clustered like PCL's EuclideanClusterExtraction (connected components of "squared distance < tolerance^2",
+ * tolerance 0.2 / 0.5 / 2 m and minimum size 50..300 by class, maximum 50 000, :283-305); each surviving cluster whose
+ * class is in node_map (:64-77) becomes a node: label = node_map[class], centre = mean of its points.
+ *   d_points  [P, point_stride] f32 (x, y, z first; point_stride >= 3, 4 for KITTI .bin scans)
+ *   d_labels  [P] u32 = semantic id | instance id << 16 (the .label file format)
+ *   outputs   d_centers [max_nodes,3] f64, d_node_labels / d_node_sizes [max_nodes] i32, in the reference's node order
+ *             (class ascending; instance id ascending / cluster size descending, lowest point index first among equal
+ *             sizes - PCL leaves that last order unspecified); d_point_node [P] i32 = node of each point or -1 (may be
+ *             NULL); d_num_nodes [1] i32 = number of nodes found (may exceed max_nodes: then only the first max_nodes are
+ *             written; -1 if more than 8192 clusters qualified).
+ * Results do not depend on execution order (integer fixed-point centroid sums, lowest-index roots).  Handle-free; runs
+ * on the caller's current device. */
+size_t sgpr_cluster_workspace_bytes(int P);
+int sgpr_cluster_scan(const float* d_points, int point_stride, const uint32_t* d_labels, int P, int max_nodes,
+                      double* d_centers, int32_t* d_node_labels, int32_t* d_node_sizes, int32_t* d_point_node,
+                      int32_t* d_num_nodes, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The edge rule of gen_graphs (gen_label_graph.py:367-385) for the n nodes of sgpr_cluster_scan: d_min_dis [n,n] f64 =
+ * for i != j the distance between the point of cluster i and the point of cluster j that lie nearest to the midpoint of
+ * the two centres (0 on the diagonal); the caller keeps the pairs i < j with distance <= 5 m as edges of weight
+ * 1 - d/5.  The scorer never reads edges (utils.py:21-38 loads nodes, centers and pose only); this serves writers of
+ * the reference's graph JSON.  d_workspace: n*n*4 bytes. */
+int sgpr_graph_edges(const float* d_points, int point_stride, const int32_t* d_point_node, int P, int n,
+                     const double* d_centers, double* d_min_dis, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Debug (per handle; not thread-safe; never set in production): a device array of 16 uint64 counters makes
  * sgpr_embed* run its profiling instance and add the
  * shader cycles wave 0 of every workgroup spends in each phase, barrier to barrier (0 stage, 1 select, 2 Gram,

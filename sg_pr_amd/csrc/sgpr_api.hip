@@ -534,6 +534,39 @@ int sgpr_ntn(const float* d_weight, const float* d_weight_block, const float* d_
     return launch_ntn(d_weight, d_weight_block, d_bias, d_e1, d_e2, B, d_out, static_cast<hipStream_t>(stream));
 }
 
+size_t sgpr_cluster_workspace_bytes(int P) { return P < 0 ? 0 : cluster_ws_bytes(P); }
+
+int sgpr_cluster_scan(const float* d_points, int point_stride, const uint32_t* d_labels, int P, int max_nodes,
+                      double* d_centers, int32_t* d_node_labels, int32_t* d_node_sizes, int32_t* d_point_node,
+                      int32_t* d_num_nodes, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (P < 0 || max_nodes < 0 || point_stride < 3 || !d_num_nodes || (P > 0 && (!d_points || !d_labels)) ||
+        (max_nodes > 0 && (!d_centers || !d_node_labels || !d_node_sizes))) {
+        set_error("sgpr_cluster_scan: NULL argument, negative count or point_stride < 3");
+        return SGPR_E_INVALID;
+    }
+    const size_t need = cluster_ws_bytes(P);
+    if (!d_workspace || workspace_bytes < need) {
+        set_error("sgpr_cluster_scan: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    return launch_cluster_scan(d_points, point_stride, d_labels, P, max_nodes, d_centers, d_node_labels, d_node_sizes,
+                               d_point_node, d_num_nodes, d_workspace, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_graph_edges(const float* d_points, int point_stride, const int32_t* d_point_node, int P, int n,
+                     const double* d_centers, double* d_min_dis, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (P < 0 || n < 0 || n > 8192 || point_stride < 3 || (n > 0 && (!d_points || !d_point_node || !d_centers || !d_min_dis))) {
+        set_error("sgpr_graph_edges: NULL argument, negative count or point_stride < 3");
+        return SGPR_E_INVALID;
+    }
+    if (n > 0 && (!d_workspace || workspace_bytes < (size_t)n * n * sizeof(int))) {
+        set_error("sgpr_graph_edges: workspace of " + std::to_string((size_t)n * n * sizeof(int)) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    return launch_graph_edges(d_points, point_stride, d_point_node, P, n, d_centers, d_min_dis, d_workspace,
+                              static_cast<hipStream_t>(stream));
+}
+
 void sgpr_debug_set_skip_mask(sgpr_handle* h, int mask) {
     if (h) h->dbg_skip = mask;
 }

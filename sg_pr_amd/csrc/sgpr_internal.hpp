@@ -118,6 +118,14 @@ int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStre
 int launch_graph_feature(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out, hipStream_t stream);
 int launch_attention_pool(const float* w, const float* emb, int B, int N, float* rep, float* att, hipStream_t stream);
 
+size_t cluster_ws_bytes(int P);
+int launch_cluster_scan(const float* pts, int stride, const uint32_t* label, int P, int max_nodes, double* centers,
+                        int32_t* node_labels, int32_t* node_sizes, int32_t* point_node, int32_t* num_nodes, void* ws,
+                        hipStream_t stream);
+
+int launch_graph_edges(const float* pts, int stride, const int32_t* point_node, int P, int n, const double* centers,
+                       double* min_dis, void* ws, hipStream_t stream);
+
 // makes `device` current for the lifetime of the object and restores the caller's device afterwards
 struct DeviceGuard {
     int prev;

@@ -36,6 +36,7 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
                "sgpr_pair_histogram_workspace_bytes", "sgpr_pair_histogram", "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
+               "sgpr_cluster_workspace_bytes", "sgpr_cluster_scan", "sgpr_graph_edges",
                "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
 
 
@@ -112,6 +113,12 @@ def load_library():
     lib.sgpr_attention_pool.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.sgpr_ntn.restype = i32
     lib.sgpr_ntn.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
+    lib.sgpr_cluster_workspace_bytes.restype = sz
+    lib.sgpr_cluster_workspace_bytes.argtypes = [i32]
+    lib.sgpr_cluster_scan.restype = i32
+    lib.sgpr_cluster_scan.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_graph_edges.restype = i32
+    lib.sgpr_graph_edges.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, sz, vp]
     lib.sgpr_debug_set_skip_mask.restype = None
     lib.sgpr_debug_set_skip_mask.argtypes = [vp, i32]
     lib.sgpr_debug_set_profile_buffer.restype = None
@@ -480,4 +487,51 @@ def ntn(weight, weight_block, bias, e1, e2):
     out = torch.empty(b, 16, dtype=torch.float32, device=e1.device)
     with torch.cuda.device(e1.device):
         _raise_if(lib, lib.sgpr_ntn(_ptr(w), _ptr(wb), _ptr(bs), _ptr(e1), _ptr(e2), b, _ptr(out), _stream_of(e1)))
+    return out
+
+
+def cluster_scan(points, labels, max_nodes=1024, want_point_node=False):
+    """sgpr_cluster_scan: points [P, >=3] f32 and raw labels [P] (u32 bit pattern) on the GPU ->
+    (centers float64 [n,3], node labels int32 [n], cluster sizes int32 [n], point -> node int32 [P] or None)."""
+    lib = load_library()
+    if not isinstance(points, torch.Tensor) or not points.is_cuda:
+        raise RuntimeError("points must be a tensor on the MI355X (there is no CPU fallback)")
+    points = points.detach().to(torch.float32).contiguous()
+    p, stride = points.shape
+    labels = labels.to(points.device).contiguous()
+    if labels.dtype not in (torch.int32, torch.uint32) or labels.numel() != p:
+        raise ValueError("labels must be [P] int32 / uint32 (the raw .label words)")
+    dev = points.device
+    centers = torch.zeros(max_nodes, 3, dtype=torch.float64, device=dev)
+    nlab = torch.zeros(max_nodes, dtype=torch.int32, device=dev)
+    nsize = torch.zeros(max_nodes, dtype=torch.int32, device=dev)
+    pnode = torch.empty(p, dtype=torch.int32, device=dev) if want_point_node else None
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.sgpr_cluster_workspace_bytes(p)
+    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _raise_if(lib, lib.sgpr_cluster_scan(_ptr(points), stride, _ptr(labels), p, max_nodes, _ptr(centers), _ptr(nlab),
+                                             _ptr(nsize), _ptr(pnode), _ptr(count), _ptr(ws), ws_bytes, _stream_of(points)))
+    n = int(count.item())
+    if n < 0 or n > max_nodes:
+        raise SgprError(-3, "scan produced %s nodes, more than max_nodes=%d" % ("> 8192" if n < 0 else n, max_nodes))
+    return centers[:n], nlab[:n], nsize[:n], pnode
+
+
+def graph_edges(points, point_node, centers):
+    """sgpr_graph_edges: the pairwise "closest points near the midpoint" distances of gen_graphs -> float64 [n, n]."""
+    lib = load_library()
+    points = points.detach().to(torch.float32).contiguous()
+    p, stride = points.shape
+    n = centers.shape[0]
+    dev = points.device
+    out = torch.zeros(n, n, dtype=torch.float64, device=dev)
+    if n == 0:
+        return out
+    ws = torch.empty(n * n * 4, dtype=torch.uint8, device=dev)
+    centers = centers.to(device=dev, dtype=torch.float64).contiguous()
+    point_node = point_node.to(device=dev, dtype=torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        _raise_if(lib, lib.sgpr_graph_edges(_ptr(points), stride, _ptr(point_node), p, n, _ptr(centers), _ptr(out), _ptr(ws),
+                                            n * n * 4, _stream_of(points)))
     return out

@@ -101,3 +101,65 @@ def effective_nodes(centers, labels, k):
     nd = last + 1
     m = n - nd
     return (nd + np.where((m >= k) & (m > 1), 1, m)).astype(np.int32)
+
+
+def labelled_scan(seed=0, scale=1.0):
+    """A SemanticKITTI-like labelled LiDAR scan for the upstream graph generator (the reference ships
+    no scans): points float32 [P,4] (x, y, z, remission) and labels uint32 [P] (raw semantic id | instance id << 16,
+    the .label format gen_label_graph.py:204-227 reads).  Contains every per-class mode of gen_labels: road / parking
+    (one cluster, never a node), discarded classes, instance-labelled vehicles (incl. an instance of <= 20 points and
+    points with instance id 0), and Euclidean classes at all three tolerances with objects above and below their
+    minimum sizes.  `scale` multiplies the point counts (1.0 -> ~70 k points).  Point order is shuffled."""
+    rng = np.random.default_rng(seed)
+    pts, lab = [], []
+
+    def add(xyz, sem, inst=0):
+        pts.append(np.asarray(xyz, dtype=np.float64))
+        lab.append(np.full(len(xyz), sem | (inst << 16), dtype=np.uint32))
+
+    def n(x):
+        return max(1, int(round(x * scale)))
+
+    def box(c, size, count):
+        return np.asarray(c) + (rng.random((count, 3)) - 0.5) * np.asarray(size)
+
+    add(box((0, 0, -1.7), (100, 8, 0.05), n(15000)), 40)                       # road
+    add(box((20, 9, -1.7), (12, 6, 0.05), n(1500)), 44)                        # parking
+    add(box((0, 6.5, -1.6), (100, 3, 0.05), n(5000)), 48)                      # sidewalk: two strips > 2 m apart
+    add(box((0, -6.5, -1.6), (100, 3, 0.05), n(5000)), 48)
+    add(box((60, 20, -1.6), (2, 2, 0.05), n(120)), 48)                         # ... and a patch below min size 300
+    for b in range(6):                                                         # buildings, > 2 m apart
+        add(box((-45 + 18 * b, 18 + (b % 2) * 4, 2), (10, 0.3, 8), n(1500 + 300 * b)), 50)
+    add(box((48, -18, 1), (1.5, 0.3, 4), n(200)), 50)                          # too small (min 300)
+    for v in range(10):                                                        # vegetation blobs (tol 2, min 200)
+        add(box((-40 + 9 * v, -14 - (v % 3) * 5, 0.5), (4, 4, 3), n(150 + 180 * v)), 70)
+    for t in range(8):                                                         # trunks: dense vertical lines (tol 0.2, min 50)
+        h = np.sort(rng.random(n(40 + 15 * t))) * 3.0 - 1.5
+        add(np.stack((np.full_like(h, -40 + 9 * t) + rng.normal(0, 0.01, h.size),
+                      np.full_like(h, -11.0) + rng.normal(0, 0.01, h.size), h), axis=1), 71)
+    for t in range(5):                                                         # poles (tol 0.2, min 100)
+        h = np.sort(rng.random(n(80 + 20 * t))) * 5.0 - 1.5
+        add(np.stack((np.full_like(h, -30 + 15 * t) + rng.normal(0, 0.01, h.size),
+                      np.full_like(h, 8.2) + rng.normal(0, 0.01, h.size), h), axis=1), 80)
+    for t in range(4):                                                         # traffic signs (tol 0.2, min 50)
+        add(box((-25 + 15 * t, 8.2, 3.2), (0.6, 0.05, 0.6), n(40 + 15 * t)), 81)
+    add(box((0, 12, -0.5), (60, 0.1, 1.2), n(2500)), 51)                       # fence (tol 0.5, min 100)
+    add(box((45, 12, -0.5), (3, 0.1, 1.2), n(60)), 51)                         # ... short piece below min size
+    add(box((0, -30, -1.5), (100, 12, 0.3), n(9000)), 72)                      # terrain (tol 2, min 300)
+    add(box((30, 30, -1.5), (20, 10, 0.3), n(800)), 49)                        # other-ground
+    for c in range(6):                                                         # cars with instance ids
+        add(box((-35 + 12 * c, 2.0 * (-1) ** c, -0.9), (4, 1.8, 1.5), n(150 + 120 * c)), 10, inst=c + 1)
+    add(box((40, 2, -0.9), (4, 1.8, 1.5), 15), 10, inst=9)                     # an instance of <= 20 points: dropped
+    add(box((46, -2, -0.9), (4, 1.8, 1.5), n(60)), 10, inst=0)                 # car points without an instance id
+    add(box((-20, 26, 0), (8, 2.5, 3), n(900)), 18, inst=1)                    # truck with an instance id
+    add(box((10, 27, 0), (10, 2.5, 3), n(700)), 20)                            # other-vehicle WITHOUT instance ids: Euclidean
+    add(box((26, 27, 0), (1, 1, 1), n(40)), 20)                                # ... and a fragment below min size 100
+    add(box((5, 6, -0.7), (0.5, 0.5, 1.7), n(120)), 30, inst=3)                # person: discarded class
+    add(box((0, 0, 5), (120, 80, 1), n(1500)), 0)                              # unlabeled
+    add(box((0, 0, 6), (120, 80, 1), n(300)), 1)                               # outlier -> unlabeled
+    add(box((-10, 9, -1.2), (1.5, 0.6, 1.0), n(150)), 11, inst=2)              # bicycle: discarded class
+    xyz = np.concatenate(pts)
+    labels = np.concatenate(lab)
+    perm = rng.permutation(len(labels))
+    points = np.concatenate((xyz, rng.random((len(labels), 1))), axis=1).astype(np.float32)[perm]
+    return np.ascontiguousarray(points), np.ascontiguousarray(labels[perm])
