@@ -134,6 +134,60 @@ def f1_max_from_histograms(hist_fn, max_prefixes=4, max_pending=256):
     return best, passes
 
 
+def roc_auc_from_histograms(hist_fn, tol=1e-9, max_passes=64, max_prefixes=4):
+    """Area under the ROC curve (eval_batch.py:48-49) from the same class-wise score histograms, no sort:
+    AUC * P * N = #{(pos, neg): s_pos > s_neg} + 0.5 #{s_pos == s_neg}.  Pairs in different bins are decided by the
+    bins; a bin holding p positives and n negatives leaves p * n pairs open, counted as ties (= the trapezoid rule)
+    until the bin is refined - largest p * n first, down to single fp32 values, where ties are exact.
+    Returns (auc, half_width): the true value lies within +- half_width (0 when every open bin was resolved or
+    `tol` when the refinement stopped there)."""
+    h = np.asarray(hist_fn(0, _LEVEL_BITS[0], (0,)), dtype=np.uint64)[0].astype(np.float64)
+    pos, neg = float(h[:, 1].sum()), float(h[:, 0].sum())
+    if pos <= 0 or neg <= 0:
+        return float("nan"), 0.0
+    known = 0.0          # decided pairs (positive above negative)
+    open_bins = []       # [p * n, prefix, prefix_bits, level]
+
+    def absorb(hb, prefix, pbits, level):
+        nonlocal known
+        p_b, n_b = hb[:, 1], hb[:, 0]
+        below = np.concatenate(([0.0], np.cumsum(n_b)[:-1]))          # negatives in lower bins of this histogram
+        known += float((p_b * below).sum())
+        lg = hb.shape[0].bit_length() - 1
+        last = pbits + lg >= 32
+        for b in np.nonzero((p_b > 0) & (n_b > 0))[0]:
+            if last:
+                known += 0.5 * p_b[b] * n_b[b]                        # single fp32 value: a true tie
+            else:
+                open_bins.append([p_b[b] * n_b[b], (prefix << lg) | int(b), pbits + lg, level + 1])
+
+    absorb(h, 0, 0, 0)
+    passes = 1
+    while open_bins and passes < max_passes:
+        if 0.5 * sum(o[0] for o in open_bins) / (pos * neg) <= tol:
+            break
+        open_bins.sort(key=lambda o: -o[0])
+        lvl_bits = open_bins[0][2]
+        group = [o for o in open_bins if o[2] == lvl_bits][:max_prefixes]
+        for o in group:
+            open_bins.remove(o)
+        bits = _LEVEL_BITS[group[0][3]]
+        hg = np.asarray(hist_fn(lvl_bits, bits, tuple(o[1] for o in group)), dtype=np.uint64).astype(np.float64)
+        passes += 1
+        for o, hb in zip(group, hg):
+            absorb(hb, o[1], o[2], o[3])
+    rest = sum(o[0] for o in open_bins)
+    return (known + 0.5 * rest) / (pos * neg), 0.5 * rest / (pos * neg)
+
+
+def roc_auc_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0, tol=1e-6, max_passes=64):
+    """ROC AUC of a score rectangle that stays on the device (see roc_auc_from_histograms)."""
+    def hist_fn(prefix_bits, bits, prefixes):
+        return engine.pair_histogram(score, row0=row0, pose_xz=pose_xz, d_pos=p_thresh, d_neg=n_thresh, gt=gt,
+                                     prefixes=prefixes, prefix_bits=prefix_bits, bits=bits)[0]
+    return roc_auc_from_histograms(hist_fn, tol=tol, max_passes=max_passes)
+
+
 def f1_max_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0):
     """F1-max of a score rectangle that stays on the device.  Ground truth from planar poses [M,2] (distance <=
     p_thresh positive, >= n_thresh negative, in between ignored) or explicit int8 labels (1 / 0 / -1)."""

@@ -718,3 +718,51 @@ def test_all_release_checkpoints(release_state_dicts, golden_dir):
         finally:
             e.close()
     print("18 release checkpoints: worst max|dscore| =", worst)
+
+
+def test_device_roc_auc(eng):
+    """eval_batch.py:48-49 on the device: AUC from the class-wise histograms equals the sorted host computation."""
+    from sg_pr_amd import synth, metrics, allpairs
+    centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=160, node_num=100, seed=8)
+    pooled, _, _ = eng.embed(centers, labels, 10)
+    m = eng.score_all_pairs(pooled, pooled)
+    xz = allpairs.pose_xz(poses).cuda()
+    auc, hw = metrics.roc_auc_device(eng, m, pose_xz=xz, tol=1e-8, max_passes=4096)
+    gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
+    want = metrics.roc_auc(gt[valid].numpy(), m.cpu()[valid].numpy())
+    print("device AUC", auc, "+-", hw, "host", want)
+    assert hw <= 1e-8 and abs(auc - want) <= hw + 1e-12
+    fast, hw2 = metrics.roc_auc_device(eng, m, pose_xz=xz, tol=1e-4)            # the default budget of 64 passes
+    assert abs(fast - want) <= hw2 + 1e-12 and hw2 <= 1e-4
+
+
+def test_config5_full_size(eng, oracle, oracle_sd):
+    """BASELINE config 5 at FULL size: 1024 pairs = 2048 graphs, node_num 256, K 20 (the fp32-row LDS layout with the
+    chunked key matrix).  A 16-pair sample against the oracle plus size-independent properties over the whole batch."""
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.config5_pairs(seed=0)
+    assert centers.shape == (2048, 256, 3)
+    order, cap = eng.size_order(centers, labels, 20)
+    pooled, att, _ = eng.embed(centers, labels, 20, want_att=True, node_cap=cap, order=order)
+    eng.check_status()
+    scores = eng.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous())
+    assert torch.isfinite(pooled).all() and torch.isfinite(scores).all()
+    sel = np.arange(0, 2048, 64)[:16]                                        # 16 pairs spread over the batch
+    gi = np.stack((2 * sel, 2 * sel + 1), axis=1).reshape(-1)
+    rp, ra, _ = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(centers[gi], labels[gi])), 20)
+    rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
+    err = (scores.cpu()[sel] - rs).abs().max().item()
+    print("config 5 full size: max|dscore| on 16 sampled pairs =", err)
+    assert err <= SCORE_TOL
+    np.testing.assert_allclose(att.cpu().numpy()[gi], ra.numpy().reshape(len(gi), -1), rtol=0, atol=ATT_TOL)
+    # plain launch (no cap, storage order) and a two-shard launch: bit-identical pooled vectors
+    p_plain, _, _ = eng.embed(centers, labels, 20)
+    assert torch.equal(p_plain, pooled)
+    p_a, _, _ = eng.embed(centers[:1000], labels[:1000], 20)
+    p_b, _, _ = eng.embed(centers[1000:], labels[1000:], 20)
+    assert torch.equal(torch.cat((p_a, p_b)), pooled)
+    # pair list == dense rectangle on a block
+    blk = eng.score_all_pairs(pooled[:64], pooled[:256]).cpu()
+    ii, jj = torch.meshgrid(torch.arange(64, dtype=torch.int32), torch.arange(256, dtype=torch.int32), indexing="ij")
+    lst = eng.score_pairs(pooled, pooled, ii.reshape(-1), jj.reshape(-1)).view(64, 256).cpu()
+    assert (blk - lst).abs().max().item() <= 2e-5      # |pooled| reaches ~25 here: both kernels are ~1e-5 from float64

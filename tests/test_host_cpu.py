@@ -214,6 +214,26 @@ def test_roc_curve_golden(golden_dir):
         assert abs(metrics.roc_auc(g["gt%d" % c], g["score%d" % c]) - float(g["auc%d" % c])) < 1e-12
 
 
+def test_roc_auc_from_histograms(golden_dir):
+    """The sort-free AUC (class-wise radix histograms, largest p*n bins refined first) equals sklearn's, ties included."""
+    from sg_pr_amd import metrics
+    g = np.load(os.path.join(golden_dir, "prf1.npz"))
+    for c in range(int(g["ncases"])):
+        gt, sc = g["gt%d" % c], g["score%d" % c]
+        auc, hw = metrics.roc_auc_from_histograms(metrics.histograms_of(sc, gt), tol=0.0, max_passes=100000)
+        assert hw == 0.0 and abs(auc - float(g["auc%d" % c])) < 1e-12, c
+        rough, hw2 = metrics.roc_auc_from_histograms(metrics.histograms_of(sc, gt), tol=1e-3)
+        assert abs(rough - float(g["auc%d" % c])) <= hw2 + 1e-12 <= 1e-3 + 1e-12
+    # saturated scores (sigmoid outputs pile up next to 0 and 1) and ignored pairs
+    rng = np.random.default_rng(4)
+    gt = rng.integers(-1, 2, size=20000)
+    sc = (1 / (1 + np.exp(-rng.normal(3 * (gt == 1), 4)))).astype(np.float32)
+    sc[rng.random(20000) < 0.2] = 1.0
+    keep = gt >= 0
+    auc, hw = metrics.roc_auc_from_histograms(metrics.histograms_of(sc, gt), tol=0.0, max_passes=100000)
+    assert hw == 0.0 and abs(auc - metrics.roc_auc(gt[keep], sc[keep])) < 1e-12
+
+
 def test_every_shipped_checkpoint_loads_strictly(release_state_dicts, ckpt_path, oracle):
     """`load_state_dict` of any of the 19 shipped checkpoints must succeed strictly, and each flattens
     into the C-ABI blob."""

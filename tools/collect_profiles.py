@@ -4,55 +4,92 @@
 usage: python tools/collect_profiles.py rNN"""
 import collections
 import csv
+import glob
 import json
 import os
-import shutil
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_hash)
 
 tag = sys.argv[1]
 src, dst = "gpurun_out/prof", "profiles"
 
 
+def find(name):
+    f = glob.glob(os.path.join(src, "**", name), recursive=True)
+    return f[0] if f else None
+
+
 def pmc(name):
+    f = find(name + "_counter_collection.csv")
+    if not f:
+        return {}
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.defaultdict(set)
-    for r in csv.DictReader(open(os.path.join(src, name + "_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k].add(r["Dispatch_Id"])
     return {k: {c: v / len(calls[k]) for c, v in d.items()} for k, d in agg.items() if "sgpr" in k}
 
 
-shutil.copy(os.path.join(src, "kt_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
-with open(os.path.join(dst, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline  (durations in us)\n")
-    for r in csv.DictReader(open(os.path.join(src, "kt_kernel_stats.csv"))):
-        f.write("%-100s calls %4s  avg %9.1f  min %9.1f  max %9.1f  %5s%%\n" % (
-            r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
-            r["Percentage"]))
-for name in ("bench.json", "bench_under_rocprof.json"):
-    line = open(os.path.join(src, name)).read().strip().splitlines()[-1]
-    json.loads(line)
-    open(os.path.join(dst, tag + "_" + name), "w").write(line + "\n")
+def kernel_stats(name, out, header):
+    f = find(name + "_kernel_stats.csv")
+    if not f:
+        return
+    with open(os.path.join(dst, out), "w") as o:
+        o.write("# " + header + "  (durations in us)\n")
+        for r in csv.DictReader(open(f)):
+            o.write("%-100s calls %5s  avg %9.1f  min %9.1f  max %9.1f  %5s%%\n" % (
+                r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                r["Percentage"]))
+    print(open(os.path.join(dst, out)).read())
 
-fetch, write = pmc("fetch"), pmc("write")
+
+def bench_line(name, out):
+    f = os.path.join(src, name)
+    if not os.path.exists(f):
+        return
+    lines = [l for l in open(f).read().strip().splitlines() if l.startswith("{")]
+    if lines:
+        json.loads(lines[-1])
+        open(os.path.join(dst, out), "w").write(lines[-1] + "\n")
+
+
+kernel_stats("kt", tag + "_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-end-to-end")
+kernel_stats("kt_stress", tag + "_stress_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload stress --no-cpu-baseline --steps 50")
+kernel_stats("kt_pairs128", tag + "_pairs128_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairs128 --no-cpu-baseline --steps 50")
+for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
+                  ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
+                  ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json")):
+    bench_line(name, tag + out)
+
 hbm = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python "
-                 "tools/run_embed.py kitti00 3; per-launch averages (" + tag + ")",
+                 "tools/run_embed.py <shape> 3; per-launch averages (" + tag + ")",
+       "source_hash": bench.source_hash(),
        "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB. WRITE_SIZE matches the known output bytes (pooled: 4541 x 128 B = "
                     "567.6 KiB). FETCH_SIZE under-reports on gfx950 (MI355X_MICROARCH.md: exactly 1/2 for 16 B/lane "
                     "streams); the corrected read traffic is bracketed by [raw, 2 x raw] - bench.py uses 2 x raw."}
-for k in fetch:
-    e = {"FETCH_SIZE_KiB": round(fetch[k].get("FETCH_SIZE", 0.0), 1), "WRITE_SIZE_KiB": round(write[k].get("WRITE_SIZE", 0.0), 1)}
-    key = k.split("<")[0]
-    if "embed" in k:
-        e.update({"graphs_per_launch": 4541, "node_num": 100, "K": 10})
-    hbm[key] = e
+shapes = {"kitti00": (4541, 100, 10), "stress": (2048, 256, 20), "pairs128": (256, 64, 10)}
+for shape, (g, n, k) in shapes.items():
+    fetch, write = pmc("fetch_" + shape), pmc("write_" + shape)
+    for kname in fetch:
+        e = {"FETCH_SIZE_KiB": round(fetch[kname].get("FETCH_SIZE", 0.0), 1),
+             "WRITE_SIZE_KiB": round(write.get(kname, {}).get("WRITE_SIZE", 0.0), 1)}
+        key = kname.split("<")[0]
+        if "embed" in kname:
+            e.update({"graphs_per_launch": g, "node_num": n, "K": k})
+        if shape == "kitti00":
+            hbm[key] = e
+        else:
+            hbm.setdefault(shape, {})[key] = e
 json.dump(hbm, open(os.path.join(dst, "pmc_hbm_latest.json"), "w"), indent=2)
 with open(os.path.join(dst, tag + "_pmc_sq.txt"), "w") as f:
-    f.write("# rocprofv3 --pmc (separate passes) on tools/run_embed.py kitti00 3; per-launch averages in millions (" + tag + ")\n")
-    for name in ("sq1", "sq2"):
-        for k, d in pmc(name).items():
-            f.write("%-36s %s\n" % (k[:36], {c: round(v / 1e6, 3) for c, v in d.items()}))
-print(open(os.path.join(dst, tag + "_kernel_stats.txt")).read())
-print(json.dumps(hbm, indent=1)[:900])
+    f.write("# rocprofv3 --pmc (separate passes) on tools/run_embed.py <shape> 3; per-launch averages in millions (" + tag + ")\n")
+    for shape in shapes:
+        for name in ("sq1_", "sq2_"):
+            for kname, d in pmc(name + shape).items():
+                f.write("%-9s %-40s %s\n" % (shape, kname[:40], {c: round(v / 1e6, 3) for c, v in sorted(d.items())}))
+print(json.dumps(hbm, indent=1)[:1500])
 print(open(os.path.join(dst, tag + "_pmc_sq.txt")).read())

@@ -1,12 +1,25 @@
 #!/bin/bash
-# Regenerate the judged artefacts under profiles/ on the GPU box (run through gpurun; outputs land in gpurun_out/prof):
-#   kernel stats of the default bench command, the bench line itself, HBM counters (separate --pmc passes), SQ counters
+# Regenerate the judged artefacts under profiles/ on the GPU box (run through gpurun; outputs land in gpurun_out/prof,
+# tools/collect_profiles.py <tag> then writes the summaries):  bash tools/refresh_profiles.sh
+#   kitti00 : bench line, kernel stats of the same command, HBM counters (separate --pmc passes), SQ counters
+#   stress / pairs128 (BASELINE configs 5 / 2): bench line, kernel stats, HBM + LDS counters
+#   kitti5seq (config 4) and a 2-rank gloo run of the N > 1 path on one GPU: bench lines
 export TMPDIR=/tmp
-O=gpurun_out/prof; rm -rf $O; mkdir -p $O
-timeout 200 python bench.py > $O/bench.json 2> $O/bench.err </dev/null
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err </dev/null
-timeout 100 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O -o fetch -- python tools/run_embed.py kitti00 3 > $O/fetch.log 2>&1 </dev/null
-timeout 100 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O -o write -- python tools/run_embed.py kitti00 3 > $O/write.log 2>&1 </dev/null
-timeout 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d $O -o sq1 -- python tools/run_embed.py kitti00 3 > $O/sq1.log 2>&1 </dev/null
-timeout 100 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O -o sq2 -- python tools/run_embed.py kitti00 3 > $O/sq2.log 2>&1 </dev/null
-ls $O
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
+cd /tmp
+timeout 300 python $R/bench.py > $O/bench.json 2> $O/bench.err </dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python $R/bench.py --no-cpu-baseline --no-end-to-end > $O/bench_under_rocprof.json 2> $O/kt.err </dev/null
+for w in stress pairs128; do
+  timeout 200 python $R/bench.py --workload $w --no-cpu-baseline --steps 100 > $O/bench_$w.json 2> $O/bench_$w.err </dev/null
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_$w -- python $R/bench.py --workload $w --no-cpu-baseline --steps 50 > $O/kt_$w.log 2>&1 </dev/null
+done
+timeout 300 python $R/bench.py --workload kitti5seq --no-cpu-baseline --steps 50 > $O/bench_kitti5seq.json 2> $O/bench_kitti5seq.err </dev/null
+SGPR_BENCH_BACKEND=gloo timeout 300 python $R/bench.py --gpus 2 --steps 50 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err </dev/null
+for shape in kitti00 stress pairs128; do
+  timeout 100 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O -o fetch_$shape -- python $R/tools/run_embed.py $shape 3 > $O/fetch_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O -o write_$shape -- python $R/tools/run_embed.py $shape 3 > $O/write_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d $O -o sq1_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq1_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O -o sq2_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq2_$shape.log 2>&1 </dev/null
+done
+ls $O | head -80

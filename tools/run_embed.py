@@ -15,13 +15,15 @@ sd = torch.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden",
 eng = engine.Engine(sd)
 if shape == "kitti00":
     c, l, _, _ = synth.kitti_like_sequence(g, n, 0)
+elif shape == "stress":
+    c, l, _ = synth.config5_pairs(seed=0)          # the bench's --workload stress input
 else:
-    c, l, _ = synth.make_graphs(g, n, n // 3, n - k, 0)
+    c, l, _ = synth.config2_pairs(seed=0)          # the bench's --workload pairs128 input
 order, cap = eng.size_order(c, l, k)
 eng.set_skip_mask(mask)
 c, l = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
 for _ in range(reps):
     p = eng.embed(c, l, k, node_cap=cap, order=order)[0]
-    m = eng.score_all_pairs(p, p) if (shape == "kitti00" and mask == 0) else None
+    m = eng.score_all_pairs(p, p) if (shape == "kitti00" and mask == 0) else eng.score_pairs(p[0::2].contiguous(), p[1::2].contiguous())
 torch.cuda.synchronize()
 print("ok", float(p.sum()))
