@@ -196,6 +196,38 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     }
 
     int ndev = 0;
+    // ---- the same seven matrices as two f16 planes (w = hi + lo), [column tile][k-step][plane][lane][8]
+    size_t off_wh[7];
+    bool f16_ok = true;
+    for (int b = 0; b < 7; ++b) {
+        const int rows = b < 6 ? 2 * bs[b].cout : bs[b].cout, kp = kp_of[b];
+        const int nks = kp == 64 ? 2 : 1, nct = rows / 16;
+        std::vector<unsigned short> wh((size_t)nct * nks * 2 * 512, 0);
+        const float* wf = packed.data() + off_wf[b];
+        for (int ct = 0; ct < nct; ++ct)
+            for (int st = 0; st < nks; ++st)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int l15 = lane & 15, lq = lane >> 4;
+                        int kk;
+                        if (nks == 2) kk = 32 * st + 8 * lq + j;
+                        else kk = j < 4 ? 4 * lq + j : -1;
+                        unsigned short pl[2] = {0, 0};
+                        if (kk >= 0 && kk < kp) {
+                            const float v = wf[(size_t)(ct * 16 + l15) * kp + kk];
+                            if (!(fabsf(v) < 60000.f)) f16_ok = false;
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            memcpy(&pl[0], &hi, 2);
+                            memcpy(&pl[1], &lo, 2);
+                        }
+                        for (int q = 0; q < 2; ++q) wh[(((size_t)(ct * nks + st) * 2 + q) * 64 + lane) * 8 + j] = pl[q];
+                    }
+        off_wh[b] = packed.size();
+        packed.resize(packed.size() + wh.size() / 2);
+        memcpy(packed.data() + off_wh[b], wh.data(), wh.size() * sizeof(unsigned short));
+    }
+
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
     if (device < 0 || device >= ndev) {
@@ -231,12 +263,15 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         h->w.wf[l] = h->d_blob + off_wf[b];
         h->w.tb[l] = h->d_blob + off_tb[b];
         h->w.wb[l] = reinterpret_cast<const unsigned short*>(h->d_blob + off_wb[b]);
+        h->w.wh[l] = reinterpret_cast<const unsigned short*>(h->d_blob + off_wh[b]);
         h->w.kp[l] = kp_of[b];
         h->w.cout[l] = bs[b].cout;
     }
     h->w.wf_end = h->d_blob + off_wf[6];
     h->w.tb_end = h->d_blob + off_tb[6];
     h->w.wb_end = reinterpret_cast<const unsigned short*>(h->d_blob + off_wb[6]);
+    h->w.wh_end = reinterpret_cast<const unsigned short*>(h->d_blob + off_wh[6]);
+    h->f16_weights = f16_ok ? 1 : 0;
     h->w.att_w = h->d_blob + o_att;
     h->w.ntn_w = h->d_blob + o_ntw;
     h->w.ntn_wt = h->d_blob + o_ntwt;
@@ -258,7 +293,10 @@ void sgpr_destroy(sgpr_handle* h) {
     delete h;
 }
 
-static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan) {
+// wide: use the wide-range X layouts (bf16 planes / fp32 rows) instead of the default f16 planes
+static bool wide_range(const sgpr_handle* h) { return !h->f16_weights || (h->dbg_skip & 8192); }
+
+static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wide) {
     if (G < 0) {
         set_error("negative graph count");
         return SGPR_E_INVALID;
@@ -275,21 +313,25 @@ static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan) {
         set_error("negative node_cap");
         return SGPR_E_INVALID;
     }
-    if (!make_embed_plan(N, node_cap, k, plan)) {
+    if (!make_embed_plan(N, node_cap, k, plan, wide)) {
         set_error("no LDS plan for node_num " + std::to_string(N) + ", K " + std::to_string(k));
         return SGPR_E_NODES;
     }
     return SGPR_OK;
 }
 
-static size_t embed_ws_bytes(const EmbedPlan& p, int G) {
-    return p.park_in_lds ? 0 : (size_t)G * p.NP * 32 * sizeof(float);
+// workspace of an embed launch over G graphs of N slots:  redo flags [G] (one byte per launch slot, written by the f16
+// instance, read by the wide-range second pass) | parked first-branch output [G][round16(N)][32] f32 when N > 128
+// (sized for the uncapped plan: the second pass never uses a node_cap)
+static size_t embed_flag_bytes(int G) { return ((size_t)G + 255) & ~(size_t)255; }
+static size_t embed_ws_bytes(int G, int N) {
+    return embed_flag_bytes(G) + (N > 128 ? (size_t)G * ((N + 15) / 16 * 16) * 32 * sizeof(float) : 0);
 }
 
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
     EmbedPlan p;
     if (!h || G < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
-    return embed_ws_bytes(p, G);
+    return embed_ws_bytes(G, N);
 }
 
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
@@ -309,15 +351,17 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     a.promise = (node_cap > 0 && node_cap < N) ? node_cap : N;   // still enforced (a broken promise stays loud)
     if (a.G <= h->num_cus) node_cap = 0;
     EmbedPlan plan;
-    int rc = check_nk(a.G, N, k, node_cap, &plan);
+    int rc = check_nk(a.G, N, k, node_cap, &plan, wide_range(h));
     if (rc != SGPR_OK) return rc;
     // graphs are addressed by their own index: an ordered launch needs rows for all of them
-    const size_t need = embed_ws_bytes(plan, total_graphs < 0 ? a.G : total_graphs);
-    if (need > 0 && (!ws || ws_bytes < need)) {
-        set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required");
+    const int gtot = total_graphs < 0 ? a.G : total_graphs;
+    const size_t need = embed_ws_bytes(gtot, N);
+    if (!ws || ws_bytes < need) {
+        set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required (sgpr_embed_workspace_bytes)");
         return SGPR_E_WORKSPACE;
     }
-    a.park_ws = static_cast<float*>(ws);
+    a.redo = static_cast<unsigned char*>(ws);
+    a.park_ws = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot));
     a.status = h->d_status;
     a.prof = h->dbg_prof;
     a.skip = h->dbg_skip;
@@ -436,7 +480,7 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
 size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k) {
     EmbedPlan p;
     if (!h || B < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
-    return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(p, 2 * B);
+    return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(2 * B, N);
 }
 
 int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const float* d_features_2, int B, int N,
@@ -447,7 +491,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
         return SGPR_E_INVALID;
     }
     EmbedPlan plan;
-    int rc = check_nk(2 * B, N, k, 0, &plan);
+    int rc = check_nk(2 * B, N, k, 0, &plan, wide_range(h));
     if (rc != SGPR_OK) return rc;
     const size_t need = sgpr_forward_workspace_bytes(h, B, N, k);
     if (!d_workspace || workspace_bytes < need) {
@@ -463,7 +507,8 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     a.g_split = B;
     a.G = 2 * B;
     a.pooled = pooled;
-    a.park_ws = pooled + (size_t)2 * B * kF3;
+    a.redo = reinterpret_cast<unsigned char*>(pooled + (size_t)2 * B * kF3);
+    a.park_ws = reinterpret_cast<float*>(a.redo + embed_flag_bytes(2 * B));
     a.status = h->d_status;
     a.prof = h->dbg_prof;
     a.skip = h->dbg_skip;
@@ -480,7 +525,8 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
         a1.dense2 = nullptr; a1.G = B; a1.att = d_att1;
         a2.dense = d_features_2; a2.dense2 = nullptr; a2.G = B; a2.att = d_att2;
         a2.pooled = pooled + (size_t)B * kF3;
-        if (a.park_ws) a2.park_ws = a.park_ws + (size_t)B * plan.NP * 32;
+        a2.redo = a.redo + B;
+        a2.park_ws = a.park_ws + (size_t)B * ((N + 15) / 16 * 16) * 32;
         rc = launch_embed(h, plan, a1, s);
         if (rc == SGPR_OK) rc = launch_embed(h, plan, a2, s);
     }

@@ -27,10 +27,17 @@
 
 namespace sgpr {
 
-constexpr int PXB = 400;      // BYTES per row of X: three bf16 planes of 64 channels (128 B each; x = hi + mid + lo,
+constexpr int PXB = 400;      // BYTES per row of X as three bf16 planes of 64 channels (128 B each; x = hi + mid + lo,
                               // exact to 24 bits) + 16 B so that rows shift one 16-B slot; the per-node term b
                               // (64 fp32 = 256 B) later overlays the row in place
-constexpr int PXF = 272;      // bytes per row of X in the fp32 layout (64 ch + 4 floats) of plans too large for the planes
+constexpr int PXF = 272;      // bytes per row of X as two f16 planes (x = hi + lo, 22 bits; 2 x 128 B + 16 B), and in the
+                              // fp32 layout (64 ch + 4 floats)
+// X layout of a kernel instance (EmbedPlan::fmt)
+constexpr int FMT_F32 = 0;    // fp32 rows, split into three bf16 planes when loaded (fallback of plans too large for FMT_BF3)
+constexpr int FMT_BF3 = 1;    // three bf16 planes, written once per layer by the gather epilogue (fp32 range: the fallback
+                              // for graphs whose activations leave the f16 range)
+constexpr int FMT_H2 = 2;     // two f16 planes (the default): half the matrix instructions and a third of the split work
+constexpr float kF16Safe = 60000.f;
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
 constexpr int PP = 32;        // floats per row of the parked sem3 block (output of the first branch)
 constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
@@ -54,7 +61,8 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // One layout attempt: X as bf16 planes (PXB bytes per row) or as fp32 rows (PXF, converted when loaded).
 // The key matrix / key chunk D always shares the A region: D is dead once the neighbour lists exist, A is written by
 // the GEMMs after them (a barrier separates the two); the attention scratch shares X (dead after conv_end).
-static bool plan_layout(int N, int NC, int k, bool planes, EmbedPlan* p) {
+static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p) {
+    const bool planes = fmt != FMT_F32;
     p->N = N;
     p->NC = NC;
     p->NP = round_up(NC, 16);
@@ -65,7 +73,8 @@ static bool plan_layout(int N, int NC, int k, bool planes, EmbedPlan* p) {
     p->park_in_lds = NC <= 128 ? 1 : 0;
     p->pitchA = NC <= 192 ? 68 : 64;      // 64 only when LDS is otherwise exhausted (bank-conflicted stores)
     p->xplanes = planes ? 1 : 0;
-    p->rowb = planes ? PXB : PXF;
+    p->fmt = fmt;
+    p->rowb = fmt == FMT_BF3 ? PXB : PXF;
     int off = 0;
     p->offX = off;    off += p->NP * p->rowb;
     p->offRed = p->offX;
@@ -110,11 +119,13 @@ static bool plan_layout(int N, int NC, int k, bool planes, EmbedPlan* p) {
     return true;
 }
 
-bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p) {
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p, bool wide_range) {
     if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > SGPR_MAX_K || k > N) return false;
     const int NC = (node_cap <= 0 || node_cap > N) ? N : node_cap;
-    // bf16 planes whenever they fit (every graph up to 208 processed slots); fp32 rows beyond
-    return plan_layout(N, NC, k, true, p) || plan_layout(N, NC, k, false, p);
+    // default: two f16 planes (fit every node_num).  wide_range (the fallback for graphs whose activations leave the
+    // f16 range): bf16 planes whenever they fit (up to 208 processed slots), fp32 rows beyond
+    if (!wide_range) return plan_layout(N, NC, k, FMT_H2, p);
+    return plan_layout(N, NC, k, FMT_BF3, p) || plan_layout(N, NC, k, FMT_F32, p);
 }
 
 struct KParams {
@@ -134,83 +145,134 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-struct Frag {          // one 32-wide k-step of one operand: lane (l15, lq) holds k slots 8*lq .. 8*lq+7 of row l15
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// one 32-wide k-step of one operand: lane (l15, lq) holds k slots 8*lq .. 8*lq+7 of row l15, one register quad per plane
+template <int FMT>
+struct FragT {          // FMT_BF3 / FMT_F32: three bf16 planes
     bf16x8 h, m, l;
+};
+template <>
+struct FragT<FMT_H2> {  // two f16 planes
+    f16x8 h, l;
 };
 
 __device__ __forceinline__ f32x4 mfma_b(bf16x8 a, bf16x8 b, f32x4 c) {
     // D[4*(l>>4)+r][l&15] += sum_k A[row][k] * B[k][col];  lane l supplies A[l&15][8*(l>>4)..+7], B[8*(l>>4)..+7][l&15]
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) {   // same operand / result layout
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 // 16x16 output tile, K = 16*NKB (NKB = 4: two k-steps; NKB = 1: one half-filled k-step).
 // The matrix core aligns the 32 products of an instruction and its C operand to the largest exponent and drops what
 // falls below fp32 precision, so the correction terms must never meet a large accumulator: they get a chain of their
-// own (2^-16 terms first, then the 2^-8 terms), the hi.hi products another, and the two sums meet in ONE fp32 add.
-// Error ~ 4 ulp of the result - tighter than a sequential fp32 dot product.  Dependent back-to-back MFMAs issue every
-// 18 cycles; more, shorter chains would be slower (tools/probes/mfma_chain_probe.hip).
-template <int NKB>
-__device__ __forceinline__ f32x4 tile16(const Frag (&a)[2], const Frag (&b)[2]) {
+// own (smallest terms first), the hi.hi products another, and the two sums meet in ONE fp32 add.
+// bf16 x 3 planes: six significant cross products, error ~ 4 ulp of the result - tighter than a sequential fp32 dot
+// product.  f16 x 2 planes: three products (lo.hi, hi.lo, hi.hi), operands exact to 22 bits.  Dependent back-to-back
+// MFMAs issue every 18 cycles; more, shorter chains would be slower (tools/probes/mfma_chain_probe.hip).
+template <int NKB, int FMT>
+__device__ __forceinline__ f32x4 tile16(const FragT<FMT> (&a)[2], const FragT<FMT> (&b)[2]) {
     constexpr int NS = NKB == 1 ? 1 : 2;
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FMT == FMT_H2) {
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        lo = mfma_b(a[st].l, b[st].h, lo);
-        lo = mfma_b(a[st].h, b[st].l, lo);
-        lo = mfma_b(a[st].m, b[st].m, lo);
+        for (int st = 0; st < NS; ++st) {
+            lo = mfma_h(a[st].l, b[st].h, lo);
+            lo = mfma_h(a[st].h, b[st].l, lo);
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) hi = mfma_h(a[st].h, b[st].h, hi);
+    } else {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            lo = mfma_b(a[st].l, b[st].h, lo);
+            lo = mfma_b(a[st].h, b[st].l, lo);
+            lo = mfma_b(a[st].m, b[st].m, lo);
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            lo = mfma_b(a[st].m, b[st].h, lo);
+            lo = mfma_b(a[st].h, b[st].m, lo);
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) hi = mfma_b(a[st].h, b[st].h, hi);
     }
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        lo = mfma_b(a[st].m, b[st].h, lo);
-        lo = mfma_b(a[st].h, b[st].m, lo);
-    }
-#pragma unroll
-    for (int st = 0; st < NS; ++st) hi = mfma_b(a[st].h, b[st].h, hi);
     return hi + lo;
 }
 
-// X operand of row `row` (byte pointer to the row): channels 32*step + 8*lq + 0..7 (NKB = 4), or channels
-// 4*lq + 0..3 followed by four zero slots (NKB = 1: 16 input channels)
-template <int NKB>
-__device__ __forceinline__ void load_xfrag(const unsigned char* row, int lq, Frag (&f)[2]) {
-    if (NKB == 1) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(row + 8 * lq);
-        const bf16x4 m = *reinterpret_cast<const bf16x4*>(row + 128 + 8 * lq);
-        const bf16x4 l = *reinterpret_cast<const bf16x4*>(row + 256 + 8 * lq);
-        f[0].h = bf16x8{h[0], h[1], h[2], h[3], 0, 0, 0, 0};
-        f[0].m = bf16x8{m[0], m[1], m[2], m[3], 0, 0, 0, 0};
-        f[0].l = bf16x8{l[0], l[1], l[2], l[3], 0, 0, 0, 0};
-    } else {
+// X operand of row `row` (byte pointer to the row) in a plane layout: channels 32*step + 8*lq + 0..7 (NKB = 4), or
+// channels 4*lq + 0..3 followed by four zero slots (NKB = 1: 16 input channels); planes are 128 bytes apart
+template <int NKB, int FMT>
+__device__ __forceinline__ void load_xfrag(const unsigned char* row, int lq, FragT<FMT> (&f)[2]) {
+    if constexpr (FMT == FMT_H2) {
+        if (NKB == 1) {
+            const f16x4 h = *reinterpret_cast<const f16x4*>(row + 8 * lq);
+            const f16x4 l = *reinterpret_cast<const f16x4*>(row + 128 + 8 * lq);
+            const _Float16 z = (_Float16)0.f;
+            f[0].h = f16x8{h[0], h[1], h[2], h[3], z, z, z, z};
+            f[0].l = f16x8{l[0], l[1], l[2], l[3], z, z, z, z};
+        } else {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f[st].h = *reinterpret_cast<const bf16x8*>(row + 64 * st + 16 * lq);
-            f[st].m = *reinterpret_cast<const bf16x8*>(row + 128 + 64 * st + 16 * lq);
-            f[st].l = *reinterpret_cast<const bf16x8*>(row + 256 + 64 * st + 16 * lq);
+            for (int st = 0; st < 2; ++st) {
+                f[st].h = *reinterpret_cast<const f16x8*>(row + 64 * st + 16 * lq);
+                f[st].l = *reinterpret_cast<const f16x8*>(row + 128 + 64 * st + 16 * lq);
+            }
+        }
+    } else {
+        if (NKB == 1) {
+            const bf16x4 h = *reinterpret_cast<const bf16x4*>(row + 8 * lq);
+            const bf16x4 m = *reinterpret_cast<const bf16x4*>(row + 128 + 8 * lq);
+            const bf16x4 l = *reinterpret_cast<const bf16x4*>(row + 256 + 8 * lq);
+            f[0].h = bf16x8{h[0], h[1], h[2], h[3], 0, 0, 0, 0};
+            f[0].m = bf16x8{m[0], m[1], m[2], m[3], 0, 0, 0, 0};
+            f[0].l = bf16x8{l[0], l[1], l[2], l[3], 0, 0, 0, 0};
+        } else {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f[st].h = *reinterpret_cast<const bf16x8*>(row + 64 * st + 16 * lq);
+                f[st].m = *reinterpret_cast<const bf16x8*>(row + 128 + 64 * st + 16 * lq);
+                f[st].l = *reinterpret_cast<const bf16x8*>(row + 256 + 64 * st + 16 * lq);
+            }
         }
     }
 }
 
-// weight operand of one 16-row column tile (DevWeights::wb layout: [k-step][plane][lane][8]); tile = wb + ct * wtile<NKB>
-template <int NKB>
-__device__ __forceinline__ constexpr int wtile() { return (NKB == 1 ? 1 : 2) * 3 * 512; }
-template <int NKB>
-__device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, Frag (&f)[2]) {
+// weight operand of one 16-row column tile (DevWeights::wb / wh layout: [k-step][plane][lane][8]);
+// tile = weights + ct * wtile<NKB, FMT>
+template <int NKB, int FMT>
+__device__ __forceinline__ constexpr int wtile() { return (NKB == 1 ? 1 : 2) * (FMT == FMT_H2 ? 2 : 3) * 512; }
+template <int NKB, int FMT>
+__device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, FragT<FMT> (&f)[2]) {
     if (tile == nullptr) {
         // ablation (mask bit 9): constant weights, no loads
-        f[0].h = f[0].m = f[0].l = f[1].h = f[1].m = f[1].l = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+        if constexpr (FMT == FMT_H2) {
+            const _Float16 c = (_Float16)0.01f;
+            f[0].h = f[0].l = f[1].h = f[1].l = f16x8{c, c, c, c, c, c, c, c};
+        } else {
+            f[0].h = f[0].m = f[0].l = f[1].h = f[1].m = f[1].l = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+        }
         return;
     }
     const unsigned short* p = tile + (phase_tid() & 63) * 8;
 #pragma unroll
     for (int st = 0; st < (NKB == 1 ? 1 : 2); ++st) {
-        f[st].h = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 0) * 512);
-        f[st].m = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 1) * 512);
-        f[st].l = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 2) * 512);
+        if constexpr (FMT == FMT_H2) {
+            f[st].h = *reinterpret_cast<const f16x8*>(p + (st * 2 + 0) * 512);
+            f[st].l = *reinterpret_cast<const f16x8*>(p + (st * 2 + 1) * 512);
+        } else {
+            f[st].h = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 0) * 512);
+            f[st].m = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 1) * 512);
+            f[st].l = *reinterpret_cast<const bf16x8*>(p + (st * 3 + 2) * 512);
+        }
     }
 }
 
-template <int NKB>
-__device__ __forceinline__ void copy_frag(Frag (&d)[2], const Frag (&s)[2]) {
+template <int NKB, int FMT>
+__device__ __forceinline__ void copy_frag(FragT<FMT> (&d)[2], const FragT<FMT> (&s)[2]) {
     d[0] = s[0];
     if (NKB != 1) d[1] = s[1];
 }
@@ -229,21 +291,38 @@ __device__ __forceinline__ void split4(float4 v, uint2& h, uint2& m, uint2& l) {
     l = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 
+// four consecutive fp32 values -> two f16 planes: hi = the value truncated to f16 (v_cvt_pkrtz_f16_f32), lo = f16(v - hi)
+// straight out of one mixed-precision FMA per value (v_fma_mixlo / mixhi_f16: f16 * f32 + f32 -> f16 half of the
+// destination); hi + lo = v to 22 bits (|v| < 2^-14: to 2^-25 absolute - the matrix core honours f16 denormals).
+// The operands come from LDS reads / vector arithmetic, never straight out of an MFMA (whose wait states the compiler
+// would not insert in front of inline asm).
+__device__ __forceinline__ void split4_h2(float4 v, uint2& h, uint2& l) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l01), "=&v"(l23)
+        : "v"(h01), "v"(h23), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    h = make_uint2(h01, h23);
+    l = make_uint2(l01, l23);
+}
+
 __device__ __forceinline__ bf16x8 pack8(uint2 a, uint2 b) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
 }
 
-// X layout policy.  XP = true: rows of three bf16 planes (PXB bytes), written once per layer by the gather epilogue.
-// XP = false: fp32 rows (PXF bytes) for plans whose LDS cannot hold the planes (N > 208), split when loaded.
-// Either way the per-node term b (fp32) overlays bytes 0..255 of the row in place.
-template <bool XP>
-__device__ __forceinline__ constexpr int xrow() { return XP ? PXB : PXF; }
+// X layout policy (FMT_*).  Plane layouts are written once per layer by the gather epilogue; FMT_F32 keeps fp32 rows
+// and splits when loading.  Either way the per-node term b (fp32) overlays bytes 0..255 of the row in place.
+template <int FMT>
+__device__ __forceinline__ constexpr int xrow() { return FMT == FMT_BF3 ? PXB : PXF; }
 
-template <int NKB, bool XP>
-__device__ __forceinline__ void xload(const unsigned char* row, int lq, Frag (&f)[2]) {
-    if (XP) {
-        load_xfrag<NKB>(row, lq, f);
+template <int NKB, int FMT>
+__device__ __forceinline__ void xload(const unsigned char* row, int lq, FragT<FMT> (&f)[2]) {
+    if constexpr (FMT != FMT_F32) {
+        load_xfrag<NKB, FMT>(row, lq, f);
     } else if (NKB == 1) {
         uint2 h, m, l;
         split4(*reinterpret_cast<const float4*>(row + 16 * lq), h, m, l);
@@ -264,15 +343,24 @@ __device__ __forceinline__ void xload(const unsigned char* row, int lq, Frag (&f
     }
 }
 
-// four consecutive channels ch..ch+3 of one row
-template <bool XP>
-__device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v) {
-    if (XP) {
+// four consecutive channels ch..ch+3 of one row.  FMT_H2 also tracks the largest magnitude it has stored (`vmax`): a
+// graph whose activations reach the f16 range is re-run on the wide-range instance (see embed_kernel)
+template <int FMT>
+__device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v, float& vmax) {
+    if constexpr (FMT == FMT_BF3) {
         uint2 h, m, l;
         split4(v, h, m, l);
         *reinterpret_cast<uint2*>(row + 2 * ch) = h;
         *reinterpret_cast<uint2*>(row + 128 + 2 * ch) = m;
         *reinterpret_cast<uint2*>(row + 256 + 2 * ch) = l;
+    } else if constexpr (FMT == FMT_H2) {
+        uint2 h, l;
+        split4_h2(v, h, l);
+        *reinterpret_cast<uint2*>(row + 2 * ch) = h;
+        *reinterpret_cast<uint2*>(row + 128 + 2 * ch) = l;
+        float m2;
+        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(m2) : "v"(v.x), "v"(v.y), "v"(vmax));
+        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(vmax) : "v"(v.z), "v"(v.w), "v"(m2));
     } else {
         *reinterpret_cast<float4*>(row + 4 * ch) = v;
     }
@@ -696,14 +784,14 @@ __device__ __forceinline__ void select_bisect(const EmbedPlan& p, int n, int np,
 }
 
 // ------------------------------------------------------------------ Gram tile -> ranking keys
-template <int NKB, bool XP>
+template <int NKB, int FMT>
 __device__ __forceinline__ void gram_tile(const unsigned char* __restrict__ X, const float* __restrict__ xx, float* __restrict__ D,
                                           int pitchD, int N, int rc0, int ti, int tj, bool mirror, int l15, int lq) {
     // ti indexes 16-row tiles inside the chunk starting at row rc0; tj indexes candidate tiles
     const int i0 = rc0 + ti * 16, j0 = tj * 16;
-    Frag a[2], b[2];
-    xload<NKB, XP>(X + (i0 + l15) * xrow<XP>(), lq, a);
-    xload<NKB, XP>(X + (j0 + l15) * xrow<XP>(), lq, b);
+    FragT<FMT> a[2], b[2];
+    xload<NKB, FMT>(X + (i0 + l15) * xrow<FMT>(), lq, a);
+    xload<NKB, FMT>(X + (j0 + l15) * xrow<FMT>(), lq, b);
     const f32x4 g = tile16<NKB>(a, b);          // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
     const int j = j0 + l15;
     const float xj = j < N ? xx[j] : INFINITY;  // invalid candidates rank last
@@ -727,7 +815,7 @@ __device__ __forceinline__ void gram_tile(const unsigned char* __restrict__ X, c
 // tile of [a | b] for them:  a = x.W1'  -> A (LDS, the gather target);  b = x.(W2-W1)' + t replaces
 // the wave's own rows of X in place (fp32, bytes 0..255 of the row) once all its column tiles are done (no other
 // wave reads those rows in this phase, so no barrier is needed).  Weight fragments stream from L1/L2.
-template <int NKB, int COUT, bool XP>
+template <int NKB, int COUT, int FMT>
 __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
                                           int gw, int GW) {
@@ -738,13 +826,13 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
     const int rt0 = gw, rt1 = gw + GW;
     if (rt0 >= nrt) return;
     const bool two = rt1 < nrt;
-    unsigned char* x0 = X + (rt0 * 16 + l15) * xrow<XP>();
-    unsigned char* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * xrow<XP>();
-    Frag w[2], wn[2];                                // weight fragments, fetched one column tile ahead (L1/L2)
+    unsigned char* x0 = X + (rt0 * 16 + l15) * xrow<FMT>();
+    unsigned char* x1 = X + ((two ? rt1 : rt0) * 16 + l15) * xrow<FMT>();
+    FragT<FMT> w[2], wn[2];                                // weight fragments, fetched one column tile ahead (L1/L2)
     load_wfrag<NKB>(Wb, w);
-    Frag xf0[2], xf1[2];
-    xload<NKB, XP>(x0, lq, xf0);
-    xload<NKB, XP>(x1, lq, xf1);
+    FragT<FMT> xf0[2], xf1[2];
+    xload<NKB, FMT>(x0, lq, xf0);
+    xload<NKB, FMT>(x1, lq, xf1);
     float4 tv[NCA];
 #pragma unroll
     for (int cb = 0; cb < NCA; ++cb) tv[cb] = *reinterpret_cast<const float4*>(tb + cb * 16 + 4 * lq);
@@ -753,7 +841,7 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
     f32x4 b0[NCA], b1[NCA];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        if (ct + 1 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)(ct + 1) * wtile<NKB>() : nullptr, wn);
+        if (ct + 1 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)(ct + 1) * wtile<NKB, FMT>() : nullptr, wn);
         // r[c] = out[channel ct*16 + 4lq + c][node rt*16 + l15]
         const f32x4 r0 = tile16<NKB>(w, xf0);
         f32x4 r1 = r0;
@@ -781,30 +869,31 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
 // the weight fragment of the tile in registers and walks the row tiles, so the weights cross L2 -> CU once per
 // workgroup instead of once per row tile and the work divides evenly whatever nrt is.  a-tiles go straight to A;
 // the (at most two) b-tiles of a wave wait in registers until every wave has read its X operands, then replace X.
-template <int NKB, int COUT>
+template <int NKB, int COUT, int FMT>
 __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
                                           int wave, int NW, int ex = 0) {
     const int lane = phase_tid() & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int NCA = COUT / 16, NCT = 2 * NCA;
-    const unsigned char* xp = X + l15 * PXB;
+    constexpr int XR = xrow<FMT>();
+    const unsigned char* xp = X + l15 * XR;
     // this wave's b-tiles: the first ct >= NCA congruent to wave (mod NW), and the one after it
     int ctb0 = wave;
     while (ctb0 < NCA) ctb0 += NW;
     const int ctb1 = ctb0 + NW;
-    Frag w[2], wn[2], xf[2];      // no operand double-buffering for X: registers are the scarce resource here
+    FragT<FMT> w[2], wn[2], xf[2];      // no operand double-buffering for X: registers are the scarce resource here
     f32x4 k0[4], k1[4];
     // ---- a-tiles
     int ct = wave;
-    if (ct < NCA) load_wfrag<NKB>(Wb ? Wb + (size_t)ct * wtile<NKB>() : nullptr, w);
-    else if (ctb0 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb0 * wtile<NKB>() : nullptr, w);
+    if (ct < NCA) load_wfrag<NKB>(Wb ? Wb + (size_t)ct * wtile<NKB, FMT>() : nullptr, w);
+    else if (ctb0 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb0 * wtile<NKB, FMT>() : nullptr, w);
     for (; ct < NCA; ct += NW) {
         const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
-        if (cn < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)cn * wtile<NKB>() : nullptr, wn);
+        if (cn < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)cn * wtile<NKB, FMT>() : nullptr, wn);
         float* ap = A + l15 * pitchA + ct * 16 + 4 * lq;
         for (int rt = 0; rt < nrt; ++rt) {
-            load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
+            load_xfrag<NKB>(xp + rt * 16 * XR, lq, xf);
             const f32x4 r = (ex & 1024) ? f32x4{1.f, 2.f, 3.f, 4.f} : tile16<NKB>(w, xf);              // r[c] = a[channel ct*16 + 4lq + c][node rt*16 + l15]
             *reinterpret_cast<float4*>(ap + rt * 16 * pitchA) = make_float4(r[0], r[1], r[2], r[3]);
         }
@@ -813,13 +902,13 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     // ---- b-tiles: results stay in registers (row-tile loop unrolled: register arrays need static indices)
     const bool has0 = ctb0 < NCT, has1 = ctb1 < NCT;
     if (has0) {
-        if (has1) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb1 * wtile<NKB>() : nullptr, wn);
+        if (has1) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb1 * wtile<NKB, FMT>() : nullptr, wn);
         const float4 t4 = *reinterpret_cast<const float4*>(tb + (ctb0 - NCA) * 16 + 4 * lq);
         const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
-                load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
+                load_xfrag<NKB>(xp + rt * 16 * XR, lq, xf);
                 k0[rt] = ((ex & 1024) ? f32x4{1.f, 2.f, 3.f, 4.f} : tile16<NKB>(w, xf)) + t;
             }
     }
@@ -829,38 +918,38 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
             if (rt < nrt) {
-                load_xfrag<NKB>(xp + rt * 16 * PXB, lq, xf);
+                load_xfrag<NKB>(xp + rt * 16 * XR, lq, xf);
                 k1[rt] = ((ex & 1024) ? f32x4{1.f, 2.f, 3.f, 4.f} : tile16<NKB>(wn, xf)) + t;
             }
     }
     if (!(ex & 2048)) __syncthreads();                                             // every wave is done reading X
-    unsigned char* bp = X + l15 * PXB + 16 * lq;
+    unsigned char* bp = X + l15 * XR + 16 * lq;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
         if (rt < nrt) {
-            if (has0) *reinterpret_cast<float4*>(bp + rt * 16 * PXB + (ctb0 - NCA) * 64) = make_float4(k0[rt][0], k0[rt][1], k0[rt][2], k0[rt][3]);
-            if (has1) *reinterpret_cast<float4*>(bp + rt * 16 * PXB + (ctb1 - NCA) * 64) = make_float4(k1[rt][0], k1[rt][1], k1[rt][2], k1[rt][3]);
+            if (has0) *reinterpret_cast<float4*>(bp + rt * 16 * XR + (ctb0 - NCA) * 64) = make_float4(k0[rt][0], k0[rt][1], k0[rt][2], k0[rt][3]);
+            if (has1) *reinterpret_cast<float4*>(bp + rt * 16 * XR + (ctb1 - NCA) * 64) = make_float4(k1[rt][0], k1[rt][1], k1[rt][2], k1[rt][3]);
         }
 }
 
-template <bool COLS, bool XP>
+template <bool COLS, int FMT>
 __device__ __forceinline__ void gemm_layer(unsigned char* X, float* A, int pitchA, const unsigned short* Wb,
                                            const float* tb, int Kp, int cout, int nrt, int gw, int GW, int ex = 0) {
     if (COLS) {   // capped plans: nrt <= 4, GW >= 2 (make_embed_plan); contains a barrier - every wave calls it
         if (Kp != 64)
-            gemm_cols<1, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<1, 64, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         else if (cout == 64)
-            gemm_cols<4, 64>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<4, 64, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         else
-            gemm_cols<4, 32>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<4, 32, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         return;
     }
     if (Kp != 64)
-        gemm_rows<1, 64, XP>(X, A, pitchA, Wb, tb, nrt, gw, GW);   // first layer of a branch: 3 / 12 -> 64 channels
+        gemm_rows<1, 64, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW);   // first layer of a branch: 3 / 12 -> 64 channels
     else if (cout == 64)
-        gemm_rows<4, 64, XP>(X, A, pitchA, Wb, tb, nrt, gw, GW);
+        gemm_rows<4, 64, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW);
     else
-        gemm_rows<4, 32, XP>(X, A, pitchA, Wb, tb, nrt, gw, GW);
+        gemm_rows<4, 32, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW);
 }
 
 // ------------------------------------------------------------------ Gram phase (whole key matrix resident)
@@ -875,7 +964,7 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
     tj = r + t;
 }
 
-template <int NKB, bool XP, bool PF>   // PF: fetch the next tile's operands during this tile's MFMAs (48 more VGPRs)
+template <int NKB, int FMT, bool PF>   // PF: fetch the next tile's operands during this tile's MFMAs (48 more VGPRs)
 __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__ X, const float* __restrict__ xx,
                                                float* __restrict__ D, int pitchD, int N, int nrt, int wave) {
     const int lane = phase_tid() & 63;
@@ -885,19 +974,19 @@ __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__
     if (t >= ntiles) return;
     int ti, tj;
     tri_decode(t, nrt, ti, tj);
-    Frag a[2], b[2];
-    xload<NKB, XP>(X + (ti * 16 + l15) * xrow<XP>(), lq, a);
-    xload<NKB, XP>(X + (tj * 16 + l15) * xrow<XP>(), lq, b);
+    FragT<FMT> a[2], b[2];
+    xload<NKB, FMT>(X + (ti * 16 + l15) * xrow<FMT>(), lq, a);
+    xload<NKB, FMT>(X + (tj * 16 + l15) * xrow<FMT>(), lq, b);
     while (true) {
         const int tn = t + (int)(blockDim.x >> 6);
         const bool more = tn < ntiles;
         int tin = 0, tjn = 0;
-        Frag an[2], bn[2];
+        FragT<FMT> an[2], bn[2];
         if (more) {                                   // operands of the next tile in flight during this tile's MFMAs
             tri_decode(tn, nrt, tin, tjn);
             if (PF) {
-                xload<NKB, XP>(X + (tin * 16 + l15) * xrow<XP>(), lq, an);
-                xload<NKB, XP>(X + (tjn * 16 + l15) * xrow<XP>(), lq, bn);
+                xload<NKB, FMT>(X + (tin * 16 + l15) * xrow<FMT>(), lq, an);
+                xload<NKB, FMT>(X + (tjn * 16 + l15) * xrow<FMT>(), lq, bn);
             }
         }
         const f32x4 g = tile16<NKB>(a, b);            // g[r] = <x_{i0+4lq+r}, x_{j0+l15}>
@@ -921,8 +1010,8 @@ __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__
             copy_frag<NKB>(a, an);
             copy_frag<NKB>(b, bn);
         } else {
-            xload<NKB, XP>(X + (tin * 16 + l15) * xrow<XP>(), lq, a);
-            xload<NKB, XP>(X + (tjn * 16 + l15) * xrow<XP>(), lq, b);
+            xload<NKB, FMT>(X + (tin * 16 + l15) * xrow<FMT>(), lq, a);
+            xload<NKB, FMT>(X + (tjn * 16 + l15) * xrow<FMT>(), lq, b);
         }
         t = tn;
         ti = tin;
@@ -980,13 +1069,14 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
 // LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
-template <int KP, int DBG, bool LEAN, bool XP>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
-__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
+template <int KP, int DBG, bool LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
+__device__ __forceinline__ void embed_graph(const KParams& kp, const int g, const int launch_slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float vmax = 0.f;                                    // FMT_H2: largest magnitude stored into the f16 planes
     const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
     const EmbedPlan& p = kp.p;
     unsigned char* X = smem + p.offX;                    // [NP][XROW]: bf16 planes (or fp32 rows) / in-place fp32 b
-    constexpr int XROW = xrow<XP>();
+    constexpr int XROW = xrow<FMT>();
     float* A = reinterpret_cast<float*>(smem + p.offA);
     float* D = reinterpret_cast<float*>(smem + p.offD);
     float* xx = reinterpret_cast<float*>(smem + p.offXX);
@@ -995,7 +1085,6 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: wave-uniform task loops and branches
     int tid = tid0, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
-    const int g = kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x;
     const int NS = p.N;                                   // slots per graph in global memory
     float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * p.NP * PP;
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
@@ -1095,6 +1184,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     if (N > p.NC || N > kp.a.promise) {          // more slots to process than the caller's node_cap promised: fail loudly
         if (tid == 0) atomicOr(kp.a.status, 2);
         if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
+        if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
         return;
     }
     if (skip & 32) return;   // ablation: input fetch + duplicate detection only
@@ -1160,17 +1250,24 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                 float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
                 bool with_rep = true;
                 if (v < kLabels) {
-                    a4 = make_float4(wf0[(c4 + 0) * 16 + v], wf0[(c4 + 1) * 16 + v], wf0[(c4 + 2) * 16 + v],
-                                     wf0[(c4 + 3) * 16 + v]);
-                    b4 = make_float4(wf0[(64 + c4 + 0) * 16 + v] + b4.x, wf0[(64 + c4 + 1) * 16 + v] + b4.y,
-                                     wf0[(64 + c4 + 2) * 16 + v] + b4.z, wf0[(64 + c4 + 3) * 16 + v] + b4.w);
+                    // the weight as the generic path's matrix product sees it: exact in three bf16 planes, hi + lo of
+                    // the two f16 planes (22 bits) in FMT_H2
+                    auto wq = [](float x) {
+                        if (FMT != FMT_H2) return x;
+                        const _Float16 h = (_Float16)x;
+                        return (float)h + (float)(_Float16)(x - (float)h);
+                    };
+                    a4 = make_float4(wq(wf0[(c4 + 0) * 16 + v]), wq(wf0[(c4 + 1) * 16 + v]), wq(wf0[(c4 + 2) * 16 + v]),
+                                     wq(wf0[(c4 + 3) * 16 + v]));
+                    b4 = make_float4(wq(wf0[(64 + c4 + 0) * 16 + v]) + b4.x, wq(wf0[(64 + c4 + 1) * 16 + v]) + b4.y,
+                                     wq(wf0[(64 + c4 + 2) * 16 + v]) + b4.z, wq(wf0[(64 + c4 + 3) * 16 + v]) + b4.w);
                     with_rep = cnt[v] < k0;
                 }
                 const float z = with_rep ? 0.f : -INFINITY;                        // the representative's a is 0
                 const float4 m4 = make_float4(max3(-INFINITY, a4.x, z), max3(-INFINITY, a4.y, z),
                                               max3(-INFINITY, a4.z, z), max3(-INFINITY, a4.w, z));
                 const float4 y = add_lrelu(m4, b4, v <= kLabels);
-                xstore<XP>(X + v * XROW, c4, y);
+                xstore<FMT>(X + v * XROW, c4, y, vmax);
                 float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
                 sa += lane_xor(sa, 1);
                 sa += lane_xor(sa, 2);
@@ -1182,7 +1279,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             // layers 2 and 3 on the 13 virtual rows
             for (int Lv = 1; Lv < 3; ++Lv) {
                 const int cout = kp.w.cout[Lv];
-                gram_tiles_sym<4, XP, false>(X, xx, D, p.pitchD, kLabels + 1, 1, wave);
+                gram_tiles_sym<4, FMT, false>(X, xx, D, p.pitchD, kLabels + 1, 1, wave);
                 __syncthreads();
                 for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
                     const int l = t >> 4, j = t & 15;
@@ -1200,7 +1297,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                     if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
                 }
                 __syncthreads();                                                   // keys consumed: A may overwrite D
-                gemm_layer<LEAN, XP>(X, A, p.pitchA, kp.w.wb[Lv], kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
+                gemm_layer<LEAN, FMT>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[Lv] : kp.w.wb[Lv]), kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
                 __syncthreads();
                 const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
                 for (int t = tid; t < 16 * lpr; t += NT) {
@@ -1218,7 +1315,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                     }
                     const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(X + l * XROW + 4 * c4), l <= kLabels);
                     if (Lv == 1) {
-                        xstore<XP>(X + l * XROW, c4, y);
+                        xstore<FMT>(X + l * XROW, c4, y, vmax);
                         float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
                         sa += lane_xor(sa, 1);
                         sa += lane_xor(sa, 2);
@@ -1241,10 +1338,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             for (int c = 0; c < kLabels; ++c) s = fmaf(sem[c], sem[c], s);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             unsigned char* xr = X + tid * XROW;
-            xstore<XP>(xr, 0, live ? make_float4(sem[0], sem[1], sem[2], sem[3]) : z4);
-            xstore<XP>(xr, 4, live ? make_float4(sem[4], sem[5], sem[6], sem[7]) : z4);
-            xstore<XP>(xr, 8, live ? make_float4(sem[8], sem[9], sem[10], sem[11]) : z4);
-            xstore<XP>(xr, 12, z4);
+            xstore<FMT>(xr, 0, live ? make_float4(sem[0], sem[1], sem[2], sem[3]) : z4, vmax);
+            xstore<FMT>(xr, 4, live ? make_float4(sem[4], sem[5], sem[6], sem[7]) : z4, vmax);
+            xstore<FMT>(xr, 8, live ? make_float4(sem[8], sem[9], sem[10], sem[11]) : z4, vmax);
+            xstore<FMT>(xr, 12, z4, vmax);
             xx[tid] = live ? s : 0.f;
         }
     }
@@ -1268,10 +1365,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             if (tid < NP) {
                 const bool live = tid < N;
                 unsigned char* xr = X + tid * XROW;
-                xstore<XP>(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
-                xstore<XP>(xr, 4, make_float4(0.f, 0.f, 0.f, 0.f));
-                xstore<XP>(xr, 8, make_float4(0.f, 0.f, 0.f, 0.f));
-                xstore<XP>(xr, 12, make_float4(0.f, 0.f, 0.f, 0.f));
+                xstore<FMT>(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                xstore<FMT>(xr, 4, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                xstore<FMT>(xr, 8, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                xstore<FMT>(xr, 12, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
                 xx[tid] = live ? fmaf(fz, fz, fmaf(fy, fy, fx * fx)) : 0.f;
             }
             __syncthreads();
@@ -1288,17 +1385,17 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             if (skip & 4) {
             } else if (p.overlap) {
                 if (k64)
-                    gram_tiles_sym<4, XP, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<4, FMT, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
                 else
-                    gram_tiles_sym<1, XP, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<1, FMT, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
                 const int nti = rows_chunk >> 4;
                 for (int tile = wave; tile < nti * nrt; tile += NW) {
                     const int ti = tile / nrt, tj = tile - ti * nrt;
                     if (k64)
-                        gram_tile<4, XP>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
+                        gram_tile<4, FMT>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
                     else
-                        gram_tile<1, XP>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
+                        gram_tile<1, FMT>(X, xx, D, p.pitchD, N, rc0, ti, tj, false, l15, lq);
                 }
             }
             __syncthreads();
@@ -1313,7 +1410,7 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<LEAN, XP>(X, A, p.pitchA, (skip & 512) ? nullptr : kp.w.wb[L], kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
+        if (!(skip & 2)) gemm_layer<LEAN, FMT>(X, A, p.pitchA, (skip & 512) ? nullptr : (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
@@ -1352,8 +1449,8 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
                     *reinterpret_cast<float4*>(park + (size_t)ia * PP + c4) = ya;
                     if (hasb) *reinterpret_cast<float4*>(park + (size_t)ib * PP + c4) = yb;
                 } else {
-                    xstore<XP>(X + ia * XROW, c4, ya);
-                    if (hasb) xstore<XP>(X + ib * XROW, c4, yb);
+                    xstore<FMT>(X + ia * XROW, c4, ya, vmax);
+                    if (hasb) xstore<FMT>(X + ib * XROW, c4, yb, vmax);
                 }
                 if (want_norm) {                          // squared norms of the next layer's input rows (cout == 64: 16 lanes/row)
                     float sa = fmaf(ya.x, ya.x, fmaf(ya.y, ya.y, fmaf(ya.z, ya.z, ya.w * ya.w)));
@@ -1378,14 +1475,14 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
 
     // conv_end weights of this wave's first tile: in flight while sem3 is moved back
-    Frag wf_end[2];
+    FragT<FMT> wf_end[2];
     int ct_end = wave & 1;
-    load_wfrag<4>(kp.w.wb_end + (size_t)ct_end * wtile<4>(), wf_end);
+    load_wfrag<4>((FMT == FMT_H2 ? kp.w.wh_end : kp.w.wb_end) + (size_t)ct_end * wtile<4, FMT>(), wf_end);
     float4 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct_end * 16 + 4 * lq);
     for (int e = tid; e < NP * 8; e += NT) {                      // sem3 -> channels 32..63: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
         const int pr = rowlab ? (int)rowlab[i] : i;              // fast path: the row of slot i's label
-        xstore<XP>(X + i * XROW, 32 + c4, *reinterpret_cast<const float4*>(park + (size_t)pr * PP + c4));
+        xstore<FMT>(X + i * XROW, 32 + c4, *reinterpret_cast<const float4*>(park + (size_t)pr * PP + c4), vmax);
     }
     __syncthreads();
 
@@ -1396,11 +1493,11 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
             const int ct = task & 1, rt = task >> 1;      // NW even: ct == wave & 1 for every task of this wave
             if (ct != ct_end) {                           // odd wave counts (192-thread workgroups) alternate
                 ct_end = ct;
-                load_wfrag<4>(kp.w.wb_end + (size_t)ct * wtile<4>(), wf_end);
+                load_wfrag<4>((FMT == FMT_H2 ? kp.w.wh_end : kp.w.wb_end) + (size_t)ct * wtile<4, FMT>(), wf_end);
                 t4_end = *reinterpret_cast<const float4*>(kp.w.tb_end + ct * 16 + 4 * lq);
             }
-            Frag xf[2];
-            xload<4, XP>(X + (rt * 16 + l15) * XROW, lq, xf);
+            FragT<FMT> xf[2];
+            xload<4, FMT>(X + (rt * 16 + l15) * XROW, lq, xf);
             const f32x4 acc = tile16<4>(wf_end, xf);
             const int c4 = ct * 16 + 4 * lq;
             float4 e4 = make_float4(acc[0] + t4_end.x, acc[1] + t4_end.y, acc[2] + t4_end.z, acc[3] + t4_end.w);
@@ -1439,8 +1536,10 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     constexpr int NPART = 8;         // partial sums per channel: fixed, so results do not depend on the block size
     float* mean = red + NPART * 32;
     float* tg = mean + 32;
+    int* ovflag = reinterpret_cast<int*>(tg + 32);          // FMT_H2: some value stored into the f16 planes was out of range
     float* sig = xx;
     const int c = tid & 31;
+    if (FMT == FMT_H2 && tid == 0) *ovflag = 0;
     for (int prt = tid >> 5; prt < NPART; prt += NT >> 5) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf(n >= nd ? wdup : 1.f, E[n * PE + c], s);
@@ -1472,12 +1571,18 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
         for (int n = prt; n < N; n += NPART) s = fmaf((n >= nd ? wdup : 1.f) * sig[n], E[n * PE + c], s);
         red[prt * 32 + c] = s;
     }
+    if (FMT == FMT_H2) {                                     // !(vmax < safe): NaN inputs count as out of range too
+        const unsigned long long bad = __ballot(!(vmax < kF16Safe));
+        if (bad && lane == 0) atomicOr(ovflag, 1);
+    }
     __syncthreads();
     if (tid < 32) {
         float s = 0.f;
         for (int q = 0; q < NPART; ++q) s += red[q * 32 + tid];
         kp.a.pooled[(size_t)g * 32 + tid] = s;
     }
+    // a graph whose activations left the f16 range is embedded again by the wide-range instance (embed_redo_kernel)
+    if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = *ovflag ? 1 : 0;
     SGPR_PROF(7)
 #undef SGPR_PROF
     if (prof && lane == 0) {
@@ -1486,26 +1591,81 @@ __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kerne
     }
 }
 
-template <int KP, int DBG, bool LEAN, bool XP>
-static int launch_t(const KParams& kp, hipStream_t stream) {
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel<KP, DBG, LEAN, XP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed_kernel)");
-        attr_set = true;
+template <int KP, int DBG, bool LEAN, int FMT>
+__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
+    embed_graph<KP, DBG, LEAN, FMT>(kp, kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x, (int)blockIdx.x);
+}
+
+// The graphs the f16 instance flagged (kp.a.redo[launch slot] != 0: a coordinate or an activation reached the f16
+// range) are embedded again with bf16 planes / fp32 rows, which have fp32's range.  A handful of persistent workgroups
+// scan the flags; on real data there is nothing to do and the launch costs a few microseconds.
+template <int KP, int FMT>
+__global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // this workgroup's contiguous range of launch slots, 64 flags at a time: wave 0 reads them with one load and hands
+    // the ballot to the other waves through the first bytes of LDS (one dependent load per slot made the empty pass
+    // cost 23 us); the mask then lives in registers, so embed_graph is free to overwrite LDS
+    const int per = (kp.a.G + gridDim.x - 1) / gridDim.x;
+    const int b0 = blockIdx.x * per, b1 = min(kp.a.G, b0 + per);
+    for (int base = b0; base < b1; base += 64) {
+        if (threadIdx.x < 64) {
+            const int slot = base + (int)threadIdx.x;
+            const unsigned long long m = __ballot(slot < b1 && kp.a.redo[slot] != 0);
+            if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(smem) = m;
+        }
+        __syncthreads();
+        unsigned long long mask = *reinterpret_cast<const unsigned long long*>(smem);
+        __syncthreads();
+        while (mask) {                                       // workgroup-uniform
+            const int slot = base + __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            embed_graph<KP, 0, false, FMT>(kp, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+            __syncthreads();                                 // LDS is reused by the next graph
+        }
     }
-    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, XP>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+}
+
+template <typename K>
+static int set_lds_limit(K kernel, bool* done) {
+    if (!*done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed kernel)");
+        *done = true;      // benign race: idempotent
+    }
+    return SGPR_OK;
+}
+
+template <int KP, int DBG, bool LEAN, int FMT>
+static int launch_t(const KParams& kp, hipStream_t stream) {
+    static bool attr_set = false;
+    int rc = set_lds_limit(&embed_kernel<KP, DBG, LEAN, FMT>, &attr_set);
+    if (rc != SGPR_OK) return rc;
+    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
 }
 
+template <int KP, int FMT>
+static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
+    static bool attr_set = false;
+    int rc = set_lds_limit(&embed_redo_kernel<KP, FMT>, &attr_set);
+    if (rc != SGPR_OK) return rc;
+    hipLaunchKernelGGL((embed_redo_kernel<KP, FMT>), dim3(blocks), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "embed_redo_kernel launch");
+    return SGPR_OK;
+}
+
 template <int KP, int DBG>
 static int launch_layout(const EmbedPlan& plan, const KParams& kp, hipStream_t stream) {
-    if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, true, true>(kp, stream);   // lean plans are planes-only
-    if (plan.xplanes) return launch_t<KP, DBG, false, true>(kp, stream);
-    return launch_t<KP, DBG, false, false>(kp, stream);
+    if (plan.fmt == FMT_H2) {
+        if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, true, FMT_H2>(kp, stream);
+        return launch_t<KP, DBG, false, FMT_H2>(kp, stream);
+    }
+    // wide-range layouts: forced by the debug mask (bit 13) - timers / dumps are not instantiated for them
+    if (plan.fmt == FMT_BF3) return launch_t<KP, 0, false, FMT_BF3>(kp, stream);
+    return launch_t<KP, 0, false, FMT_F32>(kp, stream);
 }
 
 int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a, hipStream_t stream) {
@@ -1516,12 +1676,29 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.a = a;
     if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
     // layer / kNN dumps run on the roomy instance; timers and ablation keep the production occupancy
-    const int mode = (a.dbg_layers || a.dbg_knn) ? 2 : ((a.prof || a.skip) ? 1 : 0);
+    const int mode = (a.dbg_layers || a.dbg_knn) ? 2 : ((a.prof || (a.skip & ~8192)) ? 1 : 0);
+    int rc;
     if (plan.kp == 16)
-        return mode == 2 ? launch_layout<16, 2>(plan, kp, stream)
-                         : (mode == 1 ? launch_layout<16, 1>(plan, kp, stream) : launch_layout<16, 0>(plan, kp, stream));
-    return mode == 2 ? launch_layout<32, 2>(plan, kp, stream)
-                     : (mode == 1 ? launch_layout<32, 1>(plan, kp, stream) : launch_layout<32, 0>(plan, kp, stream));
+        rc = mode == 2 ? launch_layout<16, 2>(plan, kp, stream)
+                       : (mode == 1 ? launch_layout<16, 1>(plan, kp, stream) : launch_layout<16, 0>(plan, kp, stream));
+    else
+        rc = mode == 2 ? launch_layout<32, 2>(plan, kp, stream)
+                       : (mode == 1 ? launch_layout<32, 1>(plan, kp, stream) : launch_layout<32, 0>(plan, kp, stream));
+    if (rc != SGPR_OK || plan.fmt != FMT_H2 || !a.redo || mode == 1) return rc;
+    // second pass over the graphs the f16 instance flagged, on the wide-range plan (no node_cap: any graph fits)
+    KParams kr = kp;
+    if (!make_embed_plan(plan.N, 0, plan.k, &kr.p, true)) {
+        set_error("no wide-range LDS plan for node_num " + std::to_string(plan.N));
+        return SGPR_E_NODES;
+    }
+    kr.a.dbg_layers = nullptr;
+    kr.a.dbg_knn = nullptr;
+    kr.a.prof = nullptr;
+    kr.a.skip = 0;
+    const int blocks = a.G < 64 ? a.G : 64;
+    if (plan.kp == 16)
+        return kr.p.fmt == FMT_BF3 ? launch_redo_t<16, FMT_BF3>(kr, blocks, stream) : launch_redo_t<16, FMT_F32>(kr, blocks, stream);
+    return kr.p.fmt == FMT_BF3 ? launch_redo_t<32, FMT_BF3>(kr, blocks, stream) : launch_redo_t<32, FMT_F32>(kr, blocks, stream);
 }
 
 }  // namespace sgpr

@@ -26,11 +26,14 @@ struct DevWeights {
     // [column tile][k-step][plane][lane][8]  (lane = 16*lq + l15 holds row ct*16 + l15, k = 32*step + 8*lq + 0..7;
     // first layers, K = 16: one step, k = 4*lq + 0..3 then four zeros)
     const unsigned short* wb[6];
+    // ... and as two f16 planes (w = hi + lo, 22 bits), same operand order with two planes per k-step: the default
+    const unsigned short* wh[6];
     const float* tb[6];
     int kp[6];
     int cout[6];
     const float* wf_end;  // [32][64] folded
     const unsigned short* wb_end;   // conv_end in the wb layout (2 column tiles, 2 k-steps)
+    const unsigned short* wh_end;   // conv_end in the wh layout
     const float* tb_end;  // [32]
     const float* att_w;   // [32][32]
     const float* ntn_w;   // [32][32*16]   (weight_matrix.view(F3,-1), col = j*16 + t)
@@ -56,6 +59,7 @@ struct sgpr_handle {
     // debug / ablation hooks (sgpr_debug_set_*): per handle, off by default; the only mutable state of a handle
     int dbg_skip;
     unsigned long long* dbg_prof;
+    int f16_weights;     // every folded weight fits the f16 range (else the wide-range layouts are used throughout)
 };
 
 namespace sgpr {
@@ -76,12 +80,13 @@ struct EmbedPlan {
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
     int alias_da;    // 1: the key matrix / chunk D shares the A region (a barrier separates selection and GEMMs)
     int lean;        // 1: NP <= 64 - one wave per 16-row tile, weight-stationary GEMMs, <= 168-VGPR kernel instance
-    int xplanes;     // 1: X rows are three bf16 planes (400 B); 0: fp32 rows (272 B) split when loaded (N > 208)
+    int xplanes;     // 1: X rows are bf16 / f16 planes; 0: fp32 rows (272 B) split when loaded
+    int fmt;         // X layout: 2 = two f16 planes (272 B rows, the default), 1 = three bf16 planes (400 B), 0 = fp32 rows
     int rowb;        // bytes per X row
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
 };
-bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan);
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan, bool wide_range = false);
 
 struct EmbedArgs {
     const float* centers;   // packed input, or
@@ -97,6 +102,7 @@ struct EmbedArgs {
     float* dbg_layers;
     int32_t* dbg_knn;
     float* park_ws;         // [G][NP][32] when !park_in_lds
+    unsigned char* redo;    // [launch slots] written by the f16 instance: 1 = the graph left the f16 range -> embed_redo_kernel
     int32_t* status;
     unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
     int promise;                // the caller's node_cap (or N): checked even when the plan ignores it

@@ -766,3 +766,46 @@ def test_config5_full_size(eng, oracle, oracle_sd):
     ii, jj = torch.meshgrid(torch.arange(64, dtype=torch.int32), torch.arange(256, dtype=torch.int32), indexing="ij")
     lst = eng.score_pairs(pooled, pooled, ii.reshape(-1), jj.reshape(-1)).view(64, 256).cpu()
     assert (blk - lst).abs().max().item() <= 2e-5      # |pooled| reaches ~25 here: both kernels are ~1e-5 from float64
+
+
+def test_f16_planes_range_fallback(eng, oracle, oracle_sd):
+    """embed_kernel keeps X as two f16 planes; a graph whose coordinates or activations reach the f16 range is flagged
+    and embedded again by the wide-range instance (bf16 planes / fp32 rows) in the same call.  Huge coordinates (a
+    scene in millimetres) must therefore still match the oracle, in the same batch as ordinary graphs, and the two
+    layouts must agree on ordinary data."""
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.make_graphs(24, 100, 25, 60, 31, kitti_like=True)
+    big = centers.copy()
+    big[::3] *= 2000.0                                        # every third graph: coordinates up to 1e5
+    pooled, att, _ = eng.embed(big, labels, 10, want_att=True)
+    eng.check_status()
+    assert torch.isfinite(pooled).all()
+    rp, ra, _ = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(big, labels)), 10)
+    s = eng.score_all_pairs(pooled, pooled).cpu()
+    rs = oracle.score_all_pairs(oracle_sd, rp, rp)
+    err = (s - rs).abs().max().item()
+    print("mixed-range batch: max|dscore| vs oracle =", err)
+    assert err <= SCORE_TOL
+    # ordinary graphs are untouched by their neighbours' fallback: bit-identical to a batch without the huge ones
+    p_small, _, _ = eng.embed(centers, labels, 10)
+    keep = np.arange(24) % 3 != 0
+    assert torch.equal(pooled[keep], p_small[keep])
+    # the wide-range layout forced for every graph (debug mask bit 13) agrees with the f16 planes on ordinary data
+    eng.set_skip_mask(8192)
+    try:
+        p_wide, _, _ = eng.embed(centers, labels, 10)
+        order, cap = eng.size_order(centers, labels, 10)
+        p_wide2, _, _ = eng.embed(centers, labels, 10, node_cap=cap, order=order)
+    finally:
+        eng.set_skip_mask(0)
+    assert torch.equal(p_wide, p_wide2)
+    d = (p_wide - p_small).abs().max().item()
+    print("f16 planes vs bf16 planes: max|d pooled| =", d)
+    assert d <= 1e-4
+    # the flagged graphs went through the wide-range instance: same bits as forcing it
+    eng.set_skip_mask(8192)
+    try:
+        p_big_wide, _, _ = eng.embed(big, labels, 10)
+    finally:
+        eng.set_skip_mask(0)
+    assert torch.equal(p_big_wide[~keep], pooled[~keep])

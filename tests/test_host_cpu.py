@@ -46,8 +46,10 @@ def test_lds_plans():
         assert 0 < b <= 160 * 1024, (n, k, b)
     assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 0      # > SGPR_MAX_NODES
     assert lib.sgpr_embed_lds_bytes(h, 8, 10) == 0        # K > node_num
-    assert lib.sgpr_embed_workspace_bytes(h, 10, 100, 10) == 0
-    assert lib.sgpr_embed_workspace_bytes(h, 10, 256, 20) == 10 * 256 * 32 * 4   # parked xyz3 block
+    # one redo flag per launch slot (rounded to 256 B) + the parked first-branch block for node_num > 128
+    assert lib.sgpr_embed_workspace_bytes(h, 10, 100, 10) == 256
+    assert lib.sgpr_embed_workspace_bytes(h, 300, 100, 10) == 512
+    assert lib.sgpr_embed_workspace_bytes(h, 10, 256, 20) == 256 + 10 * 256 * 32 * 4
 
 
 def test_engine_refuses_to_run_without_gpu(ckpt_path):
