@@ -296,7 +296,7 @@ void sgpr_destroy(sgpr_handle* h) {
 // wide: use the wide-range X layouts (bf16 planes / fp32 rows) instead of the default f16 planes
 static bool wide_range(const sgpr_handle* h) { return !h->f16_weights || (h->dbg_skip & 8192); }
 
-static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wide) {
+static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wide, bool small_park = false) {
     if (G < 0) {
         set_error("negative graph count");
         return SGPR_E_INVALID;
@@ -313,7 +313,7 @@ static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wid
         set_error("negative node_cap");
         return SGPR_E_INVALID;
     }
-    if (!make_embed_plan(N, node_cap, k, plan, wide)) {
+    if (!make_embed_plan(N, node_cap, k, plan, wide, small_park)) {
         set_error("no LDS plan for node_num " + std::to_string(N) + ", K " + std::to_string(k));
         return SGPR_E_NODES;
     }
@@ -351,7 +351,9 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     a.promise = (node_cap > 0 && node_cap < N) ? node_cap : N;   // still enforced (a broken promise stays loud)
     if (a.G <= h->num_cus) node_cap = 0;
     EmbedPlan plan;
-    int rc = check_nk(a.G, N, k, node_cap, &plan, wide_range(h));
+    // production launches (no dumps, timers or ablation) of lean plans park only the super-node rows
+    const bool production = !a.dbg_layers && !a.dbg_knn && !h->dbg_prof && !(h->dbg_skip & ~8192);
+    int rc = check_nk(a.G, N, k, node_cap, &plan, wide_range(h), production);
     if (rc != SGPR_OK) return rc;
     // graphs are addressed by their own index: an ordered launch needs rows for all of them
     const int gtot = total_graphs < 0 ? a.G : total_graphs;
@@ -491,7 +493,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
         return SGPR_E_INVALID;
     }
     EmbedPlan plan;
-    int rc = check_nk(2 * B, N, k, 0, &plan, wide_range(h));
+    int rc = check_nk(2 * B, N, k, 0, &plan, wide_range(h), !h->dbg_prof && !(h->dbg_skip & ~8192));
     if (rc != SGPR_OK) return rc;
     const size_t need = sgpr_forward_workspace_bytes(h, B, N, k);
     if (!d_workspace || workspace_bytes < need) {

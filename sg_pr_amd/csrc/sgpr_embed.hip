@@ -38,6 +38,7 @@ constexpr int FMT_BF3 = 1;    // three bf16 planes, written once per layer by th
                               // for graphs whose activations leave the f16 range)
 constexpr int FMT_H2 = 2;     // two f16 planes (the default): half the matrix instructions and a third of the split work
 constexpr float kF16Safe = 60000.f;
+constexpr int kSmallParkBytes = 16 * 32 * 4 + 256;   // 16 parked super-node rows + the branch's scratch (cnt[16], rowlab[NP <= 64])
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
 constexpr int PP = 32;        // floats per row of the parked sem3 block (output of the first branch)
 constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
@@ -61,7 +62,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // One layout attempt: X as bf16 planes (PXB bytes per row) or as fp32 rows (PXF, converted when loaded).
 // The key matrix / key chunk D always shares the A region: D is dead once the neighbour lists exist, A is written by
 // the GEMMs after them (a barrier separates the two); the attention scratch shares X (dead after conv_end).
-static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p) {
+static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_park = false, int min_nt = 0) {
     const bool planes = fmt != FMT_F32;
     p->N = N;
     p->NC = NC;
@@ -78,7 +79,8 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p) {
     int off = 0;
     p->offX = off;    off += p->NP * p->rowb;
     p->offRed = p->offX;
-    p->offPark = off; off += p->park_in_lds ? p->NP * PP * 4 : 0;
+    p->small_park = small_park ? 1 : 0;
+    p->offPark = off; off += p->park_in_lds ? (small_park ? kSmallParkBytes : p->NP * PP * 4) : 0;
     p->offXX = off;   off += p->NP * 4;
     p->offIdx = off;  off += round_up(p->NP * p->kpitch * 2, 16);
     p->offA = off;
@@ -93,6 +95,7 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p) {
     p->lds_bytes = off + (rc * rowD > bytesA ? rc * rowD : bytesA);
     // small graphs: 256-thread workgroups, two of them per CU, overlap each other's barriers
     p->nt = p->lds_bytes <= kLdsLimit / 2 ? 256 : 512;
+    if (p->nt < min_nt) p->nt = min_nt;
     // resident mode: the whole key matrix fits in LDS -> upper-triangular Gram tiles, mirrored
     int P = 1;
     while ((NC + P - 1) / P > CAP) P *= 2;
@@ -105,9 +108,9 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p) {
     p->P = P;                                   // lower bound; the kernel widens it per graph
     p->seg = round_up((NC + P - 1) / P, 4);
     p->RC = rc;
-    // lean plans (NP <= 64, bf16 planes): one wave per 16-row tile, 12 waves per CU on the <= 168-VGPR kernel instance
+    // lean plans (NP <= 64, plane layouts): one wave per 16-row tile, 12..16 waves per CU on the <= 128-VGPR kernel instance
     p->lean = 0;
-    if (planes && p->overlap && p->NP <= 64) {
+    if (planes && p->overlap && p->NP <= 64 && min_nt == 0) {
         int nt3 = 64 * (p->NP / 16);
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
         if (nt3 < 128) nt3 = 128;                             // gemm_cols needs two waves
@@ -116,21 +119,26 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p) {
             p->nt = nt3;
         }
     }
+    if (small_park && !p->lean) return false;   // the 16-row park only serves the lean instance's super-node branch
     return true;
 }
 
-bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p, bool wide_range) {
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p, bool wide_range, bool small_park, int min_nt) {
     if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > SGPR_MAX_K || k > N) return false;
     const int NC = (node_cap <= 0 || node_cap > N) ? N : node_cap;
     // default: two f16 planes (fit every node_num).  wide_range (the fallback for graphs whose activations leave the
     // f16 range): bf16 planes whenever they fit (up to 208 processed slots), fp32 rows beyond
-    if (!wide_range) return plan_layout(N, NC, k, FMT_H2, p);
-    return plan_layout(N, NC, k, FMT_BF3, p) || plan_layout(N, NC, k, FMT_F32, p);
+    if (wide_range) return plan_layout(N, NC, k, FMT_BF3, p, false, min_nt) || plan_layout(N, NC, k, FMT_F32, p, false, min_nt);
+    // production launches of lean plans park only the 16 super-node rows of the first branch (four workgroups per CU
+    // instead of three); a graph that needs the generic branch is handed to the second pass (embed_redo_kernel)
+    if (small_park && plan_layout(N, NC, k, FMT_H2, p, true, 0)) return true;
+    return plan_layout(N, NC, k, FMT_H2, p, false, min_nt);
 }
 
 struct KParams {
     DevWeights w;
     EmbedPlan p;
+    EmbedPlan p2;     // embed_redo_kernel only: the full f16 plan beside the wide-range plan in p
     EmbedArgs a;
 };
 
@@ -1070,11 +1078,10 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // production instance carries none of that code.
 // LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
 template <int KP, int DBG, bool LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
-__device__ __forceinline__ void embed_graph(const KParams& kp, const int g, const int launch_slot) {
+__device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& p, const int g, const int launch_slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float vmax = 0.f;                                    // FMT_H2: largest magnitude stored into the f16 planes
     const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
-    const EmbedPlan& p = kp.p;
     unsigned char* X = smem + p.offX;                    // [NP][XROW]: bf16 planes (or fp32 rows) / in-place fp32 b
     constexpr int XROW = xrow<FMT>();
     float* A = reinterpret_cast<float*>(smem + p.offA);
@@ -1226,6 +1233,11 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const int g, cons
         const bool any_bad = *flag != 0;
         __syncthreads();                                    // red shares X, which is written next
         const bool fast = DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
+        if (!fast && p.small_park) {
+            // this plan parks only the super-node rows: the graph takes the generic branch in the second pass
+            if (tid == 0 && kp.a.redo) kp.a.redo[launch_slot] = 2;
+            return;
+        }
         if (fast) {
             // scratch that must survive the branch sits behind the 16 virtual rows of the parked block (LDS, or the
             // global workspace of the large plans: same-workgroup visibility across the barriers either way)
@@ -1592,35 +1604,47 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const int g, cons
 }
 
 template <int KP, int DBG, bool LEAN, int FMT>
-__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? 3 : 1) void embed_kernel(const KParams kp) {
-    embed_graph<KP, DBG, LEAN, FMT>(kp, kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x, (int)blockIdx.x);
+__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? (DBG == 0 ? 4 : 3) : 1) void embed_kernel(const KParams kp) {
+    embed_graph<KP, DBG, LEAN, FMT>(kp, kp.p, kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x, (int)blockIdx.x);
 }
 
-// The graphs the f16 instance flagged (kp.a.redo[launch slot] != 0: a coordinate or an activation reached the f16
-// range) are embedded again with bf16 planes / fp32 rows, which have fp32's range.  A handful of persistent workgroups
-// scan the flags; on real data there is nothing to do and the launch costs a few microseconds.
-template <int KP, int FMT>
+// Second pass over the launch slots the f16 instance flagged (kp.a.redo):
+//   1  a coordinate or an activation reached the f16 range -> bf16 planes / fp32 rows (plan kp.p: fp32's range)
+//   2  the graph needs the generic semantic branch, which the lean plan's 16-row park cannot hold -> the full f16 plan kp.p2
+// A handful of persistent workgroups scan the flags; on real data there is nothing to do and the launch costs ~4 us.
+template <int KP, int FMTW>
 __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // this workgroup's contiguous range of launch slots, 64 flags at a time: wave 0 reads them with one load and hands
-    // the ballot to the other waves through the first bytes of LDS (one dependent load per slot made the empty pass
-    // cost 23 us); the mask then lives in registers, so embed_graph is free to overwrite LDS
+    // the ballots to the other waves through the first bytes of LDS (one dependent load per slot made the empty pass
+    // cost 23 us); the masks then live in registers, so embed_graph is free to overwrite LDS
     const int per = (kp.a.G + gridDim.x - 1) / gridDim.x;
     const int b0 = blockIdx.x * per, b1 = min(kp.a.G, b0 + per);
     for (int base = b0; base < b1; base += 64) {
         if (threadIdx.x < 64) {
             const int slot = base + (int)threadIdx.x;
-            const unsigned long long m = __ballot(slot < b1 && kp.a.redo[slot] != 0);
-            if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(smem) = m;
+            const int f = slot < b1 ? kp.a.redo[slot] : 0;
+            const unsigned long long m1 = __ballot(f == 1), m2 = __ballot(f == 2);
+            if (threadIdx.x == 0) {
+                reinterpret_cast<unsigned long long*>(smem)[0] = m1;
+                reinterpret_cast<unsigned long long*>(smem)[1] = m2;
+            }
         }
         __syncthreads();
-        unsigned long long mask = *reinterpret_cast<const unsigned long long*>(smem);
+        unsigned long long wide = reinterpret_cast<const unsigned long long*>(smem)[0];
+        unsigned long long full = reinterpret_cast<const unsigned long long*>(smem)[1];
         __syncthreads();
-        while (mask) {                                       // workgroup-uniform
-            const int slot = base + __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            embed_graph<KP, 0, false, FMT>(kp, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+        while (wide) {                                       // workgroup-uniform
+            const int slot = base + __ffsll((long long)wide) - 1;
+            wide &= wide - 1;
+            embed_graph<KP, 0, false, FMTW>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot);
             __syncthreads();                                 // LDS is reused by the next graph
+        }
+        while (full) {
+            const int slot = base + __ffsll((long long)full) - 1;
+            full &= full - 1;
+            embed_graph<KP, 0, false, FMT_H2>(kp, kp.p2, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+            __syncthreads();
         }
     }
 }
@@ -1651,7 +1675,8 @@ static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
     static bool attr_set = false;
     int rc = set_lds_limit(&embed_redo_kernel<KP, FMT>, &attr_set);
     if (rc != SGPR_OK) return rc;
-    hipLaunchKernelGGL((embed_redo_kernel<KP, FMT>), dim3(blocks), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    const int lds = kp.p.lds_bytes > kp.p2.lds_bytes ? kp.p.lds_bytes : kp.p2.lds_bytes;
+    hipLaunchKernelGGL((embed_redo_kernel<KP, FMT>), dim3(blocks), dim3(kp.p.nt), lds, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_redo_kernel launch");
     return SGPR_OK;
@@ -1673,6 +1698,7 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     KParams kp;
     kp.w = h->w;
     kp.p = plan;
+    kp.p2 = plan;
     kp.a = a;
     if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
     // layer / kNN dumps run on the roomy instance; timers and ablation keep the production occupancy
@@ -1687,8 +1713,10 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     if (rc != SGPR_OK || plan.fmt != FMT_H2 || !a.redo || mode == 1) return rc;
     // second pass over the graphs the f16 instance flagged, on the wide-range plan (no node_cap: any graph fits)
     KParams kr = kp;
-    if (!make_embed_plan(plan.N, 0, plan.k, &kr.p, true)) {
-        set_error("no wide-range LDS plan for node_num " + std::to_string(plan.N));
+    bool ok = make_embed_plan(plan.N, 0, plan.k, &kr.p, true) && make_embed_plan(plan.N, 0, plan.k, &kr.p2, false, false, kr.p.nt);
+    if (ok && kr.p2.nt != kr.p.nt) ok = make_embed_plan(plan.N, 0, plan.k, &kr.p, true, false, kr.p2.nt);   // one block size for both
+    if (!ok || kr.p.nt != kr.p2.nt) {
+        set_error("no second-pass LDS plan for node_num " + std::to_string(plan.N));
         return SGPR_E_NODES;
     }
     kr.a.dbg_layers = nullptr;

@@ -78,6 +78,8 @@ struct EmbedPlan {
     int pitchA;      // floats per row of the gather target A
     int overlap;     // 1: key matrix resident, selection (half the waves) overlaps the GEMMs (other half)
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
+    int small_park;  // 1: the LDS park holds only the 16 super-node rows (lean production launches): a graph that needs the
+                     // generic semantic branch is re-embedded by the second pass
     int alias_da;    // 1: the key matrix / chunk D shares the A region (a barrier separates selection and GEMMs)
     int lean;        // 1: NP <= 64 - one wave per 16-row tile, weight-stationary GEMMs, <= 168-VGPR kernel instance
     int xplanes;     // 1: X rows are bf16 / f16 planes; 0: fp32 rows (272 B) split when loaded
@@ -86,7 +88,8 @@ struct EmbedPlan {
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
     int lds_bytes;
 };
-bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan, bool wide_range = false);
+bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan, bool wide_range = false, bool small_park = false,
+                     int min_nt = 0);
 
 struct EmbedArgs {
     const float* centers;   // packed input, or
