@@ -410,6 +410,23 @@ __device__ __forceinline__ void bitonic_sort(float (&v)[N]) {  // any -> ascendi
                 }
 }
 
+// Batcher's odd-even merge sort (63 comparators for 16 values against the bitonic sorter's 80) of N values of which
+// the entries >= NV are +inf: such an entry never leaves its place in an ascending network, so comparators that touch
+// one are no-ops and are not generated (NV = 12: 42 comparators).  Outputs the caller does not use cost nothing
+// either: the comparators that feed only them are dead code.
+template <int N, int NV>
+__device__ __forceinline__ void batcher_sort(float (&v)[N]) {
+#pragma unroll
+    for (int p = 1; p < N; p *= 2)
+#pragma unroll
+        for (int k = p; k >= 1; k /= 2)
+#pragma unroll
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && i + j + k < NV) cswap(v[i + j], v[i + j + k]);
+}
+
 // value of lane (l ^ m) for m = 1, 2 (DPP quad permute), 4 (ds_swizzle), else ds_bpermute
 __device__ __forceinline__ float lane_xor(float v, int m) {
     const int iv = __float_as_int(v);
@@ -425,27 +442,34 @@ __device__ __forceinline__ float lane_xor(float v, int m) {
     return __int_as_float(r);
 }
 
-// KP smallest (ascending) of the first `cnt` (wave-uniform) of the 32 candidates d[OFF..OFF+32)
-template <int KP, int OFF, int CAPX>
+// The KEEP smallest (ascending; entries >= KEEP are +inf) of the first `cnt` (wave-uniform) of the 32 candidates
+// d[OFF..OFF+32)
+template <int KP, int KEEP, int OFF, int CAPX>
 __device__ __forceinline__ void list_from_32(const float (&d)[CAPX], int cnt, float (&L)[KP]) {
     if (cnt <= 8) {
         float lo[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) lo[u] = d[OFF + u];
-        bitonic_sort<8>(lo);
+        batcher_sort<8, 8>(lo);
 #pragma unroll
-        for (int u = 0; u < KP; ++u) L[u] = u < 8 ? lo[u & 7] : INFINITY;
+        for (int u = 0; u < KP; ++u) L[u] = (u < 8 && u < KEEP) ? lo[u & 7] : INFINITY;
         return;
     }
     float lo[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) lo[u] = d[OFF + u];
-    bitonic_sort<16>(lo);
+    if (cnt <= 12) {
+#pragma unroll
+        for (int u = 12; u < 16; ++u) lo[u] = INFINITY;      // (they are +inf at run time already: now the compiler knows)
+        batcher_sort<16, 12>(lo);
+    } else {
+        batcher_sort<16, 16>(lo);
+    }
     if (CAPX >= OFF + 32 && cnt > 16) {
         float hi[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) hi[u] = d[CAPX >= OFF + 32 ? OFF + 16 + u : 0];
-        bitonic_sort<16>(hi);
+        batcher_sort<16, 16>(hi);
         if (KP == 16) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) L[u] = kmin(lo[u], hi[15 - u]);
@@ -457,9 +481,11 @@ __device__ __forceinline__ void list_from_32(const float (&d)[CAPX], int cnt, fl
             }
         }
         bitonic_merge<KP>(L);
+#pragma unroll
+        for (int u = KEEP; u < KP; ++u) L[u] = INFINITY;
     } else {
 #pragma unroll
-        for (int u = 0; u < KP; ++u) L[u] = u < 16 ? lo[u & 15] : INFINITY;
+        for (int u = 0; u < KP; ++u) L[u] = (u < 16 && u < KEEP) ? lo[u & 15] : INFINITY;
     }
 }
 
@@ -487,7 +513,9 @@ __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, 
 // total order (key ascending, index ascending) - written as an unordered set.
 // CAPX = candidates a lane may own: CAP in general, 16 in lean plans (NP <= 64 and >= 4 lanes per row whenever a row
 // has more than 16 candidates), which drops the 32- and 64-candidate paths and their registers from that instance.
-template <int KP, int CAPX>
+// KEEP = list entries that matter (k <= KEEP <= KP): the sorted lists carry +inf beyond it, and every comparator,
+// lane exchange and minimum that would only feed those entries is never generated (KEEP = 10 for the reference's K).
+template <int KP, int CAPX, int KEEP>
 __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k, bool one_rep,
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
@@ -526,22 +554,27 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     SEL_STAMP(0)
     // this lane's KP smallest, ascending
     float L[KP];
-    list_from_32<KP, 0, CAPX>(d, seg, L);
+    list_from_32<KP, KEEP, 0, CAPX>(d, seg, L);
     if (CAPX > 32 && seg > 32) {
         float L2[KP];
-        list_from_32<KP, (CAPX > 32 ? 32 : 0), CAPX>(d, seg - 32, L2);
+        list_from_32<KP, KP, (CAPX > 32 ? 32 : 0), CAPX>(d, seg - 32, L2);
 #pragma unroll
         for (int u = 0; u < KP; ++u) L[u] = kmin(L[u], L2[KP - 1 - u]);
         bitonic_merge<KP>(L);
+#pragma unroll
+        for (int u = KEEP; u < KP; ++u) L[u] = INFINITY;
     }
     SEL_STAMP(1)
     // butterfly merge of the P sorted lists of a row: min(L[s], O[KP-1-s]) = the KP smallest of the union, bitonic
+    // (own and partner entries >= KEEP are +inf: no exchange for them, no minimum against them)
 #define SGPR_MERGE_ROUND(M)                                              \
     if (P > (M)) {                                                       \
         float o[KP];                                                     \
-        _Pragma("unroll") for (int s = 0; s < KP; ++s) o[s] = lane_xor(L[s], (M)); \
-        _Pragma("unroll") for (int s = 0; s < KP; ++s) L[s] = kmin(L[s], o[KP - 1 - s]); \
+        _Pragma("unroll") for (int s = 0; s < KP; ++s) o[s] = (KP - 1 - s < KEEP) ? lane_xor(L[KP - 1 - s], (M)) : INFINITY; \
+        _Pragma("unroll") for (int s = 0; s < KP; ++s)                   \
+            L[s] = s < KEEP ? ((KP - 1 - s < KEEP) ? kmin(L[s], o[s]) : L[s]) : o[s]; \
         bitonic_merge<KP>(L);                                            \
+        _Pragma("unroll") for (int s = KEEP; s < KP; ++s) L[s] = INFINITY; \
     }
     SGPR_MERGE_ROUND(1)
     SGPR_MERGE_ROUND(2)
@@ -552,7 +585,7 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
 #undef SGPR_MERGE_ROUND
     SEL_STAMP(2)
     float tau;                                       // the k-th smallest key of the row
-    if (k == 10) {
+    if (KEEP == 10 || k == 10) {
         tau = L[9];
     } else if (KP == 32 && k == 20) {
         tau = L[KP == 32 ? 19 : 0];
@@ -579,26 +612,34 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
                 for (int q = part; q < k; q += P) dbg_knn[(size_t)i * p.k + q] = n - 1;
         }
     }
-    // per-lane bit sets of the candidates below / at the threshold
-    unsigned lt0 = 0u, lt1 = 0u, eq0 = 0u, eq1 = 0u;
+    // per-lane bit sets of the candidates below / at the threshold: the sign bit of (key - tau) and of (tau - key),
+    // shifted into the masks with one v_alignbit each (highest candidate first, so candidate u ends up in bit u);
+    // equal keys (and inf - inf, whose NaN is positive) set neither -> the "equal" set is what remains
+    unsigned lt0 = 0u, lt1 = 0u, gt0 = 0u, gt1 = 0u;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 1; c >= 0; --c)
         if (16 * c < CAPX && 16 * c < seg) {
 #pragma unroll
-            for (int u = 16 * c; u < 16 * c + 16; ++u) {
-                lt0 |= (d[u < CAPX ? u : 0] < tau) ? (1u << u) : 0u;
-                eq0 |= (d[u < CAPX ? u : 0] == tau) ? (1u << u) : 0u;
+            for (int u = 16 * c + 15; u >= 16 * c; --u) {
+                const float dv = d[u < CAPX ? u : 0];
+                lt0 = __builtin_amdgcn_alignbit(lt0, __float_as_uint(dv - tau), 31);
+                gt0 = __builtin_amdgcn_alignbit(gt0, __float_as_uint(tau - dv), 31);
             }
         }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 1; c >= 0; --c)
         if (32 + 16 * c < CAPX && 32 + 16 * c < seg) {
 #pragma unroll
-            for (int u = 16 * c; u < 16 * c + 16; ++u) {
-                lt1 |= (d[32 + u < CAPX ? 32 + u : 0] < tau) ? (1u << u) : 0u;
-                eq1 |= (d[32 + u < CAPX ? 32 + u : 0] == tau) ? (1u << u) : 0u;
+            for (int u = 16 * c + 15; u >= 16 * c; --u) {
+                const float dv = d[32 + u < CAPX ? 32 + u : 0];
+                lt1 = __builtin_amdgcn_alignbit(lt1, __float_as_uint(dv - tau), 31);
+                gt1 = __builtin_amdgcn_alignbit(gt1, __float_as_uint(tau - dv), 31);
             }
         }
+    // slots are processed in whole blocks of 16: the valid width of a word is 16 x the blocks processed for it
+    const unsigned w0 = (CAPX > 16 && seg > 16) ? 0xffffffffu : 0xffffu;
+    const unsigned w1 = (CAPX > 32 && seg > 32) ? ((CAPX > 48 && seg > 48) ? 0xffffffffu : 0xffffu) : 0u;
+    unsigned eq0 = ~(lt0 | gt0) & w0, eq1 = ~(lt1 | gt1) & w1;
     if (dup_cut) {           // take every candidate at or below the representative's key, no tie limit
         lt0 |= eq0;
         lt1 |= eq1;
@@ -1414,7 +1455,13 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(2)
             if (!(skip & 1)) {
                 if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                    select_phase<KP, LEAN ? 16 : CAP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr);
+                {
+                    unsigned long long* const sp = (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr;
+                    if (KP == 16 && k == 10)     // the reference's K: lists of ten
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                    else
+                        select_phase<KP, LEAN ? 16 : CAP, KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                }
                 else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
             }
