@@ -59,6 +59,36 @@ __device__ __forceinline__ int phase_tid() {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// The LDS layout of every lean plan (node_cap <= 64, f16 planes) is ONE fixed layout - 64 rows, 16 neighbour slots per
+// row - so that the lean kernel instance sees its offsets and pitches as compile-time constants (no scalar registers
+// for them: the runtime plan cost that instance 160 spilled SGPRs) while the host and the instrumented instances read
+// the same numbers from the plan.  small_park: the park holds the 16 super-node rows only (production launches).
+__host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_park) {
+    p.NP = 64;
+    p.pitchD = 68;
+    p.pitchA = 68;
+    p.kpitch = 16;
+    p.RC = 64;
+    p.P = 1;
+    p.overlap = 1;
+    p.park_in_lds = 1;
+    p.small_park = small_park ? 1 : 0;
+    p.alias_da = 1;
+    p.lean = 1;
+    p.xplanes = 1;
+    p.fmt = FMT_H2;
+    p.rowb = PXF;
+    p.nt = 256;
+    p.offX = 0;
+    p.offRed = 0;
+    p.offPark = 64 * PXF;
+    p.offXX = p.offPark + (small_park ? kSmallParkBytes : 64 * PP * 4);
+    p.offIdx = p.offXX + 64 * 4;
+    p.offA = p.offIdx + 64 * 16 * 2;
+    p.offD = p.offA;
+    p.lds_bytes = p.offA + 64 * 68 * 4;
+}
+
 // One layout attempt: X as bf16 planes (PXB bytes per row) or as fp32 rows (PXF, converted when loaded).
 // The key matrix / key chunk D always shares the A region: D is dead once the neighbour lists exist, A is written by
 // the GEMMs after them (a barrier separates the two); the attention scratch shares X (dead after conv_end).
@@ -114,9 +144,9 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
         int nt3 = 64 * (p->NP / 16);
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
         if (nt3 < 128) nt3 = 128;                             // gemm_cols needs two waves
-        if (nt3 <= 256 && (12 / (nt3 / 64)) * p->lds_bytes <= kLdsLimit) {
-            p->lean = 1;
-            p->nt = nt3;
+        if (nt3 <= 256 && (12 / (nt3 / 64)) * p->lds_bytes <= kLdsLimit && fmt == FMT_H2 && p->kpitch <= 16) {
+            lean_fixed_layout(*p, small_park);       // one fixed layout for every lean plan (see above)
+            p->seg = round_up(NC, 4);
         }
     }
     if (small_park && !p->lean) return false;   // the 16-row park only serves the lean instance's super-node branch
@@ -1119,8 +1149,13 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // production instance carries none of that code.
 // LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
 template <int KP, int DBG, bool LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
-__device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& p, const int g, const int launch_slot) {
+__device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // lean instance: the layout fields are the constants of lean_fixed_layout (the host built the plan from the same
+    // function); N, NC, k stay run-time values
+    EmbedPlan plan_local = plan_in;
+    if constexpr (LEAN) lean_fixed_layout(plan_local, DBG == 0);
+    const EmbedPlan& p = plan_local;
     float vmax = 0.f;                                    // FMT_H2: largest magnitude stored into the f16 planes
     const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
     unsigned char* X = smem + p.offX;                    // [NP][XROW]: bf16 planes (or fp32 rows) / in-place fp32 b
@@ -1330,7 +1365,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             }
             __syncthreads();
             // layers 2 and 3 on the 13 virtual rows
-            for (int Lv = 1; Lv < 3; ++Lv) {
+            for (int Lv = (skip & 16384) ? 3 : 1; Lv < 3; ++Lv) {      // (ablation bit 14: super-node layers 2 and 3 off)
                 const int cout = kp.w.cout[Lv];
                 gram_tiles_sym<4, FMT, false>(X, xx, D, p.pitchD, kLabels + 1, 1, wave);
                 __syncthreads();
@@ -1590,6 +1625,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             base[(size_t)i * p.k + q] = base[(size_t)(N - 1) * p.k + q];
         }
 
+    if (skip & 32768) return;   // ablation bit 15: no attention pooling
     // ---- attention pooling over all NS slots (padding is NOT masked, divisor NS: layers_batch.py:34-38);
     //      each kept duplicate row stands for wdup slots
     constexpr int NPART = 8;         // partial sums per channel: fixed, so results do not depend on the block size
