@@ -560,6 +560,8 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     }
     const int rl = tid >> (__ffs(P) - 1), part = tid & (P - 1);
     const int i = rc0 + rl;
+    // a wave whose rows all lie past the graph's last slot has nothing to select (no barrier in this phase)
+    if (rc0 + (((tid & ~63)) >> (__ffs(P) - 1)) >= n) return;
     const bool active = (rl < rows_chunk) && (i < n);
     const float* drow = D + (active ? rl : 0) * p.pitchD;
     const int j0 = part * seg;
@@ -1516,15 +1518,17 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             const bool want_norm = (L != 2 && L != 5);
             float* dbg = dbg_layers ? dbg_layers + ((size_t)g * 6 + Ldump) * NS * 64 : nullptr;
             const int rstep = NW * rpw;
-            for (int ia = wave * rpw + sub; ia < ((skip & 8) ? 0 : NP); ia += 2 * rstep) {
+            // a wave-iteration covers two groups of rpw consecutive rows; groups that lie entirely in the padding
+            // [N, NP) are skipped (their rows are zero-filled below: the matrix phases still read them as operands)
+            for (int ia = wave * rpw + sub; ia - sub < ((skip & 8) ? 0 : N); ia += 2 * rstep) {
                 const int ib = ia + rstep;
-                const bool hasb = ib < NP;                 // uniform per row group; all lanes of a row agree
+                const bool hasb = ib - sub < N;            // wave-uniform
                 const int ra = min(ia, N - 1), rb = min(hasb ? ib : ia, N - 1);   // padded rows: compute a real row, store 0
                 float4 ma, mb;
                 gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
                             reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
-                // padded rows (>= N) simply keep a copy of row N-1: they are never candidates (their key is +inf) and
-                // nothing reads them as rows, so zero-filling them is not worth eight selects per iteration
+                // padded rows (>= N) inside a partly real group simply keep a copy of row N-1: they are never candidates
+                // (their key is +inf) and nothing reads them as rows
                 const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * XROW + 4 * c4), true);
                 const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * XROW + 4 * c4), true);
                 if (dbg) {
@@ -1563,6 +1567,13 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     }
                 }
             }
+            // rows of the skipped all-padding groups: zero planes (finite operands for the next layer's matrix phases)
+            if (L != 2 && !(skip & 8)) {
+                constexpr int QW = (FMT == FMT_BF3 ? 384 : 256) / 16;        // 16-byte pieces per row
+                const int nq = (N + rpw - 1) / rpw * rpw;
+                for (int e = tid; e < (NP - nq) * QW; e += NT)
+                    *reinterpret_cast<uint4*>(X + (nq + e / QW) * XROW + (e % QW) * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
         __syncthreads();
         SGPR_PROF(5)
@@ -1576,7 +1587,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     for (int e = tid; e < NP * 8; e += NT) {                      // sem3 -> channels 32..63: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
         const int pr = rowlab ? (int)rowlab[i] : i;              // fast path: the row of slot i's label
-        xstore<FMT>(X + i * XROW, 32 + c4, *reinterpret_cast<const float4*>(park + (size_t)pr * PP + c4), vmax);
+        const float4 v = i < N ? *reinterpret_cast<const float4*>(park + (size_t)pr * PP + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xstore<FMT>(X + i * XROW, 32 + c4, v, vmax);
     }
     __syncthreads();
 
