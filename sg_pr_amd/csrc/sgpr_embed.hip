@@ -619,7 +619,7 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
     float tau;                                       // the k-th smallest key of the row
     if (KEEP == 10 || k == 10) {
         tau = L[9];
-    } else if (KP == 32 && k == 20) {
+    } else if (KP == 32 && (KEEP == 20 || k == 20)) {
         tau = L[KP == 32 ? 19 : 0];
     } else {
         tau = L[0];
@@ -1491,16 +1491,20 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             __syncthreads();
             SGPR_PROF(2)
             if (!(skip & 1)) {
-                if (p.overlap)   // whole key matrix resident (node_num <= 128): register sorting networks
-                {
+                // register sorting networks whenever the chunk's rows x lanes-per-row fit the workgroup (always for the
+                // resident key matrix; for chunked keys too: 2x faster than the value bisection at node_num 256, which
+                // stays as the fallback), with lists cut to the reference's K (10) or the stress configuration's (20)
+                if (p.overlap || (!LEAN && rows_chunk * P <= NT && seg <= CAP)) {
                     unsigned long long* const sp = (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr;
-                    if (KP == 16 && k == 10)     // the reference's K: lists of ten
+                    if (KP == 16 && k == 10)
                         select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                    else if (KP == 32 && k == 20)
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
                     else
                         select_phase<KP, LEAN ? 16 : CAP, KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
-                }
-                else                  // chunked keys (16 rows at a time): one wave per row, bisection on the key value
+                } else {              // one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
+                }
             }
             __syncthreads();                          // the key matrix / chunk is reused (next chunk, or A)
             SGPR_PROF(1)
