@@ -69,8 +69,8 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = c0 + q;
-            if (c >= a.M) break;
+            const bool inb = c0 + q < a.M;             // (no early exit: the wave counts together below)
+            const int c = inb ? c0 + q : a.M - 1;
             int cls;                                   // 1 positive, 0 negative, -1 ignored
             if (a.pose) {
                 // utils.py:36 in float64, operation by operation (no fused multiply-add)
@@ -89,20 +89,35 @@ __global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistAr
                 const int g = a.gt[(int64_t)r * a.ldg + c];
                 cls = g < 0 ? -1 : (g != 0);
             }
-            if (cls < 0) continue;
-            const unsigned key = __float_as_uint(s[q]);
-            if (key > 0x7f800000u) {                   // negative or NaN
-                ++nbad;
-                continue;
-            }
-            const unsigned pre = a.prefix_bits ? key >> shift_p : 0u;
-            int slot = -1;
+            if (!inb) cls = -1;
+            int idx = -1;                              // the counter this element increments (-1: none)
+            if (cls >= 0) {
+                const unsigned key = __float_as_uint(s[q]);
+                if (key > 0x7f800000u) {               // negative or NaN
+                    ++nbad;
+                } else {
+                    const unsigned pre = a.prefix_bits ? key >> shift_p : 0u;
+                    int slot = -1;
 #pragma unroll
-            for (int p = 0; p < HB_MAX_PREFIX; ++p)
-                if (p < a.n_prefix && pre == a.prefix[p]) slot = p;
-            if (slot < 0) continue;
-            const unsigned bin = (key >> shift_b) & bmask;
-            atomicAdd(&hist[(((unsigned)slot << a.bits) + bin) * 2 + cls], 1u);
+                    for (int p = 0; p < HB_MAX_PREFIX; ++p)
+                        if (p < a.n_prefix && pre == a.prefix[p]) slot = p;
+                    if (slot >= 0) idx = (int)(((((unsigned)slot << a.bits) + ((key >> shift_b) & bmask)) * 2) + cls);
+                }
+            }
+            // wave-aggregated counting: sigmoid scores pile up in a few bins (next to 0 and 1), and 64 lanes hitting one
+            // LDS counter serialise.  Up to three rounds take the most common counter of the wave with ONE atomic
+            // (leader = the first lane still waiting); whoever is left counts on its own.
+            unsigned long long todo = __ballot(idx >= 0);
+#pragma unroll 1
+            for (int round = 0; round < 3 && todo; ++round) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int lidx = __shfl(idx, leader);
+                const unsigned long long same = __ballot(idx == lidx);
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lidx], (unsigned)__popcll(same));
+                if (idx == lidx) idx = -1;
+                todo &= ~same;
+            }
+            if (idx >= 0) atomicAdd(&hist[idx], 1u);
         }
     }
     if (nbad) atomicAdd(a.bad, nbad);
