@@ -63,35 +63,32 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // row - so that the lean kernel instance sees its offsets and pitches as compile-time constants (no scalar registers
 // for them: the runtime plan cost that instance 160 spilled SGPRs) while the host and the instrumented instances read
 // the same numbers from the plan.  small_park: the park holds the 16 super-node rows only (production launches).
-__host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_park) {
-    p.NP = 64;
-    p.pitchD = 68;
+__host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_park, int rows) {
+    p.NP = rows;                 // 64, or 48 (30 208 bytes: five workgroups per CU) when no graph needs more slots
+    p.pitchD = rows + 4;
     p.pitchA = 68;
     p.kpitch = 16;
-    p.RC = 64;
+    p.RC = rows;
     p.P = 1;
     p.overlap = 1;
     p.park_in_lds = 1;
     p.small_park = small_park ? 1 : 0;
     p.alias_da = 1;
-    p.lean = 1;
+    p.lean = rows;
     p.xplanes = 1;
     p.fmt = FMT_H2;
     p.rowb = PXF;
     p.nt = 256;
     p.offX = 0;
     p.offRed = 0;
-    p.offPark = 64 * PXF;
-    p.offXX = p.offPark + (small_park ? kSmallParkBytes : 64 * PP * 4);
+    p.offPark = rows * PXF;
+    p.offXX = p.offPark + (small_park ? kSmallParkBytes : rows * PP * 4);
     p.offIdx = p.offXX + 64 * 4;
-    p.offA = p.offIdx + 64 * 16 * 2;
+    p.offA = p.offIdx + rows * 16 * 2;
     p.offD = p.offA;
-    p.lds_bytes = p.offA + 64 * 68 * 4;
+    p.lds_bytes = p.offA + rows * 68 * 4;
 }
 
-// One layout attempt: X as bf16 planes (PXB bytes per row) or as fp32 rows (PXF, converted when loaded).
-// The key matrix / key chunk D always shares the A region: D is dead once the neighbour lists exist, A is written by
-// the GEMMs after them (a barrier separates the two); the attention scratch shares X (dead after conv_end).
 static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_park = false, int min_nt = 0) {
     const bool planes = fmt != FMT_F32;
     p->N = N;
@@ -145,7 +142,8 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
         if (nt3 < 128) nt3 = 128;                             // gemm_cols needs two waves
         if (nt3 <= 256 && (12 / (nt3 / 64)) * p->lds_bytes <= kLdsLimit && fmt == FMT_H2 && p->kpitch <= 16) {
-            lean_fixed_layout(*p, small_park);       // one fixed layout for every lean plan (see above)
+            // one of two fixed layouts (see above); the 48-row one only for production launches (no timers / dumps)
+            lean_fixed_layout(*p, small_park, (small_park && NC <= 48) ? 48 : 64);
             p->seg = round_up(NC, 4);
         }
     }
@@ -1150,13 +1148,13 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
 // LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
-template <int KP, int DBG, bool LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
+template <int KP, int DBG, int LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
 __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // lean instance: the layout fields are the constants of lean_fixed_layout (the host built the plan from the same
     // function); N, NC, k stay run-time values
     EmbedPlan plan_local = plan_in;
-    if constexpr (LEAN) lean_fixed_layout(plan_local, DBG == 0);
+    if constexpr (LEAN != 0) lean_fixed_layout(plan_local, DBG == 0, LEAN);
     const EmbedPlan& p = plan_local;
     float vmax = 0.f;                                    // FMT_H2: largest magnitude stored into the f16 planes
     const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
@@ -1387,7 +1385,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
                 }
                 __syncthreads();                                                   // keys consumed: A may overwrite D
-                gemm_layer<LEAN, FMT>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[Lv] : kp.w.wb[Lv]), kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
+                gemm_layer<(LEAN != 0), FMT>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[Lv] : kp.w.wb[Lv]), kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
                 __syncthreads();
                 const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
                 for (int t = tid; t < 16 * lpr; t += NT) {
@@ -1510,7 +1508,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<LEAN, FMT>(X, A, p.pitchA, (skip & 512) ? nullptr : (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
+        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT>(X, A, p.pitchA, (skip & 512) ? nullptr : (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
@@ -1702,8 +1700,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     }
 }
 
-template <int KP, int DBG, bool LEAN, int FMT>
-__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? (DBG == 0 ? 4 : 3) : 1) void embed_kernel(const KParams kp) {
+template <int KP, int DBG, int LEAN, int FMT>
+__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? (DBG == 0 ? (LEAN == 48 ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
     embed_graph<KP, DBG, LEAN, FMT>(kp, kp.p, kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x, (int)blockIdx.x);
 }
 
@@ -1736,13 +1734,13 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
         while (wide) {                                       // workgroup-uniform
             const int slot = base + __ffsll((long long)wide) - 1;
             wide &= wide - 1;
-            embed_graph<KP, 0, false, FMTW>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+            embed_graph<KP, 0, 0, FMTW>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot);
             __syncthreads();                                 // LDS is reused by the next graph
         }
         while (full) {
             const int slot = base + __ffsll((long long)full) - 1;
             full &= full - 1;
-            embed_graph<KP, 0, false, FMT_H2>(kp, kp.p2, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+            embed_graph<KP, 0, 0, FMT_H2>(kp, kp.p2, kp.a.ids ? kp.a.ids[slot] : slot, slot);
             __syncthreads();
         }
     }
@@ -1758,7 +1756,7 @@ static int set_lds_limit(K kernel, bool* done) {
     return SGPR_OK;
 }
 
-template <int KP, int DBG, bool LEAN, int FMT>
+template <int KP, int DBG, int LEAN, int FMT>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;
     int rc = set_lds_limit(&embed_kernel<KP, DBG, LEAN, FMT>, &attr_set);
@@ -1784,12 +1782,13 @@ static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
 template <int KP, int DBG>
 static int launch_layout(const EmbedPlan& plan, const KParams& kp, hipStream_t stream) {
     if (plan.fmt == FMT_H2) {
-        if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, true, FMT_H2>(kp, stream);
-        return launch_t<KP, DBG, false, FMT_H2>(kp, stream);
+        if (plan.lean == 48 && DBG == 0) return launch_t<KP, 0, 48, FMT_H2>(kp, stream);
+        if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, 64, FMT_H2>(kp, stream);
+        return launch_t<KP, DBG, 0, FMT_H2>(kp, stream);
     }
     // wide-range layouts: forced by the debug mask (bit 13) - timers / dumps are not instantiated for them
-    if (plan.fmt == FMT_BF3) return launch_t<KP, 0, false, FMT_BF3>(kp, stream);
-    return launch_t<KP, 0, false, FMT_F32>(kp, stream);
+    if (plan.fmt == FMT_BF3) return launch_t<KP, 0, 0, FMT_BF3>(kp, stream);
+    return launch_t<KP, 0, 0, FMT_F32>(kp, stream);
 }
 
 int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a, hipStream_t stream) {
