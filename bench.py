@@ -361,7 +361,7 @@ def main():
             "end_to_end": end_to_end,
             "roofline": {"kernel": "sgpr::embed_kernel", "bound": "valu",
                          "bound_note": "VALU issue + dependent latency (selection networks, gather-max, epilogues); the "
-                                       "matrix pipe is ~10 % busy and HBM ~0.3 % - priced against the fp32 vector peak",
+                                       "matrix pipe is ~8 % busy and HBM ~0.5 % - priced against the fp32 vector peak",
                          "achieved": ach_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP32_PEAK_TFLOPS, "traffic": traffic, "launch_ms": embed_ms,
                          "graphs_per_launch": g / launches_per_step, "launches_per_step": launches_per_step,

@@ -86,7 +86,9 @@ size_t sgpr_weights_count(const sgpr_dims* dims);
 int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, int device, sgpr_handle** out);
 void sgpr_destroy(sgpr_handle* h);
 
-/* Bytes of device workspace sgpr_embed* needs for (G graphs, N slots); 0 when none. */
+/* Bytes of device workspace sgpr_embed* needs for (G graphs, N slots): one flag byte per launch slot (written by the
+ * f16-plane kernel instance, read by its wide-range / generic-branch second pass in the same call) plus, for N > 128,
+ * the parked output of the first EdgeConv branch.  Never 0: always pass the workspace. */
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k);
 
 /* Per-graph half of SG.forward: SG.dgcnn_conv_pass (sg_net.py:79-110 ->
@@ -102,8 +104,8 @@ int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_la
 
 /* sgpr_embed with a promise about the input: no graph of the batch needs more than `node_cap` PROCESSED slots
  * (= slots before the trailing run of m identical padding slots, + 1 when m >= k, + m otherwise; 0 = no promise).
- * The kernel sizes its LDS for node_cap instead of N, so padded graphs of a few dozen real nodes run as
- * one wave per 16 slots, 12 waves per CU.  A graph that breaks the promise gets a NaN pooled vector and
+ * The kernel sizes its LDS for node_cap instead of N: caps <= 64 (<= 48) select a fixed 64-row (48-row) layout that
+ * runs four (five) workgroups per CU.  A graph that breaks the promise gets a NaN pooled vector and
  * sgpr_check_status returns SGPR_E_NODES.  Results are otherwise identical to sgpr_embed. */
 int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
                       int k, float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
