@@ -1367,12 +1367,25 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             // layers 2 and 3 on the 13 virtual rows
             for (int Lv = (skip & 16384) ? 3 : 1; Lv < 3; ++Lv) {      // (ablation bit 14: super-node layers 2 and 3 off)
                 const int cout = kp.w.cout[Lv];
-                gram_tiles_sym<4, FMT, false>(X, xx, D, p.pitchD, kLabels + 1, 1, wave);
-                __syncthreads();
+                const unsigned short* wl = FMT == FMT_H2 ? kp.w.wh[Lv] : kp.w.wb[Lv];
+                // the keys of the 16 virtual rows sit beside the 16 rows of A, so that in the lean instance the Gram tile
+                // (wave 0) and the a / b column tiles (the other waves) run side by side: three barriers per layer
+                float* Dv = LEAN != 0 ? A + 16 * p.pitchA : D;
+                if (LEAN != 0) {
+                    if (wave == 0) {
+                        gram_tiles_sym<4, FMT, false>(X, xx, Dv, p.pitchD, kLabels + 1, 1, 0);
+                        __syncthreads();                                           // = the barrier inside gemm_cols
+                    } else {
+                        gemm_layer<true, FMT>(X, A, p.pitchA, wl, kp.w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0);
+                    }
+                } else {
+                    gram_tiles_sym<4, FMT, false>(X, xx, Dv, p.pitchD, kLabels + 1, 1, wave);
+                    __syncthreads();
+                }
                 for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
                     const int l = t >> 4, j = t & 15;
                     const int cj = j <= kLabels ? cnt[j] : 0;
-                    const float key = cj > 0 ? D[l * p.pitchD + j] : INFINITY;
+                    const float key = cj > 0 ? Dv[l * p.pitchD + j] : INFINITY;
                     int before = 0;                                                // nodes ranked ahead of label j
 #pragma unroll
                     for (int sft = 1; sft < 16; ++sft) {
@@ -1385,21 +1398,23 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
                 }
                 __syncthreads();                                                   // keys consumed: A may overwrite D
-                gemm_layer<(LEAN != 0), FMT>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[Lv] : kp.w.wb[Lv]), kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
-                __syncthreads();
+                if (LEAN == 0) {
+                    gemm_layer<false, FMT>(X, A, p.pitchA, wl, kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
+                    __syncthreads();
+                }
                 const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
                 for (int t = tid; t < 16 * lpr; t += NT) {
                     const int l = t / lpr, c4 = (t & (lpr - 1)) * 4;
-                    const int mask = vmask[l];
+                    int mask = vmask[l];                                           // a few labels per row: walk the set bits
                     float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-#pragma unroll
-                    for (int j = 0; j <= kLabels; ++j) {
+                    while (mask) {
+                        const int j = __builtin_ctz(mask);
+                        mask &= mask - 1;
                         const float4 v = *reinterpret_cast<const float4*>(A + j * p.pitchA + c4);
-                        const bool in = (mask >> j) & 1;
-                        m4.x = kmax(m4.x, in ? v.x : -INFINITY);
-                        m4.y = kmax(m4.y, in ? v.y : -INFINITY);
-                        m4.z = kmax(m4.z, in ? v.z : -INFINITY);
-                        m4.w = kmax(m4.w, in ? v.w : -INFINITY);
+                        m4.x = kmax(m4.x, v.x);
+                        m4.y = kmax(m4.y, v.y);
+                        m4.z = kmax(m4.z, v.z);
+                        m4.w = kmax(m4.w, v.w);
                     }
                     const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(X + l * XROW + 4 * c4), l <= kLabels);
                     if (Lv == 1) {
