@@ -195,7 +195,6 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         memcpy(packed.data() + off_wb[b], wb.data(), wb.size() * sizeof(unsigned short));
     }
 
-    int ndev = 0;
     // ---- the same seven matrices as two f16 planes (w = hi + lo), [column tile][k-step][plane][lane][8]
     size_t off_wh[7];
     bool f16_ok = true;
@@ -228,6 +227,7 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         memcpy(packed.data() + off_wh[b], wh.data(), wh.size() * sizeof(unsigned short));
     }
 
+    int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
     if (device < 0 || device >= ndev) {
@@ -309,7 +309,7 @@ static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wid
         set_error("K " + std::to_string(k) + " outside [1, min(node_num, " + std::to_string(SGPR_MAX_K) + ")]");
         return SGPR_E_K;
     }
-    if (node_cap < 0 || (node_cap > 0 && node_cap < 1)) {
+    if (node_cap < 0) {
         set_error("negative node_cap");
         return SGPR_E_INVALID;
     }

@@ -356,7 +356,8 @@ __device__ __forceinline__ void slow_tile(const DevWeights& w, const float* __re
 //            the 4 lane groups leaves lane (g, l15) with row g, columns 4 l15 .. 4 l15 + 3: sigmoid, one 16-byte store.
 // OCC = resident workgroups per CU the instance is compiled for; NI = row graphs whose dependent MFMA -> vector ->
 // MFMA -> vector chains are interleaved in program order (1, 2 or 4); VAR = timing experiments only (tools/probes):
-// bit 1 drops the stores, bit 2 the operand loads of the next block
+// bit 1 drops the stores, bit 2 the operand loads of the next block, bit 4 (16) the matrix instructions, bit 5 (32) the
+// vector work between them
 template <int OCC, int NI, int VAR>
 __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeights w, int R, int M,
                                                               const unsigned short* __restrict__ Ab,
@@ -445,23 +446,43 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeig
                     f32x4 h[NI], q[NI];
                     f16x8 hb[NI];
                     if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+                    if (VAR & 16) {                      // timing: no matrix instructions (opaque copies keep the vector work alive)
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
+                        for (int i = 0; i < NI; ++i) {
+                            h[i] = u4[r0 + i];
+                            asm volatile("" : "+v"(h[i]) : "v"(bh), "v"(bl));
+                        }
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
+                    }
                     if (VAR & 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) hb[i] = split_relu4(h[i]);
+                    for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4(h[i]);
                     if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+                    if (VAR & 16) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
+                        for (int i = 0; i < NI; ++i) {
+                            q[i] = f32x4{b1v.x, b1v.y, b1v.z, b1v.w};
+                            asm volatile("" : "+v"(q[i]) : "v"(hb[i]));
+                        }
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
+                        for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
+                    }
                     if (VAR & 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
+                        if (VAR & 32) {
+                            zb[b][r0 + i] = q[i][0];
+                            continue;
+                        }
                         float z = w2v.x * relu(q[i][0]);
                         z = fmaf(w2v.y, relu(q[i][1]), z);
                         z = fmaf(w2v.z, relu(q[i][2]), z);

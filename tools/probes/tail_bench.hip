@@ -65,6 +65,6 @@ int main(int argc, char** argv) {
         hipMemcpy(ref.data(), score, ref.size() * 4, hipMemcpyDeviceToHost);
     }
 #define RUN(O, N, V) run<O, N, V>(#O "," #N "," #V, w, R, M, Ab, Cb, ur, rng, nrng, rows, cols, score, ref, cus)
-    RUN(4, 1, 0); RUN(4, 1, 8); RUN(3, 1, 0); RUN(3, 1, 8); RUN(3, 2, 0); RUN(3, 2, 8); RUN(3, 4, 0); RUN(3, 4, 8); RUN(2, 4, 0); RUN(2, 4, 8); RUN(4, 1, 2);
+    RUN(4, 1, 0); RUN(3, 1, 0); RUN(2, 1, 0); RUN(1, 1, 0); RUN(4, 1, 16); RUN(2, 1, 16); RUN(1, 1, 16); RUN(4, 1, 32); RUN(2, 1, 32); RUN(1, 1, 32);
     return 0;
 }
