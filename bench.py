@@ -20,7 +20,7 @@ One step = one pass of the hot path over the whole job with inputs already resid
 this rank's shard (fused kNN/EdgeConv/attention kernel), exchange the pooled vectors, score this rank's row block of
 the matrix (NTN + head), gather the matrix on rank 0.  N > 1: the M graphs / M rows are sharded across ranks; the
 matrix is fixed, so `scaling` is "strong".  `end_to_end` adds what `value` excludes by contract: the H2D copy of the
-packed graphs and either the D2H copy of the matrix or its device-side consumer (F1-max from histograms).
+packed graphs and either the D2H copy of the matrix or its device-side consumer (F1-max from threshold counts).
 
 Other workloads (parity-test shapes, not the headline): `pairs128` (config 2: 128 pairs, N=64, k=10, faithful
 per-pair forward) and `stress` (config 5: 1024 pairs, N=256, k=20).
@@ -274,7 +274,7 @@ def main():
     tail_calls_per_step = len(ev_tail) / max(a.steps, 1)
 
     # N > 1, extra information (not `value`): the same K steps with the matrix left sharded by rows - what the
-    # device-side consumers (F1-max histograms, top-k retrieval) work on; isolates the cost of the gather to rank 0
+    # device-side consumers (F1-max counts, top-k retrieval) work on; isolates the cost of the gather to rank 0
     sharded = None
     if world > 1 and allpairs_job and not a.no_gather:
         for _ in range(a.warmup):
@@ -312,7 +312,7 @@ def main():
             end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
         end_to_end["note"] = ("per step: H2D of the packed graphs from pinned host memory (%.1f MB) + the step + either "
                               "the D2H copy of the score matrices into pinned memory (%.1f MB; `d2h`) or the device-side "
-                              "F1-max over them with only the histograms crossing PCIe (`device_f1`); %d repetitions"
+                              "F1-max over them with only the positives' scores and the counts crossing PCIe (`device_f1`); %d repetitions"
                               % (sum(c.nbytes + l.nbytes for c, l, _ in host_inputs) / 1e6, units * 4 / 1e6, reps))
         ev_embed.clear()
         ev_tail.clear()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 2
+#define SGPR_ABI_VERSION 3
 
 enum {
     SGPR_OK = 0,
@@ -161,24 +161,41 @@ int sgpr_check_status(const sgpr_handle* h, void* stream);
 
 /* ---- consumers of the score matrix that keep it on the device ----------------------------------------
  *
- * sgpr_pair_histogram: the counting half of eval_batch.py:69-87 (sklearn precision_recall_curve -> F1 max).  One pass
- * over the R x M score rectangle (rows row0 .. row0+R-1 of the square matrix) builds class-wise radix histograms of the
- * scores: the key of a score is its fp32 bit pattern (scores are >= 0, so the order is the numeric one); a pass looks
- * only at elements whose top `prefix_bits` key bits equal one of the `n_prefix` (<= 4) host-given prefixes and counts
- * them by the next `bits` (<= 12) bits:  d_hist[p][bin][cls] (uint64), cls 1 = positive pair, 0 = negative.
+ * sgpr_pair_positives + sgpr_pair_threshold_counts: the counting half of eval_batch.py:48-49 and 69-87 (sklearn roc_curve
+ * / auc and precision_recall_curve -> F1 max) on an R x M score rectangle (rows row0 .. row0+R-1 of the square matrix).
  * Ground truth comes from the planar poses d_pose_xz [.][2] (float64 x, z of the KITTI pose; the distance is evaluated
- * in float64 operation by operation like utils.py:36): distance <= d_pos
- * positive, >= d_neg negative, in between ignored (the pairs the reference refuses, sg_net.py:302-309) - or, when
- * d_pose_xz is NULL, from explicit labels d_gt [R][ldg] (1 / 0 / negative = ignore).  prefix_bits = 0 is the first pass
- * (prefixes may be NULL).  The host walks the cumulative counts, keeps the bins that can still contain the F1 maximum
- * and refines them with further passes down to single fp32 values (sg_pr_amd/metrics.py:f1_max_device) - exact, no sort,
- * the matrix never leaves the GPU.  d_hist holds (n_prefix << bits) * 2 + 1 words: the last one counts the scores that
- * were negative or NaN (no defined rank) and were skipped. */
-size_t sgpr_pair_histogram_workspace_bytes(const sgpr_handle* h, int n_prefix, int bits);
-int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
+ * in float64 operation by operation like utils.py:36): distance <= d_pos positive, >= d_neg negative, in between
+ * ignored (the pairs the reference refuses, sg_net.py:302-309) - or, when d_pose_xz is NULL, from explicit labels
+ * d_gt [R][ldg] (1 / 0 / negative = ignore).
+ *
+ * sgpr_pair_positives appends the scores of the positive pairs to d_out (at most `capacity` of them, in no particular
+ * order; capacity 0 / d_out NULL = count only) and sets d_count[0] = number of positive pairs with a usable score,
+ * d_count[1] = positive pairs whose score is negative or NaN (no defined rank; they are skipped).
+ *
+ * sgpr_pair_threshold_counts streams the rectangle once and counts the NEGATIVE pairs by threshold bucket: for T <=
+ * 8191 ascending thresholds, d_out[b] (uint64, b = 0..T) = negatives with exactly b thresholds <= their score, so
+ * FP(score >= threshold q) = sum of d_out[b], b > q.  d_out[T+1] = negatives skipped for a negative / NaN score.
+ * With d_rank (the U ascending DISTINCT scores of positive pairs, each with the number of pairs that carry it and the
+ * number of pairs with at least that score; d_thresholds[q] == d_rank[q * S].value, T == ceil(U / S)) every negative
+ * is also ranked among all positive values and d_out[T+2] = sum over negatives of 2 #{positive pairs > s} + #{positive
+ * pairs == s} = 2 P N AUC (the Mann-Whitney form of sklearn's trapezoid area): the ROC area exactly, in the same pass.
+ * F1 peaks at the score of a positive pair, so the host (sg_pr_amd/metrics.py) takes every S-th distinct positive value
+ * as thresholds, reads exact F1 there and bounds in between, and settles the few segments that can still hold the
+ * maximum with a second call - exact, no sort of the matrix, which never leaves the GPU.  The workspace holds one
+ * slab of counters per workgroup (no global atomics). */
+typedef struct sgpr_rank_entry {
+    float value;                /* a distinct score of positive pairs */
+    uint32_t pairs;             /* positive pairs with exactly this score */
+    uint64_t pairs_at_least;    /* positive pairs with this score or a higher one */
+} sgpr_rank_entry;
+int sgpr_pair_positives(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
                         const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt, int64_t ldg,
-                        int n_prefix, int prefix_bits, int bits, const uint32_t* prefixes,
-                        unsigned long long* d_hist, void* d_workspace, size_t workspace_bytes, void* stream);
+                        float* d_out, int64_t capacity, unsigned long long* d_count, void* stream);
+size_t sgpr_pair_threshold_counts_workspace_bytes(const sgpr_handle* h, int T);
+int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
+                               const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt,
+                               int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_entry* d_rank, int64_t U,
+                               int S, unsigned long long* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Loop-closure candidates (the use the reference makes of a sequence's similarity matrix, README.md:92-97): for every
  * row r the k (1, 4, 8 or 16) best-scoring columns c with |c - (row0 + r)| > window (window = -1 keeps every column),

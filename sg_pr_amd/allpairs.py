@@ -13,8 +13,8 @@ Multi-GPU (one process per GPU, torch.distributed; backend "nccl" = RCCL over xG
 Every score depends on its two graphs only, so the matrix is bit-identical for any
 world size.
 
-Consumers that never move the matrix: `f1_max` (eval_batch.py:69-87 from class-wise score histograms,
-per-rank counts summed with one small all_reduce per pass) and `loop_closures` (best matches per query row).
+Consumers that never move the matrix: `pr_roc` / `f1_max` (eval_batch.py:48-49, 69-87: the positives'
+scores all-gathered, per-rank counts of the negatives summed with one small all_reduce per pass) and `loop_closures` (best matches per query row).
 """
 import torch
 import torch.distributed as dist
@@ -126,34 +126,43 @@ class AllPairsScorer:
                 q.wait()
         return None
 
-    def f1_max(self, block, poses, p_thresh=3.0, n_thresh=20.0, hist_fn=None):
-        """F1-max (eval_batch.py:85-87) over this job's matrix WITHOUT gathering it: `block` is this rank's row block
-        (score_rows), ground truth comes from the poses ([M,12] KITTI rows or [M,2] x/z).  Every rank returns the
-        same value.  hist_fn(block, row0, pose_xz, prefix_bits, bits, prefixes) -> uint64 counts overrides the
-        engine pass (CPU tests)."""
+    def pr_roc(self, block, poses, p_thresh=3.0, n_thresh=20.0, fns=None, want_auc=True):
+        """(F1-max of eval_batch.py:85-87, ROC area of eval_batch.py:48-49) over this job's matrix WITHOUT gathering it:
+        `block` is this rank's row block (score_rows), ground truth comes from the poses ([M,12] KITTI rows or [M,2]
+        x/z).  Every rank returns the same values: the scores of the positive pairs are all-gathered (they are few),
+        the per-threshold counts of the negatives all-reduced (sg_pr_amd/metrics.py:pr_roc_from_counts).
+        fns(block, row0, pose_xz) -> (positive scores of the block, count_fn) overrides the engine (CPU tests)."""
+        import numpy as np
         from . import metrics
         world, rank = self._world()
         xz = pose_xz(poses)
         lo, _ = shard_bounds(xz.shape[0], world, rank)
-        if hist_fn is None:
-            eng = self._engine
-            xz_dev = xz.to(block.device)
+        if fns is None:
+            pos, local_count = metrics._device_fns(self._engine, block, xz.to(block.device), p_thresh, n_thresh, None, lo,
+                                                   distinct=False)
+        else:
+            pos, local_count = fns(block, lo, xz)
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, np.asarray(pos, dtype=np.float32), group=self.group)
+            pos = np.concatenate(parts)
 
-            def hist_fn(blk, row0, _xz, prefix_bits, bits, prefixes):   # noqa: E306
-                return eng.pair_histogram(blk, row0=row0, pose_xz=xz_dev, d_pos=p_thresh, d_neg=n_thresh,
-                                          prefixes=prefixes, prefix_bits=prefix_bits, bits=bits)[0]
-
-        def summed(prefix_bits, bits, prefixes):
-            import numpy as np
-            h = np.asarray(hist_fn(block, lo, xz, prefix_bits, bits, prefixes)).astype(np.int64)
+        def count_fn(thresholds, ranking):
+            counts, rank_sum = local_count(thresholds, ranking)
             if world > 1:
-                t = torch.from_numpy(h)
+                t = torch.from_numpy(np.concatenate((np.asarray(counts, dtype=np.int64), [rank_sum or 0])))
                 if block.is_cuda and not self._host_staged(block):
                     t = t.to(block.device)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                h = t.cpu().numpy()
-            return h.astype(np.uint64)
-        return metrics.f1_max_from_histograms(summed)[0]
+                t = t.cpu().numpy()
+                counts, rank_sum = t[:-1], (int(t[-1]) if ranking is not None else None)
+            return counts, rank_sum
+        f1, auc, _ = metrics.pr_roc_from_counts(pos, count_fn, want_auc=want_auc)
+        return f1, auc
+
+    def f1_max(self, block, poses, p_thresh=3.0, n_thresh=20.0, fns=None):
+        """F1-max of pr_roc alone (no ranking of the negatives)."""
+        return self.pr_roc(block, poses, p_thresh, n_thresh, fns=fns, want_auc=False)[0]
 
     def loop_closures(self, block, k=1, window=50):
         """Per query row of this rank's block: the k best-scoring frames at least `window` frames away

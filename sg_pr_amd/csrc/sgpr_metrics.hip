@@ -1,12 +1,16 @@
 // Consumers of the all-pairs score matrix that keep it on the device:
 //
-//  * sgpr_pair_histogram  - the counting half of eval_batch.py:69-87 (sklearn precision_recall_curve + F1 max):
-//                           class-wise radix histograms of the scores, ground truth taken from the KITTI poses on
-//                           the fly (utils.py:36, sg_net.py:302-309) or from explicit labels.  The host refines the
-//                           few bins that can still hold the F1 maximum (sg_pr_amd/metrics.py:f1_max_device), so the
-//                           82 MB matrix is streamed two or three times at HBM speed instead of being copied to the
-//                           host and sorted there.  HBM-bound integer work: coalesced 16-B reads, LDS-privatised
-//                           counters, one slab per workgroup, a second kernel sums the slabs - no global atomics.
+//  * sgpr_pair_positives + sgpr_pair_threshold_counts - the counting half of eval_batch.py:48-49, 69-87 (sklearn
+//        roc_curve / auc, precision_recall_curve + F1 max), ground truth taken from the KITTI poses on the fly
+//        (utils.py:36, sg_net.py:302-309) or from explicit labels.  F1 can only peak at the score of a positive pair,
+//        and positives are rare (loop closures), so: (1) collect the scores of the positive pairs (no pass over the
+//        matrix: only the poses decide which entries are read), (2) the host sorts them and picks up to 8191 of their
+//        distinct values as thresholds, (3) ONE streaming pass counts the NEGATIVES between consecutive thresholds
+//        (binary search in LDS, LDS-privatised counters) - exact FP at every threshold, bounds in between - and, in the
+//        same pass, ranks every negative among ALL positive values (the LDS search finishes with a few probes of the
+//        L2-resident value list), which is the Mann-Whitney form of the ROC area: exact, no refinement.  (4) a second
+//        pass with the thresholds of the few segments that can still hold the F1 maximum settles it exactly
+//        (sg_pr_amd/metrics.py).  HBM-bound integer work: coalesced 16-B reads, no global atomics inside the loop.
 //  * sgpr_topk_rows       - loop-closure candidates: for every query row the K best-scoring columns outside a temporal
 //                           exclusion window, deterministic (score descending, column ascending).
 #include <math.h>
@@ -18,128 +22,271 @@
 
 namespace sgpr {
 
-constexpr int HB_THREADS = 1024;
-constexpr int HB_MAX_PREFIX = 4;          // candidate prefixes per pass
-constexpr int HB_MAX_BITS = 12;           // bins per prefix = 2^bits <= 4096  ->  4 x 4096 x 2 x 4 B = 128 KB of LDS
+constexpr int PC_THREADS = 1024;
+constexpr int PC_MAX_THRESHOLDS = 8191;   // + at least one +inf pad = 8192 floats of LDS, 8192 counters beside them
 
-struct HistArgs {
-    const float* score;
-    int R, M;
-    int64_t ld;
+// how a pair (row r of the rectangle, column c) is labelled
+struct PairTruth {
     int row0;                 // global index of row 0 (rows are a shard of the square matrix)
     const double* pose;       // [>= row0 + R and >= M][2] planar pose (x, z) or NULL; float64 like the reference
     double d_pos, d_neg;      // positive if distance <= d_pos, negative if >= d_neg, ignored in between
-    const signed char* gt;    // optional explicit labels [R][ldg]: 1 / 0 / negative = ignore (used when pose == NULL)
+    const signed char* gt;    // explicit labels [R][ldg]: 1 / 0 / negative = ignore (used when pose == NULL)
     int64_t ldg;
-    int n_prefix, prefix_bits, bits;
-    unsigned prefix[HB_MAX_PREFIX];
-    unsigned* slabs;          // [gridDim.x][n_prefix << bits][2]
-    unsigned* bad;            // counts scores that are negative or NaN (their order is undefined)
 };
 
-// key of a non-negative float = its bit pattern (monotone); the pass looks at `bits` bits below `prefix_bits`
-__global__ __launch_bounds__(HB_THREADS) void pair_histogram_kernel(const HistArgs a) {
-    extern __shared__ unsigned hist[];                  // [n_prefix << bits][2]
-    const int nb = (a.n_prefix << a.bits) * 2;
-    for (int i = threadIdx.x; i < nb; i += HB_THREADS) hist[i] = 0u;
-    __syncthreads();
-    const int shift_p = 32 - a.prefix_bits, shift_b = 32 - a.prefix_bits - a.bits;
-    const unsigned bmask = (1u << a.bits) - 1u;
-    // items = (row, group of 4 columns); a workgroup walks them with a grid stride, lanes along the row
-    const int gpr = (a.M + 3) >> 2;
-    const int64_t items = (int64_t)a.R * gpr;
+// 1 positive, 0 negative, -1 ignored
+__device__ __forceinline__ int classify_pair(const PairTruth& t, int r, int c, double px, double pz, double lo2, double hi2) {
+    if (t.pose) {
+        // utils.py:36 in float64, operation by operation (no fused multiply-add)
+        const double dx = px - t.pose[2 * c], dz = pz - t.pose[2 * c + 1];
+        const double s2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz));
+        // sqrt is monotone and correctly rounded: away from the two thresholds the squared distance decides; only
+        // within a relative 1e-12 of them is the reference's `sqrt(...) <= t` evaluated literally
+        if (s2 < lo2 * (1.0 - 1e-12)) return 1;
+        if (s2 > lo2 * (1.0 + 1e-12) && s2 < hi2 * (1.0 - 1e-12)) return -1;
+        if (s2 > hi2 * (1.0 + 1e-12)) return 0;
+        const double d = sqrt(s2);
+        return d <= t.d_pos ? 1 : (d >= t.d_neg ? 0 : -1);
+    }
+    const int g = t.gt[(int64_t)r * t.ldg + c];
+    return g < 0 ? -1 : (g != 0);
+}
+
+struct PairScan {
+    const float* score;
+    int R, M;
+    int64_t ld;
+    PairTruth truth;
+};
+
+// ---- (1) the scores of the positive pairs, appended in no particular order (the caller sorts them).
+//      out == NULL: count only.  count[0] = positives, count[1] = positives whose score is negative or NaN.
+//      Pose mode touches the matrix only where a pair is positive: the scan itself is arithmetic on the poses.
+constexpr int PP_BUF = 2048;          // staged positives per workgroup between two flushes (one global atomic each)
+__global__ __launch_bounds__(256) void pair_positives_kernel(const PairScan a, float* __restrict__ out, long long cap,
+                                                             unsigned long long* __restrict__ count) {
+    __shared__ float buf[PP_BUF];
+    __shared__ unsigned nbuf;
+    __shared__ unsigned long long gbase;
+    const int lane = threadIdx.x & 63;
+    const double lo2 = a.truth.d_pos * a.truth.d_pos, hi2 = a.truth.d_neg * a.truth.d_neg;
     unsigned nbad = 0;
-    const double lo2 = a.d_pos * a.d_pos, hi2 = a.d_neg * a.d_neg;
-    for (int64_t it = (int64_t)blockIdx.x * HB_THREADS + threadIdx.x; it < items; it += (int64_t)gridDim.x * HB_THREADS) {
-        const int r = (int)(it / gpr), c0 = (int)(it - (int64_t)r * gpr) * 4;
-        const float* sp = a.score + (int64_t)r * a.ld + c0;
+    if (threadIdx.x == 0) nbuf = 0u;
+    __syncthreads();
+    // every global atomic on the ONE list counter costs ~10 ns and they serialise: positives are staged in LDS and a
+    // workgroup reserves its piece of the list once per flush
+    auto flush = [&]() {                                 // (called by the whole workgroup, between barriers)
+        const unsigned n = nbuf;
+        if (threadIdx.x == 0 && n) gbase = atomicAdd(&count[0], (unsigned long long)n);
+        __syncthreads();
+        if (out)
+            for (unsigned i = threadIdx.x; i < n; i += 256) {
+                const long long idx = (long long)gbase + i;
+                if (idx < cap) out[idx] = buf[i];
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) nbuf = 0u;
+        __syncthreads();
+    };
+    // rows by workgroup, columns by lane, four column blocks per iteration so that four pose loads are in flight
+    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
+        double px = 0.0, pz = 0.0;
+        if (a.truth.pose) {
+            px = a.truth.pose[2 * (a.truth.row0 + r)];
+            pz = a.truth.pose[2 * (a.truth.row0 + r) + 1];
+        }
+        for (int cb = 0; cb < a.M; cb += 4 * 256) {
+            bool pos[4];
+            int cc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + q * 256 + (int)threadIdx.x;
+                cc[q] = min(c, a.M - 1);
+                pos[q] = c < a.M;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pos[q] = pos[q] && classify_pair(a.truth, r, cc[q], px, pz, lo2, hi2) == 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = 0.f;
+                if (pos[q]) {
+                    s = a.score[(int64_t)r * a.ld + cc[q]];
+                    if (__float_as_uint(s) > 0x7f800000u) {          // negative or NaN: its order is undefined
+                        ++nbad;
+                        pos[q] = false;
+                    }
+                }
+                const unsigned long long m = __ballot(pos[q]);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    unsigned at = 0u;
+                    if (lane == leader) at = atomicAdd(&nbuf, (unsigned)__popcll(m));
+                    at = __shfl(at, leader);
+                    if (pos[q]) buf[at + __popcll(m & ((1ull << lane) - 1ull))] = s;
+                }
+            }
+            __syncthreads();
+            if (nbuf > PP_BUF - 4 * 256) flush();        // (uniform) room for one more iteration is gone
+        }
+    }
+    __syncthreads();
+    flush();
+    if (nbad) atomicAdd(&count[1], (unsigned long long)nbad);
+}
+
+struct CountArgs {
+    PairScan scan;
+    const float* thr;                    // [T] ascending thresholds (scores of positive pairs)
+    int T, Tp;                           // Tp = the power of two above T (thresholds padded with +inf in LDS)
+    // optional exact ranking of every negative among ALL distinct positive values (ROC area):
+    const sgpr_rank_entry* rank;         // [U] ascending distinct positive values, thr[q] == rank[q * S].value
+    long long U;
+    int S, Sp;                           // Sp = the power of two >= S
+    unsigned* slabs;                     // [gridDim.x][slab_words]: T + 1 counters (padded to even) | bad (u64) | rank sum (u64)
+    int slab_words;
+};
+
+// ---- (3) negatives by threshold bucket; bucket b = #{q : thr[q] <= s}, so FP(>= thr[q]) = sum of buckets b > q.
+//      rank sum = sum over negatives of 2 #{positive pairs > s} + #{positive pairs == s}  (= 2 P N AUC)
+__global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+    float* thr = reinterpret_cast<float*>(pc_smem);                       // [Tp]
+    unsigned* cnt = reinterpret_cast<unsigned*>(thr + a.Tp);              // [T + 1]
+    for (int i = threadIdx.x; i < a.Tp; i += PC_THREADS) thr[i] = i < a.T ? a.thr[i] : INFINITY;
+    for (int i = threadIdx.x; i <= a.T; i += PC_THREADS) cnt[i] = 0u;
+    __syncthreads();
+    const PairScan& sc = a.scan;
+    // items = (row, group of 4 columns), row-major; a workgroup owns a contiguous range of them and its threads walk
+    // it with stride PC_THREADS (lanes along the row), carrying (row, group) along instead of dividing per item
+    const int gpr = (sc.M + 3) >> 2;
+    const int64_t items = (int64_t)sc.R * gpr;
+    const int64_t per = (items + gridDim.x - 1) / gridDim.x;
+    const int64_t it0 = blockIdx.x * per + threadIdx.x, it1 = min(items, (int64_t)(blockIdx.x + 1) * per);
+    int r = (int)(it0 / gpr), g4 = (int)(it0 - (int64_t)r * gpr);
+    const int step_r = PC_THREADS / gpr, step_g = PC_THREADS - step_r * gpr;
+    unsigned nbad = 0;
+    unsigned long long rank2 = 0ull;
+    const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
+    for (int64_t it = it0; it < it1; it += PC_THREADS, r += step_r, g4 += step_g) {
+        if (g4 >= gpr) {
+            g4 -= gpr;
+            ++r;
+        }
+        const int c0 = g4 * 4;
+        const float* sp = sc.score + (int64_t)r * sc.ld + c0;
         float s[4];
-        const bool vec = (c0 + 3 < a.M) && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0);
-        if (vec) {
+        if ((c0 + 3 < sc.M) && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0)) {
             const float4 v = *reinterpret_cast<const float4*>(sp);
             s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = c0 + q < a.M ? sp[q] : 0.f;
+            for (int q = 0; q < 4; ++q) s[q] = c0 + q < sc.M ? sp[q] : 0.f;
         }
         double px = 0.0, pz = 0.0;
-        if (a.pose) {
-            px = a.pose[2 * (a.row0 + r)];
-            pz = a.pose[2 * (a.row0 + r) + 1];
+        if (sc.truth.pose) {
+            px = sc.truth.pose[2 * (sc.truth.row0 + r)];
+            pz = sc.truth.pose[2 * (sc.truth.row0 + r) + 1];
+        }
+        bool neg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool inb = c0 + q < sc.M;            // (no early exit: the wave counts together below)
+            neg[q] = inb && classify_pair(sc.truth, r, inb ? c0 + q : sc.M - 1, px, pz, lo2, hi2) == 0;
+            if (neg[q] && __float_as_uint(s[q]) > 0x7f800000u) {          // negative or NaN
+                ++nbad;
+                neg[q] = false;
+            }
+        }
+        // four independent branch-free binary searches (LDS), interleaved
+        int b[4] = {0, 0, 0, 0};
+        for (int step = a.Tp >> 1; step > 0; step >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] += (thr[b[q] + step - 1] <= s[q]) ? step : 0;
+        }
+        if (a.rank) {
+            // the search goes on among the S values of the bucket (L2-resident table), the four elements in step;
+            // entry l then holds everything about the largest positive value <= s
+            long long l[4], end[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int bq = min(b[q], a.T);
+                l[q] = (long long)max(bq - 1, 0) * a.S;
+                end[q] = min(l[q] + a.S, a.U);
+            }
+            for (int step = a.Sp >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long probe = l[q] + step;
+                    const float v = a.rank[min(probe, a.U - 1)].value;
+                    l[q] = (probe < end[q] && v <= s[q]) ? probe : l[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const sgpr_rank_entry e = a.rank[l[q]];
+                // b == 0: s lies below every positive value, all P = pairs_at_least[0] pairs rank above it
+                const unsigned long long gt_s = b[q] > 0 ? e.pairs_at_least - e.pairs : a.rank[0].pairs_at_least;
+                const unsigned long long eq_s = (b[q] > 0 && e.value == s[q]) ? e.pairs : 0ull;
+                rank2 += neg[q] ? 2ull * gt_s + eq_s : 0ull;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool inb = c0 + q < a.M;             // (no early exit: the wave counts together below)
-            const int c = inb ? c0 + q : a.M - 1;
-            int cls;                                   // 1 positive, 0 negative, -1 ignored
-            if (a.pose) {
-                // utils.py:36 in float64, operation by operation (no fused multiply-add)
-                const double dx = px - a.pose[2 * c], dz = pz - a.pose[2 * c + 1];
-                const double s2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz));
-                // sqrt is monotone and correctly rounded: away from the two thresholds the squared distance decides;
-                // only within a relative 1e-12 of them is the reference's `sqrt(...) <= t` evaluated literally
-                if (s2 < lo2 * (1.0 - 1e-12)) cls = 1;
-                else if (s2 > lo2 * (1.0 + 1e-12) && s2 < hi2 * (1.0 - 1e-12)) cls = -1;
-                else if (s2 > hi2 * (1.0 + 1e-12)) cls = 0;
-                else {
-                    const double d = sqrt(s2);
-                    cls = d <= a.d_pos ? 1 : (d >= a.d_neg ? 0 : -1);
-                }
-            } else {
-                const int g = a.gt[(int64_t)r * a.ldg + c];
-                cls = g < 0 ? -1 : (g != 0);
-            }
-            if (!inb) cls = -1;
-            int idx = -1;                              // the counter this element increments (-1: none)
-            if (cls >= 0) {
-                const unsigned key = __float_as_uint(s[q]);
-                if (key > 0x7f800000u) {               // negative or NaN
-                    ++nbad;
-                } else {
-                    const unsigned pre = a.prefix_bits ? key >> shift_p : 0u;
-                    int slot = -1;
-#pragma unroll
-                    for (int p = 0; p < HB_MAX_PREFIX; ++p)
-                        if (p < a.n_prefix && pre == a.prefix[p]) slot = p;
-                    if (slot >= 0) idx = (int)(((((unsigned)slot << a.bits) + ((key >> shift_b) & bmask)) * 2) + cls);
-                }
-            }
-            // wave-aggregated counting: sigmoid scores pile up in a few bins (next to 0 and 1), and 64 lanes hitting one
-            // LDS counter serialise.  Up to three rounds take the most common counter of the wave with ONE atomic
+            const int bq = min(b[q], a.T);
+            // wave-aggregated counting: sigmoid scores of negatives pile up in a few buckets, and 64 lanes hitting one
+            // LDS counter serialise.  Up to three rounds take the most common bucket of the wave with ONE atomic
             // (leader = the first lane still waiting); whoever is left counts on its own.
+            int idx = neg[q] ? bq : -1;
             unsigned long long todo = __ballot(idx >= 0);
 #pragma unroll 1
             for (int round = 0; round < 3 && todo; ++round) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const int lidx = __shfl(idx, leader);
                 const unsigned long long same = __ballot(idx == lidx);
-                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lidx], (unsigned)__popcll(same));
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&cnt[lidx], (unsigned)__popcll(same));
                 if (idx == lidx) idx = -1;
                 todo &= ~same;
             }
-            if (idx >= 0) atomicAdd(&hist[idx], 1u);
+            if (idx >= 0) atomicAdd(&cnt[idx], 1u);
         }
     }
-    if (nbad) atomicAdd(a.bad, nbad);
+    // per-workgroup results go to the workgroup's own slab (no global atomics); slab_sum_kernel adds the slabs up
+    __shared__ unsigned long long tail[2];
+    if (threadIdx.x == 0) tail[0] = tail[1] = 0ull;
     __syncthreads();
-    unsigned* slab = a.slabs + (size_t)blockIdx.x * nb;
-    for (int i = threadIdx.x; i < nb; i += HB_THREADS) slab[i] = hist[i];
+    if (a.rank) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) rank2 += __shfl_xor(rank2, m);
+        if ((threadIdx.x & 63) == 0 && rank2) atomicAdd(&tail[1], rank2);
+    }
+    if (nbad) atomicAdd(&tail[0], (unsigned long long)nbad);
+    __syncthreads();
+    unsigned* slab = a.slabs + (size_t)blockIdx.x * a.slab_words;
+    for (int i = threadIdx.x; i <= a.T; i += PC_THREADS) slab[i] = cnt[i];
+    if (threadIdx.x < 2) reinterpret_cast<unsigned long long*>(slab + a.slab_words - 4)[threadIdx.x] = tail[threadIdx.x];
 }
 
-// 64 counters per workgroup, 4 threads per counter (each sums every 4th slab), 256-B coalesced reads
-__global__ __launch_bounds__(256) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int nb,
-                                                       const unsigned* __restrict__ bad,
+// out[i] = sum over the slabs: 32 counters per workgroup, 8 threads per counter (each sums every 8th slab)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int slab_words, int T,
                                                        unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long part[4][64];
-    const int b = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + b;
+    __shared__ unsigned long long part[8][32];
+    const int b = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + b;                  // counters 0..T, then T+1 = bad, T+2 = rank sum
     unsigned long long s = 0ull;
-    if (i < nb)
-        for (int q = grp; q < n_slabs; q += 4) s += slabs[(size_t)q * nb + i];
+    if (i <= T) {
+#pragma unroll 8
+        for (int q = grp; q < n_slabs; q += 8) s += slabs[(size_t)q * slab_words + i];
+    } else if (i <= T + 2) {
+        for (int q = grp; q < n_slabs; q += 8)
+            s += reinterpret_cast<const unsigned long long*>(slabs + (size_t)q * slab_words + slab_words - 4)[i - T - 1];
+    }
     part[grp][b] = s;
     __syncthreads();
-    if (grp == 0 && i < nb) out[i] = part[0][b] + part[1][b] + part[2][b] + part[3][b];
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[nb] = *bad;
+    if (grp == 0 && i <= T + 2) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += part[q][b];
+        out[i] = s;
+    }
 }
 
 // ------------------------------------------------------------------ top-K per row
@@ -214,64 +361,114 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 
 using namespace sgpr;
 
-size_t sgpr_pair_histogram_workspace_bytes(const sgpr_handle* h, int n_prefix, int bits) {
-    if (!h || n_prefix < 1 || n_prefix > HB_MAX_PREFIX || bits < 1 || bits > HB_MAX_BITS) return 0;
-    return (size_t)h->num_cus * ((size_t)n_prefix << bits) * 2 * sizeof(unsigned) + 16;
+static int check_scan(const char* who, const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld,
+                      const double* d_pose_xz, const signed char* d_gt, int64_t ldg) {
+    if (!h || !d_score || R < 0 || M < 0 || ld < M || (!d_pose_xz && !d_gt) || (d_gt && !d_pose_xz && ldg < M)) {
+        set_error(std::string(who) + ": NULL argument, negative size or leading dimension below M");
+        return SGPR_E_INVALID;
+    }
+    return SGPR_OK;
 }
 
-int sgpr_pair_histogram(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
+static PairScan make_scan(const float* d_score, int R, int M, int64_t ld, int row0, const double* d_pose_xz, double d_pos,
+                          double d_neg, const signed char* d_gt, int64_t ldg) {
+    PairScan sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.score = d_score;
+    sc.R = R;
+    sc.M = M;
+    sc.ld = ld;
+    sc.truth.row0 = row0;
+    sc.truth.pose = d_pose_xz;
+    sc.truth.d_pos = d_pos;
+    sc.truth.d_neg = d_neg;
+    sc.truth.gt = d_gt;
+    sc.truth.ldg = ldg;
+    return sc;
+}
+
+int sgpr_pair_positives(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
                         const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt, int64_t ldg,
-                        int n_prefix, int prefix_bits, int bits, const uint32_t* prefixes,
-                        unsigned long long* d_hist, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !d_score || !d_hist || R < 0 || M < 0 || ld < M || (!d_pose_xz && !d_gt) || (d_gt && !d_pose_xz && ldg < M)) {
-        set_error("sgpr_pair_histogram: NULL argument, negative size or leading dimension below M");
+                        float* d_out, int64_t capacity, unsigned long long* d_count, void* stream) {
+    int rc = check_scan("sgpr_pair_positives", h, d_score, R, M, ld, d_pose_xz, d_gt, ldg);
+    if (rc != SGPR_OK) return rc;
+    if (!d_count || capacity < 0 || (capacity > 0 && !d_out)) {
+        set_error("sgpr_pair_positives: NULL count buffer or capacity without an output buffer");
         return SGPR_E_INVALID;
     }
-    if (n_prefix < 1 || n_prefix > HB_MAX_PREFIX || bits < 1 || bits > HB_MAX_BITS || prefix_bits < 0 ||
-        prefix_bits + bits > 32 || (prefix_bits > 0 && !prefixes)) {
-        set_error("sgpr_pair_histogram: 1..4 prefixes, 1..12 bits per pass, prefix_bits + bits <= 32");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return hip_fail(e, "sgpr_pair_positives: memset");
+    if ((int64_t)R * M == 0) return SGPR_OK;
+    const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
+    hipLaunchKernelGGL(pair_positives_kernel, dim3(h->num_cus * 8), dim3(256), 0, s, sc, capacity > 0 ? d_out : nullptr,
+                       (long long)capacity, d_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pair_positives_kernel launch");
+    return SGPR_OK;
+}
+
+static int slab_words(int T) { return ((T + 2) & ~1) + 4; }
+
+size_t sgpr_pair_threshold_counts_workspace_bytes(const sgpr_handle* h, int T) {
+    if (!h || T < 0 || T > PC_MAX_THRESHOLDS) return 0;
+    return (size_t)h->num_cus * slab_words(T) * sizeof(unsigned);
+}
+
+int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
+                               const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt,
+                               int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_entry* d_rank, int64_t U,
+                               int S, unsigned long long* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_scan("sgpr_pair_threshold_counts", h, d_score, R, M, ld, d_pose_xz, d_gt, ldg);
+    if (rc != SGPR_OK) return rc;
+    if (!d_out || T < 0 || T > PC_MAX_THRESHOLDS || (T > 0 && !d_thresholds)) {
+        set_error("sgpr_pair_threshold_counts: 0.." + std::to_string(PC_MAX_THRESHOLDS) + " thresholds and an output buffer");
         return SGPR_E_INVALID;
     }
-    const size_t need = sgpr_pair_histogram_workspace_bytes(h, n_prefix, bits);
+    if (d_rank && (U < 1 || S < 1 || (U + S - 1) / S != T)) {
+        set_error("sgpr_pair_threshold_counts: the ranking needs U >= 1 values and T == ceil(U / S) thresholds");
+        return SGPR_E_INVALID;
+    }
+    const size_t need = sgpr_pair_threshold_counts_workspace_bytes(h, T);
     if (!d_workspace || workspace_bytes < need) {
-        set_error("sgpr_pair_histogram: workspace of " + std::to_string(need) + " bytes required");
+        set_error("sgpr_pair_threshold_counts: workspace of " + std::to_string(need) + " bytes required");
         return SGPR_E_WORKSPACE;
     }
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = (n_prefix << bits) * 2;
-    HistArgs a;
+    hipError_t e;
+    if ((int64_t)R * M == 0) {
+        e = hipMemsetAsync(d_out, 0, (size_t)(T + 3) * sizeof(unsigned long long), s);
+        if (e != hipSuccess) return hip_fail(e, "sgpr_pair_threshold_counts: memset");
+        return SGPR_OK;
+    }
+    CountArgs a;
     memset(&a, 0, sizeof(a));
-    a.score = d_score;
-    a.R = R;
-    a.M = M;
-    a.ld = ld;
-    a.row0 = row0;
-    a.pose = d_pose_xz;
-    a.d_pos = d_pos;
-    a.d_neg = d_neg;
-    a.gt = d_gt;
-    a.ldg = ldg;
-    a.n_prefix = n_prefix;
-    a.prefix_bits = prefix_bits;
-    a.bits = bits;
-    for (int p = 0; p < n_prefix; ++p) a.prefix[p] = prefix_bits ? prefixes[p] : 0u;
-    a.bad = reinterpret_cast<unsigned*>(d_workspace);
-    a.slabs = a.bad + 4;
-    hipError_t e = hipMemsetAsync(a.bad, 0, 16, s);
-    if (e != hipSuccess) return hip_fail(e, "sgpr_pair_histogram: memset");
+    a.scan = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
+    a.thr = d_thresholds;
+    a.T = T;
+    a.Tp = 1;
+    while (a.Tp <= T) a.Tp <<= 1;
+    a.rank = d_rank;
+    a.U = d_rank ? U : 0;
+    a.S = d_rank ? S : 1;
+    a.Sp = 1;
+    while (a.Sp < a.S) a.Sp <<= 1;
+    a.slabs = static_cast<unsigned*>(d_workspace);
+    a.slab_words = slab_words(T);
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_histogram_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(pair_histogram_kernel)");
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_threshold_count_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (+ 16 B of static LDS)
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(pair_threshold_count_kernel)");
         attr_set = true;
     }
-    const int grid = h->num_cus;
-    hipLaunchKernelGGL(pair_histogram_kernel, dim3(grid), dim3(HB_THREADS), nb * sizeof(unsigned), s, a);
+    const size_t lds = (size_t)a.Tp * sizeof(float) + (size_t)(T + 1) * sizeof(unsigned);
+    hipLaunchKernelGGL(pair_threshold_count_kernel, dim3(h->num_cus), dim3(PC_THREADS), lds, s, a);
     e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "pair_histogram_kernel launch");
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((nb + 63) / 64), dim3(256), 0, s, a.slabs, grid, nb, a.bad, d_hist);
+    if (e != hipSuccess) return hip_fail(e, "pair_threshold_count_kernel launch");
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((T + 3 + 31) / 32), dim3(256), 0, s, a.slabs, h->num_cus, a.slab_words, T, d_out);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "slab_sum_kernel launch");
     return SGPR_OK;

@@ -34,10 +34,15 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_embed_capped", "sgpr_embed_ordered",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
-               "sgpr_pair_histogram_workspace_bytes", "sgpr_pair_histogram", "sgpr_topk_rows",
+               "sgpr_pair_positives", "sgpr_pair_threshold_counts_workspace_bytes", "sgpr_pair_threshold_counts",
+               "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
                "sgpr_cluster_workspace_bytes", "sgpr_cluster_scan", "sgpr_graph_edges",
                "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
+
+
+# struct sgpr_rank_entry of include/sgpr.h
+RANK_ENTRY = np.dtype([("value", "<f4"), ("pairs", "<u4"), ("pairs_at_least", "<u8")])
 
 
 class SgprError(RuntimeError):
@@ -96,11 +101,14 @@ def load_library():
     lib.sgpr_forward_dense.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_check_status.restype = i32
     lib.sgpr_check_status.argtypes = [vp, vp]
-    lib.sgpr_pair_histogram_workspace_bytes.restype = sz
-    lib.sgpr_pair_histogram_workspace_bytes.argtypes = [vp, i32, i32]
-    lib.sgpr_pair_histogram.restype = i32
-    lib.sgpr_pair_histogram.argtypes = [vp, vp, i32, i32, i64, i32, vp, ctypes.c_double, ctypes.c_double, vp, i64, i32, i32, i32,
-                                        vp, vp, vp, sz, vp]
+    dbl = ctypes.c_double
+    lib.sgpr_pair_positives.restype = i32
+    lib.sgpr_pair_positives.argtypes = [vp, vp, i32, i32, i64, i32, vp, dbl, dbl, vp, i64, vp, i64, vp, vp]
+    lib.sgpr_pair_threshold_counts.restype = i32
+    lib.sgpr_pair_threshold_counts_workspace_bytes.restype = sz
+    lib.sgpr_pair_threshold_counts_workspace_bytes.argtypes = [vp, i32]
+    lib.sgpr_pair_threshold_counts.argtypes = [vp, vp, i32, i32, i64, i32, vp, dbl, dbl, vp, i64, vp, i32, vp, i64, i32, vp, vp, sz,
+                                               vp]
     lib.sgpr_topk_rows.restype = i32
     lib.sgpr_topk_rows.argtypes = [vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp]
     lib.sgpr_embed_lds_bytes.restype = sz
@@ -354,33 +362,68 @@ class Engine:
         return score
 
     # ------------------------------------------------------------------ consumers of the score matrix
-    def pair_histogram(self, score, row0=0, pose_xz=None, d_pos=3.0, d_neg=20.0, gt=None, prefixes=(0,),
-                       prefix_bits=0, bits=12):
-        """One counting pass of the device-side PR/F1 (sgpr_pair_histogram): uint64 [n_prefix, 2^bits, 2] counts of
-        (negative, positive) pairs by score-key bits, plus the number of skipped (negative / NaN) scores."""
+    def _truth(self, score, row0, pose_xz, gt):
         score = self._dev(score, torch.float32, "score")
         r, m = score.shape
         assert score.stride(1) == 1
         if pose_xz is not None:
             pose_xz = self._dev(pose_xz, torch.float64, "pose_xz")
             assert pose_xz.shape[1] == 2 and pose_xz.shape[0] >= max(m, row0 + r)
+            gt = None
         elif gt is not None:
             gt = self._dev(gt, torch.int8, "gt")
             assert gt.shape == (r, m)
         else:
-            raise ValueError("pair_histogram needs poses or explicit labels")
-        npre = len(prefixes)
-        nb = (npre << bits) * 2
-        hist = torch.empty(nb + 1, dtype=torch.int64, device=self.device)
-        ws_bytes = self.lib.sgpr_pair_histogram_workspace_bytes(self._h, npre, bits)
+            raise ValueError("the pair consumers need poses or explicit labels")
+        return score, r, m, pose_xz, gt
+
+    def pair_positives(self, score, row0=0, pose_xz=None, d_pos=3.0, d_neg=20.0, gt=None):
+        """Scores of the positive pairs of a rectangle that stays on the device (sgpr_pair_positives): float32 device
+        tensor (unordered) and the number of positives skipped for a negative / NaN score."""
+        score, r, m, pose_xz, gt = self._truth(score, row0, pose_xz, gt)
+        count = torch.empty(2, dtype=torch.int64, device=self.device)
+        # one launch when the list fits the first guess (positives are rare: loop closures), a second one sized exactly
+        # otherwise
+        cap = min(r * m, 1 << 20)
+        while True:
+            out = torch.empty(cap, dtype=torch.float32, device=self.device)
+            rc = self.lib.sgpr_pair_positives(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz),
+                                              float(d_pos), float(d_neg), _ptr(gt), m, _ptr(out) if cap else None, cap,
+                                              _ptr(count), self._stream())
+            self._check(rc)
+            n, bad = (int(v) for v in count.tolist())
+            if n <= cap:
+                return out[:n], bad
+            cap = n
+
+    def pair_threshold_counts(self, score, thresholds, row0=0, pose_xz=None, d_pos=3.0, d_neg=20.0, gt=None, rank=None):
+        """One streaming pass over a score rectangle (sgpr_pair_threshold_counts): negatives by threshold bucket.
+        thresholds: ascending float32 (<= 8191).  rank = (values, step, above) additionally ranks every negative among
+        all distinct positive values (see include/sgpr.h).  Returns (counts int64 [T+1], skipped, rank_sum or None)."""
+        score, r, m, pose_xz, gt = self._truth(score, row0, pose_xz, gt)
+        thr = self._dev(torch.as_tensor(np.ascontiguousarray(thresholds, dtype=np.float32)), torch.float32, "thresholds")
+        t = int(thr.numel())
+        out = torch.empty(t + 3, dtype=torch.int64, device=self.device)
+        ws_bytes = self.lib.sgpr_pair_threshold_counts_workspace_bytes(self._h, t)
         ws = self._ws(ws_bytes)
-        pre = (ctypes.c_uint32 * npre)(*[int(p) for p in prefixes])
-        rc = self.lib.sgpr_pair_histogram(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz),
-                                          float(d_pos), float(d_neg), _ptr(gt), m, npre, int(prefix_bits), int(bits),
-                                          pre, _ptr(hist), _ptr(ws), ws_bytes, self._stream())
+        table, step, u = None, 1, 0
+        if rank is not None:
+            vals, step, above = rank
+            above = np.asarray(above, dtype=np.int64)
+            u = int(np.asarray(vals).size)
+            assert above.size == u + 1
+            ent = np.zeros(u, dtype=RANK_ENTRY)
+            ent["value"] = vals
+            ent["pairs"] = above[:-1] - above[1:]
+            ent["pairs_at_least"] = above[:-1]
+            table = torch.from_numpy(ent.view(np.uint8)).to(self.device)
+        rc = self.lib.sgpr_pair_threshold_counts(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz),
+                                                 float(d_pos), float(d_neg), _ptr(gt), m, _ptr(thr), t, _ptr(table), u,
+                                                 int(step), _ptr(out), _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
-        h = hist.cpu().numpy().astype(np.uint64)
-        return h[:nb].reshape(npre, 1 << bits, 2), int(h[nb])
+        h = out.cpu().numpy()
+        rank_sum = int(h[t + 2].astype(np.uint64)) if rank is not None else None
+        return h[:t + 1].copy(), int(h[t + 1]), rank_sum
 
     def topk_rows(self, score, k=1, row0=0, window=-1):
         """Best k columns per row outside |col - (row0 + row)| <= window -> (values f32 [R,k], indices i32 [R,k])."""

@@ -10,7 +10,7 @@ engine's wire format
 
 kept as one `.npz` per sequence, together with what the engine's launch plan needs (processed slots per graph ->
 node_cap and the largest-first order).  `evaluate_all_pairs` then runs the sequence end to end on the GPU: embed
-once per graph, dense M x M scores, F1-max from class-wise histograms and the loop-closure candidates - the score
+once per graph, dense M x M scores, F1-max from threshold counts and the loop-closure candidates - the score
 matrix never leaves the device.
 """
 import os

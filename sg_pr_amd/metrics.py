@@ -66,10 +66,19 @@ def roc_auc(gt, score):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Device-side F1-max: exact, sort-free.  The engine counts (negative, positive) pairs by radix bins of
-# the score's fp32 key (sgpr_pair_histogram); this module walks the cumulative counts and asks for finer passes only
-# on the bins that can still contain the maximum.  `hist_fn(prefix_bits, bits, prefixes)` -> uint64 [n, 2^bits, 2].
-_LEVEL_BITS = (12, 12, 8)
+# Device-side F1-max and ROC area: exact, without sorting the matrix.
+#
+# F1(t) = 2 TP / (TP + P + FP) can only peak at a threshold t that is the score of a POSITIVE pair (moving t down to a
+# negative-only value adds false positives and nothing else), and positives are rare (loop closures).  So the engine
+# hands over the scores of the positive pairs (sgpr_pair_positives); their sorted distinct values u[0..U) give TP(>= u[i])
+# at once, and one streaming pass over the matrix (sgpr_pair_threshold_counts) counts the negatives between up to 8191
+# thresholds: every S-th distinct value gets its exact FP, the S - 1 values between two thresholds a bound (FP is at
+# least that of the next threshold).  Segments whose bound beats the best exact F1 are settled by a second pass that
+# takes their values as thresholds.  The same first pass ranks every negative among all u (Mann-Whitney):
+# AUC = (#{pos > neg} + #{pos == neg} / 2) / (P N), which is sklearn's trapezoid area, ties included.
+# `count_fn(thresholds, rank)` -> (int64 [T + 1] negatives with exactly b thresholds <= score, rank_sum or None);
+# rank = (u, S, above) asks for rank_sum = sum over negatives of 2 #{positive pairs > s} + #{positive pairs == s}.
+MAX_THRESHOLDS = 8191
 
 
 def _f1(tp, fp, pos):
@@ -82,137 +91,125 @@ def _f1(tp, fp, pos):
     return np.nan_to_num(f)
 
 
-def f1_max_from_histograms(hist_fn, max_prefixes=4, max_pending=256):
-    """F1-max of eval_batch.py:85-87 from class-wise score histograms; returns (f1_max, passes).
-    Raises RuntimeError if more than `max_pending` bins stay undecided (use a sorted path then)."""
-    h = np.asarray(hist_fn(0, _LEVEL_BITS[0], (0,)), dtype=np.uint64)[0].astype(np.float64)
-    pos = float(h[:, 1].sum())
-    best = 0.0
-    passes = 1
-    # pending: (prefix value, prefix_bits, TP above the bin, FP above the bin, upper bound of F1 inside the bin)
-    pending = []
-
-    def walk(hb, prefix, pbits, tp0, fp0, last):
-        nonlocal best
-        # bins in descending key order: cumulative counts ABOVE each bin, then including it
-        p_desc, n_desc = hb[::-1, 1], hb[::-1, 0]
-        tp_above = tp0 + np.concatenate(([0.0], np.cumsum(p_desc)[:-1]))
-        fp_above = fp0 + np.concatenate(([0.0], np.cumsum(n_desc)[:-1]))
-        occupied = (p_desc + n_desc) > 0
-        if not occupied.any():
-            return
-        edge = _f1(tp_above + p_desc, fp_above + n_desc, pos)          # threshold = smallest score of the bin
-        best = max(best, float(edge[occupied].max()))
-        if last:
-            return
-        ub = _f1(tp_above + p_desc, fp_above, pos)                     # all its positives, none of its negatives
-        nb = hb.shape[0]
-        lg = nb.bit_length() - 1
-        for i in np.nonzero(occupied & (p_desc > 0) & (n_desc > 0) & (ub > best))[0]:
-            b = nb - 1 - int(i)
-            pending.append(((prefix << lg) | b, pbits + lg, tp_above[i], fp_above[i], ub[i]))
-
-    walk(h, 0, 0, 0.0, 0.0, False)
-    level = 1
-    while pending and level < len(_LEVEL_BITS):
-        todo = [c for c in pending if c[4] > best]
-        pending = []
-        if len(todo) > max_pending:
-            raise RuntimeError("f1_max_from_histograms: %d undecided bins" % len(todo))
-        bits = _LEVEL_BITS[level]
-        last = level == len(_LEVEL_BITS) - 1
-        todo.sort(key=lambda c: -c[4])                                  # most promising first: raises `best` early
-        for s in range(0, len(todo), max_prefixes):
-            group = [c for c in todo[s:s + max_prefixes] if c[4] > best]
-            if not group:
-                continue
-            hg = np.asarray(hist_fn(group[0][1], bits, tuple(c[0] for c in group)), dtype=np.uint64).astype(np.float64)
-            passes += 1
-            for c, hb in zip(group, hg):
-                walk(hb, c[0], c[1], c[2], c[3], last)
-        level += 1
-    return best, passes
+def distinct_counts(pos_scores):
+    """Ascending distinct values of the positive scores and how many pairs carry each."""
+    u, mult = np.unique(np.asarray(pos_scores, dtype=np.float32).ravel(), return_counts=True)
+    return u, mult.astype(np.int64)
 
 
-def roc_auc_from_histograms(hist_fn, tol=1e-9, max_passes=64, max_prefixes=4):
-    """Area under the ROC curve (eval_batch.py:48-49) from the same class-wise score histograms, no sort:
-    AUC * P * N = #{(pos, neg): s_pos > s_neg} + 0.5 #{s_pos == s_neg}.  Pairs in different bins are decided by the
-    bins; a bin holding p positives and n negatives leaves p * n pairs open, counted as ties (= the trapezoid rule)
-    until the bin is refined - largest p * n first, down to single fp32 values, where ties are exact.
-    Returns (auc, half_width): the true value lies within +- half_width (0 when every open bin was resolved or
-    `tol` when the refinement stopped there)."""
-    h = np.asarray(hist_fn(0, _LEVEL_BITS[0], (0,)), dtype=np.uint64)[0].astype(np.float64)
-    pos, neg = float(h[:, 1].sum()), float(h[:, 0].sum())
-    if pos <= 0 or neg <= 0:
-        return float("nan"), 0.0
-    known = 0.0          # decided pairs (positive above negative)
-    open_bins = []       # [p * n, prefix, prefix_bits, level]
-
-    def absorb(hb, prefix, pbits, level):
-        nonlocal known
-        p_b, n_b = hb[:, 1], hb[:, 0]
-        below = np.concatenate(([0.0], np.cumsum(n_b)[:-1]))          # negatives in lower bins of this histogram
-        known += float((p_b * below).sum())
-        lg = hb.shape[0].bit_length() - 1
-        last = pbits + lg >= 32
-        for b in np.nonzero((p_b > 0) & (n_b > 0))[0]:
-            if last:
-                known += 0.5 * p_b[b] * n_b[b]                        # single fp32 value: a true tie
-            else:
-                open_bins.append([p_b[b] * n_b[b], (prefix << lg) | int(b), pbits + lg, level + 1])
-
-    absorb(h, 0, 0, 0)
-    passes = 1
-    while open_bins and passes < max_passes:
-        if 0.5 * sum(o[0] for o in open_bins) / (pos * neg) <= tol:
+def pr_roc_from_counts(pos_scores, count_fn, want_auc=True, max_thresholds=MAX_THRESHOLDS, distinct=None, refine=True):
+    """(F1-max of eval_batch.py:85-87, ROC area of eval_batch.py:48-49, counting passes) from the scores of the
+    positive pairs (or `distinct` = their ascending distinct values and multiplicities) and a counting function over
+    the negatives (see above).  Without positives F1-max is 0 and the area NaN, like the sorted path (metrics.f1_max /
+    roc_auc).  refine=False stops after the first pass (the area is exact then, F1-max a lower bound)."""
+    u, mult = distinct if distinct is not None else distinct_counts(pos_scores)
+    n_u, p_all = int(u.size), int(mult.sum())
+    if n_u == 0:
+        return 0.0, float("nan"), 0
+    above = np.concatenate((np.cumsum(mult[::-1])[::-1], [0])).astype(np.int64)   # positive pairs with value >= u[i]
+    # interval = values [lo, hi) whose FP is not known yet, with a lower bound of it (the exact FP of value hi, 0 past
+    # the end); F1 inside it is at most F1(TP(>= u[lo]), that bound).  A pass takes whole intervals as thresholds, best
+    # bound first, as many as fit - or, when the best one alone exceeds the budget, as the initial [0, U) may, every
+    # stride-th value of it, which leaves the values in between as new intervals.
+    ilo, ihi, ifp = np.array([0]), np.array([n_u]), np.array([0])
+    best, auc, neg, passes = -1.0, float("nan"), None, 0
+    while True:
+        bound = _f1(above[ilo], ifp, p_all)
+        keep = bound > best
+        if not keep.any():
             break
-        open_bins.sort(key=lambda o: -o[0])
-        lvl_bits = open_bins[0][2]
-        group = [o for o in open_bins if o[2] == lvl_bits][:max_prefixes]
-        for o in group:
-            open_bins.remove(o)
-        bits = _LEVEL_BITS[group[0][3]]
-        hg = np.asarray(hist_fn(lvl_bits, bits, tuple(o[1] for o in group)), dtype=np.uint64).astype(np.float64)
+        ilo, ihi, ifp, bound = ilo[keep], ihi[keep], ifp[keep], bound[keep]
+        order = np.argsort(-bound, kind="stable")
+        ilo, ihi, ifp = ilo[order], ihi[order], ifp[order]
+        lens = ihi - ilo
+        ntake = int(np.searchsorted(np.cumsum(lens), max_thresholds, side="right"))
+        if ntake == 0:                                                   # the best interval alone is too long: sample it
+            fine = np.arange(ilo[0], ihi[0], -(-int(lens[0]) // max_thresholds))
+        else:
+            ln = lens[:ntake]
+            fine = np.sort(np.repeat(ilo[:ntake] - (np.cumsum(ln) - ln), ln) + np.arange(int(ln.sum())))
+        rank = None
+        if passes == 0 and want_auc:                                     # the first pass samples [0, U) from 0
+            rank = (u, int(fine[1] - fine[0]) if fine.size > 1 else n_u, above)
+        counts, rank_sum = count_fn(u[fine], rank)
+        counts = np.asarray(counts, dtype=np.int64)
         passes += 1
-        for o, hb in zip(group, hg):
-            absorb(hb, o[1], o[2], o[3])
-    rest = sum(o[0] for o in open_bins)
-    return (known + 0.5 * rest) / (pos * neg), 0.5 * rest / (pos * neg)
+        if neg is None:
+            neg = int(counts.sum())
+            if rank is not None and neg > 0:
+                auc = float(rank_sum) / (2.0 * p_all * neg)
+        fp = neg - np.cumsum(counts)[:-1]                                # FP(score >= u[fine[q]]), exact
+        best = max(best, float(_f1(above[fine], fp, p_all).max()))
+        if ntake == 0:                                                   # the gaps of the sampled interval stay open
+            g_lo = np.concatenate(([ilo[0]], fine + 1))
+            g_hi = np.concatenate((fine, [ihi[0]]))
+            g_fp = np.concatenate((fp, [ifp[0]]))
+            open_ = g_hi > g_lo
+            ilo = np.concatenate((ilo[1:], g_lo[open_]))
+            ihi = np.concatenate((ihi[1:], g_hi[open_]))
+            ifp = np.concatenate((ifp[1:], g_fp[open_]))
+        else:
+            ilo, ihi, ifp = ilo[ntake:], ihi[ntake:], ifp[ntake:]
+        if ilo.size == 0 or not refine:
+            break
+    return max(best, 0.0), auc, passes
 
 
-def roc_auc_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0, tol=1e-6, max_passes=64):
-    """ROC AUC of a score rectangle that stays on the device (see roc_auc_from_histograms)."""
-    def hist_fn(prefix_bits, bits, prefixes):
-        return engine.pair_histogram(score, row0=row0, pose_xz=pose_xz, d_pos=p_thresh, d_neg=n_thresh, gt=gt,
-                                     prefixes=prefixes, prefix_bits=prefix_bits, bits=bits)[0]
-    return roc_auc_from_histograms(hist_fn, tol=tol, max_passes=max_passes)
+def _device_fns(engine, score, pose_xz, p_thresh, n_thresh, gt, row0, distinct=True):
+    """(positive scores of the rectangle - as (distinct values, multiplicities), sorted and counted on the device, or
+    as the raw float32 list for distinct=False - and the counting function over its negatives)."""
+    def count_fn(thresholds, rank):
+        counts, bad, rank_sum = engine.pair_threshold_counts(score, thresholds, row0=row0, pose_xz=pose_xz, d_pos=p_thresh,
+                                                             d_neg=n_thresh, gt=gt, rank=rank)
+        if bad:
+            raise ValueError("%d scores are negative or NaN" % bad)
+        return counts, rank_sum
+    pos, bad = engine.pair_positives(score, row0=row0, pose_xz=pose_xz, d_pos=p_thresh, d_neg=n_thresh, gt=gt)
+    if bad:
+        raise ValueError("%d scores are negative or NaN" % bad)
+    if not distinct:
+        return pos.cpu().numpy(), count_fn
+    import torch
+    u, mult = torch.unique(pos, sorted=True, return_counts=True)
+    return (u.cpu().numpy(), mult.cpu().numpy().astype(np.int64)), count_fn
+
+
+def pr_roc_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0, want_auc=True, refine=True):
+    """(F1-max, ROC area, counting passes) of a score rectangle that stays on the device.  Ground truth from planar
+    poses [M,2] (distance <= p_thresh positive, >= n_thresh negative, in between ignored) or explicit int8 labels
+    (1 / 0 / -1)."""
+    distinct, count_fn = _device_fns(engine, score, pose_xz, p_thresh, n_thresh, gt, row0)
+    return pr_roc_from_counts(None, count_fn, want_auc=want_auc, distinct=distinct, refine=refine)
 
 
 def f1_max_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0):
-    """F1-max of a score rectangle that stays on the device.  Ground truth from planar poses [M,2] (distance <=
-    p_thresh positive, >= n_thresh negative, in between ignored) or explicit int8 labels (1 / 0 / -1)."""
-    def hist_fn(prefix_bits, bits, prefixes):
-        h, bad = engine.pair_histogram(score, row0=row0, pose_xz=pose_xz, d_pos=p_thresh, d_neg=n_thresh, gt=gt,
-                                       prefixes=prefixes, prefix_bits=prefix_bits, bits=bits)
-        if bad:
-            raise ValueError("%d scores are negative or NaN" % bad)
-        return h
-    return f1_max_from_histograms(hist_fn)
+    """F1-max of a score rectangle that stays on the device -> (f1_max, counting passes)."""
+    f1, _, passes = pr_roc_device(engine, score, pose_xz, p_thresh, n_thresh, gt, row0, want_auc=False)
+    return f1, passes
 
 
-def histograms_of(score, gt):
-    """numpy stand-in for sgpr_pair_histogram (tests, small inputs): gt 1 / 0 / negative = ignored."""
-    key = np.ascontiguousarray(score, dtype=np.float32).ravel().view(np.uint32).astype(np.uint64)
+def roc_auc_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=None, row0=0):
+    """ROC area (eval_batch.py:48-49) of a score rectangle that stays on the device: exact, one counting pass."""
+    return pr_roc_device(engine, score, pose_xz, p_thresh, n_thresh, gt, row0, refine=False)[1]
+
+
+def counts_of(score, gt):
+    """numpy stand-ins for sgpr_pair_positives / sgpr_pair_threshold_counts (tests, small inputs): gt 1 / 0 / negative
+    = ignored.  Returns (positive scores, count_fn)."""
+    sc = np.ascontiguousarray(score, dtype=np.float32).ravel()
     cls = np.asarray(gt).ravel().astype(np.int64)
-    keep = cls >= 0
-    key, cls = key[keep], (cls[keep] != 0).astype(np.int64)
+    pos, negs = sc[cls > 0], np.sort(sc[cls == 0])
 
-    def hist_fn(prefix_bits, bits, prefixes):
-        out = np.zeros((len(prefixes), 1 << bits, 2), dtype=np.uint64)
-        pre = key >> np.uint64(32 - prefix_bits) if prefix_bits else np.zeros_like(key)
-        b = (key >> np.uint64(32 - prefix_bits - bits)) & np.uint64((1 << bits) - 1)
-        for i, p in enumerate(prefixes):
-            sel = pre == np.uint64(p)
-            np.add.at(out[i], (b[sel].astype(np.int64), cls[sel]), 1)
-        return out
-    return hist_fn
+    def count_fn(thresholds, rank):
+        thr = np.asarray(thresholds, dtype=np.float32)
+        b = np.searchsorted(thr, negs, side="right")                    # thresholds <= score
+        counts = np.bincount(b, minlength=thr.size + 1).astype(np.int64)
+        rank_sum = None
+        if rank is not None:
+            u, _, above = rank
+            le = np.searchsorted(u, negs, side="right")
+            gt_s = above[le]
+            eq_s = np.where((le > 0) & (u[np.maximum(le, 1) - 1] == negs), above[np.maximum(le, 1) - 1] - gt_s, 0)
+            rank_sum = int((2 * gt_s + eq_s).sum())
+        return counts, rank_sum
+    return pos, count_fn

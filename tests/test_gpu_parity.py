@@ -331,9 +331,10 @@ def test_ordered_embed_is_bitwise_equal_and_loud(eng):
     assert ei.value.code == -3
 
 
-def test_device_f1_max_and_histograms(eng):
-    """the score matrix stays on the GPU.  sgpr_pair_histogram == a numpy histogram of the same keys
-    (poses and explicit labels, sharded rows, refinement passes), and the refined F1-max equals the sorted one."""
+def test_device_f1_max_and_counts(eng):
+    """the score matrix stays on the GPU.  sgpr_pair_positives / sgpr_pair_threshold_counts == their numpy
+    restatements (poses and explicit labels, sharded rows, ranking of the negatives), and F1-max / ROC area equal the
+    sorted host computation - with the full threshold budget and with one that forces several refinement passes."""
     from sg_pr_amd import synth, metrics, allpairs
     centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=700, node_num=100, seed=9)
     order, cap = eng.size_order(centers, labels, 10)
@@ -342,34 +343,54 @@ def test_device_f1_max_and_histograms(eng):
     xz = allpairs.pose_xz(poses)
     d = torch.cdist(xz.double(), xz.double())
     gt = torch.where(d <= 3, 1, torch.where(d >= 20, 0, -1)).to(torch.int8)
-    host = metrics.histograms_of(m.cpu().numpy(), gt.numpy())
-    h1, bad = eng.pair_histogram(m, pose_xz=xz)
-    assert bad == 0
-    np.testing.assert_array_equal(h1, host(0, 12, (0,)))
-    assert int(h1.sum()) == int((gt >= 0).sum())
-    # explicit labels, a row shard (row0 != 0, odd sizes), a refinement pass with several prefixes
-    h2, _ = eng.pair_histogram(m[101:358], row0=101, pose_xz=xz)
-    np.testing.assert_array_equal(h2, metrics.histograms_of(m[101:358].cpu().numpy(), gt[101:358].numpy())(0, 12, (0,)))
-    h3, _ = eng.pair_histogram(m, gt=gt)
-    np.testing.assert_array_equal(h3, h1)
-    busiest = np.argsort(h1[0].sum(1))[-3:].tolist()
-    h4, _ = eng.pair_histogram(m, pose_xz=xz, prefixes=busiest, prefix_bits=12, bits=12)
-    np.testing.assert_array_equal(h4, host(12, 12, tuple(busiest)))
-    h5, _ = eng.pair_histogram(m, pose_xz=xz, prefixes=[(busiest[-1] << 12) | int(np.argmax(h4[-1].sum(1)))],
-                               prefix_bits=24, bits=8)
-    np.testing.assert_array_equal(h5, host(24, 8, ((busiest[-1] << 12) | int(np.argmax(h4[-1].sum(1))),)))
-    f_dev, passes = metrics.f1_max_device(eng, m, pose_xz=xz)
+    mh = m.cpu().numpy()
+    pos_host, count_host = metrics.counts_of(mh, gt.numpy())
+    pos, bad = eng.pair_positives(m, pose_xz=xz)
+    assert bad == 0 and pos.numel() == int((gt == 1).sum())
+    np.testing.assert_array_equal(np.sort(pos.cpu().numpy()), np.sort(pos_host))
+    u, mult = np.unique(pos_host, return_counts=True)
+    above = np.concatenate((np.cumsum(mult[::-1])[::-1], [0])).astype(np.int64)
+    for step in (1, 3, 50):                              # thresholds = every step-th distinct positive score
+        thr = u[::step]
+        if thr.size > metrics.MAX_THRESHOLDS:
+            continue
+        c_dev, bad, r_dev = eng.pair_threshold_counts(m, thr, pose_xz=xz, rank=(u, step, above))
+        c_host, r_host = count_host(thr, (u, step, above))
+        assert bad == 0 and r_dev == r_host
+        np.testing.assert_array_equal(c_dev, c_host)
+        assert int(c_dev.sum()) == int((gt == 0).sum())
+    # explicit labels, a row shard (row0 != 0, odd sizes), thresholds that are not positive scores, none at all
+    thr = np.linspace(0.0, 1.0, 777, dtype=np.float32)
+    c1, _, _ = eng.pair_threshold_counts(m, thr, pose_xz=xz)
+    c2, _, _ = eng.pair_threshold_counts(m, thr, gt=gt)
+    np.testing.assert_array_equal(c1, c2)
+    np.testing.assert_array_equal(c1, count_host(thr, None)[0])
+    c3, _, _ = eng.pair_threshold_counts(m[101:358], thr, row0=101, pose_xz=xz)
+    np.testing.assert_array_equal(c3, metrics.counts_of(mh[101:358], gt[101:358].numpy())[1](thr, None)[0])
+    p3, _ = eng.pair_positives(m[101:358], row0=101, pose_xz=xz)
+    np.testing.assert_array_equal(np.sort(p3.cpu().numpy()), np.sort(mh[101:358][gt[101:358].numpy() == 1]))
+    c4, _, _ = eng.pair_threshold_counts(m, np.zeros(0, dtype=np.float32), pose_xz=xz)
+    assert c4.tolist() == [int((gt == 0).sum())]
     valid = gt >= 0
     f_host = metrics.f1_max(gt[valid].numpy(), m.cpu()[valid].numpy())
-    print("F1-max device / host:", f_dev, f_host, "passes", passes)
-    assert abs(f_dev - f_host) < 1e-12
-    # the scorer's entry point (single process: no all_reduce)
-    from sg_pr_amd import sg_net
-    # negative scores are refused
+    a_host = metrics.roc_auc(gt[valid].numpy(), m.cpu()[valid].numpy())
+    f_dev, a_dev, passes = metrics.pr_roc_device(eng, m, pose_xz=xz)
+    print("F1-max device / host:", f_dev, f_host, "AUC", a_dev, a_host, "passes", passes, "positives", pos.numel())
+    assert abs(f_dev - f_host) < 1e-12 and abs(a_dev - a_host) < 1e-12 and passes <= 2
+    distinct, count_fn = metrics._device_fns(eng, m, xz, 3.0, 20.0, None, 0)
+    assert np.array_equal(distinct[0], u) and np.array_equal(distinct[1], mult)
+    f_small, a_small, p_small = metrics.pr_roc_from_counts(None, count_fn, max_thresholds=64, distinct=distinct)
+    assert abs(f_small - f_host) < 1e-12 and abs(a_small - a_host) < 1e-12 and p_small >= 2
+    assert metrics.f1_max_device(eng, m, pose_xz=xz)[0] == f_dev
+    assert abs(metrics.roc_auc_device(eng, m, pose_xz=xz) - a_host) < 1e-12
+    # negative scores are refused, whichever class they belong to
     bad_m = m.clone()
     bad_m[3, 5] = -0.25
-    with pytest.raises(ValueError):
-        metrics.f1_max_device(eng, bad_m, gt=torch.ones_like(gt))
+    one_positive = torch.zeros_like(gt)
+    one_positive[0, 0] = 1
+    for labels_of in (torch.ones_like(gt), one_positive):
+        with pytest.raises(ValueError):
+            metrics.f1_max_device(eng, bad_m, gt=labels_of)
 
 
 def test_topk_rows_loop_closures(eng):
@@ -537,7 +558,7 @@ def test_full_size_kitti00_properties(eng, oracle, oracle_sd):
         assert torch.equal(eng.score_all_pairs(pooled[lo:hi].contiguous(), pooled), m[lo:hi])
         o2, c2 = eng.size_order(centers[lo:hi], labels[lo:hi], 10)
         assert torch.equal(eng.embed(centers[lo:hi], labels[lo:hi], 10, node_cap=c2, order=o2)[0], pooled[lo:hi])
-    # (4) F1-max: device histograms over the whole matrix == sum-consistent with a sorted host computation on a block
+    # (4) F1-max: device counts over the whole matrix == sum-consistent with a sorted host computation on a block
     xz = allpairs.pose_xz(poses)
     blk = m[1000:1600]
     f_dev, _ = metrics.f1_max_device(eng, blk, pose_xz=xz, row0=1000)
@@ -546,7 +567,7 @@ def test_full_size_kitti00_properties(eng, oracle, oracle_sd):
     f_host = metrics.f1_max((d <= 3)[valid].numpy(), blk.cpu()[valid].numpy())
     assert abs(f_dev - f_host) < 1e-12
     f_all, passes = metrics.f1_max_device(eng, m, pose_xz=xz)
-    assert 0.0 <= f_all <= 1.0 and passes <= 16
+    assert 0.0 <= f_all <= 1.0 and passes <= 4
     # (5) loop closures: top-1 outside a 50-frame window really is the row maximum there
     vals, idx = eng.topk_rows(m, k=1, window=50)
     r = 2345
@@ -721,19 +742,24 @@ def test_all_release_checkpoints(release_state_dicts, golden_dir):
 
 
 def test_device_roc_auc(eng):
-    """eval_batch.py:48-49 on the device: AUC from the class-wise histograms equals the sorted host computation."""
+    """eval_batch.py:48-49 on the device: the ROC area from ranking every negative among the positive scores equals the
+    sorted host computation (one counting pass, exact)."""
     from sg_pr_amd import synth, metrics, allpairs
     centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=160, node_num=100, seed=8)
     pooled, _, _ = eng.embed(centers, labels, 10)
     m = eng.score_all_pairs(pooled, pooled)
     xz = allpairs.pose_xz(poses).cuda()
-    auc, hw = metrics.roc_auc_device(eng, m, pose_xz=xz, tol=1e-8, max_passes=4096)
+    auc = metrics.roc_auc_device(eng, m, pose_xz=xz)
     gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
     want = metrics.roc_auc(gt[valid].numpy(), m.cpu()[valid].numpy())
-    print("device AUC", auc, "+-", hw, "host", want)
-    assert hw <= 1e-8 and abs(auc - want) <= hw + 1e-12
-    fast, hw2 = metrics.roc_auc_device(eng, m, pose_xz=xz, tol=1e-4)            # the default budget of 64 passes
-    assert abs(fast - want) <= hw2 + 1e-12 and hw2 <= 1e-4
+    print("device AUC", auc, "host", want)
+    assert abs(auc - want) < 1e-12
+    # massive ties (scores rounded to two digits) and explicit labels with as many positives as negatives
+    r = (m * 100).round() / 100
+    g8 = (torch.rand(m.shape, generator=torch.Generator().manual_seed(1)) < 0.5).to(torch.int8)
+    f1, auc, passes = metrics.pr_roc_device(eng, r, gt=g8)
+    assert abs(auc - metrics.roc_auc(g8.numpy().ravel(), r.cpu().numpy().ravel())) < 1e-12
+    assert abs(f1 - metrics.f1_max(g8.numpy().ravel(), r.cpu().numpy().ravel())) < 1e-12 and passes == 1
 
 
 def test_config5_full_size(eng, oracle, oracle_sd):

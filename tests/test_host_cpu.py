@@ -216,24 +216,23 @@ def test_roc_curve_golden(golden_dir):
         assert abs(metrics.roc_auc(g["gt%d" % c], g["score%d" % c]) - float(g["auc%d" % c])) < 1e-12
 
 
-def test_roc_auc_from_histograms(golden_dir):
-    """The sort-free AUC (class-wise radix histograms, largest p*n bins refined first) equals sklearn's, ties included."""
+def test_roc_auc_from_counts(golden_dir):
+    """The sort-free ROC area (every negative ranked among the distinct positive scores) equals sklearn's, ties included."""
     from sg_pr_amd import metrics
     g = np.load(os.path.join(golden_dir, "prf1.npz"))
     for c in range(int(g["ncases"])):
-        gt, sc = g["gt%d" % c], g["score%d" % c]
-        auc, hw = metrics.roc_auc_from_histograms(metrics.histograms_of(sc, gt), tol=0.0, max_passes=100000)
-        assert hw == 0.0 and abs(auc - float(g["auc%d" % c])) < 1e-12, c
-        rough, hw2 = metrics.roc_auc_from_histograms(metrics.histograms_of(sc, gt), tol=1e-3)
-        assert abs(rough - float(g["auc%d" % c])) <= hw2 + 1e-12 <= 1e-3 + 1e-12
+        for budget in (metrics.MAX_THRESHOLDS, 5):
+            _, auc, _ = metrics.pr_roc_from_counts(*metrics.counts_of(g["score%d" % c], g["gt%d" % c]), max_thresholds=budget)
+            assert abs(auc - float(g["auc%d" % c])) < 1e-12, c
     # saturated scores (sigmoid outputs pile up next to 0 and 1) and ignored pairs
     rng = np.random.default_rng(4)
     gt = rng.integers(-1, 2, size=20000)
     sc = (1 / (1 + np.exp(-rng.normal(3 * (gt == 1), 4)))).astype(np.float32)
     sc[rng.random(20000) < 0.2] = 1.0
     keep = gt >= 0
-    auc, hw = metrics.roc_auc_from_histograms(metrics.histograms_of(sc, gt), tol=0.0, max_passes=100000)
-    assert hw == 0.0 and abs(auc - metrics.roc_auc(gt[keep], sc[keep])) < 1e-12
+    for budget in (metrics.MAX_THRESHOLDS, 64):
+        _, auc, _ = metrics.pr_roc_from_counts(*metrics.counts_of(sc, gt), max_thresholds=budget)
+        assert abs(auc - metrics.roc_auc(gt[keep], sc[keep])) < 1e-12
 
 
 def test_every_shipped_checkpoint_loads_strictly(release_state_dicts, ckpt_path, oracle):
@@ -304,19 +303,23 @@ def _allpairs_worker(rank, world, port, golden, out_dir):
     if rank == 0:
         torch.testing.assert_close(full, plain, rtol=0, atol=2e-6)   # torch-CPU matmuls are not batch-invariant
         torch.save(full, os.path.join(out_dir, "w%d.pt" % world))
-    # sharded F1-max without gathering: per-rank histograms (numpy stand-in for the HIP pass), one all_reduce per pass
+    # sharded F1-max / ROC area without gathering: positives all-gathered, per-rank counts of the negatives (numpy
+    # stand-in for the HIP pass) all-reduced
     from sg_pr_amd import metrics
     _, _, _, poses = synth.kitti_like_sequence(11, 100, 3)
+    poses[:, [3, 11]] *= 4.0                                 # 4 m per frame: pairs beyond 20 m exist among 11 frames
     block = scorer.score_rows(scorer.pooled_all(centers, labels))
 
-    def hist_fn(blk, row0, xz, prefix_bits, bits, prefixes):
+    def fns(blk, row0, xz):
         d = torch.cdist(xz[row0:row0 + blk.shape[0]].double(), xz.double())
         gt = torch.where(d <= 3, 1, torch.where(d >= 20, 0, -1)).numpy()
-        return metrics.histograms_of(blk.numpy(), gt)(prefix_bits, bits, prefixes)
+        return metrics.counts_of(blk.numpy(), gt)
 
-    f1 = scorer.f1_max(block, poses, hist_fn=hist_fn)
+    f1, auc = scorer.pr_roc(block, poses, fns=fns)
+    assert f1 == scorer.f1_max(block, poses, fns=fns)
+    f1 = "%r %r" % (f1, auc)
     with open(os.path.join(out_dir, "f1_w%d_r%d.txt" % (world, rank)), "w") as f:
-        f.write(repr(f1))
+        f.write(f1)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -333,6 +336,7 @@ def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
     three = torch.load(os.path.join(str(tmp_path), "w3.pt"))
     sd = oracle.load_checkpoint(os.path.join(golden_dir, "model.pth"))
     centers, labels, _, poses = synth.kitti_like_sequence(11, 100, 3)
+    poses[:, [3, 11]] *= 4.0                                 # (as in the worker)
     torch.set_num_threads(2)
     # same shard shapes as the two ranks (torch-CPU matmuls are not bitwise batch-invariant; the HIP engine is,
     # which tests/test_gpu_parity.py checks on the GPU)
@@ -348,12 +352,15 @@ def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
     torch.testing.assert_close(three, two, rtol=0, atol=2e-6)
     assert not torch.equal(two, two.t())                 # the NTN is asymmetric: full square needed
     gt, valid = allpairs.ground_truth_mask(allpairs.pose_distance_matrix(poses), 3)
-    assert gt.shape == (11, 11) and valid.diagonal().all() and gt.diagonal().all()
-    # both ranks computed the same F1-max from their own row blocks, equal to the gathered-matrix value
+    assert gt.shape == (11, 11) and valid.diagonal().all() and gt.diagonal().all() and (gt[valid] == 0).any()
+    # both ranks computed the same F1-max / ROC area from their own row blocks, equal to the gathered-matrix values
     from sg_pr_amd import metrics
     want = metrics.f1_max(gt[valid].numpy(), two[valid].numpy())
+    want_auc = metrics.roc_auc(gt[valid].numpy(), two[valid].numpy())
     for r in range(2):
-        assert abs(float(open(os.path.join(str(tmp_path), "f1_w2_r%d.txt" % r)).read()) - want) < 1e-12
+        f1, auc = (float(v) for v in open(os.path.join(str(tmp_path), "f1_w2_r%d.txt" % r)).read().split())
+        assert abs(f1 - want) < 1e-12
+        assert abs(auc - want_auc) < 1e-12
 
 
 def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, oracle_sd):
@@ -395,17 +402,18 @@ def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, ora
     assert f1 == 1.0 and float(open(os.path.join(args.output_path, "00_DL_F1_max.txt")).read()) == 1.0
 
 
-def test_f1_max_from_histograms_is_exact(golden_dir):
-    """Host half of the device-side F1-max: radix-bin refinement == sklearn-style sort, incl. ties and ignored pairs."""
+def test_f1_max_from_counts_is_exact(golden_dir):
+    """Host half of the device-side F1-max: thresholds at the positives' scores, bounds in between, refinement of the
+    segments that can still hold the maximum == sklearn-style sort, incl. ties and ignored pairs - whatever the
+    threshold budget per pass is."""
     from sg_pr_amd import metrics
     g = np.load(os.path.join(golden_dir, "prf1.npz"))
-    for c in range(3):
-        if f"gt{c}" not in g:
-            break
-        got, _ = metrics.f1_max_from_histograms(metrics.histograms_of(g[f"score{c}"], g[f"gt{c}"]))
-        assert abs(got - float(g[f"f1max{c}"])) < 1e-12
+    for c in range(int(g["ncases"])):
+        for budget in (metrics.MAX_THRESHOLDS, 7, 1):
+            got, _, _ = metrics.pr_roc_from_counts(*metrics.counts_of(g[f"score{c}"], g[f"gt{c}"]), max_thresholds=budget)
+            assert abs(got - float(g[f"f1max{c}"])) < 1e-12
     rng = np.random.default_rng(7)
-    for trial in range(5):
+    for trial in range(6):
         n = 60000
         gt = (rng.random(n) < 0.03).astype(np.int64)
         sc = (1.0 / (1.0 + np.exp(-(rng.normal(0, 3, n) + 4 * gt)))).astype(np.float32)
@@ -417,9 +425,14 @@ def test_f1_max_from_histograms_is_exact(golden_dir):
             gt[:] = 0                                           # no positives
         if trial == 4:
             sc = np.where(rng.random(n) < 0.5, np.float32(1.0), sc).astype(np.float32)   # saturated scores
+        if trial == 5:
+            gt = (rng.random(n) < 0.5).astype(np.int64)         # as many positives as negatives
         ign = rng.random(n) < 0.2
-        got, passes = metrics.f1_max_from_histograms(metrics.histograms_of(sc, np.where(ign, -1, gt)))
-        assert abs(got - metrics.f1_max(gt[~ign], sc[~ign])) < 1e-12 and passes <= 12
+        for budget, max_passes in ((metrics.MAX_THRESHOLDS, 2), (100, 6), (16, 16)):
+            got, auc, passes = metrics.pr_roc_from_counts(*metrics.counts_of(sc, np.where(ign, -1, gt)), max_thresholds=budget)
+            assert abs(got - metrics.f1_max(gt[~ign], sc[~ign])) < 1e-12 and passes <= max_passes, (trial, budget, passes)
+            if trial != 3:
+                assert abs(auc - metrics.roc_auc(gt[~ign], sc[~ign])) < 1e-12
 
 
 def test_custom_ops_registered_and_refuse_cpu():
