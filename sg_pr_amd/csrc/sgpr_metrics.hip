@@ -234,8 +234,8 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
         for (int q = 0; q < 4; ++q) {
             const int bq = min(b[q], a.T);
             // wave-aggregated counting: sigmoid scores of negatives pile up in a few buckets, and 64 lanes hitting one
-            // LDS counter serialise.  Up to three rounds take the most common bucket of the wave with ONE atomic
-            // (leader = the first lane still waiting); whoever is left counts on its own.
+            // LDS counter serialise.  Up to three rounds take the bucket of the first waiting lane with ONE atomic for all
+            // the lanes that share it; whoever is left counts on its own.
             int idx = neg[q] ? bq : -1;
             unsigned long long todo = __ballot(idx >= 0);
 #pragma unroll 1
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
                 if ((int)(threadIdx.x & 63) == leader) atomicAdd(&cnt[lidx], (unsigned)__popcll(same));
                 if (idx == lidx) idx = -1;
                 todo &= ~same;
+                if (__popcll(same) < 4) break;           // scattered buckets: the rounds would only add instructions
             }
             if (idx >= 0) atomicAdd(&cnt[idx], 1u);
         }
