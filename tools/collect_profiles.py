@@ -60,6 +60,11 @@ def bench_line(name, out):
 kernel_stats("kt", tag + "_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-end-to-end")
 kernel_stats("kt_stress", tag + "_stress_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload stress --no-cpu-baseline --steps 50")
 kernel_stats("kt_pairs128", tag + "_pairs128_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairs128 --no-cpu-baseline --steps 50")
+kernel_stats("kt_consumers", tag + "_consumers_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_f1.py 3")
+if os.path.exists(os.path.join(src, "consumers.log")):
+    with open(os.path.join(dst, tag + "_consumers.txt"), "w") as o:
+        o.write("# python tools/run_f1.py 10 check  (KITTI-00-sized matrix of the bench, device F1-max / ROC area)\n")
+        o.write("".join(l for l in open(os.path.join(src, "consumers.log")) if "amdgpu.ids" not in l))
 for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
                   ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
                   ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json")):

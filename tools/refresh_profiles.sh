@@ -4,6 +4,7 @@
 #   kitti00 : bench line, kernel stats of the same command, HBM counters (separate --pmc passes), SQ counters
 #   stress / pairs128 (BASELINE configs 5 / 2): bench line, kernel stats, HBM + LDS counters
 #   kitti5seq (config 4) and a 2-rank gloo run of the N > 1 path on one GPU: bench lines
+#   the matrix consumers (device F1-max / ROC area): wall times and kernel stats
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
@@ -22,4 +23,6 @@ for shape in kitti00 stress pairs128; do
   timeout 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d $O -o sq1_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq1_$shape.log 2>&1 </dev/null
   timeout 100 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O -o sq2_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq2_$shape.log 2>&1 </dev/null
 done
+timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_consumers -- python $R/tools/run_f1.py 3 > $O/kt_consumers.log 2>&1 </dev/null
 ls $O | head -80
