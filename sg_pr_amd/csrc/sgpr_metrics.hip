@@ -6,7 +6,7 @@
 //        and positives are rare (loop closures), so: (1) collect the scores of the positive pairs (no pass over the
 //        matrix: only the poses decide which entries are read), (2) the host sorts them and picks up to 8191 of their
 //        distinct values as thresholds, (3) ONE streaming pass counts the NEGATIVES between consecutive thresholds
-//        (binary search in LDS, LDS-privatised counters) - exact FP at every threshold, bounds in between - and, in the
+//        (a search tree in LDS, LDS-privatised counters) - exact FP at every threshold, bounds in between - and, in the
 //        same pass, ranks every negative among ALL positive values (the LDS search finishes with a few probes of the
 //        L2-resident value list), which is the Mann-Whitney form of the ROC area: exact, no refinement.  (4) a second
 //        pass with the thresholds of the few segments that can still hold the F1 maximum settles it exactly
@@ -152,7 +152,19 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
     float* thr = reinterpret_cast<float*>(pc_smem);                       // [Tp]
     unsigned* cnt = reinterpret_cast<unsigned*>(thr + a.Tp);              // [T + 1]
-    for (int i = threadIdx.x; i < a.Tp; i += PC_THREADS) thr[i] = i < a.T ? a.thr[i] : INFINITY;
+    // the thresholds as a complete binary search tree in breadth-first order (node 1 = root, children 2k / 2k + 1),
+    // padded with +inf: the probes of one level are neighbours in LDS.  In the sorted array the probes of the upper
+    // levels sit a power of two >= 32 words apart - all lanes of a wave in ONE bank, a 64-way conflict per step.
+    const int lg = 31 - __clz(a.Tp);
+    for (int node = threadIdx.x; node < a.Tp; node += PC_THREADS) {
+        float v = INFINITY;
+        if (node > 0) {
+            const int l = 31 - __clz(node), i = node - (1 << l);
+            const int idx = (((2 * i + 1) << (lg - 1 - l))) - 1;          // position of the node's key in sorted order
+            if (idx < a.T) v = a.thr[idx];
+        }
+        thr[node] = v;
+    }
     for (int i = threadIdx.x; i <= a.T; i += PC_THREADS) cnt[i] = 0u;
     __syncthreads();
     const PairScan& sc = a.scan;
@@ -197,12 +209,15 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
                 neg[q] = false;
             }
         }
-        // four independent branch-free binary searches (LDS), interleaved
-        int b[4] = {0, 0, 0, 0};
-        for (int step = a.Tp >> 1; step > 0; step >>= 1) {
+        // four independent branch-free descents of the tree (LDS), interleaved: right whenever the key is <= s; the
+        // leaf reached is the number of thresholds <= s
+        int b[4] = {1, 1, 1, 1};
+        for (int lvl = 0; lvl < lg; ++lvl) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] += (thr[b[q] + step - 1] <= s[q]) ? step : 0;
+            for (int q = 0; q < 4; ++q) b[q] = 2 * b[q] + ((thr[b[q]] <= s[q]) ? 1 : 0);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] -= a.Tp;
         if (a.rank) {
             // the search goes on among the S values of the bucket (L2-resident table), the four elements in step;
             // entry l then holds everything about the largest positive value <= s
