@@ -363,9 +363,11 @@ class Engine:
 
     # ------------------------------------------------------------------ consumers of the score matrix
     def _truth(self, score, row0, pose_xz, gt):
-        score = self._dev(score, torch.float32, "score")
+        if not isinstance(score, torch.Tensor):
+            score = torch.as_tensor(score)
+        if score.device != self.device or score.dtype != torch.float32 or score.dim() != 2 or score.stride(1) != 1:
+            score = score.to(device=self.device, dtype=torch.float32).contiguous()      # (row-strided views pass as they are)
         r, m = score.shape
-        assert score.stride(1) == 1
         if pose_xz is not None:
             pose_xz = self._dev(pose_xz, torch.float64, "pose_xz")
             assert pose_xz.shape[1] == 2 and pose_xz.shape[0] >= max(m, row0 + r)

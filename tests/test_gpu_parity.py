@@ -383,6 +383,25 @@ def test_device_f1_max_and_counts(eng):
     assert abs(f_small - f_host) < 1e-12 and abs(a_small - a_host) < 1e-12 and p_small >= 2
     assert metrics.f1_max_device(eng, m, pose_xz=xz)[0] == f_dev
     assert abs(metrics.roc_auc_device(eng, m, pose_xz=xz) - a_host) < 1e-12
+    # ragged shapes: M not a multiple of 4, rows with a padded leading dimension, one row, random labels incl. ignored
+    rng = np.random.default_rng(3)
+    for rows, cols, ld in ((37, 333, 340), (1, 5, 5), (129, 1023, 1023), (3, 2, 8)):
+        buf = torch.rand(rows, ld, generator=torch.Generator().manual_seed(rows)).cuda()
+        sc = buf[:, :cols]
+        lab = torch.from_numpy(rng.integers(-1, 2, size=(rows, cols)).astype(np.int8))
+        p_host, c_host = metrics.counts_of(sc.cpu().numpy(), lab.numpy())
+        p_dev, bad = eng.pair_positives(sc, gt=lab)
+        assert bad == 0
+        np.testing.assert_array_equal(np.sort(p_dev.cpu().numpy()), np.sort(p_host))
+        for t in (0, 1, 17, 1000):
+            thr = np.sort(rng.random(t).astype(np.float32))
+            c_dev, _, _ = eng.pair_threshold_counts(sc, thr, gt=lab)
+            np.testing.assert_array_equal(c_dev, c_host(thr, None)[0])
+        if p_host.size and (lab == 0).any():
+            f, a_, _ = metrics.pr_roc_device(eng, sc, gt=lab)
+            keep = lab.numpy().ravel() >= 0
+            assert abs(f - metrics.f1_max(lab.numpy().ravel()[keep], sc.cpu().numpy().ravel()[keep])) < 1e-12
+            assert abs(a_ - metrics.roc_auc(lab.numpy().ravel()[keep], sc.cpu().numpy().ravel()[keep])) < 1e-12
     # negative scores are refused, whichever class they belong to
     bad_m = m.clone()
     bad_m[3, 5] = -0.25
