@@ -175,27 +175,29 @@ int sgpr_check_status(const sgpr_handle* h, void* stream);
  * sgpr_pair_threshold_counts streams the rectangle once and counts the NEGATIVE pairs by threshold bucket: for T <=
  * 8191 ascending thresholds, d_out[b] (uint64, b = 0..T) = negatives with exactly b thresholds <= their score, so
  * FP(score >= threshold q) = sum of d_out[b], b > q.  d_out[T+1] = negatives skipped for a negative / NaN score.
- * With d_rank (the U ascending DISTINCT scores of positive pairs, each with the number of pairs that carry it and the
- * number of pairs with at least that score; d_thresholds[q] == d_rank[q * S].value, T == ceil(U / S)) every negative
- * is also ranked among all positive values and d_out[T+2] = sum over negatives of 2 #{positive pairs > s} + #{positive
- * pairs == s} = 2 P N AUC (the Mann-Whitney form of sklearn's trapezoid area): the ROC area exactly, in the same pass.
+ * With d_rank every negative is also ranked among ALL distinct scores of positive pairs: the thresholds are every S-th
+ * of those ascending values, and d_rank holds, for threshold q, the S values from it up to the next threshold in
+ * groups_per_threshold records of eight (padded with +inf / 0 pairs) together with the number of pairs that carry each;
+ * d_at_least[q] = positive pairs with a score >= threshold q.  d_out[T+2] = sum over negatives of 2 #{positive pairs
+ * > s} + #{positive pairs == s} = 2 P N AUC (the Mann-Whitney form of sklearn's trapezoid area): the ROC area exactly,
+ * in the same pass.
  * F1 peaks at the score of a positive pair, so the host (sg_pr_amd/metrics.py) takes every S-th distinct positive value
  * as thresholds, reads exact F1 there and bounds in between, and settles the few segments that can still hold the
  * maximum with a second call - exact, no sort of the matrix, which never leaves the GPU.  The workspace holds one
  * slab of counters per workgroup (no global atomics). */
-typedef struct sgpr_rank_entry {
-    float value;                /* a distinct score of positive pairs */
-    uint32_t pairs;             /* positive pairs with exactly this score */
-    uint64_t pairs_at_least;    /* positive pairs with this score or a higher one */
-} sgpr_rank_entry;
+typedef struct sgpr_rank_group {
+    float value[8];             /* ascending distinct scores of positive pairs (+inf padding) */
+    uint32_t pairs[8];          /* positive pairs with exactly that score (0 for padding) */
+} sgpr_rank_group;
 int sgpr_pair_positives(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
                         const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt, int64_t ldg,
                         float* d_out, int64_t capacity, unsigned long long* d_count, void* stream);
 size_t sgpr_pair_threshold_counts_workspace_bytes(const sgpr_handle* h, int T);
 int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
                                const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt,
-                               int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_entry* d_rank, int64_t U,
-                               int S, unsigned long long* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+                               int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_group* d_rank,
+                               int groups_per_threshold, const unsigned long long* d_at_least, unsigned long long* d_out,
+                               void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Loop-closure candidates (the use the reference makes of a sequence's similarity matrix, README.md:92-97): for every
  * row r the k (1, 4, 8 or 16) best-scoring columns c with |c - (row0 + r)| > window (window = -1 keeps every column),

@@ -7,8 +7,8 @@
 //        matrix: only the poses decide which entries are read), (2) the host sorts them and picks up to 8191 of their
 //        distinct values as thresholds, (3) ONE streaming pass counts the NEGATIVES between consecutive thresholds
 //        (a search tree in LDS, LDS-privatised counters) - exact FP at every threshold, bounds in between - and, in the
-//        same pass, ranks every negative among ALL positive values (the LDS search finishes with a few probes of the
-//        L2-resident value list), which is the Mann-Whitney form of the ROC area: exact, no refinement.  (4) a second
+//        same pass, ranks every negative among ALL positive values (the values of the bucket the LDS search lands in
+//        arrive in one round of loads from an L2-resident table), which is the Mann-Whitney form of the ROC area: exact, no refinement.  (4) a second
 //        pass with the thresholds of the few segments that can still hold the F1 maximum settles it exactly
 //        (sg_pr_amd/metrics.py).  HBM-bound integer work: coalesced 16-B reads, no global atomics inside the loop.
 //  * sgpr_topk_rows       - loop-closure candidates: for every query row the K best-scoring columns outside a temporal
@@ -138,10 +138,11 @@ struct CountArgs {
     PairScan scan;
     const float* thr;                    // [T] ascending thresholds (scores of positive pairs)
     int T, Tp;                           // Tp = the power of two above T (thresholds padded with +inf in LDS)
-    // optional exact ranking of every negative among ALL distinct positive values (ROC area):
-    const sgpr_rank_entry* rank;         // [U] ascending distinct positive values, thr[q] == rank[q * S].value
-    long long U;
-    int S, Sp;                           // Sp = the power of two >= S
+    // optional exact ranking of every negative among ALL distinct positive values (ROC area): bucket b > 0 of the
+    // thresholds holds the values rank[(b - 1) * gpt .. b * gpt), eight per record, thr[b - 1] the first of them
+    const sgpr_rank_group* rank;         // [T * gpt]
+    const unsigned long long* at_least;  // [T]: positive pairs with a value >= thr[q]
+    int gpt;
     unsigned* slabs;                     // [gridDim.x][slab_words]: T + 1 counters (padded to even) | bad (u64) | rank sum (u64)
     int slab_words;
 };
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
     float* thr = reinterpret_cast<float*>(pc_smem);                       // [Tp]
     unsigned* cnt = reinterpret_cast<unsigned*>(thr + a.Tp);              // [T + 1]
+    unsigned long long* at_least_lds = reinterpret_cast<unsigned long long*>(cnt + ((a.T + 2) & ~1));   // [T] (ranking only)
+    if (a.rank)
+        for (int i = threadIdx.x; i < a.T; i += PC_THREADS) at_least_lds[i] = a.at_least[i];
     // the thresholds as a complete binary search tree in breadth-first order (node 1 = root, children 2k / 2k + 1),
     // padded with +inf: the probes of one level are neighbours in LDS.  In the sorted array the probes of the upper
     // levels sit a power of two >= 32 words apart - all lanes of a wave in ONE bank, a 64-way conflict per step.
@@ -219,30 +223,43 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[q] -= a.Tp;
         if (a.rank) {
-            // the search goes on among the S values of the bucket (L2-resident table), the four elements in step;
-            // entry l then holds everything about the largest positive value <= s
-            long long l[4], end[4];
+            // the bucket's values (and how many pairs carry each) arrive in ONE round of independent 16-byte loads from
+            // the L2-resident table, two elements at a time: pairs above s = pairs from the bucket's first value on
+            // - pairs of the bucket's values <= s
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int bq = min(b[q], a.T);
-                l[q] = (long long)max(bq - 1, 0) * a.S;
-                end[q] = min(l[q] + a.S, a.U);
-            }
-            for (int step = a.Sp >> 1; step > 0; step >>= 1) {
+            for (int q0 = 0; q0 < 4; q0 += 2) {
+                unsigned le[2] = {0u, 0u}, eq[2] = {0u, 0u};
+                for (int gi = 0; gi < a.gpt; ++gi) {
+                    float4 v[2][2];
+                    uint4 m[2][2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const long long probe = l[q] + step;
-                    const float v = a.rank[min(probe, a.U - 1)].value;
-                    l[q] = (probe < end[q] && v <= s[q]) ? probe : l[q];
+                    for (int e = 0; e < 2; ++e) {
+                        const int bq = min(b[q0 + e], a.T);
+                        const uint4* rec = reinterpret_cast<const uint4*>(a.rank + (size_t)max(bq - 1, 0) * a.gpt + gi);
+                        v[e][0] = *reinterpret_cast<const float4*>(rec);
+                        v[e][1] = *reinterpret_cast<const float4*>(rec + 1);
+                        m[e][0] = rec[2];
+                        m[e][1] = rec[3];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float x = s[q0 + e];
+                        const float vv[8] = {v[e][0].x, v[e][0].y, v[e][0].z, v[e][0].w, v[e][1].x, v[e][1].y, v[e][1].z, v[e][1].w};
+                        const unsigned mm[8] = {m[e][0].x, m[e][0].y, m[e][0].z, m[e][0].w, m[e][1].x, m[e][1].y, m[e][1].z, m[e][1].w};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            le[e] += vv[i] <= x ? mm[i] : 0u;
+                            eq[e] += vv[i] == x ? mm[i] : 0u;
+                        }
+                    }
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const sgpr_rank_entry e = a.rank[l[q]];
-                // b == 0: s lies below every positive value, all P = pairs_at_least[0] pairs rank above it
-                const unsigned long long gt_s = b[q] > 0 ? e.pairs_at_least - e.pairs : a.rank[0].pairs_at_least;
-                const unsigned long long eq_s = (b[q] > 0 && e.value == s[q]) ? e.pairs : 0ull;
-                rank2 += neg[q] ? 2ull * gt_s + eq_s : 0ull;
+                for (int e = 0; e < 2; ++e) {
+                    const int bq = min(b[q0 + e], a.T);
+                    // b == 0: s lies below every positive value, all P = at_least[0] pairs rank above it
+                    const unsigned long long gt_s = bq > 0 ? at_least_lds[bq - 1] - le[e] : at_least_lds[0];
+                    rank2 += neg[q0 + e] ? 2ull * gt_s + (bq > 0 ? eq[e] : 0u) : 0ull;
+                }
             }
         }
 #pragma unroll
@@ -282,25 +299,26 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
     if (threadIdx.x < 2) reinterpret_cast<unsigned long long*>(slab + a.slab_words - 4)[threadIdx.x] = tail[threadIdx.x];
 }
 
-// out[i] = sum over the slabs: 32 counters per workgroup, 8 threads per counter (each sums every 8th slab)
-__global__ __launch_bounds__(256) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int slab_words, int T,
-                                                       unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long part[8][32];
+// out[i] = sum over the slabs: 32 counters per workgroup, 32 threads per counter (each sums every 32nd slab: one round
+// of independent loads), 128-B coalesced reads
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int slab_words, int T,
+                                                        unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[32][33];
     const int b = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + b;                  // counters 0..T, then T+1 = bad, T+2 = rank sum
     unsigned long long s = 0ull;
     if (i <= T) {
 #pragma unroll 8
-        for (int q = grp; q < n_slabs; q += 8) s += slabs[(size_t)q * slab_words + i];
+        for (int q = grp; q < n_slabs; q += 32) s += slabs[(size_t)q * slab_words + i];
     } else if (i <= T + 2) {
-        for (int q = grp; q < n_slabs; q += 8)
+        for (int q = grp; q < n_slabs; q += 32)
             s += reinterpret_cast<const unsigned long long*>(slabs + (size_t)q * slab_words + slab_words - 4)[i - T - 1];
     }
     part[grp][b] = s;
     __syncthreads();
     if (grp == 0 && i <= T + 2) {
 #pragma unroll
-        for (int q = 1; q < 8; ++q) s += part[q][b];
+        for (int q = 1; q < 32; ++q) s += part[q][b];
         out[i] = s;
     }
 }
@@ -434,16 +452,17 @@ size_t sgpr_pair_threshold_counts_workspace_bytes(const sgpr_handle* h, int T) {
 
 int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0,
                                const double* d_pose_xz, double d_pos, double d_neg, const signed char* d_gt,
-                               int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_entry* d_rank, int64_t U,
-                               int S, unsigned long long* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+                               int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_group* d_rank,
+                               int groups_per_threshold, const unsigned long long* d_at_least, unsigned long long* d_out,
+                               void* d_workspace, size_t workspace_bytes, void* stream) {
     int rc = check_scan("sgpr_pair_threshold_counts", h, d_score, R, M, ld, d_pose_xz, d_gt, ldg);
     if (rc != SGPR_OK) return rc;
     if (!d_out || T < 0 || T > PC_MAX_THRESHOLDS || (T > 0 && !d_thresholds)) {
         set_error("sgpr_pair_threshold_counts: 0.." + std::to_string(PC_MAX_THRESHOLDS) + " thresholds and an output buffer");
         return SGPR_E_INVALID;
     }
-    if (d_rank && (U < 1 || S < 1 || (U + S - 1) / S != T)) {
-        set_error("sgpr_pair_threshold_counts: the ranking needs U >= 1 values and T == ceil(U / S) thresholds");
+    if (d_rank && (T < 1 || groups_per_threshold < 1 || !d_at_least)) {
+        set_error("sgpr_pair_threshold_counts: the ranking needs thresholds, >= 1 value group per threshold and the pair counts");
         return SGPR_E_INVALID;
     }
     const size_t need = sgpr_pair_threshold_counts_workspace_bytes(h, T);
@@ -467,24 +486,23 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
     a.Tp = 1;
     while (a.Tp <= T) a.Tp <<= 1;
     a.rank = d_rank;
-    a.U = d_rank ? U : 0;
-    a.S = d_rank ? S : 1;
-    a.Sp = 1;
-    while (a.Sp < a.S) a.Sp <<= 1;
+    a.at_least = d_at_least;
+    a.gpt = d_rank ? groups_per_threshold : 0;
     a.slabs = static_cast<unsigned*>(d_workspace);
     a.slab_words = slab_words(T);
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_threshold_count_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (+ 16 B of static LDS)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   // (+ 16 B of static LDS)
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(pair_threshold_count_kernel)");
         attr_set = true;
     }
-    const size_t lds = (size_t)a.Tp * sizeof(float) + (size_t)(T + 1) * sizeof(unsigned);
+    const size_t lds = (size_t)a.Tp * sizeof(float) + (size_t)((T + 2) & ~1) * sizeof(unsigned) +
+                       (d_rank ? (size_t)T * sizeof(unsigned long long) : 0);
     hipLaunchKernelGGL(pair_threshold_count_kernel, dim3(h->num_cus), dim3(PC_THREADS), lds, s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pair_threshold_count_kernel launch");
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((T + 3 + 31) / 32), dim3(256), 0, s, a.slabs, h->num_cus, a.slab_words, T, d_out);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((T + 3 + 31) / 32), dim3(1024), 0, s, a.slabs, h->num_cus, a.slab_words, T, d_out);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "slab_sum_kernel launch");
     return SGPR_OK;

@@ -41,8 +41,8 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
 
 
-# struct sgpr_rank_entry of include/sgpr.h
-RANK_ENTRY = np.dtype([("value", "<f4"), ("pairs", "<u4"), ("pairs_at_least", "<u8")])
+# struct sgpr_rank_group of include/sgpr.h
+RANK_GROUP = np.dtype([("value", "<f4", (8,)), ("pairs", "<u4", (8,))])
 
 
 class SgprError(RuntimeError):
@@ -107,7 +107,7 @@ def load_library():
     lib.sgpr_pair_threshold_counts.restype = i32
     lib.sgpr_pair_threshold_counts_workspace_bytes.restype = sz
     lib.sgpr_pair_threshold_counts_workspace_bytes.argtypes = [vp, i32]
-    lib.sgpr_pair_threshold_counts.argtypes = [vp, vp, i32, i32, i64, i32, vp, dbl, dbl, vp, i64, vp, i32, vp, i64, i32, vp, vp, sz,
+    lib.sgpr_pair_threshold_counts.argtypes = [vp, vp, i32, i32, i64, i32, vp, dbl, dbl, vp, i64, vp, i32, vp, i32, vp, vp, vp, sz,
                                                vp]
     lib.sgpr_topk_rows.restype = i32
     lib.sgpr_topk_rows.argtypes = [vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp]
@@ -408,20 +408,30 @@ class Engine:
         out = torch.empty(t + 3, dtype=torch.int64, device=self.device)
         ws_bytes = self.lib.sgpr_pair_threshold_counts_workspace_bytes(self._h, t)
         ws = self._ws(ws_bytes)
-        table, step, u = None, 1, 0
+        table, at_least, gpt = None, None, 0
         if rank is not None:
             vals, step, above = rank
+            vals = np.asarray(vals, dtype=np.float32)
             above = np.asarray(above, dtype=np.int64)
-            u = int(np.asarray(vals).size)
-            assert above.size == u + 1
-            ent = np.zeros(u, dtype=RANK_ENTRY)
-            ent["value"] = vals
-            ent["pairs"] = above[:-1] - above[1:]
-            ent["pairs_at_least"] = above[:-1]
-            table = torch.from_numpy(ent.view(np.uint8)).to(self.device)
+            u, step = int(vals.size), int(step)
+            assert above.size == u + 1 and t == -(-u // step) and int(above[0]) < 2 ** 32
+            gpt = -(-step // 8)
+            # values / pair counts of threshold q's bucket = entries q * step .. (q + 1) * step, padded to gpt * 8
+            pad = t * step - u
+            v2 = np.concatenate((vals, np.full(pad, np.inf, dtype=np.float32))).reshape(t, step)
+            m2 = np.concatenate((above[:-1] - above[1:], np.zeros(pad, dtype=np.int64))).reshape(t, step)
+            v3 = np.full((t, gpt * 8), np.inf, dtype=np.float32)
+            m3 = np.zeros((t, gpt * 8), dtype=np.uint32)
+            v3[:, :step] = v2
+            m3[:, :step] = m2
+            ent = np.zeros((t, gpt), dtype=RANK_GROUP)
+            ent["value"] = v3.reshape(t, gpt, 8)
+            ent["pairs"] = m3.reshape(t, gpt, 8)
+            table = torch.from_numpy(ent.view(np.uint8).reshape(-1)).to(self.device)
+            at_least = torch.from_numpy(np.ascontiguousarray(above[:-1][::step])).to(self.device)
         rc = self.lib.sgpr_pair_threshold_counts(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz),
-                                                 float(d_pos), float(d_neg), _ptr(gt), m, _ptr(thr), t, _ptr(table), u,
-                                                 int(step), _ptr(out), _ptr(ws), ws_bytes, self._stream())
+                                                 float(d_pos), float(d_neg), _ptr(gt), m, _ptr(thr), t, _ptr(table), gpt,
+                                                 _ptr(at_least), _ptr(out), _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
         h = out.cpu().numpy()
         rank_sum = int(h[t + 2].astype(np.uint64)) if rank is not None else None
