@@ -71,8 +71,8 @@ def pack_directory(graph_dir, node_num, number_of_labels=12, names=None):
 
 
 def evaluate_all_pairs(model, seq, p_thresh=3.0, n_thresh=20.0, top_k=1, window=50, scorer=None):
-    """Whole-sequence evaluation on the device.  Returns {"f1_max", "closure_scores" [M,k], "closure_frames" [M,k],
-    "matrix" (device tensor: this rank's row block), "passes"}.  `scorer`: an AllPairsScorer for multi-GPU runs."""
+    """Whole-sequence evaluation on the device.  Returns {"f1_max", "roc_auc", "closure_scores" [M,k], "closure_frames"
+    [M,k], "matrix" (device tensor: this rank's row block)}.  `scorer`: an AllPairsScorer for multi-GPU runs."""
     from . import allpairs
     if scorer is None:
         scorer = allpairs.AllPairsScorer(model=model)
@@ -85,9 +85,9 @@ def evaluate_all_pairs(model, seq, p_thresh=3.0, n_thresh=20.0, top_k=1, window=
     pooled = scorer.pooled_all(seq.centers, seq.labels)
     block = scorer.score_rows(pooled)
     eng.check_status()                     # bad labels / broken node_cap promises are errors, not silent NaNs
-    f1 = scorer.f1_max(block, seq.poses, p_thresh=p_thresh, n_thresh=n_thresh)
+    f1, auc = scorer.pr_roc(block, seq.poses, p_thresh=p_thresh, n_thresh=n_thresh)
     vals, idx = scorer.loop_closures(block, k=top_k, window=window)
-    return {"f1_max": f1, "closure_scores": vals, "closure_frames": idx, "matrix": block}
+    return {"f1_max": f1, "roc_auc": auc, "closure_scores": vals, "closure_frames": idx, "matrix": block}
 
 
 def main(argv=None):
@@ -119,7 +119,7 @@ def main(argv=None):
         np.save(os.path.join(args.output_path, sequence + "_loop_closures.npy"),
                 np.stack((np.arange(m), r["closure_frames"][:, 0].cpu().numpy(),
                           r["closure_scores"][:, 0].cpu().numpy()), axis=1))
-        print("sequence", sequence, "frames", m, "F1 max score", r["f1_max"])
+        print("sequence", sequence, "frames", m, "roc_auc: ", r["roc_auc"], "F1 max score", r["f1_max"])
         results[sequence] = r["f1_max"]
     return results
 
