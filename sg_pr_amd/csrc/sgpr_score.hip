@@ -399,7 +399,12 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeig
     // under-occupied round) and reloads its row operands only when the row group changes
     const int ncc = (M + AP_COLS - 1) / AP_COLS;
     const int64_t items = (int64_t)ncc * ((R + AP_ROWS - 1) / AP_ROWS);
-    const int it0 = (int)(items * blockIdx.x / gridDim.x), it1 = (int)(items * (blockIdx.x + 1) / gridDim.x);
+    // workgroups go to the 8 XCDs round-robin and every XCD has its own L2: the workgroups of ONE XCD take neighbouring
+    // ranges, so that a row group's A' operands (shared by the ~4 workgroups that split its column chunks) are fetched
+    // through one L2 instead of four (FETCH_SIZE 37 -> see profiles)
+    const unsigned nwg = gridDim.x;
+    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
     f16x8 ah[AP_RW], al[AP_RW];
     f32x4 u4[AP_RW];
     int cur_rg = -1, rbase = 0;
