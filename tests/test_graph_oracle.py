@@ -44,6 +44,25 @@ def test_euclidean_clusters_is_connected_components(go):
     assert go.euclidean_clusters(x[:0], 0.5, 1) == []
 
 
+def test_euclidean_clusters_against_sklearn_dbscan(go):
+    """An independent, published implementation of the same definition: with min_samples = 1 every point is a core
+    point and DBSCAN's clusters are exactly the connected components of the radius graph that PCL's
+    EuclideanClusterExtraction (gen_label_graph.py:196-243) grows - size limits applied afterwards."""
+    cluster = pytest.importorskip("sklearn.cluster")
+    rng = np.random.default_rng(5)
+    for tol, lo, hi in ((0.2, 50, 10000), (0.5, 100, 10000), (2.0, 200, 10000)):
+        blobs = [rng.normal(rng.uniform(-20, 20, 3), rng.uniform(0.05, 0.6) * tol * 2, size=(int(rng.integers(5, 400)), 3))
+                 for _ in range(25)]
+        x = np.concatenate(blobs).astype(np.float32)
+        lab = cluster.DBSCAN(eps=tol, min_samples=1).fit(x.astype(np.float64)).labels_
+        want = [np.flatnonzero(lab == c) for c in np.unique(lab)]
+        want = sorted((g for g in want if lo <= len(g) <= hi), key=lambda g: (-len(g), g.min()))
+        got = go.euclidean_clusters(x, tol, lo, hi)
+        assert len(got) == len(want) and len(got) >= 1, (tol, len(got), len(want))
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(np.sort(a), b)
+
+
 def test_lut_and_class_rules(go):
     from sg_pr_amd import gen_label_graph as product
     np.testing.assert_array_equal(go.remap_lut(), product.remap_lut)
