@@ -14,7 +14,8 @@ node_num = 100, K = 10 -> 4541^2 = 20 620 681 ordered pairs per step.  KITTI gra
 (README.md:54), so the sequence is the seeded KITTI-like synthetic generator of sg_pr_amd.synth (`"data":
 "synthetic"`); weights are the shipped checkpoint tests/golden/model.pth.
 `kitti5seq` (BASELINE config 4): sequences 00+02+05+06+08 (M = 4541, 4661, 2761, 1101, 4071 -> 67.75 M pairs),
-evaluated one after another per step like the reference's loop over `eva_batch.sequences` (eval_batch.py:26-36).
+evaluated one after another per step like the reference's loop over `eva_batch.sequences` (eval_batch.py:26-36); the
+graphs of all five are embedded by one launch (`allpairs.SequenceSet`), the matrices scored / gathered in turn.
 
 One step = one pass of the hot path over the whole job with inputs already resident in HBM: embed every graph of
 this rank's shard (fused kNN/EdgeConv/attention kernel), exchange the pooled vectors, score this rank's row block of
@@ -89,6 +90,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="leave the score matrix sharded (skip the gather)")
     ap.add_argument("--chunks", type=int, default=4, help="pieces per rank of the overlapped gather (1 = plain gather)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the transfer-inclusive measurements")
+    ap.add_argument("--per-sequence-embed", action="store_true",
+                    help="kitti5seq: one embed launch per sequence instead of one for the shards of all sequences")
     return ap.parse_args()
 
 
@@ -200,8 +203,16 @@ def main():
             graphs_per_step += hi - lo
             n_eff_all.append(synth.effective_nodes(centers[lo:hi], labels[lo:hi], k))
         node_cap_report = max(j["node_cap"] for j in jobs)
+        seqset = None
+        if len(jobs) > 1 and not a.per_sequence_embed:
+            # several sequences: this rank's shards of all of them are embedded by ONE launch (allpairs.SequenceSet)
+            seqset = allpairs.SequenceSet(jobs[0]["scorer"], [(j["d_centers"], j["d_labels"]) for j in jobs])
+            set_order = (eng.size_order(seqset.centers, seqset.labels, k)[0] if a.embed_mode == "ordered" else None)
+            set_embed = timed(ev_embed, lambda c, l: eng.embed(c, l, k, node_cap=node_cap_report, order=set_order)[0])
 
         def step(gather=not a.no_gather):
+            if seqset is not None:
+                return seqset.run(embed_fn=set_embed, gather=gather, outs=[j["out"] for j in jobs], chunks=a.chunks)[-1]
             out = None
             for j in jobs:
                 out = j["scorer"].run(j["d_centers"], j["d_labels"], gather=gather, out=j["out"], chunks=a.chunks)
@@ -268,7 +279,7 @@ def main():
     ev_embed.clear()
     ev_tail.clear()
     dt = timed_steps(a.steps, step)
-    launches_per_step = len(host_inputs)
+    launches_per_step = max(1, round(len(ev_embed) / max(a.steps, 1)))
     embed_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in ev_embed])) / max(len(ev_embed), 1)
     tail_ms = (float(np.sum([e0.elapsed_time(e1) for e0, e1 in ev_tail])) / max(len(ev_tail), 1)) if ev_tail else None
     tail_calls_per_step = len(ev_tail) / max(a.steps, 1)

@@ -71,12 +71,15 @@ class AllPairsScorer:
         buf = t.cpu() if self._host_staged(t) else t.contiguous()
         return buf, dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst, self.group)])
 
-    def pooled_all(self, centers, labels):
-        """Embed this rank's shard and all_gather: every rank returns pooled [M, F]."""
+    def pooled_all(self, centers, labels, local=None):
+        """Embed this rank's shard and all_gather: every rank returns pooled [M, F].  `local`: the shard's pooled vectors
+        when they were embedded already (SequenceSet embeds the shards of several sequences with one launch)."""
         world, rank = self._world()
         m = labels.shape[0]
         lo, hi = shard_bounds(m, world, rank)
-        local = self.embed_fn(centers[lo:hi], labels[lo:hi])
+        if local is None:
+            local = self.embed_fn(centers[lo:hi], labels[lo:hi])
+        assert local.shape[0] == hi - lo
         if world == 1:
             return local
         cap = shard_bounds(m, world, 0)[1]               # largest shard
@@ -171,14 +174,15 @@ class AllPairsScorer:
         lo, _ = shard_bounds(block.shape[1], world, rank)
         return self._engine.topk_rows(block, k=k, row0=lo, window=window)
 
-    def run(self, centers, labels, gather=True, out=None, chunks=4):
+    def run(self, centers, labels, gather=True, out=None, chunks=4, local_pooled=None):
         """Whole job: returns the [M, M] matrix on rank 0 (row block elsewhere / if gather=False).
         `out` (rank 0): preallocated [M, M] buffer that receives the matrix.
         chunks > 1 (multi-rank gather): every rank scores its row block in `chunks` pieces and ships each piece to
         rank 0 as soon as it is computed, so the xGMI transfer of piece i overlaps the scoring of piece i+1; rank 0
         posts all its receives up front (one group per piece index, one receive per peer in it), straight into the
-        rows of the matrix.  chunks = 1 is the plain form: score the block, then one gather (gather_matrix)."""
-        pooled = self.pooled_all(centers, labels)
+        rows of the matrix.  chunks = 1 is the plain form: score the block, then one gather (gather_matrix).
+        local_pooled: see pooled_all."""
+        pooled = self.pooled_all(centers, labels, local=local_pooled)
         world, rank = self._world()
         if not gather or world == 1 or chunks <= 1:
             block = self.score_rows(pooled)
@@ -227,6 +231,34 @@ class AllPairsScorer:
         for q in reqs:
             q.wait()
         return torch.cat(keep, dim=0) if keep else pooled.new_empty((0, m))
+
+
+class SequenceSet:
+    """Several independent sequences evaluated as one job - the reference's loop over `eva_batch.sequences`
+    (eval_batch.py:26-36).  Graphs are independent, so this rank's shards of ALL sequences are embedded by ONE launch
+    (a KITTI sequence sharded over 8 ranks leaves 140..580 graphs per rank and sequence: less than one round of the
+    1024 workgroup slots of a GPU); the matrices are then scored and gathered sequence by sequence.  Results are
+    bit-identical to per-sequence runs."""
+
+    def __init__(self, scorer, sequences):
+        """sequences: list of (centers [M,N,3], labels [M,N]) tensors."""
+        self.scorer = scorer
+        self.sequences = list(sequences)
+        world, rank = scorer._world()
+        self.bounds = [shard_bounds(l.shape[0], world, rank) for _, l in self.sequences]
+        self.centers = torch.cat([c[lo:hi] for (c, _), (lo, hi) in zip(self.sequences, self.bounds)], dim=0)
+        self.labels = torch.cat([l[lo:hi] for (_, l), (lo, hi) in zip(self.sequences, self.bounds)], dim=0)
+
+    def run(self, embed_fn=None, gather=True, outs=None, chunks=4):
+        """embed_fn(centers, labels) -> pooled of the concatenated shards (default: the scorer's).  Returns one result
+        per sequence, each what AllPairsScorer.run returns."""
+        pooled = (embed_fn or self.scorer.embed_fn)(self.centers, self.labels)
+        results, at = [], 0
+        for i, ((c, l), (lo, hi)) in enumerate(zip(self.sequences, self.bounds)):
+            results.append(self.scorer.run(c, l, gather=gather, out=outs[i] if outs is not None else None, chunks=chunks,
+                                           local_pooled=pooled[at:at + hi - lo]))
+            at += hi - lo
+        return results
 
 
 def pose_xz(poses):

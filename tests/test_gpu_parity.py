@@ -663,6 +663,29 @@ def test_two_ranks_on_one_gpu_bitwise_equal_one_rank(tmp_path, ckpt_path):
     assert scorer.f1_max(one, poses) == two["f1"]
 
 
+def test_sequence_set_equals_per_sequence_runs(ckpt_path):
+    """allpairs.SequenceSet (one embed launch for the graphs of several sequences, eval_batch.py:26-36's loop) gives the
+    matrices of per-sequence runs bit for bit."""
+    from sg_pr_amd import synth, allpairs, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    args = sgpr_args()
+    args.model = ckpt_path
+    model = sg_net.SGTrainer(args, False).model
+    eng = model.engine()
+    seqs = []
+    for seed, m in ((1, 150), (2, 37), (3, 301)):
+        c, l, _, _ = synth.kitti_like_sequence(m, 100, seed)
+        seqs.append((torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()))
+    scorer = allpairs.AllPairsScorer(model=model)
+    one = [scorer.run(c, l) for c, l in seqs]
+    sset = allpairs.SequenceSet(scorer, seqs)
+    order, cap = eng.size_order(sset.centers, sset.labels, 10)
+    many = sset.run(embed_fn=lambda c, l: eng.embed(c, l, 10, node_cap=cap, order=order)[0])
+    assert [tuple(x.shape) for x in many] == [(150, 150), (37, 37), (301, 301)]
+    for a_, b_ in zip(one, many):
+        assert torch.equal(a_, b_)
+
+
 def _tail_float64(sd, rows, cols):
     """NTN + head (layers_batch.py:70-83, sg_net.py:131-136) for every (row, col) pair in float64 numpy."""
     w = sd["tensor_network.weight_matrix"].double().numpy()             # [32, 32, 16]
