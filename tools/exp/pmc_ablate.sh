@@ -2,11 +2,11 @@
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/pmca; rm -rf $O; mkdir -p $O
 cd /tmp
-for m in 256 271 16655 33039 49423 288; do
+for m in 256 257 258 260 264 271 16655 33039 49423 288 272; do
   timeout 100 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O -o m$m -- python $GRAFT_REPO_ROOT/tools/run_embed.py kitti00 2 $m > $O/m$m.log 2>&1 </dev/null
 done
 cd $GRAFT_REPO_ROOT
-for m in 256 271 16655 33039 49423 288; do python tools/pmc_summary.py $O m$m | grep embed; done
+for m in 256 257 258 260 264 271 16655 33039 49423 288 272; do python tools/pmc_summary.py $O m$m | grep embed; done
 python - <<'PY'
 import csv,glob,collections
 for m in [256,257,258,260,264,271,272,288]:
