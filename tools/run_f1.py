@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the device-side consumers of the KITTI-00-sized score matrix: F1-max and ROC AUC from class-wise histograms
+"""Time the device-side consumers of the KITTI-00-sized score matrix: F1-max and ROC area from threshold counts
 (sg_pr_amd.metrics.f1_max_device / roc_auc_device / pr_roc_device).  Prints the wall time per call and per engine call."""
 import os
 import sys
