@@ -15,7 +15,8 @@ node_num = 100, K = 10 -> 4541^2 = 20 620 681 ordered pairs per step.  KITTI gra
 "synthetic"`); weights are the shipped checkpoint tests/golden/model.pth.
 `kitti5seq` (BASELINE config 4): sequences 00+02+05+06+08 (M = 4541, 4661, 2761, 1101, 4071 -> 67.75 M pairs),
 evaluated one after another per step like the reference's loop over `eva_batch.sequences` (eval_batch.py:26-36); the
-graphs of all five are embedded by one launch (`allpairs.SequenceSet`), the matrices scored / gathered in turn.
+graphs of all five are embedded by one launch and, where nothing has to be gathered in between, their matrices scored
+by one pair of launches (`allpairs.SequenceSet`).
 
 One step = one pass of the hot path over the whole job with inputs already resident in HBM: embed every graph of
 this rank's shard (fused kNN/EdgeConv/attention kernel), exchange the pooled vectors, score this rank's row block of
@@ -90,6 +91,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="leave the score matrix sharded (skip the gather)")
     ap.add_argument("--chunks", type=int, default=4, help="pieces per rank of the overlapped gather (1 = plain gather)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the transfer-inclusive measurements")
+    ap.add_argument("--per-sequence-tails", action="store_true",
+                    help="kitti5seq: one prep + tail launch per sequence instead of one pair for all matrices")
     ap.add_argument("--per-sequence-embed", action="store_true",
                     help="kitti5seq: one embed launch per sequence instead of one for the shards of all sequences")
     return ap.parse_args()
@@ -206,7 +209,9 @@ def main():
         seqset = None
         if len(jobs) > 1 and not a.per_sequence_embed:
             # several sequences: this rank's shards of all of them are embedded by ONE launch (allpairs.SequenceSet)
-            seqset = allpairs.SequenceSet(jobs[0]["scorer"], [(j["d_centers"], j["d_labels"]) for j in jobs])
+            seqset = allpairs.SequenceSet(jobs[0]["scorer"], [(j["d_centers"], j["d_labels"]) for j in jobs],
+                                          batch_tails=not a.per_sequence_tails)
+            eng.score_all_pairs_multi = timed(ev_tail, eng.score_all_pairs_multi)   # (the batched tails' launches)
             set_order = (eng.size_order(seqset.centers, seqset.labels, k)[0] if a.embed_mode == "ordered" else None)
             set_embed = timed(ev_embed, lambda c, l: eng.embed(c, l, k, node_cap=node_cap_report, order=set_order)[0])
 

@@ -147,6 +147,23 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
                          int M, float* d_score, int64_t ld, void* d_workspace, size_t workspace_bytes,
                          void* stream);
 
+/* Several independent rectangles with ONE pair of launches - the matrices of the sequences of an evaluation job
+ * (eval_batch.py:26-36 loops over `eva_batch.sequences`): the work items of all jobs form one list that the workgroups
+ * split evenly, so small matrices do not leave the GPU half empty and the launch gaps between them disappear.  `jobs` is
+ * a HOST array (its device pointers are read at launch); results are bit-identical to one sgpr_score_all_pairs per job. */
+#define SGPR_MAX_PAIR_JOBS 8
+typedef struct sgpr_pairs_job {
+    const float* d_pooled_rows;   /* [R][32] */
+    int R;
+    const float* d_pooled_cols;   /* [M][32] */
+    int M;
+    float* d_score;               /* [R][ld] */
+    int64_t ld;
+} sgpr_pairs_job;
+size_t sgpr_score_all_pairs_multi_workspace_bytes(const sgpr_handle* h, int n_jobs, const sgpr_pairs_job* jobs);
+int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pairs_job* jobs, void* d_workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* Drop-in SG.forward (sg_net.py:112-138): dense features of both sides in,
  * (score [B], att1 [B,N], att2 [B,N]) out; att pointers may be NULL. */
 size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k);

@@ -237,12 +237,14 @@ class SequenceSet:
     """Several independent sequences evaluated as one job - the reference's loop over `eva_batch.sequences`
     (eval_batch.py:26-36).  Graphs are independent, so this rank's shards of ALL sequences are embedded by ONE launch
     (a KITTI sequence sharded over 8 ranks leaves 140..580 graphs per rank and sequence: less than one round of the
-    1024 workgroup slots of a GPU); the matrices are then scored and gathered sequence by sequence.  Results are
+    1024 workgroup slots of a GPU); the matrices are then scored with one pair of launches when nothing has to be shipped
+    between them (one process, or the row blocks stay sharded), else scored and gathered sequence by sequence.  Results are
     bit-identical to per-sequence runs."""
 
-    def __init__(self, scorer, sequences):
+    def __init__(self, scorer, sequences, batch_tails=True):
         """sequences: list of (centers [M,N,3], labels [M,N]) tensors."""
         self.scorer = scorer
+        self.batch_tails = batch_tails
         self.sequences = list(sequences)
         world, rank = scorer._world()
         self.bounds = [shard_bounds(l.shape[0], world, rank) for _, l in self.sequences]
@@ -253,12 +255,22 @@ class SequenceSet:
         """embed_fn(centers, labels) -> pooled of the concatenated shards (default: the scorer's).  Returns one result
         per sequence, each what AllPairsScorer.run returns."""
         pooled = (embed_fn or self.scorer.embed_fn)(self.centers, self.labels)
-        results, at = [], 0
-        for i, ((c, l), (lo, hi)) in enumerate(zip(self.sequences, self.bounds)):
-            results.append(self.scorer.run(c, l, gather=gather, out=outs[i] if outs is not None else None, chunks=chunks,
-                                           local_pooled=pooled[at:at + hi - lo]))
+        world, _ = self.scorer._world()
+        locals_, at = [], 0
+        for lo, hi in self.bounds:
+            locals_.append(pooled[at:at + hi - lo])
             at += hi - lo
-        return results
+        eng = self.scorer._engine
+        if eng is not None and self.batch_tails and (world == 1 or not gather):
+            # nothing to ship between the tails: all row blocks with one pair of launches (sgpr_score_all_pairs_multi)
+            jobs = []
+            for i, ((c, l), local) in enumerate(zip(self.sequences, locals_)):
+                full = self.scorer.pooled_all(c, l, local=local)
+                lo, hi = self.bounds[i]
+                jobs.append((full[lo:hi].contiguous(), full, outs[i] if (outs is not None and world == 1) else None))
+            return eng.score_all_pairs_multi(jobs)
+        return [self.scorer.run(c, l, gather=gather, out=outs[i] if outs is not None else None, chunks=chunks,
+                                local_pooled=local) for i, ((c, l), local) in enumerate(zip(self.sequences, locals_))]
 
 
 def pose_xz(poses):

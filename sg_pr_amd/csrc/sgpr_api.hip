@@ -478,6 +478,40 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
                                   static_cast<hipStream_t>(stream));
 }
 
+static int check_jobs(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs) {
+    if (!h || n < 0 || n > SGPR_MAX_PAIR_JOBS || (n > 0 && !jobs)) {
+        set_error("sgpr_score_all_pairs_multi: NULL argument or not 0.." + std::to_string(SGPR_MAX_PAIR_JOBS) + " jobs");
+        return SGPR_E_INVALID;
+    }
+    for (int j = 0; j < n; ++j) {
+        const sgpr_pairs_job& q = jobs[j];
+        if (q.R < 0 || q.M < 0 || q.ld < q.M ||
+            (q.R > 0 && q.M > 0 && (!q.d_pooled_rows || !q.d_pooled_cols || !q.d_score))) {
+            set_error("sgpr_score_all_pairs_multi: job " + std::to_string(j) + ": NULL pointer, negative count or ld < M");
+            return SGPR_E_INVALID;
+        }
+    }
+    return SGPR_OK;
+}
+
+size_t sgpr_score_all_pairs_multi_workspace_bytes(const sgpr_handle* h, int n_jobs, const sgpr_pairs_job* jobs) {
+    if (check_jobs(h, n_jobs, jobs) != SGPR_OK) return 0;
+    return score_all_pairs_multi_ws_bytes(n_jobs, jobs);
+}
+
+int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pairs_job* jobs, void* d_workspace,
+                               size_t workspace_bytes, void* stream) {
+    int rc = check_jobs(h, n_jobs, jobs);
+    if (rc != SGPR_OK) return rc;
+    const size_t need = score_all_pairs_multi_ws_bytes(n_jobs, jobs);
+    if (need > 0 && (!d_workspace || workspace_bytes < need)) {
+        set_error("sgpr_score_all_pairs_multi: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    DeviceGuard guard(h->device);
+    return launch_score_all_pairs_multi(h, n_jobs, jobs, d_workspace, static_cast<hipStream_t>(stream));
+}
+
 // workspace of sgpr_forward_dense: pooled [2B][32] | embed workspace for 2B graphs
 size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k) {
     EmbedPlan p;

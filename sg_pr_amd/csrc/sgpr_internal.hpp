@@ -121,6 +121,8 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 size_t score_all_pairs_ws_bytes(int R, int M);
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream);
+size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs);
+int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs, void* ws, hipStream_t stream);
 int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,
                float* out, hipStream_t stream);
 int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);

@@ -13,6 +13,8 @@
 //                            walks 64-column super-blocks; every store instruction writes 4 rows x 256 contiguous bytes.
 #include <math.h>
 
+#include <string.h>
+
 #include "sgpr_internal.hpp"
 
 namespace sgpr {
@@ -168,15 +170,15 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
 // instead of once per graph - plus the column half of the block term, split into two f16 planes on the way out, and
 // u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
-__global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
-                                                       const float* __restrict__ cols, int M,
-                                                       unsigned short* __restrict__ Ab, float* __restrict__ ur,
-                                                       float* __restrict__ rng, unsigned short* __restrict__ Cb) {
+__device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* __restrict__ rows, int R,
+                                              const float* __restrict__ cols, int M, unsigned short* __restrict__ Ab,
+                                              float* __restrict__ ur, float* __restrict__ rng,
+                                              unsigned short* __restrict__ Cb, const int block) {
     __shared__ float red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
-    const int g0 = (blockIdx.x >> 1) * 16, half = blockIdx.x & 1;
+    const int g0 = (block >> 1) * 16, half = block & 1;
     float amax = 0.f, umax = 0.f, emax = 0.f;
     if (g0 < R) {
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
@@ -248,9 +250,44 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
     __syncthreads();
     if (threadIdx.x < 3) {
         const int q = threadIdx.x;
-        rng[(size_t)blockIdx.x * 4 + q] = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
+        rng[(size_t)block * 4 + q] = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
     }
-    if (threadIdx.x == 3) rng[(size_t)blockIdx.x * 4 + 3] = 0.f;
+    if (threadIdx.x == 3) rng[(size_t)block * 4 + 3] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
+                                                       const float* __restrict__ cols, int M,
+                                                       unsigned short* __restrict__ Ab, float* __restrict__ ur,
+                                                       float* __restrict__ rng, unsigned short* __restrict__ Cb) {
+    ntn_prep_body(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
+}
+
+// several independent rectangles in one launch (sgpr_score_all_pairs_multi): job j owns the prep workgroups
+// [block0[j], block0[j+1]) and the work items [item0[j], item0[j+1]) of the main kernel
+constexpr int AP_MAX_JOBS = 8;
+struct ApJob {
+    const float* rows;
+    const float* cols;
+    float* score;
+    int64_t ld;
+    unsigned short* Ab;
+    unsigned short* Cb;
+    float* ur;
+    float* rng;
+    int R, M, nrng;
+};
+struct ApJobs {
+    int n;
+    int block0[AP_MAX_JOBS + 1];
+    int item0[AP_MAX_JOBS + 1];
+    ApJob job[AP_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void ntn_prep_multi_kernel(const DevWeights w, const ApJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
+    const ApJob& q = jobs.job[j];
+    ntn_prep_body(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j]);
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
@@ -358,53 +395,57 @@ __device__ __forceinline__ void slow_tile(const DevWeights& w, const float* __re
 // MFMA -> vector chains are interleaved in program order (1, 2 or 4); VAR = timing experiments only (tools/probes):
 // bit 1 drops the stores, bit 2 the operand loads of the next block, bit 4 (16) the matrix instructions, bit 5 (32) the
 // vector work between them
-template <int OCC, int NI, int VAR>
-__global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeights w, int R, int M,
-                                                              const unsigned short* __restrict__ Ab,
-                                                              const unsigned short* __restrict__ Cb,
-                                                              const float* __restrict__ ur,
-                                                              const float* __restrict__ rng, int nrng,
-                                                              const float* __restrict__ prow,
-                                                              const float* __restrict__ pcol,
-                                                              float* __restrict__ score, int64_t ld) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    // ---- can every f16 this launch forms be represented?  |A'|, |e2| and |H| <= |u| + 32 max|A'| max|e2|
-    bool fast;
-    {
-        float am = 0.f, um = 0.f, em = 0.f;
-        for (int i = lane; i < nrng; i += 64) {
-            const float4 v = *reinterpret_cast<const float4*>(rng + (size_t)i * 4);
-            am = fmaxf(am, v.x);
-            um = fmaxf(um, v.y);
-            em = fmaxf(em, v.z);
-        }
-        am = wave_max_f32(am);
-        um = wave_max_f32(um);
-        em = wave_max_f32(em);
-        fast = (am < AP_F16_SAFE) && (em < AP_F16_SAFE) && (um + 32.f * am * em < AP_F16_SAFE);
-    }
+// per-wave constants of the tail: the head's weights in the lane layout of the MFMA results
+struct ApConsts {
+    f16x8 w1hi, w1lo;
+    float4 b1v, w2v;
+    float nb2;
+};
+
+__device__ __forceinline__ ApConsts ap_consts(const DevWeights& w, int l15, int g) {
+    ApConsts c;
     const float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);   // W1[o = l15][t = 4g..4g+3]
     const _Float16 wh0 = (_Float16)w1v.x, wh1 = (_Float16)w1v.y, wh2 = (_Float16)w1v.z, wh3 = (_Float16)w1v.w;
     const _Float16 z16 = (_Float16)0.f;
-    const f16x8 w1hi = {wh0, wh1, wh2, wh3, wh0, wh1, wh2, wh3};                      // meets H's hi and lo planes
-    const f16x8 w1lo = {(_Float16)(w1v.x - (float)wh0), (_Float16)(w1v.y - (float)wh1), (_Float16)(w1v.z - (float)wh2),
+    c.w1hi = f16x8{wh0, wh1, wh2, wh3, wh0, wh1, wh2, wh3};                      // meets H's hi and lo planes
+    c.w1lo = f16x8{(_Float16)(w1v.x - (float)wh0), (_Float16)(w1v.y - (float)wh1), (_Float16)(w1v.z - (float)wh2),
                         (_Float16)(w1v.w - (float)wh3), z16, z16, z16, z16};            // meets the hi plane only
-    const float4 b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
-    const float4 w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
+    c.b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
+    c.w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
+    c.nb2 = -w.fc2_b[0] * 1.4426950408889634f;
+    return c;
+}
+
+// max |A'|, max |u|, max |e2| partials -> can every f16 the launch forms be represented?
+__device__ __forceinline__ void ap_range(const float* __restrict__ rng, int nrng, int lane, float& am, float& um, float& em) {
+    for (int i = lane; i < nrng; i += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(rng + (size_t)i * 4);
+        am = fmaxf(am, v.x);
+        um = fmaxf(um, v.y);
+        em = fmaxf(em, v.z);
+    }
+}
+__device__ __forceinline__ bool ap_fast(float am, float um, float em) {
+    am = wave_max_f32(am);
+    um = wave_max_f32(um);
+    em = wave_max_f32(em);
+    return (am < AP_F16_SAFE) && (em < AP_F16_SAFE) && (um + 32.f * am * em < AP_F16_SAFE);
+}
+
+// the work items [it0, it1) of one R x M rectangle
+template <int NI, int VAR>
+__device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k, const bool fast, int R, int M,
+                                         const unsigned short* __restrict__ Ab, const unsigned short* __restrict__ Cb,
+                                         const float* __restrict__ ur, const float* __restrict__ prow,
+                                         const float* __restrict__ pcol, float* __restrict__ score, int64_t ld,
+                                         const int it0, const int it1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
+    const float4 b1v = k.b1v, w2v = k.w2v;
     const float kL2E = 1.4426950408889634f;
-    const float nb2 = -w.fc2_b[0] * kL2E;
-    // work items = (row group of AP_ROWS, column chunk of AP_COLS), row-major; every workgroup takes a contiguous,
-    // equally long range (the grid is sized to one resident slot per workgroup, so there is no second,
-    // under-occupied round) and reloads its row operands only when the row group changes
+    const float nb2 = k.nb2;
     const int ncc = (M + AP_COLS - 1) / AP_COLS;
-    const int64_t items = (int64_t)ncc * ((R + AP_ROWS - 1) / AP_ROWS);
-    // workgroups go to the 8 XCDs round-robin and every XCD has its own L2: the workgroups of ONE XCD take neighbouring
-    // ranges, so that a row group's A' operands (shared by the ~4 workgroups that split its column chunks) are fetched
-    // through one L2 instead of four (FETCH_SIZE 37 -> see profiles)
-    const unsigned nwg = gridDim.x;
-    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
     f16x8 ah[AP_RW], al[AP_RW];
     f32x4 u4[AP_RW];
     int cur_rg = -1, rbase = 0;
@@ -525,6 +566,58 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeig
     }
 }
 
+template <int OCC, int NI, int VAR>
+__global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeights w, int R, int M,
+                                                              const unsigned short* __restrict__ Ab,
+                                                              const unsigned short* __restrict__ Cb,
+                                                              const float* __restrict__ ur,
+                                                              const float* __restrict__ rng, int nrng,
+                                                              const float* __restrict__ prow,
+                                                              const float* __restrict__ pcol,
+                                                              float* __restrict__ score, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    // ---- can every f16 this launch forms be represented?  |A'|, |e2| and |H| <= |u| + 32 max|A'| max|e2|
+    float am = 0.f, um = 0.f, em = 0.f;
+    ap_range(rng, nrng, lane, am, um, em);
+    const bool fast = ap_fast(am, um, em);
+    const ApConsts k = ap_consts(w, l15, g);
+    // work items = (row group of AP_ROWS, column chunk of AP_COLS), row-major; every workgroup takes a contiguous,
+    // equally long range (the grid is sized to one resident slot per workgroup, so there is no second,
+    // under-occupied round) and reloads its row operands only when the row group changes
+    const int ncc = (M + AP_COLS - 1) / AP_COLS;
+    const int64_t items = (int64_t)ncc * ((R + AP_ROWS - 1) / AP_ROWS);
+    // workgroups go to the 8 XCDs round-robin and every XCD has its own L2: the workgroups of ONE XCD take neighbouring
+    // ranges, so that a row group's A' operands (shared by the ~4 workgroups that split its column chunks) are fetched
+    // through one L2 instead of four (FETCH_SIZE 37 -> see profiles)
+    const unsigned nwg = gridDim.x;
+    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
+    ap_items<NI, VAR>(w, k, fast, R, M, Ab, Cb, ur, prow, pcol, score, ld, it0, it1);
+}
+
+// the same for several rectangles: the work items of all jobs form one row-major list that the workgroups split evenly
+template <int OCC, int NI>
+__global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const DevWeights w, const ApJobs jobs) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    float am = 0.f, um = 0.f, em = 0.f;
+    for (int j = 0; j < jobs.n; ++j) ap_range(jobs.job[j].rng, jobs.job[j].nrng, lane, am, um, em);
+    const bool fast = ap_fast(am, um, em);
+    const ApConsts k = ap_consts(w, l15, g);
+    const int64_t items = jobs.item0[jobs.n];
+    const unsigned nwg = gridDim.x;
+    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int g0 = (int)(items * wg / nwg), g1 = (int)(items * (wg + 1) / nwg);
+#pragma unroll 1
+    for (int j = 0; j < jobs.n; ++j) {
+        const int lo = max(g0, jobs.item0[j]) - jobs.item0[j], hi = min(g1, jobs.item0[j + 1]) - jobs.item0[j];
+        if (lo >= hi) continue;
+        const ApJob& q = jobs.job[j];
+        ap_items<NI, 0>(w, k, fast, q.R, q.M, q.Ab, q.Cb, q.ur, q.rows, q.cols, q.score, q.ld, lo, hi);
+    }
+}
+
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream) {
     if (R == 0 || M == 0) return SGPR_OK;
@@ -545,6 +638,61 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
                        cols, score, ld);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
+    return SGPR_OK;
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs) {
+    size_t total = 0;
+    for (int j = 0; j < n; ++j) total += align256(score_all_pairs_ws_bytes(jobs[j].R, jobs[j].M));
+    return total;
+}
+
+int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs, void* ws, hipStream_t stream) {
+    ApJobs a;
+    memset(&a, 0, sizeof(a));
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    int64_t items = 0;
+    int blocks = 0;
+    for (int j = 0; j < n; ++j) {
+        const int R = jobs[j].R, M = jobs[j].M;
+        if (R == 0 || M == 0) continue;                    // empty rectangles take no work
+        ApJob& q = a.job[a.n];
+        const int nrng = 2 * ap_prep_groups(R, M);
+        q.rows = jobs[j].d_pooled_rows;
+        q.cols = jobs[j].d_pooled_cols;
+        q.score = jobs[j].d_score;
+        q.ld = jobs[j].ld;
+        q.R = R;
+        q.M = M;
+        q.nrng = nrng;
+        q.ur = reinterpret_cast<float*>(base);             // the layout of launch_score_all_pairs, per job
+        q.rng = q.ur + (size_t)R * T;
+        q.Ab = reinterpret_cast<unsigned short*>(q.rng + (size_t)nrng * 4);
+        q.Cb = q.Ab + (size_t)R * 2 * 64 * 8;
+        base += align256(score_all_pairs_ws_bytes(R, M));
+        a.block0[a.n] = blocks;
+        a.item0[a.n] = (int)items;
+        blocks += nrng;
+        items += (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
+        if (items > 0x7fffffff) {
+            set_error("sgpr_score_all_pairs_multi: more than 2^31 work items");
+            return SGPR_E_INVALID;
+        }
+        ++a.n;
+    }
+    if (a.n == 0) return SGPR_OK;
+    a.block0[a.n] = blocks;
+    a.item0[a.n] = (int)items;
+    hipLaunchKernelGGL(ntn_prep_multi_kernel, dim3(blocks), dim3(256), 0, stream, h->w, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "ntn_prep_multi_kernel launch");
+    const int64_t slots = (int64_t)h->num_cus * AP_OCC;
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((score_all_pairs_multi_kernel<AP_OCC, AP_NI>), dim3(grid), dim3(256), 0, stream, h->w, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "score_all_pairs_multi_kernel launch");
     return SGPR_OK;
 }
 

@@ -33,7 +33,8 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_capped", "sgpr_embed_ordered",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
-               "sgpr_score_all_pairs", "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
+               "sgpr_score_all_pairs", "sgpr_score_all_pairs_multi_workspace_bytes", "sgpr_score_all_pairs_multi",
+               "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
                "sgpr_pair_positives", "sgpr_pair_threshold_counts_workspace_bytes", "sgpr_pair_threshold_counts",
                "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
@@ -49,6 +50,12 @@ class SgprError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "SGPR_E_?"), code, message))
         self.code = code
+
+
+class SgprPairsJob(ctypes.Structure):
+    """struct sgpr_pairs_job of include/sgpr.h"""
+    _fields_ = [("d_pooled_rows", ctypes.c_void_p), ("R", ctypes.c_int32), ("d_pooled_cols", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("d_score", ctypes.c_void_p), ("ld", ctypes.c_int64)]
 
 
 class SgprDims(ctypes.Structure):
@@ -95,6 +102,10 @@ def load_library():
     lib.sgpr_score_all_pairs_workspace_bytes.argtypes = [vp, i32, i32]
     lib.sgpr_score_all_pairs.restype = i32
     lib.sgpr_score_all_pairs.argtypes = [vp, vp, i32, vp, i32, vp, i64, vp, sz, vp]
+    lib.sgpr_score_all_pairs_multi_workspace_bytes.restype = sz
+    lib.sgpr_score_all_pairs_multi_workspace_bytes.argtypes = [vp, i32, vp]
+    lib.sgpr_score_all_pairs_multi.restype = i32
+    lib.sgpr_score_all_pairs_multi.argtypes = [vp, i32, vp, vp, sz, vp]
     lib.sgpr_forward_workspace_bytes.restype = sz
     lib.sgpr_forward_workspace_bytes.argtypes = [vp, i32, i32, i32]
     lib.sgpr_forward_dense.restype = i32
@@ -360,6 +371,31 @@ class Engine:
                                            _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
         return score
+
+    MAX_PAIR_JOBS = 8
+
+    def score_all_pairs_multi(self, jobs):
+        """Several independent rectangles with one pair of launches (sgpr_score_all_pairs_multi).  jobs: list of
+        (pooled_rows, pooled_cols) or (pooled_rows, pooled_cols, out) -> list of [R, M] score tensors."""
+        outs, keep, descr = [], [], []
+        for job in jobs:
+            rows = self._dev(job[0], torch.float32, "pooled_rows")
+            cols = self._dev(job[1], torch.float32, "pooled_cols")
+            out = job[2] if len(job) > 2 and job[2] is not None else torch.empty(rows.shape[0], cols.shape[0],
+                                                                                   dtype=torch.float32, device=self.device)
+            assert out.shape == (rows.shape[0], cols.shape[0]) and out.stride(1) == 1
+            keep.append((rows, cols))
+            outs.append(out)
+            descr.append(SgprPairsJob(rows.data_ptr(), rows.shape[0], cols.data_ptr(), cols.shape[0], out.data_ptr(),
+                                      out.stride(0) if out.shape[0] > 1 else max(out.shape[1], 1)))
+        for i in range(0, len(descr), self.MAX_PAIR_JOBS):
+            part = descr[i:i + self.MAX_PAIR_JOBS]
+            arr = (SgprPairsJob * len(part))(*part)
+            ws_bytes = self.lib.sgpr_score_all_pairs_multi_workspace_bytes(self._h, len(part), arr)
+            ws = self._ws(ws_bytes)
+            rc = self.lib.sgpr_score_all_pairs_multi(self._h, len(part), arr, _ptr(ws), ws_bytes, self._stream())
+            self._check(rc)
+        return outs
 
     # ------------------------------------------------------------------ consumers of the score matrix
     def _truth(self, score, row0, pose_xz, gt):

@@ -684,6 +684,19 @@ def test_sequence_set_equals_per_sequence_runs(ckpt_path):
     assert [tuple(x.shape) for x in many] == [(150, 150), (37, 37), (301, 301)]
     for a_, b_ in zip(one, many):
         assert torch.equal(a_, b_)
+    # ... and so does the per-sequence form of the set (batch_tails=False) and the engine entry point on ragged
+    # rectangles (rows != columns, an empty one, outputs with a padded leading dimension, more jobs than one call takes)
+    for a_, b_ in zip(one, allpairs.SequenceSet(scorer, seqs, batch_tails=False).run()):
+        assert torch.equal(a_, b_)
+    pooled = [eng.embed(c, l, 10)[0] for c, l in seqs]
+    jobs = [(pooled[0][:17], pooled[2]), (pooled[1], pooled[1][:0]), (pooled[2][5:300], pooled[0]),
+            (pooled[1][:1], pooled[1]), (pooled[0], pooled[1], torch.empty(150, 64, device="cuda")[:, :37])]
+    jobs = jobs + jobs                                   # 10 jobs: two calls of the C entry point
+    got = eng.score_all_pairs_multi(jobs)
+    for (rows, cols, *_), g_ in zip(jobs, got):
+        assert g_.shape == (rows.shape[0], cols.shape[0])
+        if g_.numel():
+            assert torch.equal(g_, eng.score_all_pairs(rows.contiguous(), cols))
 
 
 def _tail_float64(sd, rows, cols):
