@@ -601,9 +601,6 @@ template <int OCC, int NI>
 __global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const DevWeights w, const ApJobs jobs) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g = lane >> 4;
-    float am = 0.f, um = 0.f, em = 0.f;
-    for (int j = 0; j < jobs.n; ++j) ap_range(jobs.job[j].rng, jobs.job[j].nrng, lane, am, um, em);
-    const bool fast = ap_fast(am, um, em);
     const ApConsts k = ap_consts(w, l15, g);
     const int64_t items = jobs.item0[jobs.n];
     const unsigned nwg = gridDim.x;
@@ -614,6 +611,9 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const D
         const int lo = max(g0, jobs.item0[j]) - jobs.item0[j], hi = min(g1, jobs.item0[j + 1]) - jobs.item0[j];
         if (lo >= hi) continue;
         const ApJob& q = jobs.job[j];
+        float am = 0.f, um = 0.f, em = 0.f;                  // the f16 range question is answered per rectangle, like
+        ap_range(q.rng, q.nrng, lane, am, um, em);           // a call of its own would
+        const bool fast = ap_fast(am, um, em);
         ap_items<NI, 0>(w, k, fast, q.R, q.M, q.Ab, q.Cb, q.ur, q.rows, q.cols, q.score, q.ld, lo, hi);
     }
 }

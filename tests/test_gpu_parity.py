@@ -691,7 +691,8 @@ def test_sequence_set_equals_per_sequence_runs(ckpt_path):
     pooled = [eng.embed(c, l, 10)[0] for c, l in seqs]
     jobs = [(pooled[0][:17], pooled[2]), (pooled[1], pooled[1][:0]), (pooled[2][5:300], pooled[0]),
             (pooled[1][:1], pooled[1]), (pooled[0], pooled[1], torch.empty(150, 64, device="cuda")[:, :37])]
-    jobs = jobs + jobs                                   # 10 jobs: two calls of the C entry point
+    jobs.append((pooled[0][:40] * 400.0, pooled[2][:90] * 400.0))     # outside the f16 range: its own exact path, alone
+    jobs = jobs + jobs                                   # 12 jobs: two calls of the C entry point
     got = eng.score_all_pairs_multi(jobs)
     for (rows, cols, *_), g_ in zip(jobs, got):
         assert g_.shape == (rows.shape[0], cols.shape[0])
