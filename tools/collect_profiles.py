@@ -65,6 +65,18 @@ if os.path.exists(os.path.join(src, "consumers.log")):
     with open(os.path.join(dst, tag + "_consumers.txt"), "w") as o:
         o.write("# python tools/run_f1.py 10 check  (KITTI-00-sized matrix of the bench, device F1-max / ROC area)\n")
         o.write("".join(l for l in open(os.path.join(src, "consumers.log")) if "amdgpu.ids" not in l))
+cons = {}
+for nm in ("sq_consumers", "FETCH_SIZE_consumers", "WRITE_SIZE_consumers"):
+    for kname, d in pmc(nm).items():
+        if "pair_" in kname or "slab" in kname:
+            cons.setdefault(kname, {}).update(d)
+if cons:
+    with open(os.path.join(dst, tag + "_consumers_pmc.txt"), "w") as o:
+        o.write("# rocprofv3 --pmc (separate passes) -- python tools/run_f1.py 1; per-launch averages over the passes with and without the\n"
+                "# ranking; SQ counters in millions, FETCH_SIZE / WRITE_SIZE in KiB (the matrix read is 80 549 KiB)\n")
+        for kname, d in cons.items():
+            o.write("%-40s %s\n" % (kname[:40], {c: (round(v, 1) if "SIZE" in c else round(v / 1e6, 3)) for c, v in sorted(d.items())}))
+    print(open(os.path.join(dst, tag + "_consumers_pmc.txt")).read())
 for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
                   ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
                   ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json")):

@@ -25,4 +25,6 @@ for shape in kitti00 stress pairs128; do
 done
 timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_consumers -- python $R/tools/run_f1.py 3 > $O/kt_consumers.log 2>&1 </dev/null
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O -o sq_consumers -- python $R/tools/run_f1.py 1 > $O/sq_consumers.log 2>&1 </dev/null
+for c in FETCH_SIZE WRITE_SIZE; do timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o ${c}_consumers -- python $R/tools/run_f1.py 1 > $O/${c}_consumers.log 2>&1 </dev/null; done
 ls $O | head -80
