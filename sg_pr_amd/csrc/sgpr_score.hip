@@ -16,7 +16,6 @@
 #include <string.h>
 
 #include "sgpr_internal.hpp"
-#include "sgpr_prep.hpp"
 
 namespace sgpr {
 
@@ -138,14 +137,14 @@ constexpr int AP_OCC = 4;      // resident workgroups per CU the kernel is compi
 constexpr int AP_NI = 1;       // row graphs interleaved in program order (see score_all_pairs_kernel)
 constexpr float AP_F16_SAFE = 60000.f;
 
-static inline int ap_prep_groups(int R, int M) {        // = prep workgroups = range records
+static inline int ap_prep_groups(int R, int M) {
     const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
-    return ((R > msb ? R : msb) + 7) / 8;
+    return ((R > msb ? R : msb) + 15) / 16;
 }
 
 size_t score_all_pairs_ws_bytes(int R, int M) {
     const size_t nsb = (size_t)(M + AP_SB - 1) / AP_SB;
-    return (size_t)R * T * sizeof(float) + (size_t)ap_prep_groups(R, M) * 4 * sizeof(float) +
+    return (size_t)R * T * sizeof(float) + (size_t)2 * ap_prep_groups(R, M) * 4 * sizeof(float) +
            (size_t)R * 2 * 64 * 8 * sizeof(unsigned short) + nsb * 2 * 4 * 64 * 8 * sizeof(unsigned short);
 }
 
@@ -167,31 +166,77 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return fmaxf(v, __shfl_xor(v, 32));
 }
 
-// AP_PREP_GRAPHS graphs per workgroup (prep_rows: plain fp32 FMA chains - 17 k per graph -, every weight fetched once for
-// the 8 graphs; the 64 KB weight tensor comes from L1 / L2); block `block` owns graph indices [8 block, 8 block + 8) in BOTH roles: row
-// operands for indices < R, column operands for indices < round_up(M, 64) (zeros past M).  One range record per workgroup.
-constexpr int AP_PREP_GRAPHS = 8;
+// 16 graphs per pair of workgroups.  Row graphs get A' (16 x 32 per graph) as ONE small GEMM per workgroup,
+// [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
+// instead of once per graph - plus the column half of the block term, split into two f16 planes on the way out, and
+// u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
 __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* __restrict__ rows, int R,
                                               const float* __restrict__ cols, int M, unsigned short* __restrict__ Ab,
                                               float* __restrict__ ur, float* __restrict__ rng,
                                               unsigned short* __restrict__ Cb, const int block) {
     __shared__ float red[4][4];
-    __shared__ float e[AP_PREP_GRAPHS][F];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
-    const int g0 = block * AP_PREP_GRAPHS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
+    const int g0 = (block >> 1) * 16, half = block & 1;
     float amax = 0.f, umax = 0.f, emax = 0.f;
-    // column operands: thread (graph tid >> 5, feature tid & 31)
-    {
-        const int g = g0 + (tid >> 5), j = tid & 31;
-        if (g < msb) prep_col(g < M ? cols[(size_t)g * F + j] : 0.f, j, g, Cb, emax);
+    if (g0 < R) {
+        // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
+        const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
+        const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
+        for (int tile = half * 16 + wave * 4; tile < half * 16 + wave * 4 + 4; ++tile) {
+            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
+            const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wp[0 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wp[1 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wp[2 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wp[3 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wp[16 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wp[17 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wp[18 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wp[19 * T * F], acc, 0, 0, 0);
+            // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
+            const float wbc = w.ntn_wb[t * 2 * F + F + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = g0 + 4 * lq + r;
+                if (g < R) {
+                    const float a = acc[r] + wbc;
+                    amax = fmaxf(amax, fabsf(a));
+                    _Float16 h, l;
+                    split2_f16(a, h, l);
+                    unsigned short* dst = Ab + ((size_t)g * 2 * 64 + (j >> 3) * 16 + t) * 8 + (j & 7);
+                    dst[0] = __builtin_bit_cast(unsigned short, h);
+                    dst[64 * 8] = __builtin_bit_cast(unsigned short, l);
+                }
+            }
+        }
     }
-    // row operands of the 8 graphs together
-    const int n = min(AP_PREP_GRAPHS, R - g0);
-    if (n > 0) {
-        e[tid >> 5][tid & 31] = (tid >> 5) < n ? rows[(size_t)(g0 + (tid >> 5)) * F + (tid & 31)] : 0.f;
-        __syncthreads();
-        prep_rows<AP_PREP_GRAPHS>(w, e, tid, 256, g0, n, Ab, ur, amax, umax);
+    // block term of the row graphs and the column operands: one graph per wave pass
+    for (int gi = half * 8 + wave * 2; gi < half * 8 + wave * 2 + 2; ++gi) {
+        const int g = g0 + gi;
+        if (g < R) {
+            const float* e1 = rows + (size_t)g * F;
+            float s = 0.f;
+            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            s += w.ntn_bias[l15];
+            umax = fmaxf(umax, fabsf(s));
+            if (lq == 0) ur[(size_t)g * T + l15] = s;
+        }
+        const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
+        if (g < msb && lane < F) {                          // the column operand itself, two f16 planes (zeros past M)
+            const float x = g < M ? cols[(size_t)g * F + lane] : 0.f;
+            emax = fmaxf(emax, fabsf(x));
+            _Float16 h, l;
+            split2_f16(x, h, l);
+            const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
+            unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
+            dst[0] = __builtin_bit_cast(unsigned short, h);
+            dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+        }
     }
     // NaN inputs: fmaxf drops them, so fold an explicit "not finite" marker in (infinity fails every bound)
     amax = wave_max_f32(amax);
@@ -576,7 +621,7 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const D
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream) {
     if (R == 0 || M == 0) return SGPR_OK;
-    const int nrng = ap_prep_groups(R, M);
+    const int ngroups = ap_prep_groups(R, M), nrng = 2 * ngroups;
     const size_t nsb = (size_t)(M + AP_SB - 1) / AP_SB;
     float* ur = static_cast<float*>(ws);
     float* rng = ur + (size_t)R * T;
@@ -614,7 +659,7 @@ int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_j
         const int R = jobs[j].R, M = jobs[j].M;
         if (R == 0 || M == 0) continue;                    // empty rectangles take no work
         ApJob& q = a.job[a.n];
-        const int nrng = ap_prep_groups(R, M);
+        const int nrng = 2 * ap_prep_groups(R, M);
         q.rows = jobs[j].d_pooled_rows;
         q.cols = jobs[j].d_pooled_cols;
         q.score = jobs[j].d_score;

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     float* rows = dev(rnd((size_t)R * 32, 3.f)); float* cols = dev(rnd((size_t)M * 32, 3.f));
     void* ws; hipMalloc(&ws, score_all_pairs_ws_bytes(R, M));
     float* score; hipMalloc(&score, (size_t)R * M * 4);
-    const int nrng = ap_prep_groups(R, M);
+    const int ngroups = ap_prep_groups(R, M), nrng = 2 * ngroups;
     float* ur = static_cast<float*>(ws); float* rng = ur + (size_t)R * T;
     unsigned short* Ab = reinterpret_cast<unsigned short*>(rng + (size_t)nrng * 4); unsigned short* Cb = Ab + (size_t)R * 2 * 64 * 8;
     hipLaunchKernelGGL(ntn_prep_kernel, dim3(nrng), dim3(256), 0, 0, w, rows, R, cols, M, Ab, ur, rng, Cb);
