@@ -303,6 +303,15 @@ def _allpairs_worker(rank, world, port, golden, out_dir):
     if rank == 0:
         torch.testing.assert_close(full, plain, rtol=0, atol=2e-6)   # torch-CPU matmuls are not batch-invariant
         torch.save(full, os.path.join(out_dir, "w%d.pt" % world))
+    # several sequences as one job (allpairs.SequenceSet): the shards of both embedded by one call, matrices as before
+    tc, tl = torch.from_numpy(centers), torch.from_numpy(labels)
+    sset = allpairs.SequenceSet(scorer, [(tc, tl), (tc[:5], tl[:5])])
+    many = sset.run(embed_fn=lambda c, l: embed_fn(c.numpy(), l.numpy()), chunks=1)
+    short = scorer.run(centers[:5], labels[:5], chunks=1)
+    if rank == 0:
+        torch.testing.assert_close(many[0], plain, rtol=0, atol=2e-6)
+        torch.testing.assert_close(many[1], short, rtol=0, atol=2e-6)
+        assert many[1].shape == (5, 5)
     # sharded F1-max / ROC area without gathering: positives all-gathered, per-rank counts of the negatives (numpy
     # stand-in for the HIP pass) all-reduced
     from sg_pr_amd import metrics
