@@ -27,6 +27,57 @@ def shard_bounds(total, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _world_of(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _host_staged(t, group=None):
+    """gloo (the CPU tests, and the debugging aid that runs several ranks on one GPU) moves host memory only:
+    device tensors are staged through the host for it.  RCCL takes the device buffers directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_varlen(t, group=None):
+    """Concatenation over ranks (rank order) of 1-D tensors of different lengths, on every rank: one all_gather of the
+    lengths + one of the buffers padded to the longest (plain tensor collectives - nothing is pickled, nothing
+    crosses the host under RCCL).  -> (concatenated tensor on t's device, per-rank lengths list)."""
+    world, _ = _world_of(group)
+    t = t.reshape(-1).contiguous()
+    if world == 1:
+        return t, [int(t.numel())]
+    staged = _host_staged(t, group)
+    dev = t.device
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=torch.device("cpu") if staged else dev)
+    lens = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(v.item()) for v in lens]
+    cap = max(max(lens), 1)
+    buf = t.new_zeros(cap)
+    buf[: t.numel()] = t
+    if staged:
+        buf = buf.cpu()
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    out = torch.cat([p[:l] for p, l in zip(parts, lens)])
+    return (out.to(dev) if staged else out), lens
+
+
+def agree_on_error(err, like=None, group=None):
+    """Rank-local failures ahead of a collective would leave the other ranks blocked in it: every rank contributes
+    its exception (or None) to one MAX all_reduce of a flag and ALL ranks raise when any of them failed."""
+    world, rank = _world_of(group)
+    if world > 1:
+        on_dev = like is not None and like.is_cuda and not _host_staged(like, group)
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=like.device if on_dev else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) and err is None:
+            err = RuntimeError("another rank of the job failed (rank %d is fine): see its error" % rank)
+    if err is not None:
+        raise err
+
+
 class AllPairsScorer:
     """embed_fn(centers[g0:g1], labels[g0:g1]) -> pooled [g, F];  score_fn(rows, cols) -> [R, M].
 
@@ -46,14 +97,10 @@ class AllPairsScorer:
         self.group = group
 
     def _world(self):
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_world_size(self.group), dist.get_rank(self.group)
-        return 1, 0
+        return _world_of(self.group)
 
     def _host_staged(self, t):
-        """gloo (the CPU tests, and the debugging aid that runs several ranks on one GPU) moves host memory only:
-        device tensors are staged through the host for it.  RCCL takes the device buffers directly."""
-        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+        return _host_staged(t, self.group)
 
     def _irecv_ops(self, views, srcs):
         """P2POps receiving into `views` (+ the copies to run after the wait when staged)."""
@@ -140,25 +187,44 @@ class AllPairsScorer:
         world, rank = self._world()
         xz = pose_xz(poses)
         lo, _ = shard_bounds(xz.shape[0], world, rank)
-        if fns is None:
-            pos, local_count = metrics._device_fns(self._engine, block, xz.to(block.device), p_thresh, n_thresh, None, lo,
-                                                   distinct=False)
-        else:
-            pos, local_count = fns(block, lo, xz)
+        # a rank-local failure (negative / NaN scores in this rank's block, a bad label seen by the embed launch) must
+        # not strand the other ranks in the collectives below: the error is agreed on first, every rank raises
+        err, pos, local_count = None, None, None
+        try:
+            if fns is None:
+                pos, local_count = metrics._device_fns(self._engine, block, xz.to(block.device), p_thresh, n_thresh, None,
+                                                       lo, distinct=False, to_host=False)
+            else:
+                pos, local_count = fns(block, lo, xz)
+        except (ValueError, RuntimeError) as e:
+            err = e
+        agree_on_error(err, like=block, group=self.group)
         if world > 1:
-            parts = [None] * world
-            dist.all_gather_object(parts, np.asarray(pos, dtype=np.float32), group=self.group)
-            pos = np.concatenate(parts)
+            # the positives' scores of all row blocks: a padded tensor all_gather (device buffers under RCCL)
+            pt = pos if isinstance(pos, torch.Tensor) else torch.from_numpy(np.asarray(pos, dtype=np.float32))
+            if block.is_cuda and not pt.is_cuda:
+                pt = pt.to(block.device)
+            pos = all_gather_varlen(pt.to(torch.float32), self.group)[0]
+        if isinstance(pos, torch.Tensor):
+            pos = pos.cpu().numpy()
 
         def count_fn(thresholds, ranking):
-            counts, rank_sum = local_count(thresholds, ranking)
+            bad = 0
+            try:
+                counts, rank_sum = local_count(thresholds, ranking)
+            except ValueError as e:                              # agreed on below, together with the counts
+                counts, rank_sum, bad, err_c = np.zeros(len(thresholds) + 1, dtype=np.int64), 0, 1, e
             if world > 1:
-                t = torch.from_numpy(np.concatenate((np.asarray(counts, dtype=np.int64), [rank_sum or 0])))
+                t = torch.from_numpy(np.concatenate((np.asarray(counts, dtype=np.int64), [rank_sum or 0, bad])))
                 if block.is_cuda and not self._host_staged(block):
                     t = t.to(block.device)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 t = t.cpu().numpy()
-                counts, rank_sum = t[:-1], (int(t[-1]) if ranking is not None else None)
+                counts, rank_sum = t[:-2], (int(t[-2]) if ranking is not None else None)
+                if int(t[-1]):
+                    raise (err_c if bad else RuntimeError("another rank saw negative or NaN scores in its row block"))
+            elif bad:
+                raise err_c
             return counts, rank_sum
         f1, auc, _ = metrics.pr_roc_from_counts(pos, count_fn, want_auc=want_auc)
         return f1, auc

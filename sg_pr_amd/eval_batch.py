@@ -25,12 +25,23 @@ from .sg_net import SGTrainer
 from .utils import load_paires, pose_distance, tab_printer
 
 
-def score_pair_list(trainer, graph_pairs):
-    """[[path_a, path_b], ...] -> (pred float32 [P], gt float64 [P]); embeds each graph once."""
+def score_pair_list(trainer, graph_pairs, group=None):
+    """[[path_a, path_b], ...] -> (pred float32 [P], gt float64 [P]); embeds each graph once.
+
+    Under torch.distributed (one process per GPU) the list is split contiguously across the ranks (SURVEY.md 8e,
+    "pair-list mode": the reference's loop eval_batch.py:30-36 walks the list in order, so rank r takes pairs
+    [lo_r, hi_r) of it): every rank parses and embeds only the graphs its own pairs name, scores them, and the
+    per-rank `float32[P_r]` / `float64[P_r]` vectors are all-gathered in rank order (two padded tensor collectives,
+    allpairs.all_gather_varlen) - every rank returns the full vectors, identical to the single-process ones because a
+    score depends on its two graphs only."""
+    from . import allpairs
+    world, rank = allpairs._world_of(group)
+    lo, hi = allpairs.shard_bounds(len(graph_pairs), world, rank)
+    mine = graph_pairs[lo:hi]
     index, paths = {}, []
-    ia = np.empty(len(graph_pairs), dtype=np.int32)
-    ib = np.empty(len(graph_pairs), dtype=np.int32)
-    for p, (a, b) in enumerate(graph_pairs):
+    ia = np.empty(len(mine), dtype=np.int32)
+    ib = np.empty(len(mine), dtype=np.int32)
+    for p, (a, b) in enumerate(mine):
         for path in (a, b):
             if path not in index:
                 index[path] = len(paths)
@@ -40,19 +51,36 @@ def score_pair_list(trainer, graph_pairs):
     centers = np.empty((len(paths), n, 3), dtype=np.float32)
     labels = np.empty((len(paths), n), dtype=np.int32)
     poses = []
-    for g, path in enumerate(paths):
-        c, l, pose = trainer._load_graph(path)
-        centers[g], labels[g] = c, l
-        poses.append(pose)
-    gt = np.array([trainer.target_from_distance(pose_distance(poses[i], poses[j])) for i, j in zip(ia, ib)],
-                  dtype=np.float64)
     model = trainer.model
-    chunk = max(1, int(trainer.args.batch_size)) * 64
-    pooled = torch.cat([model.embed(centers[s:s + chunk], labels[s:s + chunk])[0]
-                        for s in range(0, len(paths), chunk)]) if paths else torch.empty(0, 32)
-    pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib))
-    model.engine().check_status()          # bad labels / broken node_cap promises are errors, not silent NaNs
-    return pred.cpu().numpy().reshape(-1), gt
+    dev = getattr(model.engine(), "device", None) if world > 1 else None    # (the CPU tests' stand-in has none)
+    err, pred, gt = None, torch.empty(0, device=dev if isinstance(dev, torch.device) else "cpu"), np.empty(0, dtype=np.float64)
+    try:
+        for g, path in enumerate(paths):
+            c, l, pose = trainer._load_graph(path)
+            centers[g], labels[g] = c, l
+            poses.append(pose)
+        gt = np.array([trainer.target_from_distance(pose_distance(poses[i], poses[j])) for i, j in zip(ia, ib)],
+                      dtype=np.float64)
+        chunk = max(1, int(trainer.args.batch_size)) * 64
+        if paths:
+            pooled = torch.cat([model.embed(centers[s:s + chunk], labels[s:s + chunk])[0]
+                                for s in range(0, len(paths), chunk)])
+            pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib)).reshape(-1)
+        model.engine().check_status()      # bad labels / broken node_cap promises are errors, not silent NaNs
+    except (KeyError, OSError, ValueError, RuntimeError) as e:
+        if world == 1:
+            raise
+        err = e
+    if world == 1:
+        return pred.cpu().numpy().reshape(-1), gt
+    # a rank-local failure (missing file, label outside 0..11) is raised on every rank instead of stranding the others
+    dev_like = pred if pred.is_cuda else None
+    allpairs.agree_on_error(err, like=dev_like, group=group)
+    pred_all, lens = allpairs.all_gather_varlen(pred.to(torch.float32), group)
+    gt_t = torch.from_numpy(gt)
+    gt_all, _ = allpairs.all_gather_varlen(gt_t.to(pred.device) if pred.is_cuda else gt_t, group)
+    assert lens == [b - a for a, b in (allpairs.shard_bounds(len(graph_pairs), world, r) for r in range(world))]
+    return pred_all.cpu().numpy().reshape(-1), gt_all.cpu().numpy().reshape(-1)
 
 
 def plot_curves(args, sequence, fpr, tpr, roc_auc, precision, recall):
@@ -89,11 +117,16 @@ def plot_curves(args, sequence, fpr, tpr, roc_auc, precision, recall):
     plt.close(1)
 
 
-def evaluate_sequence(trainer, sequence, args, plots=True):
+def evaluate_sequence(trainer, sequence, args, plots=True, group=None):
+    """One sequence of eval_batch.py:26-91.  Under torch.distributed the pair list is scored in shards
+    (score_pair_list); every rank gets the full vectors and computes the same metrics, rank 0 alone writes files."""
+    from . import allpairs
     graph_pairs = load_paires(os.path.join(args.pair_list_dir, sequence + ".txt"), args.graph_pairs_dir)
-    pred_db, gt_db = score_pair_list(trainer, graph_pairs)
+    pred_db, gt_db = score_pair_list(trainer, graph_pairs, group=group)
     assert len(pred_db) == len(gt_db)
     assert np.sum(gt_db) > 0  # gt_db should have positive samples   (eval_batch.py:38)
+    if allpairs._world_of(group)[1] != 0:
+        return metrics.f1_max(gt_db, pred_db)
     np.save(os.path.join(args.output_path, sequence + "_gt_db.npy"), gt_db)
     np.save(os.path.join(args.output_path, sequence + "_DL_db.npy"), pred_db)
     # ROC (eval_batch.py:48-53)
@@ -118,6 +151,17 @@ def main(argv=None):
     args = sgpr_args()
     args.load(argv[0] if argv else './config/config.yml')
     tab_printer(args)
+    # launched as `python -m torch.distributed.run --nproc-per-node N -m sg_pr_amd.eval_batch cfg`: one process per GPU
+    # (backend nccl = RCCL), every pair list scored in contiguous shards (score_pair_list)
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        args.gpu = local
+        args.cuda = str(local)
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("SGPR_BACKEND", "nccl"), device_id=torch.device("cuda", local))
     trainer = SGTrainer(args, False)
     trainer.model.eval()
     os.makedirs(args.output_path, exist_ok=True)
@@ -125,6 +169,8 @@ def main(argv=None):
     for sequence in args.sequences:
         print("sequence: ", sequence)
         results[sequence] = evaluate_sequence(trainer, sequence, args)
+    if world > 1:
+        dist.barrier()
     return results
 
 

@@ -84,7 +84,12 @@ def evaluate_all_pairs(model, seq, p_thresh=3.0, n_thresh=20.0, top_k=1, window=
     scorer.embed_fn = lambda c, l: eng.embed(c, l, k, node_cap=cap, order=order)[0]     # noqa: E731
     pooled = scorer.pooled_all(seq.centers, seq.labels)
     block = scorer.score_rows(pooled)
-    eng.check_status()                     # bad labels / broken node_cap promises are errors, not silent NaNs
+    err = None
+    try:
+        eng.check_status()                 # bad labels / broken node_cap promises are errors, not silent NaNs
+    except RuntimeError as e:              # ... on EVERY rank: agreed on before the collectives of pr_roc
+        err = e
+    allpairs.agree_on_error(err, like=block, group=scorer.group)
     f1, auc = scorer.pr_roc(block, seq.poses, p_thresh=p_thresh, n_thresh=n_thresh)
     vals, idx = scorer.loop_closures(block, k=top_k, window=window)
     return {"f1_max": f1, "roc_auc": auc, "closure_scores": vals, "closure_frames": idx, "matrix": block}

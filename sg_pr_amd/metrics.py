@@ -155,9 +155,10 @@ def pr_roc_from_counts(pos_scores, count_fn, want_auc=True, max_thresholds=MAX_T
     return max(best, 0.0), auc, passes
 
 
-def _device_fns(engine, score, pose_xz, p_thresh, n_thresh, gt, row0, distinct=True):
+def _device_fns(engine, score, pose_xz, p_thresh, n_thresh, gt, row0, distinct=True, to_host=True):
     """(positive scores of the rectangle - as (distinct values, multiplicities), sorted and counted on the device, or
-    as the raw float32 list for distinct=False - and the counting function over its negatives)."""
+    as the raw float32 list for distinct=False (left on the device for to_host=False: the sharded job all-gathers it
+    there) - and the counting function over its negatives)."""
     def count_fn(thresholds, rank):
         counts, bad, rank_sum = engine.pair_threshold_counts(score, thresholds, row0=row0, pose_xz=pose_xz, d_pos=p_thresh,
                                                              d_neg=n_thresh, gt=gt, rank=rank)
@@ -168,7 +169,7 @@ def _device_fns(engine, score, pose_xz, p_thresh, n_thresh, gt, row0, distinct=T
     if bad:
         raise ValueError("%d scores are negative or NaN" % bad)
     if not distinct:
-        return pos.cpu().numpy(), count_fn
+        return (pos.cpu().numpy() if to_host else pos), count_fn
     import torch
     u, mult = torch.unique(pos, sorted=True, return_counts=True)
     return (u.cpu().numpy(), mult.cpu().numpy().astype(np.int64)), count_fn

@@ -329,6 +329,15 @@ def _allpairs_worker(rank, world, port, golden, out_dir):
     f1 = "%r %r" % (f1, auc)
     with open(os.path.join(out_dir, "f1_w%d_r%d.txt" % (world, rank)), "w") as f:
         f.write(f1)
+    # a failure in ONE rank's block (the engine raises ValueError for negative / NaN scores) reaches every rank before
+    # any collective of the metric: the others raise too instead of blocking in the all_gather
+    def bad_fns(blk, row0, xz):
+        if rank == world - 1:
+            raise ValueError("3 scores are negative or NaN")
+        return fns(blk, row0, xz)
+
+    with pytest.raises(ValueError if rank == world - 1 else RuntimeError, match="negative or NaN|another rank"):
+        scorer.pr_roc(block, poses, fns=bad_fns)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -372,6 +381,105 @@ def test_allpairs_two_ranks_equals_one(tmp_path, golden_dir):
         assert abs(auc - want_auc) < 1e-12
 
 
+class _OracleModel:
+    """CPU stand-in for the two HIP entry points eval_batch uses (tests of the host / sharding logic only)."""
+
+    def __init__(self, oracle, sd):
+        self.oracle, self.sd = oracle, sd
+
+    def embed(self, c, l):
+        from sg_pr_amd import synth
+        return self.oracle.embed(self.sd, torch.from_numpy(synth.dense_features(np.asarray(c), np.asarray(l))), 10)
+
+    def score_pooled(self, p1, p2, i1, i2):
+        return self.oracle.score_from_pooled(self.sd, p1[i1.long()], p2[i2.long()])
+
+    def engine(self):
+        return self
+
+    def check_status(self):
+        pass
+
+
+def _pair_list_worker(rank, world, port, golden, out_dir, cfg, break_rank):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, REPO)
+    from oracle import sgpr_oracle as oracle
+    from sg_pr_amd import eval_batch, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    torch.set_num_threads(2)
+    args = sgpr_args()
+    args.load(cfg)
+    trainer = sg_net.SGTrainer(args, False)
+    trainer.model = _OracleModel(oracle, oracle.load_checkpoint(os.path.join(golden, "model.pth")))
+    os.makedirs(args.output_path, exist_ok=True)
+    if break_rank is None:
+        f1 = eval_batch.evaluate_sequence(trainer, "00", args, plots=False)
+        pairs = eval_batch.load_paires(os.path.join(args.pair_list_dir, "00.txt"), args.graph_pairs_dir)
+        pred, gt = eval_batch.score_pair_list(trainer, pairs)
+        np.save(os.path.join(out_dir, "pred_w%d_r%d.npy" % (world, rank)), pred)
+        np.save(os.path.join(out_dir, "gt_w%d_r%d.npy" % (world, rank)), gt)
+        assert f1 == 1.0
+    else:
+        # a failure on ONE rank (a graph file that does not exist) is raised on EVERY rank, not a hang of the others
+        pairs = eval_batch.load_paires(os.path.join(args.pair_list_dir, "00.txt"), args.graph_pairs_dir)
+        lo, hi = __import__("sg_pr_amd.allpairs", fromlist=["x"]).shard_bounds(len(pairs), world, break_rank)
+        pairs[lo][0] = pairs[lo][0] + ".missing"
+        try:
+            eval_batch.score_pair_list(trainer, pairs)
+            outcome = "no error"
+        except FileNotFoundError:
+            outcome = "own"
+        except RuntimeError as e:
+            outcome = "other" if "another rank" in str(e) else "unexpected %r" % e
+        with open(os.path.join(out_dir, "err_r%d.txt" % rank), "w") as f:
+            f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pair_list_sharded_equals_single_process(tmp_path, golden_dir, ckpt_path, oracle, oracle_sd):
+    """SURVEY 8e pair-list mode: contiguous split of the list over the ranks, per-rank forward, gather of float32[P_r]
+    (gloo, world sizes 2 and 3 - 7 pairs: uneven shards, and more ranks than some shards have distinct graphs).  Every
+    rank ends up with the single-process vectors; rank 0 alone writes the artefacts; a rank-local failure is raised
+    by all ranks."""
+    import torch.multiprocessing as mp
+    from sg_pr_amd import eval_batch, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    data = os.path.join(golden_dir, "data")
+    lines = ["0.json 250.json", "0.json 3.json", "250.json 250.json", "3.json 0.json", "250.json 0.json", "3.json 3.json",
+             "0.json 0.json"]
+    (tmp_path / "00.txt").write_text("\n".join(lines) + "\n")
+    cfg = _write_config(tmp_path, model=ckpt_path, graphs=data, lists=str(tmp_path), out=str(tmp_path / "eva"))
+    args = sgpr_args()
+    args.load(cfg)
+    trainer = sg_net.SGTrainer(args, False)
+    trainer.model = _OracleModel(oracle, oracle_sd)
+    pairs = eval_batch.load_paires(str(tmp_path / "00.txt"), data)
+    want_pred, want_gt = eval_batch.score_pair_list(trainer, pairs)
+    assert want_pred.dtype == np.float32 and want_gt.dtype == np.float64 and len(want_pred) == 7
+    for world, port in ((2, 29621), (3, 29623)):
+        mp.spawn(_pair_list_worker, args=(world, port, golden_dir, str(tmp_path), cfg, None), nprocs=world, join=True)
+        for r in range(world):
+            pred = np.load(str(tmp_path / ("pred_w%d_r%d.npy" % (world, r))))
+            gt = np.load(str(tmp_path / ("gt_w%d_r%d.npy" % (world, r))))
+            assert pred.dtype == np.float32 and gt.dtype == np.float64
+            np.testing.assert_array_equal(gt, want_gt)
+            # (torch-CPU matmuls are not bitwise batch-invariant: the oracle stand-in embeds other batch shapes per
+            # rank; the HIP engine is batch-invariant and the GPU suite holds the sharded run to bit equality)
+            np.testing.assert_allclose(pred, want_pred, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.load(str(tmp_path / "eva" / "00_DL_db.npy")), want_pred, rtol=0, atol=2e-6)
+    assert float(open(str(tmp_path / "eva" / "00_DL_F1_max.txt")).read()) == 1.0
+    mp.spawn(_pair_list_worker, args=(2, 29625, golden_dir, str(tmp_path), cfg, 1), nprocs=2, join=True)
+    assert open(str(tmp_path / "err_r1.txt")).read() == "own"
+    assert open(str(tmp_path / "err_r0.txt")).read() == "other"
+
+
 def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, oracle_sd):
     """eval_batch counterpart: graphs embedded once, index lists drive the tail; artefacts like the reference's."""
     from sg_pr_amd import eval_batch, sg_net, synth
@@ -383,20 +491,7 @@ def test_eval_batch_pair_list_logic(tmp_path, golden_dir, ckpt_path, oracle, ora
     args.load(cfg)
     trainer = sg_net.SGTrainer(args, False)
 
-    class OracleModel:   # CPU stand-in for the two HIP entry points used by eval_batch
-        def embed(self, c, l):
-            return oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(np.asarray(c), np.asarray(l))), 10)
-
-        def score_pooled(self, p1, p2, i1, i2):
-            return oracle.score_from_pooled(oracle_sd, p1[i1.long()], p2[i2.long()])
-
-        def engine(self):
-            return self
-
-        def check_status(self):
-            pass
-
-    trainer.model = OracleModel()
+    trainer.model = _OracleModel(oracle, oracle_sd)
     os.makedirs(args.output_path, exist_ok=True)
     f1 = eval_batch.evaluate_sequence(trainer, "00", args, plots=True)
     for png in ("00_DL_roc_curve.png", "00_DL_pr_curve.png"):                    # eval_batch.py:66, 80
