@@ -1,11 +1,15 @@
 """Build libsgpr_hip.so (the C-ABI in include/sgpr.h) for gfx950 with hipcc, in-tree.
 
-Every HIP source is compiled to its own object (in parallel; an object is reused while it is newer than its source
-and the shared headers) and the objects are linked into sg_pr_amd/lib/libsgpr_hip.so.  `force=True` (or
-SGPR_FORCE_BUILD=1 in the environment) recompiles everything from scratch.
+Every HIP source is compiled to its own object (in parallel) and the objects are linked into
+sg_pr_amd/lib/libsgpr_hip.so.  Staleness is decided by CONTENT, never by timestamps or by where the code runs: the
+sha256 of every source, header and the compiler flags is stored next to each object and next to the library
+(`*.srchash`); an artefact is reused only while its recorded hash equals the hash of what is on disk now.
+`force=True` (or SGPR_FORCE_BUILD=1 in the environment) recompiles everything from scratch.
 """
 import concurrent.futures
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -36,16 +40,36 @@ def _obj(src):
     return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
 
 
-def _newer_than(path, deps):
-    if not os.path.exists(path):
-        return False
-    t = os.path.getmtime(path)
-    return all(os.path.getmtime(d) <= t for d in deps)
+def _hash_of(paths):
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def source_hash():
+    """sha256 over every HIP source, the shared headers and the compiler flags (what the library is a function of)."""
+    return _hash_of([os.path.join(CSRC, s) for s in _sources()] + HEADERS)
+
+
+def header_abi_version():
+    """SGPR_ABI_VERSION of include/sgpr.h - what a loaded library must answer from sgpr_abi_version()."""
+    with open(HEADERS[0]) as f:
+        return int(re.search(r"#define\s+SGPR_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
+def _recorded(path):
+    try:
+        with open(path + ".srchash") as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def is_stale():
-    deps = [os.path.join(CSRC, s) for s in _sources()] + HEADERS
-    return not _newer_than(LIB_PATH, deps)
+    return not os.path.exists(LIB_PATH) or _recorded(LIB_PATH) != source_hash()
 
 
 def build_library(force=False, verbose=False):
@@ -59,15 +83,19 @@ def build_library(force=False, verbose=False):
 
     def compile_one(src):
         path, obj = os.path.join(CSRC, src), _obj(src)
-        if not force and _newer_than(obj, [path] + HEADERS):
+        want = _hash_of([path] + HEADERS)
+        if not force and os.path.exists(obj) and _recorded(obj) == want:
             return obj
         cmd = [hipcc] + FLAGS + inc + ["-c", path, "-o", obj + ".tmp"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         os.replace(obj + ".tmp", obj)
+        with open(obj + ".srchash", "w") as f:
+            f.write(want)
         return obj
 
+    total = source_hash()
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(_sources())) as pool:
         objs = list(pool.map(compile_one, _sources()))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
@@ -75,6 +103,8 @@ def build_library(force=False, verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(LIB_PATH + ".srchash", "w") as f:
+        f.write(total)
     return LIB_PATH
 
 

@@ -464,10 +464,12 @@ size_t sgpr_score_all_pairs_workspace_bytes(const sgpr_handle* h, int R, int M) 
 
 int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols, int M,
                          float* d_score, int64_t ld, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !d_pooled_rows || !d_pooled_cols || !d_score || R < 0 || M < 0 || ld < M) {
+    // an empty rectangle (a rank whose row shard is empty: fewer graphs than ranks) needs no buffers at all
+    if (!h || R < 0 || M < 0 || ld < M || (R > 0 && M > 0 && (!d_pooled_rows || !d_pooled_cols || !d_score))) {
         set_error("sgpr_score_all_pairs: NULL argument, negative count or ld < M");
         return SGPR_E_INVALID;
     }
+    if (R == 0 || M == 0) return SGPR_OK;
     const size_t need = score_all_pairs_ws_bytes(R, M);
     if (need > 0 && (!d_workspace || workspace_bytes < need)) {
         set_error("sgpr_score_all_pairs: workspace of " + std::to_string(need) + " bytes required");

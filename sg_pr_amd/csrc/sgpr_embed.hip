@@ -10,17 +10,20 @@
 //      W.[x_j - x_i ; x_i] = W1.x_j + (W2-W1).x_i,  BN(eval) folded into W, and since
 //      LeakyReLU is monotone   max_m lrelu(a_j + b_i) = lrelu(max_m a_j + b_i)
 //    => two per-node GEMMs (a = W1'x, b = (W2-W1)'x + t) and a gather-max over the k neighbours.
-//  * every matrix product (Gram, per-node GEMMs, conv_end) runs on v_mfma_f32_16x16x32_bf16 with both operands split
-//    into three bf16 planes (x = hi + mid + lo, exact to 24 bits; fp32-class results, see tile16): the fp32 MFMA
-//    blocks the VALU of its SIMD for 32 cycles per instruction and is 2.7x slower per product.
+//  * every matrix product (Gram, per-node GEMMs, conv_end) runs on v_mfma_f32_16x16x32_f16 with both operands split
+//    into two f16 planes (x = hi + lo, 22 bits; three cross products in two fp32 chains, see tile16); graphs whose
+//    values leave the f16 range are embedded again by the wide-range instance (three bf16 planes = 24 bits on
+//    v_mfma_f32_16x16x32_bf16, or fp32 rows split on load).  The fp32 MFMA blocks the VALU of its SIMD for 32 cycles
+//    per instruction and is several times slower per product.
 //  * kNN: Gram matrix X.X^T (upper triangle only when the whole key matrix fits in LDS), ranking key
 //    |x_j|^2 - 2 x_i.x_j (= the reference's -pairwise_distance up to the row constant |x_i|^2), then an exact
 //    k-smallest selection per row: register sorting networks + butterfly merges, deterministic lowest-index tie-break.
 //  * trailing duplicate (padding) slots collapse to one representative; with packed input the whole semantic branch
 //    runs on 13 label super-nodes (embed_kernel, "semantic branch on label super-nodes").
 //  * one workgroup per graph, 128..512 threads chosen by the host plan (make_embed_plan): graphs of <= 64 processed
-//    slots run as three 4-wave workgroups per CU on an instance that needs <= 168 VGPRs and no scratch; everything
-//    between the input read and the pooled vector lives in LDS / registers.
+//    slots run on the lean instance - one fixed 39 424-byte LDS layout (30 208 bytes for <= 48 slots), 88 VGPRs, no
+//    scratch: four (five) 4-wave (3-wave) workgroups per CU; everything between the input read and the pooled vector
+//    lives in LDS / registers.
 #include <math.h>
 
 #include "sgpr_internal.hpp"
@@ -171,11 +174,13 @@ struct KParams {
 };
 
 // ------------------------------------------------------------------ MFMA helpers
-// Every matrix product of the kernel (Gram, per-node GEMMs, conv_end) runs on v_mfma_f32_16x16x32_bf16 with both
-// operands split into three bf16 planes, x = hi + mid + lo (exact to 24 bits): the six significant cross products
-// are accumulated in fp32, smallest first, which reproduces the fp32 product to ~2^-24.  fp32 MFMA
-// (v_mfma_f32_16x16x4_f32) blocks the VALU of its SIMD for 32 cycles per instruction (tools/probes/coexec_probe.hip);
-// the bf16 instruction does not, and six of them cost 96 cycles per 16x16x32 block against 256 in fp32.
+// Every matrix product of the kernel (Gram, per-node GEMMs, conv_end) runs on the 16x16x32 half-precision matrix
+// instructions with both operands split into planes: two f16 planes (x = hi + lo, 22 bits, three significant cross
+// products) in the default instance, three bf16 planes (x = hi + mid + lo, exact to 24 bits, six products) in the
+// wide-range instance; products are accumulated in fp32, the correction terms in a chain of their own (tile16).
+// fp32 MFMA (v_mfma_f32_16x16x4_f32) blocks the VALU of its SIMD for 32 cycles per instruction
+// (tools/probes/coexec_probe.hip); the half-precision instructions do not, and three of them cost 48 cycles per
+// 16x16x32 block against 256 in fp32.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
@@ -1147,7 +1152,7 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
 
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
-// LEAN: the instance for alias_da plans - 256 threads, three workgroups per CU (<= 168 VGPRs)
+// LEAN (64 / 48): the instance of the fixed lean layouts - 256 / 192 threads, four / five workgroups per CU (88 VGPRs)
 template <int KP, int DBG, int LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
 __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1746,16 +1751,21 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
         unsigned long long wide = reinterpret_cast<const unsigned long long*>(smem)[0];
         unsigned long long full = reinterpret_cast<const unsigned long long*>(smem)[1];
         __syncthreads();
-        while (wide) {                                       // workgroup-uniform
+        // the graphs that need the generic semantic branch first: the full f16 plan resets the slot's flag and raises it
+        // again (1) when an activation or a coordinate leaves the f16 range - such a slot joins the wide-range list
+        while (full) {                                       // workgroup-uniform
+            const int bit = __ffsll((long long)full) - 1;
+            const int slot = base + bit;
+            full &= full - 1;
+            embed_graph<KP, 0, 0, FMT_H2>(kp, kp.p2, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+            __threadfence();
+            __syncthreads();                                 // LDS is reused by the next graph; thread 0's flag is visible
+            if (__hip_atomic_load(&kp.a.redo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) wide |= 1ull << bit;
+        }
+        while (wide) {
             const int slot = base + __ffsll((long long)wide) - 1;
             wide &= wide - 1;
             embed_graph<KP, 0, 0, FMTW>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot);
-            __syncthreads();                                 // LDS is reused by the next graph
-        }
-        while (full) {
-            const int slot = base + __ffsll((long long)full) - 1;
-            full &= full - 1;
-            embed_graph<KP, 0, 0, FMT_H2>(kp, kp.p2, kp.a.ids ? kp.a.ids[slot] : slot, slot);
             __syncthreads();
         }
     }

@@ -126,7 +126,12 @@ __global__ __launch_bounds__(256) void pair_positives_kernel(const PairScan a, f
                 }
             }
             __syncthreads();
-            if (nbuf > PP_BUF - 4 * 256) flush();        // (uniform) room for one more iteration is gone
+            // room for one more iteration is gone?  The decision is latched by every thread BEFORE anyone can append
+            // again (the next iteration's atomicAdd on nbuf): a fast wave must not change what a slow wave still reads,
+            // or the waves would disagree on entering flush() and its barriers
+            const bool full = nbuf > PP_BUF - 4 * 256;
+            __syncthreads();
+            if (full) flush();
         }
     }
     __syncthreads();

@@ -146,6 +146,10 @@ def load_library():
     lib.sgpr_last_error.argtypes = []
     lib.sgpr_abi_version.restype = i32
     lib.sgpr_abi_version.argtypes = []
+    want = _build.header_abi_version()
+    if lib.sgpr_abi_version() != want:     # a library built from other sources than the header this binding follows
+        raise ImportError("%s reports C-ABI version %d, include/sgpr.h declares %d: rebuild it "
+                          "(`python -m sg_pr_amd._build --force`)" % (path, lib.sgpr_abi_version(), want))
     _lib = lib
     return lib
 

@@ -188,6 +188,8 @@ def pack_graph(centers, nodes, node_num, number_of_labels=12, strict=False):
 class SGTrainer(object):
     """Inference half of the reference harness (sg_net.py:141-206, 241-310, 434-525)."""
 
+    GRAPH_CACHE_MAX = 65536      # packed graphs kept by _load_graph (LRU): ~110 MB at node_num 100, > 14 KITTI-00s
+
     def __init__(self, args, train=True):
         if train:
             raise NotImplementedError("training (SGTrainer.fit) is out of scope of the MI355X engine; "
@@ -196,7 +198,7 @@ class SGTrainer(object):
         self.model_pth = self.args.model
         self.initial_label_enumeration(train)
         self.setup_model(train)
-        self._graph_cache = {}
+        self._graph_cache = OrderedDict()            # path -> packed graph, least recently used first
 
     def initial_label_enumeration(self, train=True):
         """sg_net.py:178-206 - twelve SemanticKITTI-derived node classes."""
@@ -226,6 +228,10 @@ class SGTrainer(object):
             c, l = pack_graph(d["centers"], d["nodes"], int(self.args.node_num), self.number_of_labels)
             g = (c, l, d["pose"])
             self._graph_cache[path] = g
+            while len(self._graph_cache) > self.GRAPH_CACHE_MAX:       # bounded: 1.7 KB per packed graph at node_num 100
+                self._graph_cache.popitem(last=False)
+        else:
+            self._graph_cache.move_to_end(path)
         return g
 
     def target_from_distance(self, distance):

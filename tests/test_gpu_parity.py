@@ -700,6 +700,136 @@ def test_sequence_set_equals_per_sequence_runs(ckpt_path):
             assert torch.equal(g_, eng.score_all_pairs(rows.contiguous(), cols))
 
 
+# ------------------------------------------------------------------ config 4 on real RCCL (needs >= 2 GPUs; skips cleanly on a 1-GPU box)
+def _rccl_worker(rank, world, port, ckpt, golden, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sg_pr_amd import synth, allpairs, sg_net, eval_batch
+    from sg_pr_amd.parser_sg import sgpr_args
+    args = sgpr_args()
+    args.model = ckpt
+    args.gpu = rank
+    args.cuda = str(rank)
+    trainer = sg_net.SGTrainer(args, False)
+    dev = torch.device("cuda", rank)
+    seqs, poses = [], []
+    for seed, m in ((6, 403), (7, 131), (8, 7)):                       # uneven shards; 7 graphs < 8 ranks: empty shards
+        c, l, _, p = synth.kitti_like_sequence(m, 100, seed)
+        seqs.append((torch.from_numpy(c).to(dev), torch.from_numpy(l).to(dev)))
+        poses.append(p)
+    scorer = allpairs.AllPairsScorer(model=trainer.model)
+    full = scorer.run(*seqs[0], chunks=4)                               # pieces shipped over xGMI while the next is scored
+    plain = scorer.run(*seqs[0], chunks=1)                              # plain gather
+    block = scorer.run(*seqs[0], gather=False)
+    f1, auc = scorer.pr_roc(block, poses[0])                            # all_gather of positives + all_reduce of counts
+    many = allpairs.SequenceSet(scorer, seqs).run(chunks=4)             # config 4's shape: sequences back to back
+    sharded = allpairs.SequenceSet(scorer, seqs).run(gather=False)      # batched tails, matrices left sharded
+    # pair-list mode (eval_batch.py:30-36) in shards over RCCL
+    data = os.path.join(golden, "data")
+    names = ["0.json", "3.json", "250.json"]
+    pairs = [[os.path.join(data, a), os.path.join(data, b)] for a in names for b in names] * 3
+    pred, gt = eval_batch.score_pair_list(trainer, pairs)
+    lo, hi = allpairs.shard_bounds(seqs[1][1].shape[0], world, rank)
+    torch.save({"rows": sharded[1].cpu(), "lo": lo, "hi": hi}, os.path.join(out_dir, "rows_r%d.pt" % rank))
+    if rank == 0:
+        assert torch.equal(full, plain)
+        torch.save({"full": full.cpu(), "many": [x.cpu() for x in many], "f1": f1, "auc": auc, "pred": pred, "gt": gt},
+                   os.path.join(out_dir, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than two")
+def test_rccl_ranks_bitwise_equal_one_rank(tmp_path, ckpt_path, golden_dir):
+    """BASELINE config 4's machinery on the real backend: min(8, #GPUs) ranks, backend nccl (= RCCL over xGMI), one GPU
+    each.  all_gather of pooled vectors, the overlapped point-to-point gather in 4 pieces and the plain gather, several
+    sequences as one job, the sharded F1-max / ROC area and the sharded pair list - every result bit-identical to the
+    one-rank run (each score depends on its two graphs only)."""
+    import torch.multiprocessing as mp
+    from sg_pr_amd import synth, allpairs, sg_net, eval_batch
+    from sg_pr_amd.parser_sg import sgpr_args
+    world = min(8, torch.cuda.device_count())
+    mp.spawn(_rccl_worker, args=(world, 29651, ckpt_path, golden_dir, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "rccl.pt"), weights_only=False)
+    args = sgpr_args()
+    args.model = ckpt_path
+    trainer = sg_net.SGTrainer(args, False)
+    scorer = allpairs.AllPairsScorer(model=trainer.model)
+    mats = []
+    for (seed, m), g_ in zip(((6, 403), (7, 131), (8, 7)), got["many"]):
+        c, l, _, poses = synth.kitti_like_sequence(m, 100, seed)
+        one = scorer.run(torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda())
+        assert torch.equal(one.cpu(), g_)
+        mats.append((one, poses))
+    assert torch.equal(mats[0][0].cpu(), got["full"])
+    f1, auc = scorer.pr_roc(mats[0][0], mats[0][1])
+    assert f1 == got["f1"] and auc == got["auc"]
+    for r in range(world):                                               # the sharded (ungathered) row blocks
+        blk = torch.load(os.path.join(str(tmp_path), "rows_r%d.pt" % r))
+        assert torch.equal(blk["rows"], mats[1][0][blk["lo"]:blk["hi"]].cpu())
+    data = os.path.join(golden_dir, "data")
+    names = ["0.json", "3.json", "250.json"]
+    pairs = [[os.path.join(data, a), os.path.join(data, b)] for a in names for b in names] * 3
+    pred, gt = eval_batch.score_pair_list(trainer, pairs)
+    np.testing.assert_array_equal(pred, got["pred"])
+    np.testing.assert_array_equal(gt, got["gt"])
+
+
+@pytest.mark.timeout(900)
+def test_config4_full_size_on_one_gpu(oracle, oracle_sd, ckpt_path):
+    """BASELINE config 4 at FULL size on one GPU: KITTI 00+02+05+06+08-sized sequences, 17 135 graphs, 67.75 M pairs.
+    `allpairs.SequenceSet` (one embed launch for all graphs, one pair of launches for the five matrices) gives the
+    matrices of per-sequence runs bit for bit; 16 sampled pairs per sequence are within 1e-4 of the oracle; every
+    matrix has the properties a correct one must have whatever its size (finite, in (0,1), asymmetric, pair-list
+    kernel agreement on sampled pairs)."""
+    from sg_pr_amd import synth, allpairs, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    frames = (("00", 4541), ("02", 4661), ("05", 2761), ("06", 1101), ("08", 4071))
+    args = sgpr_args()
+    args.model = ckpt_path
+    model = sg_net.SGTrainer(args, False).model
+    eng = model.engine()
+    host, seqs = [], []
+    for si, (_, m) in enumerate(frames):
+        c, l, _, _ = synth.kitti_like_sequence(num_graphs=m, node_num=100, seed=si)
+        host.append((c, l))
+        seqs.append((torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()))
+    assert sum(m for _, m in frames) == 17135 and sum(m * m for _, m in frames) == 67749285
+    scorer = allpairs.AllPairsScorer(model=model)
+    sset = allpairs.SequenceSet(scorer, seqs)
+    order, cap = eng.size_order(sset.centers, sset.labels, 10)
+    many = sset.run(embed_fn=lambda c, l: eng.embed(c, l, 10, node_cap=cap, order=order)[0])
+    eng.check_status()
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for (name, m), (c, l), (dc, dl), got in zip(frames, host, seqs, many):
+        assert got.shape == (m, m)
+        one = scorer.run(dc, dl)                                     # the per-sequence job (eval_batch.py:26-36's loop body)
+        assert torch.equal(one, got), name
+        del one
+        assert torch.isfinite(got).all() and float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+        assert not torch.equal(got[:64, :64], got[:64, :64].t())     # the NTN is asymmetric
+        ii, jj = rng.integers(0, m, size=16), rng.integers(0, m, size=16)
+        gi = np.concatenate((ii, jj))
+        rp = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(c[gi], l[gi])), 10)[0]
+        rs = oracle.score_from_pooled(oracle_sd, rp[:16], rp[16:])
+        sample = got[torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()].cpu()
+        err = (sample - rs).abs().max().item()
+        worst = max(worst, err)
+        assert err <= SCORE_TOL, (name, err)
+        pooled = eng.embed(dc[gi], dl[gi], 10)[0]
+        lst = eng.score_pairs(pooled[:16].contiguous(), pooled[16:].contiguous()).cpu()
+        assert (lst - sample).abs().max().item() <= 2e-6             # pair-list kernel (fp32) vs the dense tail (f16 planes)
+    print("config 4 full size: worst max|dscore| on 5 x 16 oracle-sampled pairs =", worst)
+
+
 def _tail_float64(sd, rows, cols):
     """NTN + head (layers_batch.py:70-83, sg_net.py:131-136) for every (row, col) pair in float64 numpy."""
     w = sd["tensor_network.weight_matrix"].double().numpy()             # [32, 32, 16]
@@ -891,3 +1021,40 @@ def test_f16_planes_range_fallback(eng, oracle, oracle_sd):
     finally:
         eng.set_skip_mask(0)
     assert torch.equal(p_big_wide[~keep], pooled[~keep])
+
+
+def test_generic_branch_graph_outside_f16_range(eng, oracle, oracle_sd):
+    """The second pass (embed_redo_kernel) chains its two reasons: a graph that the lean plan hands over for the
+    generic semantic branch (fewer than 17 processed slots) is embedded on the full f16 plan - and when THAT run leaves
+    the f16 range (coordinates in millimetres) it must still reach the wide-range instance instead of keeping an
+    overflowed pooled vector."""
+    from sg_pr_amd import synth
+    centers, labels, _ = synth.make_graphs(40, 100, 25, 60, 77, kitti_like=True)
+    small = np.arange(0, 40, 4)                                # every fourth graph: 6 real nodes -> 7 processed slots
+    centers[small, 6:] = 0.0
+    labels[small, 6:] = -1
+    big = centers.copy()
+    big[small[::2]] *= 2000.0                                  # half of the small ones also leave the f16 range
+    big[1::8] *= 2000.0                                        # ... and some ordinary graphs (flag 1 straight away)
+    order, cap = eng.size_order(big, labels, 10)
+    assert cap <= 64                                           # the lean plan (16-row park) is the one launched
+    pooled, _, _ = eng.embed(big, labels, 10, node_cap=cap, order=order)
+    eng.check_status()
+    assert torch.isfinite(pooled).all()
+    rp = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(big, labels)), 10)[0]
+    s = eng.score_all_pairs(pooled, pooled).cpu()
+    rs = oracle.score_all_pairs(oracle_sd, rp, rp)
+    err = (s - rs).abs().max().item()
+    print("generic-branch graphs outside the f16 range: max|dscore| vs oracle =", err)
+    assert err <= SCORE_TOL
+    eng.set_skip_mask(8192)                                    # every graph on the wide-range instance
+    try:
+        p_wide, _, _ = eng.embed(big, labels, 10)
+    finally:
+        eng.set_skip_mask(0)
+    hit = np.zeros(40, dtype=bool)
+    hit[small[::2]] = True
+    hit[1::8] = True
+    assert torch.equal(p_wide[hit], pooled[hit])               # the out-of-range graphs: same bits as forcing the wide instance
+    p_plain, _, _ = eng.embed(big, labels, 10)                 # uncapped plan (no second-pass reason 2): same results
+    assert torch.equal(p_plain, pooled)

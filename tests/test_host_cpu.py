@@ -611,6 +611,31 @@ def _build_c_demo(tmp_path):
     return exe
 
 
+def test_build_staleness_is_by_content_and_abi_is_checked(tmp_path, monkeypatch):
+    """The library is reused exactly while the hash recorded next to it equals the hash of the sources on disk
+    (no timestamps, no sniffing of the machine), and a library that answers another C-ABI version than include/sgpr.h
+    is refused at load time."""
+    import shutil
+    from sg_pr_amd import _build, engine
+    _build.build_library()
+    assert not _build.is_stale()
+    assert open(_build.LIB_PATH + ".srchash").read().strip() == _build.source_hash()
+    real = _build.HEADERS[0]
+    fake = tmp_path / "sgpr.h"
+    fake.write_text(open(real).read().replace("#define SGPR_ABI_VERSION %d" % _build.header_abi_version(),
+                                              "#define SGPR_ABI_VERSION 99"))
+    monkeypatch.setattr(_build, "HEADERS", [str(fake)] + _build.HEADERS[1:])
+    assert _build.is_stale() and _build.header_abi_version() == 99          # other header bytes -> other hash
+    monkeypatch.setattr(engine, "_lib", None)
+    with pytest.raises(ImportError, match="C-ABI version"):
+        engine.load_library()
+    monkeypatch.undo()
+    assert not _build.is_stale()
+    # newer timestamps alone change nothing
+    os.utime(os.path.join(_build.CSRC, "sgpr_api.hip"))
+    assert not _build.is_stale()
+
+
 def test_c_abi_links_from_plain_c(tmp_path):
     """The boundary is a C ABI: a C11 translation unit including only sgpr.h + the HIP runtime API compiles with gcc
     and links against libsgpr_hip.so (examples/sgpr_demo.c; it is RUN by the GPU suite)."""
