@@ -60,6 +60,23 @@ __device__ __forceinline__ int phase_tid() {
     return t;
 }
 
+// SIMD balance.  The waves of a workgroup land on the SIMDs of a CU cyclically (wave w -> SIMD w & 3, tools/probes/
+// simd_probe.hip), so wave 0 of EVERY resident workgroup shares one SIMD - and wave 0 is where the single-wave sections
+// of the kernel run (the tanh mat-vec and the sigmoid of the attention pool, `tid < 32` reductions, the super-node Gram
+// tile) while the last wave idles through the selection of graphs with few slots.  The lean instances therefore rotate
+// the ROLES of the waves by a per-workgroup offset: logical thread id = (threadIdx.x + 64 * rot) mod blockDim.x with
+// rot taken from the launch slot, so the heavy and the light roles of co-resident workgroups meet on different SIMDs.
+// Results do not depend on which hardware wave plays which role.
+#ifndef SGPR_ROTATE_ROLES
+#define SGPR_ROTATE_ROLES 1
+#endif
+template <int NT_>
+__device__ __forceinline__ int rot_tid(int t, int rot64) {
+    if (NT_ == 0) return t;                              // not a lean instance: identity
+    t += rot64;
+    return t >= NT_ ? t - NT_ : t;
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // The LDS layout of every lean plan (node_cap <= 64, f16 planes) is ONE fixed layout - 64 rows, 16 neighbour slots per
@@ -407,6 +424,22 @@ __device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v, flo
     }
 }
 
+// four zero channels ch..ch+3 of one row: plain stores, no split arithmetic
+template <int FMT>
+__device__ __forceinline__ void xzero(unsigned char* row, int ch) {
+    const uint2 z = make_uint2(0u, 0u);
+    if constexpr (FMT == FMT_BF3) {
+        *reinterpret_cast<uint2*>(row + 2 * ch) = z;
+        *reinterpret_cast<uint2*>(row + 128 + 2 * ch) = z;
+        *reinterpret_cast<uint2*>(row + 256 + 2 * ch) = z;
+    } else if constexpr (FMT == FMT_H2) {
+        *reinterpret_cast<uint2*>(row + 2 * ch) = z;
+        *reinterpret_cast<uint2*>(row + 128 + 2 * ch) = z;
+    } else {
+        *reinterpret_cast<float4*>(row + 4 * ch) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // ------------------------------------------------------------------ selection helpers
 // v_med3_f32 as an exact, canonicalisation-free min / max (keys are never NaN)
 __device__ __forceinline__ float kmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
@@ -528,6 +561,26 @@ __device__ __forceinline__ int row_shr(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x110 + SH, 0xF, 0xF, true);   // row_shr:SH, bound_ctrl: zero fill
 }
 
+// the value of another lane of the same 16-lane row: DPP row rotation by S (which of the two neighbours at distance S
+// it is does not matter to the caller below, which visits all fifteen distances and carries the lane's identity along)
+template <int S>
+__device__ __forceinline__ int row_rot(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x120 + S, 0xF, 0xF, false);   // row_ror:S
+}
+// super-node counting selection: nodes of the labels ranked ahead of label j = sum of the counts of the other 15
+// candidates of the row whose key is smaller (or equal with a smaller label).  packed = count | label << 16
+template <int S>
+__device__ __forceinline__ int count_before(float key, unsigned packed, unsigned jhi, int before) {
+    if constexpr (S < 16) {
+        const float ko = __int_as_float(row_rot<S>(__float_as_int(key)));
+        const unsigned po = (unsigned)row_rot<S>((int)packed);
+        before += (ko < key || (ko == key && po < jhi)) ? (int)(po & 0xffffu) : 0;
+        return count_before<S + 1>(key, packed, jhi, before);
+    } else {
+        return before;
+    }
+}
+
 // emit the candidates whose bits are set in `take` (32 candidate slots starting at index jbase)
 __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, unsigned short* __restrict__ out,
                                           int32_t* __restrict__ dbg_row, int& pos) {
@@ -548,12 +601,12 @@ __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, 
 // has more than 16 candidates), which drops the 32- and 64-candidate paths and their registers from that instance.
 // KEEP = list entries that matter (k <= KEEP <= KP): the sorted lists carry +inf beyond it, and every comparator,
 // lane exchange and minimum that would only feed those entries is never generated (KEEP = 10 for the reference's K).
-template <int KP, int CAPX, int KEEP>
+template <int KP, int CAPX, int KEEP, int NTR = 0>
 __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k, bool one_rep,
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
-                                             unsigned long long* __restrict__ prof8) {
-    const int tid = phase_tid(), lane = tid & 63;
+                                             unsigned long long* __restrict__ prof8, int rot64 = 0) {
+    const int tid = rot_tid<NTR>(phase_tid(), rot64), lane = tid & 63;
     unsigned long long ts = (prof8 && tid == 0) ? clock64() : 0ull;
 #define SEL_STAMP(i)                                                   \
     if (prof8 && tid == 0) {                                           \
@@ -1170,7 +1223,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     float* xx = reinterpret_cast<float*>(smem + p.offXX);
     float* red = reinterpret_cast<float*>(smem + p.offRed);
     unsigned short* nbr = reinterpret_cast<unsigned short*>(smem + p.offIdx);
-    const int tid0 = threadIdx.x;
+    // lean production instances: wave roles rotated per workgroup (rot_tid above); every `tid` / `wave` below is logical
+    constexpr int NTR = (LEAN != 0 && DBG == 0 && SGPR_ROTATE_ROLES) ? 256 : 0;
+    const int rot64 = NTR ? ((launch_slot >> 8) & 3) << 6 : 0;
+    const int tid0 = rot_tid<NTR>(threadIdx.x, rot64);
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: wave-uniform task loops and branches
     int tid = tid0, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int NS = p.N;                                   // slots per graph in global memory
@@ -1392,13 +1448,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     const int cj = j <= kLabels ? cnt[j] : 0;
                     const float key = cj > 0 ? Dv[l * p.pitchD + j] : INFINITY;
                     int before = 0;                                                // nodes ranked ahead of label j
-#pragma unroll
-                    for (int sft = 1; sft < 16; ++sft) {
-                        const int jj = (j + sft) & 15, src = (lane & ~15) | jj;
-                        const float ko = __shfl(key, src);
-                        const int co = __shfl(cj, src);
-                        before += (ko < key || (ko == key && jj < j)) ? co : 0;
-                    }
+                    // the 16 candidates of a row sit in one 16-lane DPP row (t is a multiple of NT >= 64 away from the
+                    // lane id): candidate (j + s) & 15 arrives by a row rotation - two v_mov_dpp instead of two
+                    // ds_bpermute round trips per step; every lane of the wave is active here (256 % 64 == 0)
+                    before = count_before<1>(key, (unsigned)cj | ((unsigned)j << 16), (unsigned)j << 16, before);
                     const unsigned long long inc = __ballot(cj > 0 && before < k0);
                     if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
                 }
@@ -1449,7 +1502,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             xstore<FMT>(xr, 0, live ? make_float4(sem[0], sem[1], sem[2], sem[3]) : z4, vmax);
             xstore<FMT>(xr, 4, live ? make_float4(sem[4], sem[5], sem[6], sem[7]) : z4, vmax);
             xstore<FMT>(xr, 8, live ? make_float4(sem[8], sem[9], sem[10], sem[11]) : z4, vmax);
-            xstore<FMT>(xr, 12, z4, vmax);
+            xzero<FMT>(xr, 12);
             xx[tid] = live ? s : 0.f;
         }
     }
@@ -1474,9 +1527,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 const bool live = tid < N;
                 unsigned char* xr = X + tid * XROW;
                 xstore<FMT>(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f), vmax);
-                xstore<FMT>(xr, 4, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
-                xstore<FMT>(xr, 8, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
-                xstore<FMT>(xr, 12, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                xzero<FMT>(xr, 4);
+                xzero<FMT>(xr, 8);
+                xzero<FMT>(xr, 12);
                 xx[tid] = live ? fmaf(fz, fz, fmaf(fy, fy, fx * fx)) : 0.f;
             }
             __syncthreads();
@@ -1515,11 +1568,11 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 if (p.overlap || (!LEAN && rows_chunk * P <= NT && seg <= CAP)) {
                     unsigned long long* const sp = (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr;
                     if (KP == 16 && k == 10)
-                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), NTR>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
                     else if (KP == 32 && k == 20)
-                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP), NTR>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
                     else
-                        select_phase<KP, LEAN ? 16 : CAP, KP>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                        select_phase<KP, LEAN ? 16 : CAP, KP, NTR>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
                 } else {              // one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
                 }
