@@ -293,6 +293,10 @@ void sgpr_destroy(sgpr_handle* h) {
     delete h;
 }
 
+#ifndef SGPR_SPLIT_SEM
+#define SGPR_SPLIT_SEM 1     // lean production launches on packed input hand the semantic branch to semantic waves
+#endif
+
 // wide: use the wide-range X layouts (bf16 planes / fp32 rows) instead of the default f16 planes
 static bool wide_range(const sgpr_handle* h) { return !h->f16_weights || (h->dbg_skip & 8192); }
 
@@ -324,9 +328,12 @@ static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wid
 // instance, read by the wide-range second pass) | parked first-branch output [G][round16(N)][32] f32 when N > 128
 // (sized for the uncapped plan: the second pass never uses a node_cap)
 static size_t embed_flag_bytes(int G) { return ((size_t)G + 255) & ~(size_t)255; }
-static size_t embed_ws_bytes(int G, int N) {
-    return embed_flag_bytes(G) + (N > 128 ? (size_t)G * ((N + 15) / 16 * 16) * 32 * sizeof(float) : 0);
+static size_t embed_park_bytes(int G, int N) {
+    return ((N > 128 ? (size_t)G * ((N + 15) / 16 * 16) * 32 * sizeof(float) : 0) + 255) & ~(size_t)255;
 }
+// ... | split launch (sgpr_internal.hpp, EmbedArgs::sem_tab): one 64-bit flag + 16 rows of 32 floats per launch slot
+static size_t embed_sem_bytes(int G) { return (size_t)G * (sizeof(unsigned long long) + 16 * 32 * sizeof(float)); }
+static size_t embed_ws_bytes(int G, int N) { return embed_flag_bytes(G) + embed_park_bytes(G, N) + embed_sem_bytes(G); }
 
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
     EmbedPlan p;
@@ -364,6 +371,12 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     }
     a.redo = static_cast<unsigned char*>(ws);
     a.park_ws = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot));
+    unsigned char* sem = static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot) + embed_park_bytes(gtot, N);
+    a.sem_flag = reinterpret_cast<unsigned long long*>(sem);               // indexed by launch slot (< a.G <= gtot)
+    a.sem_tab = reinterpret_cast<float*>(sem + (size_t)gtot * sizeof(unsigned long long));
+#if !SGPR_SPLIT_SEM
+    a.sem_tab = nullptr;                                                   // (A/B builds: the unsplit launch)
+#endif
     a.status = h->d_status;
     a.prof = h->dbg_prof;
     a.skip = h->dbg_skip;
@@ -674,6 +687,10 @@ int sgpr_check_status(const sgpr_handle* h, void* stream) {
         e = hipMemsetAsync(h->d_status, 0, sizeof(flag), s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return hip_fail(e, "sgpr_check_status: reset");
+        if (flag & 4) {
+            set_error("internal: a semantic wave of the split embed launch did not deliver (pooled vector set to NaN)");
+            return SGPR_E_HIP;
+        }
         if (flag & 2) {
             set_error("a graph needed more slots than the node_cap passed to sgpr_embed_capped (its pooled vector is NaN)");
             return SGPR_E_NODES;

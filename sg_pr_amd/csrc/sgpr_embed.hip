@@ -26,6 +26,8 @@
 //    lives in LDS / registers.
 #include <math.h>
 
+#include <atomic>
+
 #include "sgpr_internal.hpp"
 
 namespace sgpr {
@@ -33,8 +35,19 @@ namespace sgpr {
 constexpr int PXB = 400;      // BYTES per row of X as three bf16 planes of 64 channels (128 B each; x = hi + mid + lo,
                               // exact to 24 bits) + 16 B so that rows shift one 16-B slot; the per-node term b
                               // (64 fp32 = 256 B) later overlays the row in place
-constexpr int PXF = 272;      // bytes per row of X as two f16 planes (x = hi + lo, 22 bits; 2 x 128 B + 16 B), and in the
-                              // fp32 layout (64 ch + 4 floats)
+constexpr int PXF = 272;      // bytes per row of X in the fp32 layout (64 ch + 4 floats)
+// bytes per row of X as two f16 planes (x = hi + lo, 22 bits; 2 x 128 B + padding).  The rows are read as MFMA operands
+// with ds_read_b128, whose lane groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): at
+// a pitch of 17 16-byte slots lane (row r, k-slice q) starts at slot r + q (mod 16), and every group holds one pair of
+// lanes on the same slot - a 2-way conflict in all four groups of every operand read (8 LDS cycles instead of 4).  At 18
+// slots the start is 2 r + q: the k-slices of even / odd q sit on even / odd slots and all 16 lanes of a group differ.
+// Measured (round 3, same box, -DSGPR_PXH=288 against 272): KITTI-00 launch 186.8 vs 185.2 us, stress 866.2 vs 865.8,
+// pairs128 33.3 vs 33.1 - the conflicts are real (SQ_LDS_BANK_CONFLICT: 39 % of them sit in the GEMM phase, 25 % in the
+// Gram phase) but the LDS array is only ~38 % busy and nothing waits on it: the smaller rows stay.
+#ifndef SGPR_PXH
+#define SGPR_PXH 272
+#endif
+constexpr int PXH = SGPR_PXH;
 // X layout of a kernel instance (EmbedPlan::fmt)
 constexpr int FMT_F32 = 0;    // fp32 rows, split into three bf16 planes when loaded (fallback of plans too large for FMT_BF3)
 constexpr int FMT_BF3 = 1;    // three bf16 planes, written once per layer by the gather epilogue (fp32 range: the fallback
@@ -68,7 +81,7 @@ __device__ __forceinline__ int phase_tid() {
 // rot taken from the launch slot, so the heavy and the light roles of co-resident workgroups meet on different SIMDs.
 // Results do not depend on which hardware wave plays which role.
 #ifndef SGPR_ROTATE_ROLES
-#define SGPR_ROTATE_ROLES 1
+#define SGPR_ROTATE_ROLES 0
 #endif
 template <int NT_>
 __device__ __forceinline__ int rot_tid(int t, int rot64) {
@@ -97,11 +110,11 @@ __host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_pa
     p.lean = rows;
     p.xplanes = 1;
     p.fmt = FMT_H2;
-    p.rowb = PXF;
+    p.rowb = PXH;
     p.nt = 256;
     p.offX = 0;
     p.offRed = 0;
-    p.offPark = rows * PXF;
+    p.offPark = rows * PXH;
     p.offXX = p.offPark + (small_park ? kSmallParkBytes : rows * PP * 4);
     p.offIdx = p.offXX + 64 * 4;
     p.offA = p.offIdx + rows * 16 * 2;
@@ -122,7 +135,7 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
     p->pitchA = NC <= 192 ? 68 : 64;      // 64 only when LDS is otherwise exhausted (bank-conflicted stores)
     p->xplanes = planes ? 1 : 0;
     p->fmt = fmt;
-    p->rowb = fmt == FMT_BF3 ? PXB : PXF;
+    p->rowb = fmt == FMT_BF3 ? PXB : (fmt == FMT_H2 ? PXH : PXF);
     int off = 0;
     p->offX = off;    off += p->NP * p->rowb;
     p->offRed = p->offX;
@@ -375,7 +388,7 @@ __device__ __forceinline__ bf16x8 pack8(uint2 a, uint2 b) {
 // X layout policy (FMT_*).  Plane layouts are written once per layer by the gather epilogue; FMT_F32 keeps fp32 rows
 // and splits when loading.  Either way the per-node term b (fp32) overlays bytes 0..255 of the row in place.
 template <int FMT>
-__device__ __forceinline__ constexpr int xrow() { return FMT == FMT_BF3 ? PXB : PXF; }
+__device__ __forceinline__ constexpr int xrow() { return FMT == FMT_BF3 ? PXB : (FMT == FMT_H2 ? PXH : PXF); }
 
 template <int NKB, int FMT>
 __device__ __forceinline__ void xload(const unsigned char* row, int lq, FragT<FMT> (&f)[2]) {
@@ -561,6 +574,13 @@ __device__ __forceinline__ int row_shr(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x110 + SH, 0xF, 0xF, true);   // row_shr:SH, bound_ctrl: zero fill
 }
 
+// order-preserving float -> uint32
+__device__ __forceinline__ unsigned ord_u32(float f) {
+    f += 0.0f;  // -0 -> +0
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+
 // the value of another lane of the same 16-lane row: DPP row rotation by S (which of the two neighbours at distance S
 // it is does not matter to the caller below, which visits all fifteen distances and carries the lane's identity along)
 template <int S>
@@ -569,13 +589,15 @@ __device__ __forceinline__ int row_rot(int v) {
 }
 // super-node counting selection: nodes of the labels ranked ahead of label j = sum of the counts of the other 15
 // candidates of the row whose key is smaller (or equal with a smaller label).  packed = count | label << 16
+// One 64-bit unsigned comparison per step: (order-preserving image of the key, label << 16 | count) against (own image,
+// own label << 16) is "smaller key, or the same key and a smaller label" - no lane-mask logic on the scalar unit.
 template <int S>
-__device__ __forceinline__ int count_before(float key, unsigned packed, unsigned jhi, int before) {
+__device__ __forceinline__ int count_before(unsigned okey, unsigned packed, unsigned long long mine, int before) {
     if constexpr (S < 16) {
-        const float ko = __int_as_float(row_rot<S>(__float_as_int(key)));
+        const unsigned ko = (unsigned)row_rot<S>((int)okey);
         const unsigned po = (unsigned)row_rot<S>((int)packed);
-        before += (ko < key || (ko == key && po < jhi)) ? (int)(po & 0xffffu) : 0;
-        return count_before<S + 1>(key, packed, jhi, before);
+        before += (((unsigned long long)ko << 32) | po) < mine ? (int)(po & 0xffffu) : 0;
+        return count_before<S + 1>(okey, packed, mine, before);
     } else {
         return before;
     }
@@ -601,11 +623,12 @@ __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, 
 // has more than 16 candidates), which drops the 32- and 64-candidate paths and their registers from that instance.
 // KEEP = list entries that matter (k <= KEEP <= KP): the sorted lists carry +inf beyond it, and every comparator,
 // lane exchange and minimum that would only feed those entries is never generated (KEEP = 10 for the reference's K).
-template <int KP, int CAPX, int KEEP, int NTR = 0>
-__device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P, int seg, int k, bool one_rep,
+template <int KP, int CAPX, int KEEP, int NTR = 0, int PC = 0>   // PC: lanes per row when it is a compile-time constant
+__device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P_, int seg, int k, bool one_rep,
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
                                              unsigned long long* __restrict__ prof8, int rot64 = 0) {
+    const int P = PC ? PC : P_;
     const int tid = rot_tid<NTR>(phase_tid(), rot64), lane = tid & 63;
     unsigned long long ts = (prof8 && tid == 0) ? clock64() : 0ull;
 #define SEL_STAMP(i)                                                   \
@@ -803,13 +826,6 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
 }
 
 // ------------------------------------------------------------------ selection by value bisection (wave per row)
-// order-preserving float -> uint32
-__device__ __forceinline__ unsigned ord_u32(float f) {
-    f += 0.0f;  // -0 -> +0
-    const unsigned b = __float_as_uint(f);
-    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
-}
-
 // wave64 min / max of a u32 (result uniform)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
@@ -1006,10 +1022,11 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
 // the weight fragment of the tile in registers and walks the row tiles, so the weights cross L2 -> CU once per
 // workgroup instead of once per row tile and the work divides evenly whatever nrt is.  a-tiles go straight to A;
 // the (at most two) b-tiles of a wave wait in registers until every wave has read its X operands, then replace X.
-template <int NKB, int COUT, int FMT>
+template <int NKB, int COUT, int FMT, int NWC = 0>   // NWC: the number of waves when it is a compile-time constant (lean instances)
 __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
-                                          int wave, int NW, int ex = 0) {
+                                          int wave, int NW_, int ex = 0) {
+    const int NW = NWC ? NWC : NW_;
     const int lane = phase_tid() & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int NCA = COUT / 16, NCT = 2 * NCA;
@@ -1069,16 +1086,16 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
         }
 }
 
-template <bool COLS, int FMT>
+template <bool COLS, int FMT, int NWC = 0>
 __device__ __forceinline__ void gemm_layer(unsigned char* X, float* A, int pitchA, const unsigned short* Wb,
                                            const float* tb, int Kp, int cout, int nrt, int gw, int GW, int ex = 0) {
     if (COLS) {   // capped plans: nrt <= 4, GW >= 2 (make_embed_plan); contains a barrier - every wave calls it
         if (Kp != 64)
-            gemm_cols<1, 64, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<1, 64, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         else if (cout == 64)
-            gemm_cols<4, 64, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<4, 64, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         else
-            gemm_cols<4, 32, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<4, 32, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
         return;
     }
     if (Kp != 64)
@@ -1101,7 +1118,7 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
     tj = r + t;
 }
 
-template <int NKB, int FMT, bool PF>   // PF: fetch the next tile's operands during this tile's MFMAs (48 more VGPRs)
+template <int NKB, int FMT, bool PF, int NWC = 0>   // PF: fetch the next tile's operands during this tile's MFMAs (48 more VGPRs)
 __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__ X, const float* __restrict__ xx,
                                                float* __restrict__ D, int pitchD, int N, int nrt, int wave) {
     const int lane = phase_tid() & 63;
@@ -1115,7 +1132,7 @@ __device__ __forceinline__ void gram_tiles_sym(const unsigned char* __restrict__
     xload<NKB, FMT>(X + (ti * 16 + l15) * xrow<FMT>(), lq, a);
     xload<NKB, FMT>(X + (tj * 16 + l15) * xrow<FMT>(), lq, b);
     while (true) {
-        const int tn = t + (int)(blockDim.x >> 6);
+        const int tn = t + (NWC ? NWC : (int)(blockDim.x >> 6));
         const bool more = tn < ntiles;
         int tin = 0, tjn = 0;
         FragT<FMT> an[2], bn[2];
@@ -1203,11 +1220,157 @@ __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
     return live ? y : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------ the semantic branch on label super-nodes
+// workgroup barrier, or - for a group that is ONE wave - nothing but a compiler fence: the LDS serves the accesses of a
+// wave in program order, so a lane's read sees every earlier write of any lane of its own wave
+template <bool WAVE>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// Layers 1-3 of the semantic branch on the 13 label super-nodes (see embed_graph): cnt[0..11] = nodes per label,
+// cnt[12] = K.  Runs on a thread group of NT threads = NW waves that owns X rows 0..15, A / D (16 rows each; D may alias
+// A unless LEAN), xx[16], vmask[16]: either the whole workgroup of a graph (group_sync = barrier) or a single wave
+// (WAVE: NT = 64, NW = 1, the "semantic waves" of the split launch).  Result: sem3 rows 0..15 -> out[16][PP] (LDS or
+// global).  Every value comes from the instructions of the generic path on the same operands.
+template <int FMT, int LEAN, bool WAVE>
+__device__ __forceinline__ void supernode_branch(const DevWeights& w, const int k0, const int skip, unsigned char* X,
+                                                 float* xx, float* A, float* D, const int pitchA, const int pitchD,
+                                                 const int* cnt, int* vmask, float* out, const int tid, const int wave,
+                                                 const int NT, const int NW, float& vmax) {
+    constexpr int XROW = xrow<FMT>();
+    const int lane = tid & 63;
+    // layer 1: the table, straight into X rows 0..15 (rows 13..15 zero)
+    const float* wf0 = w.wf[0];                                         // [2 * 64][16] folded fp32 weights
+    const float* tb0 = w.tb[0];
+    for (int t = (skip & 65536) ? 256 : tid; t < 16 * 16; t += NT) {   // (ablation bit 16: no layer-1 table)
+        const int v = t >> 4, c4 = (t & 15) * 4;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
+        bool with_rep = true;
+        if (v < kLabels) {
+            // the weight as the generic path's matrix product sees it: exact in three bf16 planes, hi + lo of
+            // the two f16 planes (22 bits) in FMT_H2
+            auto wq = [](float x) {
+                if (FMT != FMT_H2) return x;
+                const _Float16 h = (_Float16)x;
+                return (float)h + (float)(_Float16)(x - (float)h);
+            };
+            a4 = make_float4(wq(wf0[(c4 + 0) * 16 + v]), wq(wf0[(c4 + 1) * 16 + v]), wq(wf0[(c4 + 2) * 16 + v]),
+                             wq(wf0[(c4 + 3) * 16 + v]));
+            b4 = make_float4(wq(wf0[(64 + c4 + 0) * 16 + v]) + b4.x, wq(wf0[(64 + c4 + 1) * 16 + v]) + b4.y,
+                             wq(wf0[(64 + c4 + 2) * 16 + v]) + b4.z, wq(wf0[(64 + c4 + 3) * 16 + v]) + b4.w);
+            with_rep = cnt[v] < k0;
+        }
+        const float z = with_rep ? 0.f : -INFINITY;                        // the representative's a is 0
+        const float4 m4 = make_float4(max3(-INFINITY, a4.x, z), max3(-INFINITY, a4.y, z),
+                                      max3(-INFINITY, a4.z, z), max3(-INFINITY, a4.w, z));
+        const float4 y = add_lrelu(m4, b4, v <= kLabels);
+        xstore<FMT>(X + v * XROW, c4, y, vmax);
+        float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+        sa += lane_xor(sa, 1);
+        sa += lane_xor(sa, 2);
+        sa += lane_xor(sa, 4);
+        sa += lane_xor(sa, 8);
+        if ((t & 15) == 0) xx[v] = sa;
+    }
+    group_sync<WAVE>();
+    // layers 2 and 3 on the 13 virtual rows
+    for (int Lv = (skip & 16384) ? 3 : 1; Lv < 3; ++Lv) {      // (ablation bit 14: super-node layers 2 and 3 off)
+        const int cout = w.cout[Lv];
+        const unsigned short* wl = FMT == FMT_H2 ? w.wh[Lv] : w.wb[Lv];
+        // the keys of the 16 virtual rows sit beside the 16 rows of A, so that in the lean instance the Gram tile
+        // (wave 0) and the a / b column tiles (the other waves) run side by side: three barriers per layer
+        float* Dv = LEAN != 0 ? A + 16 * pitchA : D;
+        if (LEAN != 0) {
+            if (wave == 0) {
+                gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, 0);
+                group_sync<WAVE>();                                           // = the barrier inside gemm_cols
+            } else {
+                gemm_layer<true, FMT, 3>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0);   // (lean: four waves)
+            }
+        } else {
+            gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, wave);
+            group_sync<WAVE>();
+        }
+        for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
+            const int l = t >> 4, j = t & 15;
+            const int cj = j <= kLabels ? cnt[j] : 0;
+            const float key = cj > 0 ? Dv[l * pitchD + j] : INFINITY;
+            int before = 0;                                                // nodes ranked ahead of label j
+            // the 16 candidates of a row sit in one 16-lane DPP row (t is a multiple of NT >= 64 away from the
+            // lane id): candidate (j + s) & 15 arrives by a row rotation - two v_mov_dpp instead of two
+            // ds_bpermute round trips per step; every lane of the wave is active here (256 % 64 == 0)
+            const unsigned okey = ord_u32(key);                            // (-0 == +0; +inf for labels the graph lacks)
+            before = count_before<1>(okey, (unsigned)cj | ((unsigned)j << 16),
+                                     ((unsigned long long)okey << 32) | ((unsigned)j << 16), before);
+            const unsigned long long inc = __ballot(cj > 0 && before < k0);
+            if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
+        }
+        group_sync<WAVE>();                                                   // keys consumed: A may overwrite D
+        if (LEAN == 0) {
+            gemm_layer<false, FMT>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave, NW, 0);
+            group_sync<WAVE>();
+        }
+        const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
+        for (int t = tid; t < 16 * lpr; t += NT) {
+            const int l = t / lpr, c4 = (t & (lpr - 1)) * 4;
+            int mask = vmask[l];                                           // a few labels per row: walk the set bits
+            float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            while (mask) {
+                const int j = __builtin_ctz(mask);
+                mask &= mask - 1;
+                const float4 v = *reinterpret_cast<const float4*>(A + j * pitchA + c4);
+                m4.x = kmax(m4.x, v.x);
+                m4.y = kmax(m4.y, v.y);
+                m4.z = kmax(m4.z, v.z);
+                m4.w = kmax(m4.w, v.w);
+            }
+            const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(X + l * XROW + 4 * c4), l <= kLabels);
+            if (Lv == 1) {
+                xstore<FMT>(X + l * XROW, c4, y, vmax);
+                float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+                sa += lane_xor(sa, 1);
+                sa += lane_xor(sa, 2);
+                sa += lane_xor(sa, 4);
+                sa += lane_xor(sa, 8);
+                if ((t & 15) == 0) xx[l] = sa;
+            } else {
+                *reinterpret_cast<float4*>(out + (size_t)l * PP + c4) = y;
+            }
+        }
+        group_sync<WAVE>();
+    }
+}
+
+// ------------------------------------------------------------------ split launch (few graphs: the latency regime)
+// The two branches of dgcnn_conv_pass are independent until conv_end (sg_net.py:81-104).  When a launch has at most half
+// as many graphs as the GPU has CUs, every graph gets TWO workgroups, each on a CU of its own: workgroup s < G runs the
+// input phase and the xyz branch, meets the rows of the other half before conv_end and finishes the graph (role 2);
+// workgroup G + s runs the input phase and the semantic branch (role 1) and publishes the 16 sem3 rows through global
+// memory (sem_tab[s] + sem_flag[s] = token(s)).  All 2 G workgroups are resident at once, so the waiting side cannot
+// starve the producing side; should a flag nevertheless not arrive, the waiting workgroup gives up loudly (status bit 4,
+// NaN pooled vector) instead of hanging.  With more graphs the halves would share CUs, which costs each more than the
+// split saves (launch_embed), and in the throughput regime the kernel's time is its instruction count: every workgroup
+// does both branches (role 0).  Measured and dropped on the way here: the semantic branch of EVERY launch on single
+// waves ("semantic waves", 4 graphs per leading workgroup): the same instructions at lower parallelism, 197 -> 303 us.
+__host__ __device__ __forceinline__ unsigned long long sem_token(unsigned epoch, int slot) {
+    return ((unsigned long long)epoch << 32) | (unsigned)(slot + 1);   // (bit 31: an f16 overflow in the branch)
+}
+
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
 // LEAN (64 / 48): the instance of the fixed lean layouts - 256 / 192 threads, four / five workgroups per CU (88 VGPRs)
-template <int KP, int DBG, int LEAN, int FMT>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
-__device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot) {
+// KC: K as a compile-time constant (10, the reference's, in the lean production instances; 0 = read from the plan): the
+// K-derived loop bounds and predicates of every phase fold away
+template <int KP, int DBG, int LEAN, int FMT, int KC = 0>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
+__device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot,
+                                            const int role = 0) {   // role: 0 whole graph, 1 / 2 the halves of a split launch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // lean instance: the layout fields are the constants of lean_fixed_layout (the host built the plan from the same
     // function); N, NC, k stay run-time values
@@ -1215,7 +1378,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if constexpr (LEAN != 0) lean_fixed_layout(plan_local, DBG == 0, LEAN);
     const EmbedPlan& p = plan_local;
     float vmax = 0.f;                                    // FMT_H2: largest magnitude stored into the f16 planes
-    const int NT = blockDim.x, NW = NT >> 6;          // 64 .. 512 threads (EmbedPlan::nt)
+    const int NT = LEAN != 0 ? 256 : (int)blockDim.x, NW = NT >> 6;   // 64 .. 512 threads (EmbedPlan::nt); lean: a constant
     unsigned char* X = smem + p.offX;                    // [NP][XROW]: bf16 planes (or fp32 rows) / in-place fp32 b
     constexpr int XROW = xrow<FMT>();
     float* A = reinterpret_cast<float*>(smem + p.offA);
@@ -1225,7 +1388,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     unsigned short* nbr = reinterpret_cast<unsigned short*>(smem + p.offIdx);
     // lean production instances: wave roles rotated per workgroup (rot_tid above); every `tid` / `wave` below is logical
     constexpr int NTR = (LEAN != 0 && DBG == 0 && SGPR_ROTATE_ROLES) ? 256 : 0;
-    const int rot64 = NTR ? ((launch_slot >> 8) & 3) << 6 : 0;
+    #ifndef SGPR_ROT_SHIFT
+#define SGPR_ROT_SHIFT 8
+#endif
+    const int rot64 = NTR ? ((launch_slot >> SGPR_ROT_SHIFT) & 3) << 6 : 0;
     const int tid0 = rot_tid<NTR>(threadIdx.x, rot64);
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: wave-uniform task loops and branches
     int tid = tid0, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
@@ -1234,7 +1400,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
     unsigned long long t_prev = 0;
     unsigned long long* const prof_buf = DBG ? kp.a.prof : nullptr;
-    const int skip = DBG ? kp.a.skip : 0;
+#ifndef SGPR_EXP_SKIP
+#define SGPR_EXP_SKIP 0       // timing experiments only (tools/build_variant.sh): an ablation mask compiled into the production instance
+#endif
+    const int skip = DBG ? kp.a.skip : SGPR_EXP_SKIP;
     float* const dbg_layers = DBG == 2 ? kp.a.dbg_layers : nullptr;
     int32_t* const dbg_knn_all = DBG == 2 ? kp.a.dbg_knn : nullptr;
     // timers live in scalar registers of wave 0 and reach memory once, at the end of the kernel: per-phase global
@@ -1326,6 +1495,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         __syncthreads();                        // red / D region is reused below
     }
     if (N > p.NC || N > kp.a.promise) {          // more slots to process than the caller's node_cap promised: fail loudly
+        if (role == 1) return;                   // (reported by the graph's other workgroup)
         if (tid == 0) atomicOr(kp.a.status, 2);
         if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
         if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
@@ -1336,12 +1506,17 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     const int nrt = NP >> 4;
     // lanes per row in the selection: as many as the workgroup has (two VALU waves per SIMD are needed
     // to keep the vector pipe busy), but at least 8 candidates per lane
-    int P = p.P;
-    {
+    // (P is a power of two: shifts, not integer divisions - the scalar division sequences of this handful of lines were
+    // several hundred instructions per wave and graph)
+    int lp = 31 - __clz(p.P);
+    if (LEAN != 0) {
+        lp = 2;        // lean instances: always four lanes per row (<= 64 rows x 4 = the workgroup), <= 16 candidates per lane
+    } else {
         const int rows = p.overlap ? NP : p.RC;
-        while (2 * P * rows <= NT && (N + 2 * P - 1) / (2 * P) >= 8) P *= 2;
+        while (((2 * rows) << lp) <= NT && ((N + (2 << lp) - 1) >> (lp + 1)) >= 8) ++lp;
     }
-    const int seg = (((N + P - 1) / P) + 3) & ~3;
+    const int P = 1 << lp;
+    const int seg = (((N + P - 1) >> lp) + 3) & ~3;
 
     // ---- the semantic branch on label super-nodes.  Packed input = one-hot rows, so nodes with the same label have
     //      identical features - and, by the argument that lets duplicate slots be dropped, identical
@@ -1357,6 +1532,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     //      all-zero rows among the nodes, < 17 slots.
     int L0 = 0;
     const signed char* rowlab = nullptr;                     // fast path: table row of every slot (13 = zero row)
+    const bool split = LEAN != 0 && DBG == 0 && role == 2;   // this graph's semantic branch runs in another workgroup
     {
         const int k0 = p.k;
         const bool bad = (tid < nd && mylab < 0) || (tid == nd && mylab != -1);
@@ -1370,9 +1546,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         const bool any_bad = *flag != 0;
         __syncthreads();                                    // red shares X, which is written next
         const bool fast = DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
-        if (!fast && p.small_park) {
+        if (!fast && (p.small_park || role == 1)) {
             // this plan parks only the super-node rows: the graph takes the generic branch in the second pass
-            if (tid == 0 && kp.a.redo) kp.a.redo[launch_slot] = 2;
+            // (split launch: decided and reported by the graph's xyz workgroup, which takes the same decision)
+            if (tid == 0 && kp.a.redo && role != 1) kp.a.redo[launch_slot] = 2;
             return;
         }
         if (fast) {
@@ -1382,114 +1559,36 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             signed char* rl = reinterpret_cast<signed char*>(cnt + 16);            // [NP]
             int* vmask = reinterpret_cast<int*>(nbr);                              // [16] neighbour label sets
             rowlab = rl;
-            if (tid < 16) cnt[tid] = tid == kLabels ? k0 : 0;
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < kLabels; ++c) {
-                const unsigned long long mk = __ballot(tid < nd && mylab == c);
-                if (lane == 0 && mk) atomicAdd(&cnt[c], __popcll(mk));
-            }
             if (tid < NP) rl[tid] = (signed char)(tid < N ? (tid == nd ? kLabels : mylab) : kLabels + 1);
-            __syncthreads();
-            // layer 1: the table, straight into X rows 0..15 (rows 13..15 zero)
-            const float* wf0 = kp.w.wf[0];                                         // [2 * 64][16] folded fp32 weights
-            const float* tb0 = kp.w.tb[0];
-            for (int t = tid; t < 16 * 16; t += NT) {
-                const int v = t >> 4, c4 = (t & 15) * 4;
-                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
-                bool with_rep = true;
-                if (v < kLabels) {
-                    // the weight as the generic path's matrix product sees it: exact in three bf16 planes, hi + lo of
-                    // the two f16 planes (22 bits) in FMT_H2
-                    auto wq = [](float x) {
-                        if (FMT != FMT_H2) return x;
-                        const _Float16 h = (_Float16)x;
-                        return (float)h + (float)(_Float16)(x - (float)h);
-                    };
-                    a4 = make_float4(wq(wf0[(c4 + 0) * 16 + v]), wq(wf0[(c4 + 1) * 16 + v]), wq(wf0[(c4 + 2) * 16 + v]),
-                                     wq(wf0[(c4 + 3) * 16 + v]));
-                    b4 = make_float4(wq(wf0[(64 + c4 + 0) * 16 + v]) + b4.x, wq(wf0[(64 + c4 + 1) * 16 + v]) + b4.y,
-                                     wq(wf0[(64 + c4 + 2) * 16 + v]) + b4.z, wq(wf0[(64 + c4 + 3) * 16 + v]) + b4.w);
-                    with_rep = cnt[v] < k0;
-                }
-                const float z = with_rep ? 0.f : -INFINITY;                        // the representative's a is 0
-                const float4 m4 = make_float4(max3(-INFINITY, a4.x, z), max3(-INFINITY, a4.y, z),
-                                              max3(-INFINITY, a4.z, z), max3(-INFINITY, a4.w, z));
-                const float4 y = add_lrelu(m4, b4, v <= kLabels);
-                xstore<FMT>(X + v * XROW, c4, y, vmax);
-                float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
-                sa += lane_xor(sa, 1);
-                sa += lane_xor(sa, 2);
-                sa += lane_xor(sa, 4);
-                sa += lane_xor(sa, 8);
-                if ((t & 15) == 0) xx[v] = sa;
-            }
-            __syncthreads();
-            // layers 2 and 3 on the 13 virtual rows
-            for (int Lv = (skip & 16384) ? 3 : 1; Lv < 3; ++Lv) {      // (ablation bit 14: super-node layers 2 and 3 off)
-                const int cout = kp.w.cout[Lv];
-                const unsigned short* wl = FMT == FMT_H2 ? kp.w.wh[Lv] : kp.w.wb[Lv];
-                // the keys of the 16 virtual rows sit beside the 16 rows of A, so that in the lean instance the Gram tile
-                // (wave 0) and the a / b column tiles (the other waves) run side by side: three barriers per layer
-                float* Dv = LEAN != 0 ? A + 16 * p.pitchA : D;
-                if (LEAN != 0) {
-                    if (wave == 0) {
-                        gram_tiles_sym<4, FMT, false>(X, xx, Dv, p.pitchD, kLabels + 1, 1, 0);
-                        __syncthreads();                                           // = the barrier inside gemm_cols
-                    } else {
-                        gemm_layer<true, FMT>(X, A, p.pitchA, wl, kp.w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0);
-                    }
-                } else {
-                    gram_tiles_sym<4, FMT, false>(X, xx, Dv, p.pitchD, kLabels + 1, 1, wave);
-                    __syncthreads();
-                }
-                for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
-                    const int l = t >> 4, j = t & 15;
-                    const int cj = j <= kLabels ? cnt[j] : 0;
-                    const float key = cj > 0 ? Dv[l * p.pitchD + j] : INFINITY;
-                    int before = 0;                                                // nodes ranked ahead of label j
-                    // the 16 candidates of a row sit in one 16-lane DPP row (t is a multiple of NT >= 64 away from the
-                    // lane id): candidate (j + s) & 15 arrives by a row rotation - two v_mov_dpp instead of two
-                    // ds_bpermute round trips per step; every lane of the wave is active here (256 % 64 == 0)
-                    before = count_before<1>(key, (unsigned)cj | ((unsigned)j << 16), (unsigned)j << 16, before);
-                    const unsigned long long inc = __ballot(cj > 0 && before < k0);
-                    if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
-                }
-                __syncthreads();                                                   // keys consumed: A may overwrite D
-                if (LEAN == 0) {
-                    gemm_layer<false, FMT>(X, A, p.pitchA, wl, kp.w.tb[Lv], 64, cout, 1, wave, NW, 0);
-                    __syncthreads();
-                }
-                const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
-                for (int t = tid; t < 16 * lpr; t += NT) {
-                    const int l = t / lpr, c4 = (t & (lpr - 1)) * 4;
-                    int mask = vmask[l];                                           // a few labels per row: walk the set bits
-                    float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                    while (mask) {
-                        const int j = __builtin_ctz(mask);
-                        mask &= mask - 1;
-                        const float4 v = *reinterpret_cast<const float4*>(A + j * p.pitchA + c4);
-                        m4.x = kmax(m4.x, v.x);
-                        m4.y = kmax(m4.y, v.y);
-                        m4.z = kmax(m4.z, v.z);
-                        m4.w = kmax(m4.w, v.w);
-                    }
-                    const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(X + l * XROW + 4 * c4), l <= kLabels);
-                    if (Lv == 1) {
-                        xstore<FMT>(X + l * XROW, c4, y, vmax);
-                        float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
-                        sa += lane_xor(sa, 1);
-                        sa += lane_xor(sa, 2);
-                        sa += lane_xor(sa, 4);
-                        sa += lane_xor(sa, 8);
-                        if ((t & 15) == 0) xx[l] = sa;
-                    } else {
-                        *reinterpret_cast<float4*>(park + (size_t)l * PP + c4) = y;
-                    }
+            if (!split) {                                   // (split launch: the graph's other workgroup computes the branch)
+                if (tid < 16) cnt[tid] = tid == kLabels ? k0 : 0;
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < kLabels; ++c) {
+                    const unsigned long long mk = __ballot(tid < nd && mylab == c);
+                    if (lane == 0 && mk) atomicAdd(&cnt[c], __popcll(mk));
                 }
                 __syncthreads();
+                supernode_branch<FMT, LEAN, false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
             }
             L0 = 3;
+            if (LEAN != 0 && DBG == 0 && role == 1) {
+                // ---- split launch, semantic half: publish the 16 rows (release at agent scope), then the flag
+                int* ovf = reinterpret_cast<int*>(xx);      // (the squared norms are dead)
+                if (tid == 0) *ovf = 0;
+                __syncthreads();
+                for (int e = tid; e < 16 * 8; e += NT)
+                    *reinterpret_cast<float4*>(kp.a.sem_tab + ((size_t)launch_slot * 16 + (e >> 3)) * PP + (e & 7) * 4) =
+                        *reinterpret_cast<const float4*>(park + (size_t)(e >> 3) * PP + (e & 7) * 4);
+                if (FMT == FMT_H2 && __ballot(!(vmax < kF16Safe)) != 0ull && lane == 0) atomicOr(ovf, 1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(kp.a.sem_flag + launch_slot,
+                                       sem_token(kp.a.sem_epoch, launch_slot) | (*ovf ? 0x80000000ull : 0ull), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
         } else if (tid < NP) {
             // ---- generic: stage the first branch's input (12 semantic channels, zero padded to 16 / NP rows) +
             //      squared norms, ahead of the layer loop so that the 12 input registers die here
@@ -1512,8 +1611,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     for (int L = L0; L < 6; ++L) {
         // per-iteration opaque copy: keeps the compiler from hoisting (and then spilling) dozens of
         // k-derived predicates out of the layer loop
-        int k = p.k;
-        asm volatile("" : "+s"(k));
+        int k = KC ? KC : p.k;
+        if (!KC) asm volatile("" : "+s"(k));
         // same for the lane-derived addresses: re-derived per layer (a few VALU ops) instead of living in - and
         // spilling from - dozens of registers across all phases
         tid = tid0;
@@ -1546,9 +1645,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             if (skip & 4) {
             } else if (p.overlap) {
                 if (k64)
-                    gram_tiles_sym<4, FMT, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<4, FMT, !LEAN, (LEAN != 0 ? 4 : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
                 else
-                    gram_tiles_sym<1, FMT, !LEAN>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<1, FMT, !LEAN, (LEAN != 0 ? 4 : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
                 const int nti = rows_chunk >> 4;
                 for (int tile = wave; tile < nti * nrt; tile += NW) {
@@ -1568,11 +1667,11 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 if (p.overlap || (!LEAN && rows_chunk * P <= NT && seg <= CAP)) {
                     unsigned long long* const sp = (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr;
                     if (KP == 16 && k == 10)
-                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), NTR>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), NTR, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
                     else if (KP == 32 && k == 20)
-                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP), NTR>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP), NTR, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
                     else
-                        select_phase<KP, LEAN ? 16 : CAP, KP, NTR>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
+                        select_phase<KP, LEAN ? 16 : CAP, KP, NTR, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
                 } else {              // one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
                 }
@@ -1581,7 +1680,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT>(X, A, p.pitchA, (skip & 512) ? nullptr : (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
+        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? 4 : 0)>(X, A, p.pitchA, (skip & 512) ? nullptr : (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
@@ -1654,6 +1753,38 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         SGPR_PROF(5)
     }
 
+    if (skip & 131072) return;   // ablation bit 17: nothing after the layer loop
+    const float* sem3 = park;                                // the first branch's output: [row][PP]
+    if (split && rowlab) {
+        // ---- meet the semantic half: its 16 rows are in global memory once sem_flag[slot] carries this launch's token
+        int* met = reinterpret_cast<int*>(xx);               // (the squared norms are dead: no Gram phase is left)
+        if (tid == 0) {
+            const unsigned long long want = sem_token(kp.a.sem_epoch, launch_slot);
+            unsigned long long got = 0ull;
+            int spins = 0;
+            while (true) {
+                got = __hip_atomic_load(kp.a.sem_flag + launch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SGPR_EXP_NOWAIT
+                got = want;
+#endif
+                if ((got & ~0x80000000ull) == want || ++spins > (1 << 20)) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            *met = (got & ~0x80000000ull) == want ? ((got & 0x80000000ull) ? 2 : 1) : 0;
+        }
+        __syncthreads();
+        const int st = *met;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows were published before the flag
+        if (st == 0) {       // never expected (all 2 G workgroups are resident): fail loudly instead of hanging or guessing
+            if (tid == 0) atomicOr(kp.a.status, 4);
+            if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
+            if (kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
+            return;
+        }
+        if (st == 2 && tid == 0) vmax = INFINITY;            // the branch left the f16 range: this graph goes to the second pass
+        sem3 = kp.a.sem_tab + (size_t)launch_slot * 16 * PP;
+        __syncthreads();                                     // `met` is read before xx is used again
+    }
     // conv_end weights of this wave's first tile: in flight while sem3 is moved back
     FragT<FMT> wf_end[2];
     int ct_end = wave & 1;
@@ -1662,7 +1793,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     for (int e = tid; e < NP * 8; e += NT) {                      // sem3 -> channels 32..63: X = cat(xyz3, sem3)
         const int i = e >> 3, c4 = (e & 7) * 4;
         const int pr = rowlab ? (int)rowlab[i] : i;              // fast path: the row of slot i's label
-        const float4 v = i < N ? *reinterpret_cast<const float4*>(park + (size_t)pr * PP + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = i < N ? *reinterpret_cast<const float4*>(sem3 + (size_t)pr * PP + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         xstore<FMT>(X + i * XROW, 32 + c4, v, vmax);
     }
     __syncthreads();
@@ -1773,9 +1904,17 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     }
 }
 
-template <int KP, int DBG, int LEAN, int FMT>
+template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
 __global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? (DBG == 0 ? (LEAN == 48 ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
-    embed_graph<KP, DBG, LEAN, FMT>(kp, kp.p, kp.a.ids ? kp.a.ids[blockIdx.x] : (int)blockIdx.x, (int)blockIdx.x);
+    // (ONE call site: two inlined copies of embed_graph would double the kernel's footprint in the instruction cache)
+    int slot = (int)blockIdx.x, role = 0;
+    if constexpr (LEAN != 0 && DBG == 0) {
+        if (kp.a.sem_tab) {            // split launch: workgroups [0, G) xyz halves (the critical path starts first),
+            role = slot >= kp.a.G ? 1 : 2;                        // [G, 2 G) semantic halves
+            slot -= role == 1 ? kp.a.G : 0;
+        }
+    }
+    embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role);
 }
 
 // Second pass over the launch slots the f16 instance flagged (kp.a.redo):
@@ -1834,12 +1973,13 @@ static int set_lds_limit(K kernel, bool* done) {
     return SGPR_OK;
 }
 
-template <int KP, int DBG, int LEAN, int FMT>
+template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
 static int launch_t(const KParams& kp, hipStream_t stream) {
     static bool attr_set = false;
-    int rc = set_lds_limit(&embed_kernel<KP, DBG, LEAN, FMT>, &attr_set);
+    int rc = set_lds_limit(&embed_kernel<KP, DBG, LEAN, FMT, KC>, &attr_set);
     if (rc != SGPR_OK) return rc;
-    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    const int grid = kp.a.G * ((LEAN != 0 && DBG == 0 && kp.a.sem_tab) ? 2 : 1);
+    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT, KC>), dim3(grid), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
@@ -1860,6 +2000,8 @@ static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
 template <int KP, int DBG>
 static int launch_layout(const EmbedPlan& plan, const KParams& kp, hipStream_t stream) {
     if (plan.fmt == FMT_H2) {
+        if (KP == 16 && DBG == 0 && plan.lean && plan.k == 10)     // the reference's K: compile-time constant
+            return plan.lean == 48 ? launch_t<16, 0, 48, FMT_H2, 10>(kp, stream) : launch_t<16, 0, 64, FMT_H2, 10>(kp, stream);
         if (plan.lean == 48 && DBG == 0) return launch_t<KP, 0, 48, FMT_H2>(kp, stream);
         if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, 64, FMT_H2>(kp, stream);
         return launch_t<KP, DBG, 0, FMT_H2>(kp, stream);
@@ -1877,6 +2019,20 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.p2 = plan;
     kp.a = a;
     if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
+    // split launch: lean production plans on packed input when every workgroup of both halves gets a CU of its own
+    // (measured: two workgroups sharing a CU cost each other more than the split saves - 64 graphs 38.0 -> 31.7 us per
+    // call, 128 graphs 38.1 -> 34.6, 256 graphs 37.9 -> 44.2); the caller reserved sem_tab / sem_flag in the workspace
+    const bool can_split = plan.fmt == FMT_H2 && plan.lean && !a.dense && !a.dbg_layers && !a.dbg_knn && !a.prof &&
+                           !(a.skip & ~8192) && a.sem_tab && a.sem_flag && 2 * a.G <= h->num_cus;
+    if (can_split) {
+        static std::atomic<unsigned> epoch{0u};
+        unsigned e = ++epoch;
+        if (e == 0u) e = ++epoch;
+        kp.a.sem_epoch = e;
+    } else {
+        kp.a.sem_tab = nullptr;
+        kp.a.sem_flag = nullptr;
+    }
     // layer / kNN dumps run on the roomy instance; timers and ablation keep the production occupancy
     const int mode = (a.dbg_layers || a.dbg_knn) ? 2 : ((a.prof || (a.skip & ~8192)) ? 1 : 0);
     int rc;
