@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 3
+#define SGPR_ABI_VERSION 4
 
 enum {
     SGPR_OK = 0,
@@ -215,6 +215,19 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
                                int64_t ldg, const float* d_thresholds, int T, const sgpr_rank_group* d_rank,
                                int groups_per_threshold, const unsigned long long* d_at_least, unsigned long long* d_out,
                                void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* F1-max of a score rectangle (eval_batch.py:69, 85-87) in ONE call, no host round trip between its steps: the scores of
+ * the positive pairs, thresholds picked among them on the device (sorted and de-duplicated in LDS), one streaming pass
+ * over the matrix for the negatives between them, exact F1 at every threshold and bounds for the positives in between,
+ * a second pass over the few values that can still hold the maximum.  Same ground truth arguments as
+ * sgpr_pair_positives.  d_result (device, 8 doubles): [0] F1-max (exact), [1] status - 0 ok, 1 the rectangle needs the
+ * multi-call path (more than 2^20 positive pairs, or more than 8191 values left to settle), 2 negative / NaN scores
+ * among the labelled pairs -, [2] positive pairs, [3] negative pairs, [4] passes over the matrix, [5] thresholds of the
+ * first pass, [6] values settled by the second.  Asynchronous on `stream`; the caller copies d_result when it needs it. */
+size_t sgpr_f1_max_workspace_bytes(const sgpr_handle* h, int R, int M);
+int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0, const double* d_pose_xz,
+                double d_pos, double d_neg, const signed char* d_gt, int64_t ldg, double* d_result, void* d_workspace,
+                size_t workspace_bytes, void* stream);
 
 /* Loop-closure candidates (the use the reference makes of a sequence's similarity matrix, README.md:92-97): for every
  * row r the k (1, 4, 8 or 16) best-scoring columns c with |c - (row0 + r)| > window (window = -1 keeps every column),

@@ -150,12 +150,22 @@ struct CountArgs {
     int gpt;
     unsigned* slabs;                     // [gridDim.x][slab_words]: T + 1 counters (padded to even) | bad (u64) | rank sum (u64)
     int slab_words;
+    const int* dT;                       // optional: T lives on the device (sgpr_f1_max: the thresholds are picked by a kernel);
+                                         // *dT < 0 = nothing to count (the launch returns without touching the slabs)
 };
 
 // ---- (3) negatives by threshold bucket; bucket b = #{q : thr[q] <= s}, so FP(>= thr[q]) = sum of buckets b > q.
 //      rank sum = sum over negatives of 2 #{positive pairs > s} + #{positive pairs == s}  (= 2 P N AUC)
-__global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const CountArgs a) {
+__global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const CountArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+    CountArgs a = a_in;
+    if (a.dT) {                          // thresholds picked on the device: their number, too
+        const int t = *a.dT;
+        if (t < 0) return;
+        a.T = t;
+        a.Tp = 1;
+        while (a.Tp <= t) a.Tp <<= 1;
+    }
     float* thr = reinterpret_cast<float*>(pc_smem);                       // [Tp]
     unsigned* cnt = reinterpret_cast<unsigned*>(thr + a.Tp);              // [T + 1]
     unsigned long long* at_least_lds = reinterpret_cast<unsigned long long*>(cnt + ((a.T + 2) & ~1));   // [T] (ranking only)
@@ -307,8 +317,12 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
 // out[i] = sum over the slabs: 32 counters per workgroup, 32 threads per counter (each sums every 32nd slab: one round
 // of independent loads), 128-B coalesced reads
 __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int slab_words, int T,
-                                                        unsigned long long* __restrict__ out) {
+                                                        unsigned long long* __restrict__ out, const int* __restrict__ dT = nullptr) {
     __shared__ unsigned long long part[32][33];
+    if (dT) {
+        T = *dT;
+        if (T < 0) return;
+    }
     const int b = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + b;                  // counters 0..T, then T+1 = bad, T+2 = rank sum
     unsigned long long s = 0ull;
@@ -325,6 +339,359 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 #pragma unroll
         for (int q = 1; q < 32; ++q) s += part[q][b];
         out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------ F1-max in one call (sgpr_f1_max)
+// eval_batch.py:69, 85-87 without a sort of the matrix and without a host round trip between the steps.  F1(t) can only
+// peak at the score t of a POSITIVE pair, F1 = f(TP(>= t), FP(>= t)) grows with TP and falls with FP, so:
+//   1. pair_positives_kernel            the scores of the positive pairs (a short list: loop closures are rare)
+//   2. f1_pick_kernel (one workgroup)   up to 8191 of them, evenly spaced in list order, sorted and de-duplicated in LDS
+//                                       = the thresholds; every positive is bucketed among them (b = #{thr <= s})
+//   3. pair_threshold_count_kernel      the negatives by bucket: one streaming pass over the matrix
+//   4. f1_plan_kernel (one workgroup)   exact F1 at every threshold; for the positives strictly inside bucket b the
+//                                       bound F1(#{pos > thr[b-1]}, #{neg >= thr[b]}); buckets whose bound beats the
+//                                       best exact value hand their interior positives to a second list
+//   5. steps 2-3 on that list (every value a threshold), f1_final_kernel: exact F1 there; the maximum is exact.
+// Everything the steps decide lives in a control block on the device; the host reads 8 doubles at the end.  Lists the
+// device path is not built for (more than 2^20 positives, more than 8191 values to settle) are reported in the status
+// word and the caller falls back to the multi-call path (sg_pr_amd/metrics.py), which handles any size.
+constexpr int F1_MAXT = PC_MAX_THRESHOLDS;     // 8191
+constexpr int F1_SORT = 8192;
+struct F1Ctrl {
+    int T1, T2;                  // thresholds of pass 1 / 2 (-1: pass not needed)
+    int n2;                      // values collected for pass 2
+    int status;                  // 0 ok, 1 fall back (sizes), 2 negative / NaN scores
+    double best1;
+    unsigned long long P, N;     // positive / negative pairs
+};
+
+__device__ __forceinline__ double f1_of(double tp, double fp, double pos) {
+    // metrics._f1: p = tp / (tp + fp) (0 without predictions), r = tp / pos, f = 2 p r / (p + r), nan -> 0
+    const double p = tp + fp > 0.0 ? tp / (tp + fp) : 0.0;
+    const double r = pos > 0.0 ? tp / pos : 1.0;
+    const double f = 2.0 * p * r / (p + r);
+    return f == f ? f : 0.0;
+}
+
+// One workgroup.  cand[0..nc): values to draw the thresholds from (every stride-th, at most F1_PICK of them).
+// Out: thr[T] ascending distinct, *dT = T, posc / eqc zeroed for f1_bucket_kernel.
+// The bitonic network runs on 16 waves that each own 1/16 of the array: every step whose partner distance stays inside
+// a wave's block needs no workgroup barrier (the LDS serves a wave's accesses in order), only the log2(16) + ... steps
+// that cross blocks do.
+constexpr int F1_PICK = 4095;                  // thresholds of a pass at most (a 4096-entry sort; 12 levels of the count tree)
+__global__ __launch_bounds__(1024) void f1_pick_kernel(const float* __restrict__ cand, const unsigned long long* __restrict__ nc_dev,
+                                                       const int* __restrict__ nc_int, const unsigned long long* __restrict__ na_dev,
+                                                       long long cap, float* __restrict__ thr, int* __restrict__ dT,
+                                                       unsigned* __restrict__ posc, unsigned* __restrict__ eqc,
+                                                       F1Ctrl* __restrict__ ctrl, int pass) {
+    __shared__ float v[F1_PICK + 1];
+    __shared__ int scan[1024 / 64 + 1];
+    __shared__ int total;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long na = (long long)na_dev[0];
+    const long long nc = nc_int ? (long long)*nc_int : (long long)nc_dev[0];
+    for (int i = tid; i < F1_SORT; i += 1024) {
+        posc[i] = 0u;
+        eqc[i] = 0u;
+    }
+    if (pass == 1 && (na > cap || ctrl->status != 0)) {                    // list longer than its buffer: the caller falls back
+        if (tid == 0) {
+            if (ctrl->status == 0) ctrl->status = 1;
+            *dT = -1;
+        }
+        return;
+    }
+    if (pass == 2 && (ctrl->status != 0 || nc <= 0)) {                     // nothing left to settle (or a fall-back already)
+        if (tid == 0) *dT = -1;
+        return;
+    }
+    // ---- sample: every stride-th candidate, +inf padding to a power of two (>= 1024: one pair per thread and step)
+    const long long stride = (nc + F1_PICK - 1) / F1_PICK > 0 ? (nc + F1_PICK - 1) / F1_PICK : 1;
+    const int ns = (int)((nc + stride - 1) / stride);                      // <= F1_PICK
+    int np2 = 2048;
+    while (np2 < ns) np2 <<= 1;
+    for (int i = tid; i < np2; i += 1024) v[i] = i < ns ? cand[(long long)i * stride] : INFINITY;
+    __syncthreads();
+    // ---- bitonic sort: wave w owns pairs [w * np2/32, (w+1) * np2/32), i.e. elements [w * np2/16, (w+1) * np2/16)
+    const int ppw = np2 >> 5, blk = np2 >> 4;                              // pairs / elements per wave
+    bool crossed = false;                                                  // the previous step crossed wave blocks
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = 2 * j > blk;
+            if (cross || crossed) __syncthreads();
+            crossed = cross;
+            for (int u = lane; u < ppw; u += 64) {
+                const int t = w * ppw + u;                                 // pair t: elements i and i + j
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const float a = v[i], b = v[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    v[i] = b;
+                    v[l] = a;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (program order inside the wave is all it takes)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    __syncthreads();
+    // ---- distinct values: flag, block scan, compact (ascending order is kept)
+    constexpr int PER = (F1_PICK + 1) / 1024;                              // 4 consecutive entries per thread
+    int keep[PER], mine = 0;
+    float vals[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = tid * PER + q;
+        vals[q] = i < np2 ? v[i] : INFINITY;
+        keep[q] = (i < ns && (i == 0 || vals[q] != v[i - 1])) ? 1 : 0;
+        mine += keep[q];
+    }
+    int incl = mine;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_up(incl, m);
+        if (lane >= m) incl += o;
+    }
+    if (lane == 63) scan[w] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < 1024 / 64; ++q) {
+            const int c = scan[q];
+            scan[q] = run;
+            run += c;
+        }
+        total = run;
+    }
+    __syncthreads();
+    int at = scan[w] + incl - mine;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (keep[q]) thr[at++] = vals[q];
+    if (tid == 0) {
+        *dT = total;
+        if (pass == 1) ctrl->T1 = total; else ctrl->T2 = total;
+    }
+}
+
+// Every positive among the thresholds of a pass: b = #{thr <= s} (bisection in an LDS copy of the thresholds), bid[i] = b |
+// (equal to thr[b-1]) << 15; counters posc[b] / eqc[b] first in LDS (random LDS atomics are cheap; 47 k global atomics on
+// 4 k hot addresses were measured at 0.5 ms), then one global atomic per bucket the workgroup touched.
+__global__ __launch_bounds__(1024) void f1_bucket_kernel(const float* __restrict__ all, const unsigned long long* __restrict__ na_dev,
+                                                         const float* __restrict__ thr, const int* __restrict__ dT,
+                                                         unsigned* __restrict__ posc, unsigned* __restrict__ eqc,
+                                                         unsigned short* __restrict__ bid) {
+    __shared__ float v[F1_PICK + 1];
+    __shared__ unsigned pc[F1_PICK + 1], ec[F1_PICK + 1];
+    const int T = *dT;
+    if (T < 0) return;
+    for (int i = threadIdx.x; i <= T; i += 1024) {
+        v[i] = i < T ? thr[i] : INFINITY;
+        pc[i] = 0u;
+        ec[i] = 0u;
+    }
+    __syncthreads();
+    const long long na = (long long)na_dev[0];
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < na; i += (long long)gridDim.x * 1024) {
+        const float s = all[i];
+        int lo = 0, hi = T;                                                // thr[lo-1] <= s < thr[hi]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (v[mid] <= s) lo = mid + 1; else hi = mid;
+        }
+        const bool eq = lo > 0 && v[lo - 1] == s;
+        atomicAdd(&pc[lo], 1u);
+        if (eq) atomicAdd(&ec[lo], 1u);
+        bid[i] = (unsigned short)(lo | (eq ? 0x8000 : 0));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= T; i += 1024) {
+        if (pc[i]) atomicAdd(&posc[i], pc[i]);
+        if (ec[i]) atomicAdd(&eqc[i], ec[i]);
+    }
+}
+
+// The interior positives of the marked buckets = the values the second pass settles (f1_plan_kernel decided: ctrl->n2 of
+// them, at most F1_PICK)
+__global__ __launch_bounds__(256) void f1_collect_kernel(const float* __restrict__ all, const unsigned long long* __restrict__ na_dev,
+                                                         const unsigned short* __restrict__ bid, const unsigned char* __restrict__ mark,
+                                                         const F1Ctrl* __restrict__ ctrl, float* __restrict__ list2,
+                                                         int* __restrict__ cursor) {
+    __shared__ unsigned char mk[F1_SORT];
+    if (ctrl->status != 0 || ctrl->n2 <= 0) return;
+    for (int i = threadIdx.x; i < F1_SORT; i += 256) mk[i] = mark[i];
+    __syncthreads();
+    const long long na = (long long)na_dev[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long long)gridDim.x * 256) {
+        const unsigned b = bid[i];
+        if (!(b & 0x8000u) && mk[b]) list2[atomicAdd(cursor, 1)] = all[i];
+    }
+}
+
+// block-wide sums of two 64-bit values per thread -> exclusive prefix over the threads in DESCENDING thread order (suffix
+// sums: thread t gets the total of the threads above it); sh: [2][1024 / 64 + 1] scratch
+__device__ __forceinline__ void suffix_scan2(unsigned long long& a, unsigned long long& b, unsigned long long (*sh)[17]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned long long ia = a, ib = b;                                     // inclusive over lanes >= this one
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long oa = __shfl_down(ia, m), ob = __shfl_down(ib, m);
+        if (lane + m < 64) {
+            ia += oa;
+            ib += ob;
+        }
+    }
+    if (lane == 0) {
+        sh[0][w] = ia;
+        sh[1][w] = ib;
+    }
+    __syncthreads();
+    unsigned long long ua = 0ull, ub = 0ull;                               // waves above this one
+    for (int q = w + 1; q < 16; ++q) {
+        ua += sh[0][q];
+        ub += sh[1][q];
+    }
+    __syncthreads();
+    a = ua + ia - a;                                                       // exclusive: everything above this thread
+    b = ub + ib - b;
+}
+
+__device__ __forceinline__ double block_max(double x, double* sh) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) x = fmax(x, __shfl_xor(x, m));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double r = sh[0];
+    for (int q = 1; q < 16; ++q) r = fmax(r, sh[q]);
+    __syncthreads();
+    return r;
+}
+
+// One workgroup.  negc[b] (uint64, from slab_sum_kernel; negc[T+1] = negatives with unusable scores), posc / eqc of pass 1.
+__global__ __launch_bounds__(1024) void f1_plan_kernel(const unsigned long long* __restrict__ negc, const unsigned* __restrict__ posc,
+                                                       const unsigned* __restrict__ eqc, const unsigned long long* __restrict__ count,
+                                                       unsigned char* __restrict__ mark, int* __restrict__ n2_dev,
+                                                       F1Ctrl* __restrict__ ctrl) {
+    __shared__ unsigned long long sh[2][17];
+    __shared__ double shd[16];
+    __shared__ unsigned n2s;
+    const int tid = threadIdx.x;
+    if (ctrl->status != 0) return;
+    const int T = ctrl->T1;
+    if (tid == 0) n2s = 0u;
+    if (count[1] != 0ull || negc[T + 1] != 0ull) {                         // negative / NaN scores have no rank
+        if (tid == 0) {
+            ctrl->status = 2;
+            *n2_dev = 0;
+        }
+        return;
+    }
+    constexpr int PER = F1_SORT / 1024;
+    unsigned long long ng[PER + 1], ps[PER + 1];                           // [q]: buckets tid*PER+q .. of this thread and above
+    unsigned long long sn = 0ull, sp = 0ull;
+#pragma unroll
+    for (int q = PER - 1; q >= 0; --q) {
+        const int b = tid * PER + q;
+        sn += b <= T ? negc[b] : 0ull;
+        sp += b <= T ? (unsigned long long)posc[b] : 0ull;
+        ng[q] = sn;
+        ps[q] = sp;
+    }
+    unsigned long long an = sn, ap = sp;
+    suffix_scan2(an, ap, sh);                                              // totals of the buckets of the threads above
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        ng[q] += an;
+        ps[q] += ap;
+    }
+    ng[PER] = an;
+    ps[PER] = ap;
+    __shared__ unsigned long long tot[2];
+    if (tid == 0) {
+        tot[0] = ps[0];                                                    // all positives / negatives
+        tot[1] = ng[0];
+    }
+    __syncthreads();
+    const double P = (double)tot[0];
+    // exact F1 at threshold b - 1 = F1(positives / negatives in buckets >= b)
+    double best = 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int b = tid * PER + q;
+        if (b >= 1 && b <= T) best = fmax(best, f1_of((double)ps[q], (double)ng[q], P));
+    }
+    best = block_max(best, shd);
+    // bound for the positives strictly inside bucket b: at most the positives above thr[b-1], at least the negatives >= thr[b]
+    unsigned mine2 = 0u;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int b = tid * PER + q;
+        unsigned char m = 0;
+        if (b <= T) {
+            const unsigned inside = posc[b] - eqc[b];
+            if (inside > 0u && f1_of((double)(ps[q] - eqc[b]), (double)ng[q + 1], P) > best) {
+                m = 1;
+                mine2 += inside;
+            }
+        }
+        if (b < F1_SORT) mark[b] = m;
+    }
+    if (mine2) atomicAdd(&n2s, mine2);
+    __threadfence_block();
+    __syncthreads();
+    const unsigned n2 = n2s;
+    if (tid == 0) {
+        ctrl->best1 = best;
+        ctrl->P = tot[0];
+        ctrl->N = tot[1];
+        ctrl->n2 = (int)n2;
+        if (n2 > (unsigned)F1_PICK) ctrl->status = 1;                      // too many values to settle in one more pass
+        *n2_dev = n2 > (unsigned)F1_PICK ? 0 : (int)n2;
+    }
+}
+
+__global__ __launch_bounds__(1024) void f1_final_kernel(const unsigned long long* __restrict__ negc2, const unsigned* __restrict__ posc2,
+                                                        const F1Ctrl* __restrict__ ctrl, double* __restrict__ result) {
+    __shared__ unsigned long long sh[2][17];
+    __shared__ double shd[16];
+    const int tid = threadIdx.x;
+    double best = ctrl->best1;
+    int passes = 1;
+    if (ctrl->status == 0 && ctrl->n2 > 0) {
+        const int T = ctrl->T2;
+        constexpr int PER = F1_SORT / 1024;
+        unsigned long long ng[PER], ps[PER], sn = 0ull, sp = 0ull;
+#pragma unroll
+        for (int q = PER - 1; q >= 0; --q) {
+            const int b = tid * PER + q;
+            sn += b <= T ? negc2[b] : 0ull;
+            sp += b <= T ? (unsigned long long)posc2[b] : 0ull;
+            ng[q] = sn;
+            ps[q] = sp;
+        }
+        unsigned long long an = sn, ap = sp;
+        suffix_scan2(an, ap, sh);
+        const double P = (double)ctrl->P;
+        double b2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int b = tid * PER + q;
+            if (b >= 1 && b <= T) b2 = fmax(b2, f1_of((double)(ps[q] + ap), (double)(ng[q] + an), P));
+        }
+        best = fmax(best, block_max(b2, shd));
+        passes = 2;
+    }
+    if (tid == 0) {
+        result[0] = ctrl->status == 0 ? fmax(best, 0.0) : 0.0;
+        result[1] = (double)ctrl->status;
+        result[2] = (double)ctrl->P;
+        result[3] = (double)ctrl->N;
+        result[4] = (double)passes;
+        result[5] = (double)ctrl->T1;
+        result[6] = (double)ctrl->n2;
+        result[7] = 0.0;
     }
 }
 
@@ -510,6 +877,123 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
     hipLaunchKernelGGL(slab_sum_kernel, dim3((T + 3 + 31) / 32), dim3(1024), 0, s, a.slabs, h->num_cus, a.slab_words, T, d_out);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "slab_sum_kernel launch");
+    return SGPR_OK;
+}
+
+// ---- sgpr_f1_max: workspace = header (counts, control block, device-side sizes) | thresholds, bucket counters, marks of
+//      both passes | negatives by bucket of both passes | second list | positives | their buckets | counter slabs
+static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct F1Layout {
+    size_t off_thr1, off_thr2, off_posc1, off_eqc1, off_posc2, off_eqc2, off_mark, off_neg1, off_neg2, off_list2, off_pos, off_bid,
+        off_slabs, total;
+    long long cap;
+};
+static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
+    F1Layout L;
+    const long long pairs = (long long)R * M;
+    L.cap = pairs < (1LL << 20) ? pairs : (1LL << 20);
+    if (L.cap < 1) L.cap = 1;
+    size_t off = 256;                                                       // header
+    L.off_thr1 = off;  off += a256(F1_SORT * sizeof(float));
+    L.off_thr2 = off;  off += a256(F1_SORT * sizeof(float));
+    L.off_posc1 = off; off += a256(F1_SORT * sizeof(unsigned));
+    L.off_eqc1 = off;  off += a256(F1_SORT * sizeof(unsigned));
+    L.off_posc2 = off; off += a256(F1_SORT * sizeof(unsigned));
+    L.off_eqc2 = off;  off += a256(F1_SORT * sizeof(unsigned));
+    L.off_mark = off;  off += a256(F1_SORT);
+    L.off_neg1 = off;  off += a256((F1_SORT + 4) * sizeof(unsigned long long));
+    L.off_neg2 = off;  off += a256((F1_SORT + 4) * sizeof(unsigned long long));
+    L.off_list2 = off; off += a256(F1_SORT * sizeof(float));
+    L.off_pos = off;   off += a256((size_t)L.cap * sizeof(float));
+    L.off_bid = off;   off += a256((size_t)L.cap * sizeof(unsigned short));
+    L.off_slabs = off; off += a256((size_t)h->num_cus * slab_words(F1_MAXT) * sizeof(unsigned));
+    L.total = off;
+    return L;
+}
+
+size_t sgpr_f1_max_workspace_bytes(const sgpr_handle* h, int R, int M) {
+    if (!h || R < 0 || M < 0) return 0;
+    return f1_layout(h, R, M).total;
+}
+
+int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0, const double* d_pose_xz,
+                double d_pos, double d_neg, const signed char* d_gt, int64_t ldg, double* d_result, void* d_workspace,
+                size_t workspace_bytes, void* stream) {
+    int rc = check_scan("sgpr_f1_max", h, d_score, R, M, ld, d_pose_xz, d_gt, ldg);
+    if (rc != SGPR_OK) return rc;
+    if (!d_result) {
+        set_error("sgpr_f1_max: NULL result buffer");
+        return SGPR_E_INVALID;
+    }
+    const F1Layout L = f1_layout(h, R, M);
+    if (!d_workspace || workspace_bytes < L.total) {
+        set_error("sgpr_f1_max: workspace of " + std::to_string(L.total) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char* ws = static_cast<unsigned char*>(d_workspace);
+    unsigned long long* count = reinterpret_cast<unsigned long long*>(ws);            // [2]
+    F1Ctrl* ctrl = reinterpret_cast<F1Ctrl*>(ws + 64);
+    int* dT1 = reinterpret_cast<int*>(ws + 192);
+    int* dT2 = dT1 + 1;
+    int* n2 = dT1 + 2;
+    float* thr1 = reinterpret_cast<float*>(ws + L.off_thr1);
+    float* thr2 = reinterpret_cast<float*>(ws + L.off_thr2);
+    unsigned* posc1 = reinterpret_cast<unsigned*>(ws + L.off_posc1);
+    unsigned* eqc1 = reinterpret_cast<unsigned*>(ws + L.off_eqc1);
+    unsigned* posc2 = reinterpret_cast<unsigned*>(ws + L.off_posc2);
+    unsigned* eqc2 = reinterpret_cast<unsigned*>(ws + L.off_eqc2);
+    unsigned char* mark = ws + L.off_mark;
+    unsigned long long* neg1 = reinterpret_cast<unsigned long long*>(ws + L.off_neg1);
+    unsigned long long* neg2 = reinterpret_cast<unsigned long long*>(ws + L.off_neg2);
+    float* list2 = reinterpret_cast<float*>(ws + L.off_list2);
+    float* pos = reinterpret_cast<float*>(ws + L.off_pos);
+    unsigned short* bid = reinterpret_cast<unsigned short*>(ws + L.off_bid);
+    unsigned* slabs = reinterpret_cast<unsigned*>(ws + L.off_slabs);
+    static_assert(sizeof(F1Ctrl) <= 128, "control block");
+    hipError_t e = hipMemsetAsync(ws, 0, 256, s);                                      // counts, control block, sizes
+    if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_threshold_count_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(f1 kernels)");
+        attr_set = true;
+    }
+    const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
+    if ((int64_t)R * M > 0)
+        hipLaunchKernelGGL(pair_positives_kernel, dim3(h->num_cus * 8), dim3(256), 0, s, sc, pos, L.cap, count);
+    const size_t count_lds = (size_t)F1_SORT * sizeof(float) + (size_t)F1_SORT * sizeof(unsigned);
+    CountArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scan = sc;
+    a.slabs = slabs;
+    a.slab_words = slab_words(F1_MAXT);
+    int* cursor = n2 + 1;                                                              // append cursor of the second list
+    for (int pass = 1; pass <= 2; ++pass) {
+        float* thr = pass == 1 ? thr1 : thr2;
+        int* dT = pass == 1 ? dT1 : dT2;
+        unsigned* posc = pass == 1 ? posc1 : posc2;
+        unsigned* eqc = pass == 1 ? eqc1 : eqc2;
+        hipLaunchKernelGGL(f1_pick_kernel, dim3(1), dim3(1024), 0, s, pass == 1 ? pos : list2, count,
+                           pass == 1 ? (const int*)nullptr : n2, count, L.cap, thr, dT, posc, eqc, ctrl, pass);
+        hipLaunchKernelGGL(f1_bucket_kernel, dim3(32), dim3(1024), 0, s, pos, count, thr, dT, posc, eqc, bid);
+        a.thr = thr;
+        a.dT = dT;
+        if ((int64_t)R * M > 0) {
+            hipLaunchKernelGGL(pair_threshold_count_kernel, dim3(h->num_cus), dim3(PC_THREADS), count_lds, s, a);
+            hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_MAXT + 3 + 31) / 32), dim3(1024), 0, s, slabs, h->num_cus, a.slab_words,
+                               0, pass == 1 ? neg1 : neg2, dT);
+        }
+        if (pass == 1) {
+            hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(1024), 0, s, neg1, posc1, eqc1, count, mark, n2, ctrl);
+            hipLaunchKernelGGL(f1_collect_kernel, dim3(64), dim3(256), 0, s, pos, count, bid, mark, ctrl, list2, cursor);
+        }
+    }
+    hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(1024), 0, s, neg2, posc2, ctrl, d_result);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max launches");
     return SGPR_OK;
 }
 

@@ -36,7 +36,7 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_score_all_pairs", "sgpr_score_all_pairs_multi_workspace_bytes", "sgpr_score_all_pairs_multi",
                "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
                "sgpr_pair_positives", "sgpr_pair_threshold_counts_workspace_bytes", "sgpr_pair_threshold_counts",
-               "sgpr_topk_rows",
+               "sgpr_f1_max_workspace_bytes", "sgpr_f1_max", "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
                "sgpr_cluster_workspace_bytes", "sgpr_cluster_scan", "sgpr_graph_edges",
                "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
@@ -120,6 +120,10 @@ def load_library():
     lib.sgpr_pair_threshold_counts_workspace_bytes.argtypes = [vp, i32]
     lib.sgpr_pair_threshold_counts.argtypes = [vp, vp, i32, i32, i64, i32, vp, dbl, dbl, vp, i64, vp, i32, vp, i32, vp, vp, vp, sz,
                                                vp]
+    lib.sgpr_f1_max_workspace_bytes.restype = sz
+    lib.sgpr_f1_max_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_f1_max.restype = i32
+    lib.sgpr_f1_max.argtypes = [vp, vp, i32, i32, i64, i32, vp, dbl, dbl, vp, i64, vp, vp, sz, vp]
     lib.sgpr_topk_rows.restype = i32
     lib.sgpr_topk_rows.argtypes = [vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp]
     lib.sgpr_embed_lds_bytes.restype = sz
@@ -476,6 +480,19 @@ class Engine:
         h = out.cpu().numpy()
         rank_sum = int(h[t + 2].astype(np.uint64)) if rank is not None else None
         return h[:t + 1].copy(), int(h[t + 1]), rank_sum
+
+    def f1_max(self, score, row0=0, pose_xz=None, d_pos=3.0, d_neg=20.0, gt=None):
+        """F1-max of a score rectangle in ONE engine call (sgpr_f1_max): every step on the device, one 64-byte copy
+        at the end.  Returns the raw result vector (numpy float64 [8], see include/sgpr.h): [0] F1-max, [1] status (0 ok,
+        1 = use the multi-call path, 2 = negative / NaN scores), [2] positives, [3] negatives, [4] passes."""
+        score, r, m, pose_xz, gt = self._truth(score, row0, pose_xz, gt)
+        res = torch.empty(8, dtype=torch.float64, device=self.device)
+        ws_bytes = self.lib.sgpr_f1_max_workspace_bytes(self._h, r, m)
+        ws = self._ws(ws_bytes)
+        rc = self.lib.sgpr_f1_max(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz), float(d_pos),
+                                  float(d_neg), _ptr(gt), m, _ptr(res), _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        return res.cpu().numpy()
 
     def topk_rows(self, score, k=1, row0=0, window=-1):
         """Best k columns per row outside |col - (row0 + row)| <= window -> (values f32 [R,k], indices i32 [R,k])."""

@@ -1058,3 +1058,54 @@ def test_generic_branch_graph_outside_f16_range(eng, oracle, oracle_sd):
     assert torch.equal(p_wide[hit], pooled[hit])               # the out-of-range graphs: same bits as forcing the wide instance
     p_plain, _, _ = eng.embed(big, labels, 10)                 # uncapped plan (no second-pass reason 2): same results
     assert torch.equal(p_plain, pooled)
+
+
+def test_f1_max_one_call(eng):
+    """sgpr_f1_max (positives, thresholds, counting passes and the F1 reduction in one engine call, one 64-byte copy back)
+    equals the sorted host computation to < 1e-12 - poses and explicit labels, ties, ragged shapes, no positives, only
+    positives - and reports the rectangles it is not built for, which metrics.f1_max_device then settles on the
+    multi-call path."""
+    from sg_pr_amd import synth, metrics, allpairs
+    centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=900, node_num=100, seed=5)
+    order, cap = eng.size_order(centers, labels, 10)
+    pooled = eng.embed(centers, labels, 10, node_cap=cap, order=order)[0]
+    m = eng.score_all_pairs(pooled, pooled)
+    xz = allpairs.pose_xz(poses)
+    d = torch.cdist(xz.double(), xz.double())
+    gt = torch.where(d <= 3, 1, torch.where(d >= 20, 0, -1)).to(torch.int8)
+
+    def host(sc, lab):
+        keep = lab.ravel() >= 0
+        return metrics.f1_max(lab.ravel()[keep], sc.ravel()[keep])
+
+    res = eng.f1_max(m, pose_xz=xz)
+    want = host(m.cpu().numpy(), gt.numpy())
+    print("one-call F1-max", res.tolist(), "host", want)
+    assert res[1] == 0 and abs(res[0] - want) < 1e-12
+    assert res[2] == int((gt == 1).sum()) and res[3] == int((gt == 0).sum()) and res[4] in (1, 2)
+    assert metrics.f1_max_device(eng, m, pose_xz=xz) == metrics.f1_max_device(eng, m, pose_xz=xz, one_call=False)
+    # a row shard with explicit labels; massive ties; a padded leading dimension; tiny shapes
+    res = eng.f1_max(m[101:358], row0=101, gt=gt[101:358])
+    assert res[1] == 0 and abs(res[0] - host(m[101:358].cpu().numpy(), gt[101:358].numpy())) < 1e-12
+    r2 = (m * 50).round() / 50
+    res = eng.f1_max(r2, pose_xz=xz)
+    assert res[1] == 0 and abs(res[0] - host(r2.cpu().numpy(), gt.numpy())) < 1e-12
+    rng = np.random.default_rng(12)
+    for rows, cols, ld, ppos in ((37, 333, 340, 0.3), (1, 5, 5, 0.5), (129, 1023, 1023, 0.02), (3, 2, 8, 0.5), (300, 300, 300, 0.0),
+                                 (64, 64, 64, 1.0)):
+        buf = torch.rand(rows, ld, generator=torch.Generator().manual_seed(rows + cols)).cuda()
+        sc = buf[:, :cols]
+        lab = np.where(rng.random((rows, cols)) < 0.15, -1, (rng.random((rows, cols)) < ppos).astype(np.int8)).astype(np.int8)
+        res = eng.f1_max(sc, gt=torch.from_numpy(lab))
+        assert res[1] == 0, (rows, cols, res.tolist())
+        assert abs(res[0] - host(sc.cpu().numpy(), lab)) < 1e-12, (rows, cols, res.tolist())
+        assert res[2] == int((lab == 1).sum()) and res[3] == int((lab == 0).sum())
+    # as many positives as negatives, random scores: the F1 curve is flat, far more than 8191 values stay open after
+    # the first pass - the engine says so (status 1) and the multi-call path settles it
+    big = torch.rand(1100, 1100, generator=torch.Generator().manual_seed(2)).cuda()
+    lab = (rng.random((1100, 1100)) < 0.5).astype(np.int8)
+    res = eng.f1_max(big, gt=torch.from_numpy(lab))
+    f1, passes = metrics.f1_max_device(eng, big, gt=torch.from_numpy(lab))
+    print("flat curve: one-call status", res[1], "open values", res[6], "-> multi-call passes", passes)
+    assert abs(f1 - host(big.cpu().numpy(), lab)) < 1e-12
+    assert res[1] in (0, 1) and (res[1] == 1 or abs(res[0] - f1) < 1e-12)

@@ -36,7 +36,8 @@ def timed(name):
     return orig, f
 
 
-for name, fn in (("f1_max_device", lambda: metrics.f1_max_device(eng, mat, pose_xz=xz)),
+for name, fn in (("f1_max one call", lambda: metrics.f1_max_device(eng, mat, pose_xz=xz)),
+                 ("f1_max multi-call", lambda: metrics.f1_max_device(eng, mat, pose_xz=xz, one_call=False)),
                  ("roc_auc_device", lambda: metrics.roc_auc_device(eng, mat, pose_xz=xz)),
                  ("pr_roc_device", lambda: metrics.pr_roc_device(eng, mat, pose_xz=xz))):
     fn()
