@@ -15,7 +15,7 @@ def test_library_exports_every_header_symbol():
     from sg_pr_amd import engine
     lib = engine.load_library()
     header = open(os.path.join(REPO, "include", "sgpr.h")).read()
-    declared = set(re.findall(r"\b(sgpr_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(sgpr_[a-z0-9_]+)\s*\(", header))
     assert declared == set(engine.ABI_SYMBOLS), declared ^ set(engine.ABI_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
