@@ -47,9 +47,10 @@ def test_lds_plans():
     assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 0      # > SGPR_MAX_NODES
     assert lib.sgpr_embed_lds_bytes(h, 8, 10) == 0        # K > node_num
     # one redo flag per launch slot (rounded to 256 B) + the parked first-branch block for node_num > 128
-    assert lib.sgpr_embed_workspace_bytes(h, 10, 100, 10) == 256
-    assert lib.sgpr_embed_workspace_bytes(h, 300, 100, 10) == 512
-    assert lib.sgpr_embed_workspace_bytes(h, 10, 256, 20) == 256 + 10 * 256 * 32 * 4
+    sem = lambda g: g * (8 + 16 * 32 * 4)          # split launch: one flag + 16 sem3 rows per launch slot
+    assert lib.sgpr_embed_workspace_bytes(h, 10, 100, 10) == 256 + sem(10)
+    assert lib.sgpr_embed_workspace_bytes(h, 300, 100, 10) == 512 + sem(300)
+    assert lib.sgpr_embed_workspace_bytes(h, 10, 256, 20) == 256 + 10 * 256 * 32 * 4 + sem(10)
 
 
 def test_engine_refuses_to_run_without_gpu(ckpt_path):
