@@ -42,6 +42,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak (= fp32 matrix peak)
+SHADER_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: peak engine clock
 KITTI_FRAMES = {"00": 4541, "02": 4661, "05": 2761, "06": 1101, "08": 4071}
 
 
@@ -95,6 +96,12 @@ def parse():
                     help="kitti5seq: one prep + tail launch per sequence instead of one pair for all matrices")
     ap.add_argument("--per-sequence-embed", action="store_true",
                     help="kitti5seq: one embed launch per sequence instead of one for the shards of all sequences")
+    ap.add_argument("--data-dir", default=os.environ.get("SG_PR_DATA_DIR", ""),
+                    help="kitti00: a directory of real graph JSONs (e.g. $SG_PR_DATA/graphs_sk/00) packed once through "
+                         "sg_pr_amd.graph_store.pack_directory instead of the synthetic sequence; the line then says "
+                         "\"data\": \"real\" and M is the number of graphs found")
+    ap.add_argument("--d2h-pieces", type=int, default=4,
+                    help="end_to_end.d2h: row blocks whose device-to-host copy overlaps the scoring of the next one")
     return ap.parse_args()
 
 
@@ -149,6 +156,7 @@ def main():
     args.model = os.path.join(REPO, "tests", "golden", "model.pth")
     args.gpu = dev.index
     allpairs_job = a.workload in ("kitti00", "kitti5seq")
+    data_kind = "synthetic"
     if a.workload == "kitti00":
         n, k = 100, 10
         seqs = [("00", a.graphs)]
@@ -170,6 +178,7 @@ def main():
         trainer = sg_net.SGTrainer(args, False)
     model = trainer.model
     eng = model.engine()
+    eng_cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
     ev_embed, ev_tail = [], []      # (start, stop) events around the embed launch / the all-pairs tail launches
     graphs_per_step = 0             # graphs this rank embeds per step
@@ -189,8 +198,20 @@ def main():
     if allpairs_job:
         jobs = []
         units = 0
+        if a.workload == "kitti00" and a.data_dir:
+            # real graphs (README.md:54, 92-97: <graph_pairs_dir>/<seq>/*.json), parsed and packed once
+            from sg_pr_amd import graph_store
+            real = graph_store.pack_directory(a.data_dir, n)
+            if len(real) < 2:
+                sys.exit("bench.py: --data-dir %s holds %d graph JSONs" % (a.data_dir, len(real)))
+            seqs = [(os.path.basename(os.path.normpath(a.data_dir)) or "real", len(real))]
+            data_kind = "real"
+            wl_name = "all-pairs matrix of the %d graphs in %s, node_num=100, K=10" % (len(real), a.data_dir)
         for si, (name, m) in enumerate(seqs):
-            centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=si)
+            if data_kind == "real":
+                centers, labels, poses = real.centers, real.labels, real.poses
+            else:
+                centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=si)
             host_inputs.append((centers, labels, poses))
             lo, hi = allpairs.shard_bounds(m, world, rank)
             node_cap = eng.node_cap_of(centers, labels, k)   # dataset property (the graph store knows its node counts)
@@ -307,14 +328,28 @@ def main():
         xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
         reps = max(3, min(20, a.steps))
 
+        copy_stream = torch.cuda.Stream(device=dev)
+        pieces = max(1, a.d2h_pieces)
+        dev_out = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
+
         def e2e(consumer):
-            for j, (pc, pl), ho, pz in zip(jobs, pinned, host_out, xz):
+            for j, (pc, pl), ho, do, pz in zip(jobs, pinned, host_out, dev_out, xz):
                 dc, dl = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True)
-                mat = j["scorer"].run(dc, dl)
                 if consumer == "d2h":
-                    ho.copy_(mat, non_blocking=True)
+                    # the matrix leaves in row blocks: block i crosses PCIe on the copy stream while block i + 1 is scored
+                    pooled = j["scorer"].embed_fn(dc, dl)
+                    m = j["m"]
+                    for q in range(pieces):
+                        r0, r1 = m * q // pieces, m * (q + 1) // pieces
+                        model.score_all_pairs(pooled[r0:r1].contiguous(), pooled, out=do[r0:r1])
+                        ready = torch.cuda.Event()
+                        ready.record()
+                        copy_stream.wait_event(ready)
+                        with torch.cuda.stream(copy_stream):
+                            ho[r0:r1].copy_(do[r0:r1], non_blocking=True)
                 else:
                     from sg_pr_amd import metrics
+                    mat = j["scorer"].run(dc, dl)
                     metrics.f1_max_device(eng, mat, pose_xz=pz)
             torch.cuda.synchronize()
 
@@ -327,9 +362,10 @@ def main():
             te = (time.perf_counter() - t0) / reps
             end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
         end_to_end["note"] = ("per step: H2D of the packed graphs from pinned host memory (%.1f MB) + the step + either "
-                              "the D2H copy of the score matrices into pinned memory (%.1f MB; `d2h`) or the device-side "
-                              "F1-max over them with only the positives' scores and the counts crossing PCIe (`device_f1`); %d repetitions"
-                              % (sum(c.nbytes + l.nbytes for c, l, _ in host_inputs) / 1e6, units * 4 / 1e6, reps))
+                              "the D2H copy of the score matrices into pinned memory (%.1f MB, in %d row blocks whose copies "
+                              "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "
+                              "engine call with 64 bytes crossing PCIe (`device_f1`); %d repetitions"
+                              % (sum(c.nbytes + l.nbytes for c, l, _ in host_inputs) / 1e6, units * 4 / 1e6, pieces, reps))
         ev_embed.clear()
         ev_tail.clear()
 
@@ -348,7 +384,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value comes from
         # the committed rocprofv3 --pmc passes of the same workload (profiles/pmc_hbm_latest.json) and is reported only
         # while that profile was taken from exactly these kernel sources
-        traffic, traffic_tail = None, None
+        traffic, traffic_tail, issue = None, None, None
         try:
             with open(os.path.join(REPO, "profiles", "pmc_hbm_latest.json")) as f:
                 pmc = json.load(f)
@@ -356,6 +392,22 @@ def main():
                 pe = pmc["sgpr::embed_kernel"]
                 if pe["graphs_per_launch"] == g and pe["node_num"] == n:
                     traffic = (2 * pe["FETCH_SIZE_KiB"] + pe["WRITE_SIZE_KiB"]) * 1024.0   # gfx950 FETCH_SIZE correction
+                    pc = pmc.get("embed_kernel_counters")
+                    if pc and pc.get("SQ_INSTS_VALU"):
+                        # the resource that binds the kernel: instruction issue.  Busy cycles of the vector / matrix pipe
+                        # = 4 x SQ_ACTIVE_INST_VALU (the counter ticks once per 4 cycles an instruction occupies the
+                        # pipe, matrix instructions included) against the SIMD-cycles of the launch (4 SIMDs per CU at
+                        # the shader clock); the kernel's launch time tracks its instruction count
+                        simd_cycles = embed_ms * 1e-3 * SHADER_CLOCK_HZ * 4 * eng_cus
+                        busy = 4.0 * pc.get("SQ_ACTIVE_INST_VALU", 0)
+                        issue = {"bound": "valu_issue", "achieved": busy, "peak": simd_cycles, "unit": "SIMD-cycles",
+                                 "frac": busy / simd_cycles,
+                                 "instructions_per_launch": {k_: pc.get(k_) for k_ in (
+                                     "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM")},
+                                 "mfma_busy_cycles": pc.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                                 "wave_cycles": pc.get("SQ_WAVE_CYCLES"), "wait_cycles": pc.get("SQ_WAIT_ANY"),
+                                 "note": "counters from the committed rocprofv3 --pmc passes of these sources; "
+                                         "launch time from this run; shader clock %.1f GHz assumed" % (SHADER_CLOCK_HZ / 1e9)}
                 pt = pmc.get("sgpr::score_all_pairs_kernel")
                 if pt and a.graphs == 4541:
                     traffic_tail = (2 * pt["FETCH_SIZE_KiB"] + pt["WRITE_SIZE_KiB"]) * 1024.0
@@ -365,7 +417,8 @@ def main():
             "metric": "graph-pairs/sec", "value": value, "unit": "graph-pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if allpairs_job else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (2xf16-plane operands on the matrix cores, fp32 accumulate; fp32 vector math)",
+            "data": data_kind,
             "config": {"workload": wl_name, "graphs": int(sum(mm for _, mm in seqs)) if allpairs_job else int(m),
                        "node_num": n, "K": k, "pairs_per_step": int(units), "node_cap": int(node_cap_report),
                        "embed_launch_order": "largest graph first" if a.embed_mode == "ordered" else "as stored",
@@ -379,7 +432,7 @@ def main():
                          "bound_note": "VALU issue + dependent latency (selection networks, gather-max, epilogues); the "
                                        "matrix pipe is ~8 % busy and HBM ~0.5 % - priced against the fp32 vector peak",
                          "achieved": ach_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP32_PEAK_TFLOPS, "traffic": traffic, "launch_ms": embed_ms,
+                         "frac": ach_tflops / FP32_PEAK_TFLOPS, "traffic": traffic, "issue": issue, "launch_ms": embed_ms,
                          "graphs_per_launch": g / launches_per_step, "launches_per_step": launches_per_step,
                          "flops_per_launch_algorithmic": flops, "mean_nodes_processed": float(np.mean(n_eff)),
                          "dense_equivalent_tflops": flops_dense / (embed_ms * 1e-3) / 1e12,

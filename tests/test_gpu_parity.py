@@ -1109,3 +1109,18 @@ def test_f1_max_one_call(eng):
     print("flat curve: one-call status", res[1], "open values", res[6], "-> multi-call passes", passes)
     assert abs(f1 - host(big.cpu().numpy(), lab)) < 1e-12
     assert res[1] in (0, 1) and (res[1] == 1 or abs(res[0] - f1) < 1e-12)
+
+
+def test_bench_on_real_graph_directory(golden_dir):
+    """bench.py --data-dir packs a directory of real graph JSONs once (graph_store.pack_directory) and benchmarks their
+    all-pairs matrix: the three shipped graphs here, $SG_PR_DATA/graphs_sk/00 on a machine that has KITTI mounted."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--data-dir", os.path.join(golden_dir, "data"),
+                          "--steps", "3", "--warmup", "1", "--prewarm", "0", "--no-cpu-baseline"],
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["data"] == "real" and line["config"]["graphs"] == 3 and line["config"]["pairs_per_step"] == 9
+    assert line["value"] > 0 and line["end_to_end"]["d2h"]["value"] > 0

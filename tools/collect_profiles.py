@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (source_hash)
 
 tag = sys.argv[1]
+pmc_only = "--pmc-only" in sys.argv[2:]      # on the GPU box, between the counter passes and the bench runs of one refresh
 src, dst = "gpurun_out/prof", "profiles"
 
 
@@ -57,30 +58,31 @@ def bench_line(name, out):
         open(os.path.join(dst, out), "w").write(lines[-1] + "\n")
 
 
-kernel_stats("kt", tag + "_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-end-to-end")
-kernel_stats("kt_stress", tag + "_stress_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload stress --no-cpu-baseline --steps 50")
-kernel_stats("kt_pairs128", tag + "_pairs128_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairs128 --no-cpu-baseline --steps 50")
-kernel_stats("kt_consumers", tag + "_consumers_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_f1.py 3")
-if os.path.exists(os.path.join(src, "consumers.log")):
-    with open(os.path.join(dst, tag + "_consumers.txt"), "w") as o:
-        o.write("# python tools/run_f1.py 10 check  (KITTI-00-sized matrix of the bench, device F1-max / ROC area)\n")
-        o.write("".join(l for l in open(os.path.join(src, "consumers.log")) if "amdgpu.ids" not in l))
-cons = {}
-for nm in ("sq_consumers", "FETCH_SIZE_consumers", "WRITE_SIZE_consumers"):
-    for kname, d in pmc(nm).items():
-        if "pair_" in kname or "slab" in kname:
-            cons.setdefault(kname, {}).update(d)
-if cons:
-    with open(os.path.join(dst, tag + "_consumers_pmc.txt"), "w") as o:
-        o.write("# rocprofv3 --pmc (separate passes) -- python tools/run_f1.py 1; per-launch averages over the passes with and without the\n"
-                "# ranking; SQ counters in millions, FETCH_SIZE / WRITE_SIZE in KiB (the matrix read is 80 549 KiB)\n")
-        for kname, d in cons.items():
-            o.write("%-40s %s\n" % (kname[:40], {c: (round(v, 1) if "SIZE" in c else round(v / 1e6, 3)) for c, v in sorted(d.items())}))
-    print(open(os.path.join(dst, tag + "_consumers_pmc.txt")).read())
-for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
-                  ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
-                  ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json")):
-    bench_line(name, tag + out)
+if not pmc_only:
+    kernel_stats("kt", tag + "_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-end-to-end")
+    kernel_stats("kt_stress", tag + "_stress_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload stress --no-cpu-baseline --steps 50")
+    kernel_stats("kt_pairs128", tag + "_pairs128_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairs128 --no-cpu-baseline --steps 50")
+    kernel_stats("kt_consumers", tag + "_consumers_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_f1.py 3")
+    if os.path.exists(os.path.join(src, "consumers.log")):
+        with open(os.path.join(dst, tag + "_consumers.txt"), "w") as o:
+            o.write("# python tools/run_f1.py 10 check  (KITTI-00-sized matrix of the bench, device F1-max / ROC area)\n")
+            o.write("".join(l for l in open(os.path.join(src, "consumers.log")) if "amdgpu.ids" not in l))
+    cons = {}
+    for nm in ("sq_consumers", "FETCH_SIZE_consumers", "WRITE_SIZE_consumers"):
+        for kname, d in pmc(nm).items():
+            if "pair_" in kname or "slab" in kname:
+                cons.setdefault(kname, {}).update(d)
+    if cons:
+        with open(os.path.join(dst, tag + "_consumers_pmc.txt"), "w") as o:
+            o.write("# rocprofv3 --pmc (separate passes) -- python tools/run_f1.py 1; per-launch averages over the passes with and without the\n"
+                    "# ranking; SQ counters in millions, FETCH_SIZE / WRITE_SIZE in KiB (the matrix read is 80 549 KiB)\n")
+            for kname, d in cons.items():
+                o.write("%-40s %s\n" % (kname[:40], {c: (round(v, 1) if "SIZE" in c else round(v / 1e6, 3)) for c, v in sorted(d.items())}))
+        print(open(os.path.join(dst, tag + "_consumers_pmc.txt")).read())
+    for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
+                      ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
+                      ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json")):
+        bench_line(name, tag + out)
 
 hbm = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python "
                  "tools/run_embed.py <shape> 3; per-launch averages (" + tag + ")",
@@ -101,7 +103,20 @@ for shape, (g, n, k) in shapes.items():
             hbm[key] = e
         else:
             hbm.setdefault(shape, {})[key] = e
+# instruction mix / issue counters of the dominant kernel (bench.py's roofline.issue), same source hash
+for shape in shapes:
+    ins = {}
+    for name in ("sq1_", "sq2_"):
+        for kname, d in pmc(name + shape).items():
+            if "embed_kernel" in kname:
+                ins.update({c: round(v) for c, v in d.items()})
+                ins["kernel"] = kname
+    if ins:
+        (hbm if shape == "kitti00" else hbm.setdefault(shape, {}))["embed_kernel_counters"] = ins
 json.dump(hbm, open(os.path.join(dst, "pmc_hbm_latest.json"), "w"), indent=2)
+if pmc_only:
+    print("pmc_hbm_latest.json written for source hash", hbm["source_hash"])
+    sys.exit(0)
 with open(os.path.join(dst, tag + "_pmc_sq.txt"), "w") as f:
     f.write("# rocprofv3 --pmc (separate passes) on tools/run_embed.py <shape> 3; per-launch averages in millions (" + tag + ")\n")
     for shape in shapes:

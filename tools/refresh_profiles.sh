@@ -9,6 +9,16 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
 cd /tmp
+# (1) the counter passes, (2) their summary for exactly these sources (tools/collect_profiles.py --pmc-only writes
+# profiles/pmc_hbm_latest.json with the hash of csrc/), (3) the bench lines - which report roofline.traffic / .issue only
+# when that hash is the hash of the tree they run from: a refresh whose bench line lacks them fails
+for shape in kitti00 stress pairs128; do
+  timeout 100 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O -o fetch_$shape -- python $R/tools/run_embed.py $shape 3 > $O/fetch_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O -o write_$shape -- python $R/tools/run_embed.py $shape 3 > $O/write_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d $O -o sq1_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq1_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O -o sq2_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq2_$shape.log 2>&1 </dev/null
+done
+( cd $R && python tools/collect_profiles.py ${1:-rXX} --pmc-only ) > $O/collect_pmc.log 2>&1
 timeout 300 python $R/bench.py > $O/bench.json 2> $O/bench.err </dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python $R/bench.py --no-cpu-baseline --no-end-to-end > $O/bench_under_rocprof.json 2> $O/kt.err </dev/null
 for w in stress pairs128; do
@@ -17,12 +27,12 @@ for w in stress pairs128; do
 done
 timeout 300 python $R/bench.py --workload kitti5seq --no-cpu-baseline --steps 50 > $O/bench_kitti5seq.json 2> $O/bench_kitti5seq.err </dev/null
 SGPR_BENCH_BACKEND=gloo timeout 300 python $R/bench.py --gpus 2 --steps 50 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err </dev/null
-for shape in kitti00 stress pairs128; do
-  timeout 100 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O -o fetch_$shape -- python $R/tools/run_embed.py $shape 3 > $O/fetch_$shape.log 2>&1 </dev/null
-  timeout 100 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O -o write_$shape -- python $R/tools/run_embed.py $shape 3 > $O/write_$shape.log 2>&1 </dev/null
-  timeout 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d $O -o sq1_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq1_$shape.log 2>&1 </dev/null
-  timeout 100 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O -o sq2_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq2_$shape.log 2>&1 </dev/null
-done
+python - <<PY || { echo "REFRESH FAILED: bench line without roofline.traffic (PMC profile and sources differ)"; exit 1; }
+import json
+r = json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1])
+assert r["roofline"]["traffic"] is not None and r["roofline"].get("issue"), r["roofline"]
+print("bench line carries traffic", r["roofline"]["traffic"], "and issue", r["roofline"]["issue"]["frac"])
+PY
 timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_consumers -- python $R/tools/run_f1.py 3 > $O/kt_consumers.log 2>&1 </dev/null
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O -o sq_consumers -- python $R/tools/run_f1.py 1 > $O/sq_consumers.log 2>&1 </dev/null
