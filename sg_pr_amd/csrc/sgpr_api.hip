@@ -227,6 +227,10 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         memcpy(packed.data() + off_wh[b], wh.data(), wh.size() * sizeof(unsigned short));
     }
 
+    while (packed.size() % 4) packed.push_back(0.f);
+    const size_t o_semtab = packed.size();      // graph-independent tables of the super-node branch + the largest value in them
+    packed.resize(packed.size() + kSemTableFloats + 4, 0.f);
+
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
@@ -281,6 +285,30 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     h->w.fc1_b = h->d_blob + o_fc1b;
     h->w.fc2_w = h->d_blob + o_fc2w;
     h->w.fc2_b = h->d_blob + o_fc2b;
+    h->w.sem_g = h->w.sem_xx = h->w.sem_a2 = h->w.sem_b2 = nullptr;
+    if (f16_ok) {
+        // the graph-independent part of the super-node branch, by the kernels' own instructions (bit-identical to the
+        // per-graph path); skipped when a layer-1 output leaves the f16 range (the per-graph path then flags the graph)
+        float* tab = h->d_blob + o_semtab;
+        float vmax = INFINITY;
+        int rc = launch_sem_tables(h->w, tab, tab + kSemTableFloats, nullptr);
+        if (rc == SGPR_OK) {
+            e = hipMemcpy(&vmax, tab + kSemTableFloats, sizeof(float), hipMemcpyDeviceToHost);   // (synchronises)
+            if (e != hipSuccess) rc = hip_fail(e, "sgpr_create: super-node tables");
+        }
+        if (rc != SGPR_OK) {
+            (void)hipFree(h->d_blob);
+            (void)hipFree(h->d_status);
+            delete h;
+            return rc;
+        }
+        if (vmax < 60000.f) {
+            h->w.sem_g = tab;
+            h->w.sem_xx = tab + 4 * 256;
+            h->w.sem_a2 = h->w.sem_xx + 32;
+            h->w.sem_b2 = h->w.sem_a2 + 2 * 16 * 64;
+        }
+    }
     *out = h;
     return SGPR_OK;
 }

@@ -1246,10 +1246,14 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
                                                  const int NT, const int NW, float& vmax) {
     constexpr int XROW = xrow<FMT>();
     const int lane = tid & 63;
+    // Layer 1 and the matrix products of layer 2 see the graph only through the bits "fewer than K nodes carry label v":
+    // with the tables of sem_table_kernel (same instructions, run once at sgpr_create) layer 1 costs nothing per graph
+    // and layer 2 is its selection and its gather.
+    const bool tabled = FMT == FMT_H2 && w.sem_g != nullptr && !(skip & (65536 | 262144));
     // layer 1: the table, straight into X rows 0..15 (rows 13..15 zero)
     const float* wf0 = w.wf[0];                                         // [2 * 64][16] folded fp32 weights
     const float* tb0 = w.tb[0];
-    for (int t = (skip & 65536) ? 256 : tid; t < 16 * 16; t += NT) {   // (ablation bit 16: no layer-1 table)
+    for (int t = ((skip & 65536) || tabled) ? 256 : tid; t < 16 * 16; t += NT) {   // (ablation bit 16: no layer-1 table)
         const int v = t >> 4, c4 = (t & 15) * 4;
         float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
         bool with_rep = true;
@@ -1287,7 +1291,9 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
         // the keys of the 16 virtual rows sit beside the 16 rows of A, so that in the lean instance the Gram tile
         // (wave 0) and the a / b column tiles (the other waves) run side by side: three barriers per layer
         float* Dv = LEAN != 0 ? A + 16 * pitchA : D;
-        if (LEAN != 0) {
+        const bool tab2 = tabled && Lv == 1;                           // layer 2: keys, a and b come from the tables
+        if (tab2) {
+        } else if (LEAN != 0) {
             if (wave == 0) {
                 gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, 0);
                 group_sync<WAVE>();                                           // = the barrier inside gemm_cols
@@ -1301,7 +1307,13 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
         for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
             const int l = t >> 4, j = t & 15;
             const int cj = j <= kLabels ? cnt[j] : 0;
-            const float key = cj > 0 ? Dv[l * pitchD + j] : INFINITY;
+            float key = INFINITY;
+            if (tab2) {
+                const int bl = (l >= kLabels || cnt[l] < k0) ? 1 : 0, bj = (j >= kLabels || cj < k0) ? 1 : 0;
+                if (cj > 0) key = fmaf(-2.f, w.sem_g[((bl * 2 + bj) * 16 + l) * 16 + j], w.sem_xx[bj * 16 + j]);
+            } else if (cj > 0) {
+                key = Dv[l * pitchD + j];
+            }
             int before = 0;                                                // nodes ranked ahead of label j
             // the 16 candidates of a row sit in one 16-lane DPP row (t is a multiple of NT >= 64 away from the
             // lane id): candidate (j + s) & 15 arrives by a row rotation - two v_mov_dpp instead of two
@@ -1313,7 +1325,7 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
         }
         group_sync<WAVE>();                                                   // keys consumed: A may overwrite D
-        if (LEAN == 0) {
+        if (LEAN == 0 && !tab2) {
             gemm_layer<false, FMT>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave, NW, 0);
             group_sync<WAVE>();
         }
@@ -1325,13 +1337,16 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             while (mask) {
                 const int j = __builtin_ctz(mask);
                 mask &= mask - 1;
-                const float4 v = *reinterpret_cast<const float4*>(A + j * pitchA + c4);
+                const float* arow = tab2 ? w.sem_a2 + (((j >= kLabels || cnt[j] < k0) ? 16 : 0) + j) * 64 : A + j * pitchA;
+                const float4 v = *reinterpret_cast<const float4*>(arow + c4);
                 m4.x = kmax(m4.x, v.x);
                 m4.y = kmax(m4.y, v.y);
                 m4.z = kmax(m4.z, v.z);
                 m4.w = kmax(m4.w, v.w);
             }
-            const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(X + l * XROW + 4 * c4), l <= kLabels);
+            const float* brow = tab2 ? w.sem_b2 + (((l >= kLabels || cnt[l] < k0) ? 16 : 0) + l) * 64
+                                     : reinterpret_cast<const float*>(X + l * XROW);
+            const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(brow + c4), l <= kLabels);
             if (Lv == 1) {
                 xstore<FMT>(X + l * XROW, c4, y, vmax);
                 float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
@@ -1361,6 +1376,87 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
 // waves ("semantic waves", 4 graphs per leading workgroup): the same instructions at lower parallelism, 197 -> 303 us.
 __host__ __device__ __forceinline__ unsigned long long sem_token(unsigned epoch, int slot) {
     return ((unsigned long long)epoch << 32) | (unsigned)(slot + 1);   // (bit 31: an f16 overflow in the branch)
+}
+
+// ------------------------------------------------------------------ graph-independent part of the super-node branch
+// One workgroup of 256 threads, once per handle (sgpr_create).  Row set p (p = 1: "with the representative", p = 0:
+// without) of layer 1 -> X rows 16 p + v by the code of supernode_branch's first loop; layer 2's Gram tile for the four
+// combinations of row sets and its a / b terms for both sets by tile16 / gemm_rows - the instructions the per-graph path
+// would execute on the same operands, so that a table entry carries the bits the per-graph path would produce.
+__global__ __launch_bounds__(256) void sem_table_kernel(const DevWeights w, float* __restrict__ table, float* __restrict__ vmax_out) {
+    constexpr int FMT = FMT_H2;
+    constexpr int XROW = xrow<FMT>();
+    __shared__ __attribute__((aligned(16))) unsigned char X[32 * XROW];
+    __shared__ __attribute__((aligned(16))) float A[32 * 68];
+    __shared__ float xx[32];
+    __shared__ float vm[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    float vmax = 0.f;
+    const float* wf0 = w.wf[0];
+    const float* tb0 = w.tb[0];
+    for (int t2 = tid; t2 < 2 * 256; t2 += 256) {
+        const int p = t2 >> 8, t = t2 & 255;
+        const int v = t >> 4, c4 = (t & 15) * 4;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = *reinterpret_cast<const float4*>(tb0 + c4);
+        bool with_rep = true;
+        if (v < kLabels) {
+            auto wq = [](float x) {
+                const _Float16 h = (_Float16)x;
+                return (float)h + (float)(_Float16)(x - (float)h);
+            };
+            a4 = make_float4(wq(wf0[(c4 + 0) * 16 + v]), wq(wf0[(c4 + 1) * 16 + v]), wq(wf0[(c4 + 2) * 16 + v]),
+                             wq(wf0[(c4 + 3) * 16 + v]));
+            b4 = make_float4(wq(wf0[(64 + c4 + 0) * 16 + v]) + b4.x, wq(wf0[(64 + c4 + 1) * 16 + v]) + b4.y,
+                             wq(wf0[(64 + c4 + 2) * 16 + v]) + b4.z, wq(wf0[(64 + c4 + 3) * 16 + v]) + b4.w);
+            with_rep = p == 1;
+        }
+        const float z = with_rep ? 0.f : -INFINITY;
+        const float4 m4 = make_float4(max3(-INFINITY, a4.x, z), max3(-INFINITY, a4.y, z), max3(-INFINITY, a4.z, z),
+                                      max3(-INFINITY, a4.w, z));
+        const float4 y = add_lrelu(m4, b4, v <= kLabels);
+        xstore<FMT>(X + (16 * p + v) * XROW, c4, y, vmax);
+        float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+        sa += lane_xor(sa, 1);
+        sa += lane_xor(sa, 2);
+        sa += lane_xor(sa, 4);
+        sa += lane_xor(sa, 8);
+        if ((t & 15) == 0) xx[16 * p + v] = sa;
+    }
+    __syncthreads();
+    float* tg = table;                 // [2][2][16][16]
+    float* txx = tg + 4 * 256;         // [2][16]
+    float* ta = txx + 32;              // [2][16][64]
+    float* tb = ta + 2 * 16 * 64;      // [2][16][64]
+    {   // Gram: wave = (row set of the A operand, row set of the B operand)
+        const int pa = wave >> 1, pb = wave & 1;
+        FragT<FMT> a[2], b[2];
+        xload<4, FMT>(X + (16 * pa + l15) * XROW, lq, a);
+        xload<4, FMT>(X + (16 * pb + l15) * XROW, lq, b);
+        const f32x4 g = tile16<4>(a, b);              // g[r] = <x_{4 lq + r} (set pa), x_{l15} (set pb)>
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tg[((pa * 2 + pb) * 16 + 4 * lq + r) * 16 + l15] = g[r];
+    }
+    if (tid < 32) txx[tid] = xx[tid];
+    __syncthreads();
+    gemm_rows<4, 64, FMT>(X, A, 68, w.wh[1], w.tb[1], 2, wave, 4);   // row tile = row set (waves 0 and 1)
+    __syncthreads();
+    for (int e = tid; e < 32 * 16; e += 256) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<float4*>(ta + r * 64 + c4) = *reinterpret_cast<const float4*>(A + r * 68 + c4);
+        *reinterpret_cast<float4*>(tb + r * 64 + c4) = *reinterpret_cast<const float4*>(X + r * XROW + 4 * c4);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+    if (lane == 0) vm[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) *vmax_out = fmaxf(fmaxf(vm[0], vm[1]), fmaxf(vm[2], vm[3]));
+}
+
+int launch_sem_tables(const DevWeights& w, float* d_table, float* d_vmax, hipStream_t stream) {
+    hipLaunchKernelGGL(sem_table_kernel, dim3(1), dim3(256), 0, stream, w, d_table, d_vmax);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "sem_table_kernel launch");
+    return SGPR_OK;
 }
 
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
@@ -2002,6 +2098,8 @@ static int launch_layout(const EmbedPlan& plan, const KParams& kp, hipStream_t s
     if (plan.fmt == FMT_H2) {
         if (KP == 16 && DBG == 0 && plan.lean && plan.k == 10)     // the reference's K: compile-time constant
             return plan.lean == 48 ? launch_t<16, 0, 48, FMT_H2, 10>(kp, stream) : launch_t<16, 0, 64, FMT_H2, 10>(kp, stream);
+        if (KP == 32 && DBG == 0 && !plan.lean && plan.k == 20)    // the stress configuration's K: compile-time constant, too
+            return launch_t<32, 0, 0, FMT_H2, 20>(kp, stream);
         if (plan.lean == 48 && DBG == 0) return launch_t<KP, 0, 48, FMT_H2>(kp, stream);
         if (plan.lean && DBG != 2) return launch_t<KP, DBG == 2 ? 0 : DBG, 64, FMT_H2>(kp, stream);
         return launch_t<KP, DBG, 0, FMT_H2>(kp, stream);

@@ -44,7 +44,16 @@ struct DevWeights {
     const float* fc1_b;   // [16]
     const float* fc2_w;   // [16]
     const float* fc2_b;   // [1]
+    // Semantic branch on label super-nodes, what does not depend on the graph (sgpr_embed.hip, sem_table_kernel; filled on
+    // the device at sgpr_create by the instructions of the per-graph path; NULL: the per-graph path computes it).  A label
+    // row of layer 1 has two versions - "fewer than K nodes carry the label" (bit 1: the padding representative is among
+    // its neighbours) or not (bit 0) -, rows 12..15 (representative, unused) have one:
+    const float* sem_g;   // [2][2][16][16] <x1_l (version p), x1_j (version q)> of the layer-1 rows (layer 2's Gram tile)
+    const float* sem_xx;  // [2][16]        |x1_j|^2
+    const float* sem_a2;  // [2][16][64]    layer 2's per-node term a = W1' x1
+    const float* sem_b2;  // [2][16][64]    ... and b = (W2 - W1)' x1 + t
 };
+constexpr int kSemTableFloats = 4 * 256 + 32 + 2 * 2 * 16 * 64;
 
 }  // namespace sgpr
 
@@ -121,6 +130,8 @@ void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
 
 int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a, hipStream_t stream);
+// fills table[kSemTableFloats] (layout: sem_g | sem_xx | sem_a2 | sem_b2) and *vmax_out (largest |layer-1 output|)
+int launch_sem_tables(const DevWeights& w, float* d_table, float* d_vmax, hipStream_t stream);
 int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,
                        int64_t P, float* score, hipStream_t stream);
 size_t score_all_pairs_ws_bytes(int R, int M);
