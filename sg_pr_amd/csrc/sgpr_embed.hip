@@ -27,6 +27,7 @@
 #include <math.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "sgpr_internal.hpp"
 
@@ -1210,6 +1211,24 @@ __device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const 
     }
 }
 
+// one row (the last, unpaired group of a wave)
+__device__ __forceinline__ void gather_max1(const float* __restrict__ A4, const uint32_t* __restrict__ nwa, int k, float4& ma) {
+    ma = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const int kw = (k + 1) >> 1;
+#pragma unroll 5
+    for (int q = 0; q < kw; ++q) {
+        const uint32_t wa = nwa[q];
+        const bool odd = 2 * q + 1 < k;
+        const int a0 = wa & 0xffffu, a1 = odd ? (int)(wa >> 16) : a0;
+        const float4 va0 = *reinterpret_cast<const float4*>(A4 + a0);
+        const float4 va1 = *reinterpret_cast<const float4*>(A4 + a1);
+        ma.x = max3(ma.x, va0.x, va1.x);
+        ma.y = max3(ma.y, va0.y, va1.y);
+        ma.z = max3(ma.z, va0.z, va1.z);
+        ma.w = max3(ma.w, va0.w, va1.w);
+    }
+}
+
 __device__ __forceinline__ float4 add_lrelu(float4 m, float4 b, bool live) {
     float4 y = make_float4(m.x + b.x, m.y + b.y, m.z + b.z, m.w + b.w);
     // LeakyReLU(0.2) = max(y, 0.2 y): two instructions per channel instead of compare / multiply / select
@@ -1790,52 +1809,65 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             const int rstep = NW * rpw;
             // a wave-iteration covers two groups of rpw consecutive rows; groups that lie entirely in the padding
             // [N, NP) are skipped (their rows are zero-filled below: the matrix phases still read them as operands)
-            for (int ia = wave * rpw + sub; ia - sub < ((skip & 8) ? 0 : N); ia += 2 * rstep) {
+            // (a wave's last group may have no partner: that iteration runs the one-row form instead of computing - and
+            // discarding - a second copy of the same row)
+            auto rows = [&](auto two_tag, const int ia) {
+                constexpr bool TWO = decltype(two_tag)::value;
                 const int ib = ia + rstep;
-                const bool hasb = ib - sub < N;            // wave-uniform
-                const int ra = min(ia, N - 1), rb = min(hasb ? ib : ia, N - 1);   // padded rows: compute a real row, store 0
+                const int ra = min(ia, N - 1), rb = TWO ? min(ib, N - 1) : ra;   // padded rows: compute a real row
                 float4 ma, mb;
-                gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
-                            reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
+                if constexpr (TWO) {
+                    gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
+                                reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
+                } else {
+                    gather_max1(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch), k, ma);
+                    mb = ma;
+                }
                 // padded rows (>= N) inside a partly real group simply keep a copy of row N-1: they are never candidates
                 // (their key is +inf) and nothing reads them as rows
                 const float4 ya = add_lrelu(ma, *reinterpret_cast<const float4*>(X + ra * XROW + 4 * c4), true);
-                const float4 yb = add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * XROW + 4 * c4), true);
+                const float4 yb = TWO ? add_lrelu(mb, *reinterpret_cast<const float4*>(X + rb * XROW + 4 * c4), true) : ya;
                 if (dbg) {
                     if (ia < N) {
                         *reinterpret_cast<float4*>(dbg + (size_t)ia * 64 + c4) = ya;
                         if (cout == 32) *reinterpret_cast<float4*>(dbg + (size_t)ia * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    if (hasb && ib < N) {
+                    if (TWO && ib < N) {
                         *reinterpret_cast<float4*>(dbg + (size_t)ib * 64 + c4) = yb;
                         if (cout == 32) *reinterpret_cast<float4*>(dbg + (size_t)ib * 64 + 32 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-                // the next layer's operand: three bf16 planes over the row's own (already consumed) b; all lanes
-                // of a row sit in one wave, whose LDS reads above precede these writes
+                // the next layer's operand: planes over the row's own (already consumed) b; all lanes of a row sit in
+                // one wave, whose LDS reads above precede these writes
                 if (L == 2) {
                     *reinterpret_cast<float4*>(park + (size_t)ia * PP + c4) = ya;
-                    if (hasb) *reinterpret_cast<float4*>(park + (size_t)ib * PP + c4) = yb;
+                    if (TWO) *reinterpret_cast<float4*>(park + (size_t)ib * PP + c4) = yb;
                 } else {
                     xstore<FMT>(X + ia * XROW, c4, ya, vmax);
-                    if (hasb) xstore<FMT>(X + ib * XROW, c4, yb, vmax);
+                    if (TWO) xstore<FMT>(X + ib * XROW, c4, yb, vmax);
                 }
                 if (want_norm) {                          // squared norms of the next layer's input rows (cout == 64: 16 lanes/row)
                     float sa = fmaf(ya.x, ya.x, fmaf(ya.y, ya.y, fmaf(ya.z, ya.z, ya.w * ya.w)));
-                    float sb = fmaf(yb.x, yb.x, fmaf(yb.y, yb.y, fmaf(yb.z, yb.z, yb.w * yb.w)));
+                    float sb = TWO ? fmaf(yb.x, yb.x, fmaf(yb.y, yb.y, fmaf(yb.z, yb.z, yb.w * yb.w))) : 0.f;
                     sa += lane_xor(sa, 1);
-                    sb += lane_xor(sb, 1);
+                    if (TWO) sb += lane_xor(sb, 1);
                     sa += lane_xor(sa, 2);
-                    sb += lane_xor(sb, 2);
+                    if (TWO) sb += lane_xor(sb, 2);
                     sa += lane_xor(sa, 4);
-                    sb += lane_xor(sb, 4);
+                    if (TWO) sb += lane_xor(sb, 4);
                     sa += lane_xor(sa, 8);
-                    sb += lane_xor(sb, 8);
+                    if (TWO) sb += lane_xor(sb, 8);
                     if ((lane & 15) == 0) {
                         xx[ia] = sa;
-                        if (hasb) xx[ib] = sb;
+                        if (TWO) xx[ib] = sb;
                     }
                 }
+            };
+            for (int ia = wave * rpw + sub; ia - sub < ((skip & 8) ? 0 : N); ia += 2 * rstep) {
+                if (ia + rstep - sub < N)                  // wave-uniform
+                    rows(std::true_type{}, ia);
+                else
+                    rows(std::false_type{}, ia);
             }
             // rows of the skipped all-padding groups: zero planes (finite operands for the next layer's matrix phases)
             if (L != 2 && !(skip & 8)) {
