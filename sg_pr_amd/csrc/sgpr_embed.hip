@@ -42,13 +42,10 @@ constexpr int PXF = 272;      // bytes per row of X in the fp32 layout (64 ch + 
 // a pitch of 17 16-byte slots lane (row r, k-slice q) starts at slot r + q (mod 16), and every group holds one pair of
 // lanes on the same slot - a 2-way conflict in all four groups of every operand read (8 LDS cycles instead of 4).  At 18
 // slots the start is 2 r + q: the k-slices of even / odd q sit on even / odd slots and all 16 lanes of a group differ.
-// Measured (round 3, same box, -DSGPR_PXH=288 against 272): KITTI-00 launch 186.8 vs 185.2 us, stress 866.2 vs 865.8,
+// Measured (round 3, same box, 288-byte rows against 272): KITTI-00 launch 186.8 vs 185.2 us, stress 866.2 vs 865.8,
 // pairs128 33.3 vs 33.1 - the conflicts are real (SQ_LDS_BANK_CONFLICT: 39 % of them sit in the GEMM phase, 25 % in the
 // Gram phase) but the LDS array is only ~38 % busy and nothing waits on it: the smaller rows stay.
-#ifndef SGPR_PXH
-#define SGPR_PXH 272
-#endif
-constexpr int PXH = SGPR_PXH;
+constexpr int PXH = 272;
 // X layout of a kernel instance (EmbedPlan::fmt)
 constexpr int FMT_F32 = 0;    // fp32 rows, split into three bf16 planes when loaded (fallback of plans too large for FMT_BF3)
 constexpr int FMT_BF3 = 1;    // three bf16 planes, written once per layer by the gather epilogue (fp32 range: the fallback
@@ -72,23 +69,6 @@ __device__ __forceinline__ int phase_tid() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     return t;
-}
-
-// SIMD balance.  The waves of a workgroup land on the SIMDs of a CU cyclically (wave w -> SIMD w & 3, tools/probes/
-// simd_probe.hip), so wave 0 of EVERY resident workgroup shares one SIMD - and wave 0 is where the single-wave sections
-// of the kernel run (the tanh mat-vec and the sigmoid of the attention pool, `tid < 32` reductions, the super-node Gram
-// tile) while the last wave idles through the selection of graphs with few slots.  The lean instances therefore rotate
-// the ROLES of the waves by a per-workgroup offset: logical thread id = (threadIdx.x + 64 * rot) mod blockDim.x with
-// rot taken from the launch slot, so the heavy and the light roles of co-resident workgroups meet on different SIMDs.
-// Results do not depend on which hardware wave plays which role.
-#ifndef SGPR_ROTATE_ROLES
-#define SGPR_ROTATE_ROLES 0
-#endif
-template <int NT_>
-__device__ __forceinline__ int rot_tid(int t, int rot64) {
-    if (NT_ == 0) return t;                              // not a lean instance: identity
-    t += rot64;
-    return t >= NT_ ? t - NT_ : t;
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -624,13 +604,13 @@ __device__ __forceinline__ void emit_bits(unsigned take, int jbase, int pitchA, 
 // has more than 16 candidates), which drops the 32- and 64-candidate paths and their registers from that instance.
 // KEEP = list entries that matter (k <= KEEP <= KP): the sorted lists carry +inf beyond it, and every comparator,
 // lane exchange and minimum that would only feed those entries is never generated (KEEP = 10 for the reference's K).
-template <int KP, int CAPX, int KEEP, int NTR = 0, int PC = 0>   // PC: lanes per row when it is a compile-time constant
+template <int KP, int CAPX, int KEEP, int PC = 0>   // PC: lanes per row when it is a compile-time constant
 __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, int P_, int seg, int k, bool one_rep,
                                              const float* __restrict__ D, int rc0, int rows_chunk,
                                              unsigned short* __restrict__ nbr, int32_t* __restrict__ dbg_knn,
-                                             unsigned long long* __restrict__ prof8, int rot64 = 0) {
+                                             unsigned long long* __restrict__ prof8) {
     const int P = PC ? PC : P_;
-    const int tid = rot_tid<NTR>(phase_tid(), rot64), lane = tid & 63;
+    const int tid = phase_tid(), lane = tid & 63;
     unsigned long long ts = (prof8 && tid == 0) ? clock64() : 0ull;
 #define SEL_STAMP(i)                                                   \
     if (prof8 && tid == 0) {                                           \
@@ -722,6 +702,35 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
             for (int q = part; q < k; q += P) out0[q] = rep;
             if (dbg_knn)
                 for (int q = part; q < k; q += P) dbg_knn[(size_t)i * p.k + q] = n - 1;
+        }
+    }
+    if constexpr (PC == 4 && CAPX == 16) {
+        // Lean instances, the common case first: when exactly k keys of the row lie at or below tau (no ties across the
+        // cut) - or the representative cuts the list - the neighbour set is {key <= tau}: ONE mask (the sign bits of
+        // tau - key, complemented), a prefix over the four lanes of the row, emission.  Rows with ties across the cut
+        // (identical nodes; kept padding copies) take the general path below, the whole wave together.
+        unsigned gt = 0u;
+#pragma unroll
+        for (int u = 15; u >= 0; --u) gt = __builtin_amdgcn_alignbit(gt, __float_as_uint(tau - d[u]), 31);
+        const unsigned le = ~gt & 0xffffu;
+        const int n_le = __popc(le);
+        int incl = n_le;
+        {
+            const int t = row_shr<1>(incl);
+            incl += (part >= 1) ? t : 0;
+        }
+        {
+            const int t = row_shr<2>(incl);
+            incl += (part >= 2) ? t : 0;
+        }
+        const int total_le = __builtin_amdgcn_update_dpp(0, incl, 0xFF, 0xF, 0xF, false);   // quad_perm [3,3,3,3]
+        if (__ballot(active && !(dup_cut || total_le == k)) == 0ull) {
+            if (active) {
+                int pos = incl - n_le;
+                emit_bits(le, j0, p.pitchA, nbr + i * p.kpitch, dbg_knn ? dbg_knn + (size_t)i * p.k : nullptr, pos);
+            }
+            SEL_STAMP(5)
+            return;
         }
     }
     // per-lane bit sets of the candidates below / at the threshold: the sign bit of (key - tau) and of (tau - key),
@@ -1501,13 +1510,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     float* xx = reinterpret_cast<float*>(smem + p.offXX);
     float* red = reinterpret_cast<float*>(smem + p.offRed);
     unsigned short* nbr = reinterpret_cast<unsigned short*>(smem + p.offIdx);
-    // lean production instances: wave roles rotated per workgroup (rot_tid above); every `tid` / `wave` below is logical
-    constexpr int NTR = (LEAN != 0 && DBG == 0 && SGPR_ROTATE_ROLES) ? 256 : 0;
-    #ifndef SGPR_ROT_SHIFT
-#define SGPR_ROT_SHIFT 8
-#endif
-    const int rot64 = NTR ? ((launch_slot >> SGPR_ROT_SHIFT) & 3) << 6 : 0;
-    const int tid0 = rot_tid<NTR>(threadIdx.x, rot64);
+    const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: wave-uniform task loops and branches
     int tid = tid0, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int NS = p.N;                                   // slots per graph in global memory
@@ -1782,11 +1785,11 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 if (p.overlap || (!LEAN && rows_chunk * P <= NT && seg <= CAP)) {
                     unsigned long long* const sp = (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr;
                     if (KP == 16 && k == 10)
-                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), NTR, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
                     else if (KP == 32 && k == 20)
-                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP), NTR, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP), (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
                     else
-                        select_phase<KP, LEAN ? 16 : CAP, KP, NTR, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp, rot64);
+                        select_phase<KP, LEAN ? 16 : CAP, KP, (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
                 } else {              // one wave per row, bisection on the key value
                     select_bisect<4>(p, N, NP, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn);
                 }
@@ -1892,9 +1895,6 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             int spins = 0;
             while (true) {
                 got = __hip_atomic_load(kp.a.sem_flag + launch_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef SGPR_EXP_NOWAIT
-                got = want;
-#endif
                 if ((got & ~0x80000000ull) == want || ++spins > (1 << 20)) break;
                 __builtin_amdgcn_s_sleep(8);
             }
