@@ -298,8 +298,8 @@ __device__ __forceinline__ void load_xfrag(const unsigned char* row, int lq, Fra
 template <int NKB, int FMT>
 __device__ __forceinline__ constexpr int wtile() { return (NKB == 1 ? 1 : 2) * (FMT == FMT_H2 ? 2 : 3) * 512; }
 template <int NKB, int FMT>
-__device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, FragT<FMT> (&f)[2]) {
-    if (tile == nullptr) {
+__device__ __forceinline__ void load_wfrag(const unsigned short* __restrict__ tile, FragT<FMT> (&f)[2], const bool constw = false) {
+    if (constw) {
         // ablation (mask bit 9): constant weights, no loads
         if constexpr (FMT == FMT_H2) {
             const _Float16 c = (_Float16)0.01f;
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
     f32x4 b0[NCA], b1[NCA];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        if (ct + 1 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)(ct + 1) * wtile<NKB, FMT>() : nullptr, wn);
+        if (ct + 1 < NCT) load_wfrag<NKB>(Wb + (size_t)(ct + 1) * wtile<NKB, FMT>(), wn);
         // r[c] = out[channel ct*16 + 4lq + c][node rt*16 + l15]
         const f32x4 r0 = tile16<NKB>(w, xf0);
         f32x4 r1 = r0;
@@ -1037,6 +1037,7 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
                                           int wave, int NW_, int ex = 0) {
     const int NW = NWC ? NWC : NW_;
+    const bool constw = (ex & 512) != 0;       // ablation bit 9: constant weights instead of loads (a compile-time 0 in production)
     const int lane = phase_tid() & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int NCA = COUT / 16, NCT = 2 * NCA;
@@ -1050,11 +1051,11 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     f32x4 k0[4], k1[4];
     // ---- a-tiles
     int ct = wave;
-    if (ct < NCA) load_wfrag<NKB>(Wb ? Wb + (size_t)ct * wtile<NKB, FMT>() : nullptr, w);
-    else if (ctb0 < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb0 * wtile<NKB, FMT>() : nullptr, w);
+    if (ct < NCA) load_wfrag<NKB>(Wb + (size_t)ct * wtile<NKB, FMT>(), w, constw);
+    else if (ctb0 < NCT) load_wfrag<NKB>(Wb + (size_t)ctb0 * wtile<NKB, FMT>(), w, constw);
     for (; ct < NCA; ct += NW) {
         const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
-        if (cn < NCT) load_wfrag<NKB>(Wb ? Wb + (size_t)cn * wtile<NKB, FMT>() : nullptr, wn);
+        if (cn < NCT) load_wfrag<NKB>(Wb + (size_t)cn * wtile<NKB, FMT>(), wn, constw);
         float* ap = A + l15 * pitchA + ct * 16 + 4 * lq;
         for (int rt = 0; rt < nrt; ++rt) {
             load_xfrag<NKB>(xp + rt * 16 * XR, lq, xf);
@@ -1066,7 +1067,7 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     // ---- b-tiles: results stay in registers (row-tile loop unrolled: register arrays need static indices)
     const bool has0 = ctb0 < NCT, has1 = ctb1 < NCT;
     if (has0) {
-        if (has1) load_wfrag<NKB>(Wb ? Wb + (size_t)ctb1 * wtile<NKB, FMT>() : nullptr, wn);
+        if (has1) load_wfrag<NKB>(Wb + (size_t)ctb1 * wtile<NKB, FMT>(), wn, constw);
         const float4 t4 = *reinterpret_cast<const float4*>(tb + (ctb0 - NCA) * 16 + 4 * lq);
         const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
@@ -1798,7 +1799,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? 4 : 0)>(X, A, p.pitchA, (skip & 512) ? nullptr : (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
+        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? 4 : 0)>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
