@@ -1124,3 +1124,27 @@ def test_bench_on_real_graph_directory(golden_dir):
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["data"] == "real" and line["config"]["graphs"] == 3 and line["config"]["pairs_per_step"] == 9
     assert line["value"] > 0 and line["end_to_end"]["d2h"]["value"] > 0
+
+
+def test_f16_planes_against_wide_range_on_the_shipped_graphs(eng, golden_dir):
+    """the default datapath keeps operands as two f16 planes (22 bits); the wide-range instance (three bf16
+    planes, 24 bits) is the reference point for what that costs on REAL graphs.  On the three shipped KITTI graphs the two
+    must give the same neighbour sets (the f16 path's lists equal the golden's in test_shipped_graphs_every_intermediate;
+    here: the pooled vectors, attention weights and all nine scores of the two datapaths agree far inside the gates)."""
+    g = np.load(os.path.join(golden_dir, "kitti3_n100_k10.npz"))
+    centers, labels = _packed_from_golden_features(g["features"])
+    p16, a16, _ = eng.embed(centers, labels, 10, want_att=True)
+    eng.set_skip_mask(8192)                                    # every graph on the wide-range instance
+    try:
+        pw, aw, _ = eng.embed(centers, labels, 10, want_att=True)
+    finally:
+        eng.set_skip_mask(0)
+    dp = (p16 - pw).abs().max().item()
+    da = (a16 - aw).abs().max().item()
+    s16 = eng.score_all_pairs(p16, p16).cpu().numpy()
+    sw = eng.score_all_pairs(pw, pw).cpu().numpy()
+    ds = float(np.abs(s16 - sw).max())
+    print("f16 planes vs wide range on the shipped graphs: max|d pooled| %.3g, max|d att| %.3g, max|d score| %.3g" % (dp, da, ds))
+    assert dp <= 2e-5 and da <= 2e-6 and ds <= 5e-6
+    np.testing.assert_allclose(s16.reshape(-1), g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
+    np.testing.assert_allclose(sw.reshape(-1), g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
