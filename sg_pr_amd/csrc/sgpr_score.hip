@@ -184,20 +184,36 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
         const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
         const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
-        for (int tile = half * 16 + wave * 4; tile < half * 16 + wave * 4 + 4; ++tile) {
+        // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
+        // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
+        float wv[4][8], wbv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = half * 16 + wave * 4 + q;
             const int t = tile >> 1, j = (tile & 1) * 16 + l15;
             const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                wv[q][s4] = wp[s4 * T * F];
+                wv[q][4 + s4] = wp[(16 + s4) * T * F];
+            }
+            wbv[q] = w.ntn_wb[t * 2 * F + F + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = half * 16 + wave * 4 + q;
+            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wp[0 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wp[1 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wp[2 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wp[3 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wp[16 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wp[17 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wp[18 * T * F], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wp[19 * T * F], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wv[q][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wv[q][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wv[q][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wv[q][3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wv[q][4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wv[q][5], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wv[q][6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wv[q][7], acc, 0, 0, 0);
             // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
-            const float wbc = w.ntn_wb[t * 2 * F + F + j];
+            const float wbc = wbv[q];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = g0 + 4 * lq + r;
