@@ -733,6 +733,59 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
             return;
         }
     }
+    if constexpr (PC == 0) {
+        // the same shortcut for the general instances (up to 64 candidates per lane, 2..16 lanes per row)
+        if (P <= 16) {
+            unsigned g0 = 0u, g1 = 0u;
+#pragma unroll
+            for (int c = 1; c >= 0; --c)
+                if (16 * c < CAPX && 16 * c < seg) {
+#pragma unroll
+                    for (int u = 16 * c + 15; u >= 16 * c; --u)
+                        g0 = __builtin_amdgcn_alignbit(g0, __float_as_uint(tau - d[u < CAPX ? u : 0]), 31);
+                }
+#pragma unroll
+            for (int c = 1; c >= 0; --c)
+                if (32 + 16 * c < CAPX && 32 + 16 * c < seg) {
+#pragma unroll
+                    for (int u = 16 * c + 15; u >= 16 * c; --u)
+                        g1 = __builtin_amdgcn_alignbit(g1, __float_as_uint(tau - d[32 + u < CAPX ? 32 + u : 0]), 31);
+                }
+            const unsigned v0 = (CAPX > 16 && seg > 16) ? 0xffffffffu : 0xffffu;
+            const unsigned v1 = (CAPX > 32 && seg > 32) ? ((CAPX > 48 && seg > 48) ? 0xffffffffu : 0xffffu) : 0u;
+            const unsigned le0 = ~g0 & v0, le1 = ~g1 & v1;
+            const int n_le = __popc(le0) + __popc(le1);
+            int incl = n_le;
+            if (P > 1) {
+                const int t = row_shr<1>(incl);
+                incl += (part >= 1) ? t : 0;
+            }
+            if (P > 2) {
+                const int t = row_shr<2>(incl);
+                incl += (part >= 2) ? t : 0;
+            }
+            if (P > 4) {
+                const int t = row_shr<4>(incl);
+                incl += (part >= 4) ? t : 0;
+            }
+            if (P > 8) {
+                const int t = row_shr<8>(incl);
+                incl += (part >= 8) ? t : 0;
+            }
+            const int total_le = __shfl(incl, (lane & ~(P - 1)) + P - 1);
+            if (__ballot(active && !(dup_cut || total_le == k)) == 0ull) {
+                if (active) {
+                    int pos = incl - n_le;
+                    unsigned short* out = nbr + i * p.kpitch;
+                    int32_t* dbg_row = dbg_knn ? dbg_knn + (size_t)i * p.k : nullptr;
+                    emit_bits(le0, j0, p.pitchA, out, dbg_row, pos);
+                    if (seg > 32) emit_bits(le1, j0 + 32, p.pitchA, out, dbg_row, pos);
+                }
+                SEL_STAMP(5)
+                return;
+            }
+        }
+    }
     // per-lane bit sets of the candidates below / at the threshold: the sign bit of (key - tau) and of (tau - key),
     // shifted into the masks with one v_alignbit each (highest candidate first, so candidate u ends up in bit u);
     // equal keys (and inf - inf, whose NaN is positive) set neither -> the "equal" set is what remains
