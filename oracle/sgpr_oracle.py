@@ -88,10 +88,14 @@ def target_from_distance(distance, p_thresh):
 def knn(x, k):
     """dgcnn.py:14-20 - x [B,C,N] -> idx [B,N,k] of the k largest -||xi-xj||^2,
     distance by expansion, self included."""
+    return neg_sq_dist(x).topk(k=k, dim=-1)[1]
+
+
+def neg_sq_dist(x):
+    """dgcnn.py:15-17 - x [B,C,N] -> pd [B,N,N] = -||xi-xj||^2 by expansion, in exactly the reference's fp32 operations."""
     inner = -2 * torch.matmul(x.transpose(2, 1), x)
     xx = torch.sum(x ** 2, dim=1, keepdim=True)
-    pd = -xx - inner - xx.transpose(2, 1)
-    return pd.topk(k=k, dim=-1)[1]
+    return -xx - inner - xx.transpose(2, 1)
 
 
 def graph_feature(x, k, idx=None):

@@ -1170,6 +1170,40 @@ __device__ __forceinline__ void gemm_layer(unsigned char* X, float* A, int pitch
         gemm_rows<4, 32, FMT>(X, A, pitchA, Wb, tb, nrt, gw, GW);
 }
 
+// ------------------------------------------------------------------ coordinate-space keys (first layer of the xyz branch)
+// Node centres reach +-50 m, so the expansion |x_j|^2 - 2<x_i, x_j> cancels numbers near 5000 to rank distances near
+// 300: on two f16 planes (22 bits) its error is about 1e-3, in the reference's fp32 about 5e-4, and candidates closer
+// than that at the k-th place do occur (1.1e-4 apart in a fuzzed graph of 135 nodes, where the planes picked the other
+// one).  With three coordinates the reference's own arithmetic is five fp32 operations per pair, so this layer restates
+// it operation for operation on the vector ALU (model/layers_batch.py:8-12 / dgcnn.py:14-20 as torch evaluates them:
+// the K=3 matmul is the FMA chain x, y, z; |x|^2 = (x*x + y*y) + z*z with every step rounded; pd = (-|x_j|^2 -
+// inner) - |x_i|^2) and ranks by -pd: bit for bit the reference's keys, hence its neighbour sets even between
+// near-ties (tools/exp/fuzz_oracle.py; the operation order is pinned against torch in tests/test_oracle_golden.py::test_coordinate_keys_operation_order).  (x, y, z, |x|^2)
+// of each slot sit in the 16 pad bytes at the end of its X row (written by the staging of this layer; an empty slot
+// carries |x|^2 = +inf, which makes its key +inf in every row: invalid candidates rank last); four lanes per row, four
+// candidates per 16-byte store.
+template <int FMT>
+__device__ __forceinline__ void gram_xyz_direct(const unsigned char* __restrict__ X, float* __restrict__ D, int pitchD, int N,
+                                                int NP, int rc0, int rows_chunk, int tid, int NT) {
+    constexpr int XR = xrow<FMT>(), OFF = XR - 16;
+    const int part = tid & 3;
+    for (int r = tid >> 2; r < rows_chunk; r += NT >> 2) {
+        const float4 ci = *reinterpret_cast<const float4*>(X + (rc0 + r) * XR + OFF);
+        float* drow = D + r * pitchD;
+        for (int j0 = 4 * part; j0 < NP; j0 += 16) {
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 cj = *reinterpret_cast<const float4*>(X + (j0 + u) * XR + OFF);
+                const float dot = fmaf(ci.z, cj.z, fmaf(ci.y, cj.y, __fmul_rn(ci.x, cj.x)));
+                const float t = fmaf(2.f, dot, -cj.w);                       // -|x_j|^2 - inner,  inner = -2 dot (exact)
+                d[u] = __fsub_rn(ci.w, t);                                   // -pd (+inf for an invalid candidate: its |x|^2 is)
+            }
+            *reinterpret_cast<float4*>(drow + j0) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ Gram phase (whole key matrix resident)
 // upper-triangular tile t (row-major) -> (ti, tj), wave-uniform
 __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
@@ -1793,7 +1827,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         l15 = lane & 15;
         lq = lane >> 4;
         if (L == 3) {
-            // ---- stage the second branch's input (xyz, zero padded to 16 channels / NP rows) + squared norms
+            // ---- stage the second branch's input (xyz, zero padded to 16 channels / NP rows) + (x, y, z, |x|^2) in fp32
             if (tid < NP) {
                 const bool live = tid < N;
                 unsigned char* xr = X + tid * XROW;
@@ -1801,7 +1835,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 xzero<FMT>(xr, 4);
                 xzero<FMT>(xr, 8);
                 xzero<FMT>(xr, 12);
-                xx[tid] = live ? fmaf(fz, fz, fmaf(fy, fy, fx * fx)) : 0.f;
+                const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));   // as torch.sum(x ** 2)
+                *reinterpret_cast<float4*>(xr + XROW - 16) = live ? make_float4(fx, fy, fz, n2) : make_float4(0.f, 0.f, 0.f, INFINITY);
             }
             __syncthreads();
             SGPR_PROF(0)
@@ -1815,6 +1850,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
             const int rows_chunk = min(p.RC, NP - rc0);
             if (skip & 4) {
+            } else if (L == 3) {
+                gram_xyz_direct<FMT>(X, D, p.pitchD, N, NP, rc0, rows_chunk, tid, NT);
             } else if (p.overlap) {
                 if (k64)
                     gram_tiles_sym<4, FMT, !LEAN, (LEAN != 0 ? 4 : 0)>(X, xx, D, p.pitchD, N, nrt, wave);

@@ -1023,6 +1023,50 @@ def test_f16_planes_range_fallback(eng, oracle, oracle_sd):
     assert torch.equal(p_big_wide[~keep], pooled[~keep])
 
 
+@pytest.mark.parametrize("n,k,spread", [(128, 10, 50.0), (61, 10, 50.0), (256, 20, 100.0)])
+def test_coordinate_layer_ranks_by_the_reference_fp32_keys(eng, oracle, n, k, spread):
+    """The first xyz layer's neighbour sets are the reference's even between near-ties: the kernel restates the fp32
+    expansion (dgcnn.py:14-20) operation for operation, so over ~60 k rows of random centres up to +-`spread` m no row
+    may differ (two f16 planes flipped about one row in 10 k here).  Compared through the reference's own key values
+    of the selected nodes, which is indifferent to the order among exactly equal keys."""
+    rng = np.random.default_rng(77)
+    g = 65536 // n
+    centers = (rng.uniform(-spread, spread, (g, n, 3))).astype(np.float32)
+    centers[:, :, 1] *= 0.1                                             # flat like a road scene: denser near-ties
+    labels = rng.integers(0, 12, (g, n)).astype(np.int32)
+    knn = eng.embed(centers, labels, k, debug=True)[4][:, 0].cpu().numpy().astype(np.int64)     # [G, N, k], layer xyz1
+    pd = oracle.neg_sq_dist(torch.from_numpy(np.ascontiguousarray(centers.transpose(0, 2, 1))))
+    ref = np.sort(pd.topk(k=k, dim=-1)[0].numpy(), -1)
+    got = np.sort(np.take_along_axis(pd.numpy(), knn, -1), -1)
+    bad = (ref != got).any(-1)
+    assert not bad.any(), "rows with a neighbour set other than the reference's: %d of %d" % (bad.sum(), bad.size)
+    assert (np.sort(knn, -1)[..., 1:] != np.sort(knn, -1)[..., :-1]).all()                       # k distinct nodes per row
+
+
+def test_sequence_census_of_near_tie_neighbour_flips(eng, oracle, oracle_sd):
+    """Whole-sequence parity, counted honestly (tools/exp/seq_parity.py does all 4541 graphs: 6 differ).  In the 64-channel
+    layers the reference ranks by an fp32 sgemm whose rounding even differs between identical nodes, so a handful of
+    graphs per sequence pick the other of two candidates a few 1e-7 apart (24-bit operand planes flip as many as the
+    shipped 22-bit ones: it is the reference's rounding, not ours); every other graph must agree to rounding and so
+    must every score between them."""
+    from sg_pr_amd import synth
+    G = 1500
+    c, l, _, _ = synth.kitti_like_sequence(G, 100, seed=0)
+    ref = torch.cat([oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(c[s:s + 250], l[s:s + 250])), 10)[0]
+                     for s in range(0, G, 250)])
+    pooled = eng.embed(c, l, 10)[0]
+    dev = (pooled.cpu() - ref).abs().amax(1).numpy()
+    flipped = np.flatnonzero(dev > 2e-4)
+    print("graphs with a differently chosen neighbour:", flipped.tolist())
+    assert len(flipped) <= 6                                           # 2 here at the time of writing (172, 1490)
+    clean = np.setdiff1d(np.arange(G), flipped)
+    assert dev[clean].max() < 1e-4
+    rows = clean[:256]
+    s = eng.score_all_pairs(pooled[torch.from_numpy(rows).cuda()], pooled[torch.from_numpy(clean).cuda()]).cpu()
+    rs = oracle.score_all_pairs(oracle_sd, ref[rows], ref[clean])
+    assert (s - rs).abs().max().item() < SCORE_TOL
+
+
 def test_generic_branch_graph_outside_f16_range(eng, oracle, oracle_sd):
     """The second pass (embed_redo_kernel) chains its two reasons: a graph that the lean plan hands over for the
     generic semantic branch (fewer than 17 processed slots) is embedded on the full f16 plan - and when THAT run leaves

@@ -164,3 +164,27 @@ def test_all_release_checkpoints(oracle, release_state_dicts, golden_dir):
         np.testing.assert_allclose(s9.numpy(), g["scores9/" + name], rtol=0, atol=5e-6, err_msg=name)
         ss, _, _ = oracle.forward(sd, dsyn[0::2], dsyn[1::2], 10)
         np.testing.assert_allclose(ss.numpy(), g["scores_syn/" + name], rtol=0, atol=5e-6, err_msg=name)
+
+
+def test_coordinate_keys_operation_order(oracle):
+    """The HIP path restates the reference's fp32 arithmetic of the first xyz layer's ranking keys operation for
+    operation (sgpr_embed.hip gram_xyz_direct): this pins what that arithmetic IS as torch evaluates dgcnn.py:15-17 -
+    the K=3 matmul as the FMA chain over x, y, z, |x|^2 = (x*x + y*y) + z*z with every step rounded, then
+    (-|x_j|^2 - inner) - |x_i|^2.  (FMA emulated in float64: products of two fp32 are exact there.)"""
+    rng = np.random.default_rng(5)
+    f32, f64 = np.float32, np.float64
+
+    def fma(a, b, c):
+        return (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+
+    for n in (44, 100, 135):
+        x = rng.uniform(-50, 50, (4, 3, n)).astype(f32)
+        pd = oracle.neg_sq_dist(torch.from_numpy(x)).numpy()
+        xi, xj = x[:, :, :, None], x[:, :, None, :]
+        dot = fma(xi[:, 2], xj[:, 2], fma(xi[:, 1], xj[:, 1], (xi[:, 0] * xj[:, 0]).astype(f32)))
+        sq = (x * x).astype(f32)
+        n2 = ((sq[:, 0] + sq[:, 1]).astype(f32) + sq[:, 2]).astype(f32)
+        t = fma(np.full_like(dot, 2), dot, -n2[:, None, :])
+        mine = (t - n2[:, :, None]).astype(f32)
+        # the float64 emulation double-rounds about one FMA in 1e7; everything else must be bit-identical
+        assert np.mean(mine != pd) < 1e-5
