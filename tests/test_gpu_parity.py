@@ -745,6 +745,38 @@ def _rccl_worker(rank, world, port, ckpt, golden, out_dir):
     dist.destroy_process_group()
 
 
+def _rccl_single_worker(rank, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dev = torch.device("cuda", 0)
+    t = torch.arange(8, dtype=torch.float32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    parts = [torch.empty(5, dtype=torch.int64, device=dev)]
+    dist.all_gather(parts, torch.arange(5, dtype=torch.int64, device=dev))
+    b = torch.full((3,), 7.0, device=dev)
+    dist.broadcast(b, src=0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save({"reduced": t.cpu(), "gathered": parts[0].cpu(), "bcast": b.cpu(), "backend": dist.get_backend()}, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_runs_on_this_box(tmp_path):
+    """The multi-rank paths cannot run on a one-GPU box; what can be shown here is that torch's nccl backend (= RCCL)
+    initialises on this GPU and carries the collectives those paths are built from (all_reduce, all_gather, broadcast,
+    barrier) - so that a failure of the >= 2-GPU test below is a failure of the sharding logic, not of the environment."""
+    import torch.multiprocessing as mp
+    out = os.path.join(str(tmp_path), "single.pt")
+    mp.spawn(_rccl_single_worker, args=(29653, out), nprocs=1, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got["backend"] == "nccl"
+    assert torch.equal(got["reduced"], torch.arange(8, dtype=torch.float32))
+    assert torch.equal(got["gathered"], torch.arange(5)) and torch.equal(got["bcast"], torch.full((3,), 7.0))
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than two")
 def test_rccl_ranks_bitwise_equal_one_rank(tmp_path, ckpt_path, golden_dir):
