@@ -134,7 +134,10 @@ constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
 constexpr int AP_SB = 64;      // columns per super-block (4 MFMA column blocks)
 constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
 constexpr int AP_OCC = 4;      // resident workgroups per CU the kernel is compiled for (waves per SIMD)
-constexpr int AP_NI = 1;       // row graphs interleaved in program order (see score_all_pairs_kernel)
+#ifndef SGPR_AP_NI
+#define SGPR_AP_NI 1
+#endif
+constexpr int AP_NI = SGPR_AP_NI;   // row graphs interleaved in program order (see score_all_pairs_kernel)
 constexpr float AP_F16_SAFE = 60000.f;
 
 static inline int ap_prep_groups(int R, int M) {
@@ -179,14 +182,14 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     const int l15 = lane & 15, lq = lane >> 4;
     // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
     const int g0 = (block >> 1) * 16, half = block & 1;
-    float amax = 0.f, umax = 0.f, emax = 0.f;
+    float amax = 0.f, umax = 0.f, emax = 0.f, l1max = 0.f;       // l1max: max over (graph, t) of sum_j |A'[t][j]|
     if (g0 < R) {
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
         const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
         const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
         // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
         // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
-        float wv[4][8], wbv[4];
+        float wv[4][8], wbv[4], l1r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int tile = half * 16 + wave * 4 + q;
@@ -214,17 +217,35 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wv[q][7], acc, 0, 0, 0);
             // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
             const float wbc = wbv[q];
+            // tiles q = 0, 1 (and 2, 3) are the two halves j < 16 / j >= 16 of the same t: a row of A' is the 16 lanes of
+            // a lane group in both of them
+            if ((q & 1) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) l1r[r] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = g0 + 4 * lq + r;
                 if (g < R) {
                     const float a = acc[r] + wbc;
                     amax = fmaxf(amax, fabsf(a));
+                    l1r[r] += fabsf(a);
                     _Float16 h, l;
                     split2_f16(a, h, l);
                     unsigned short* dst = Ab + ((size_t)g * 2 * 64 + (j >> 3) * 16 + t) * 8 + (j & 7);
                     dst[0] = __builtin_bit_cast(unsigned short, h);
                     dst[64 * 8] = __builtin_bit_cast(unsigned short, l);
+                }
+            }
+            if (q & 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = l1r[r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    l1max = fmaxf(l1max, v);
                 }
             }
         }
@@ -258,17 +279,18 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     amax = wave_max_f32(amax);
     umax = wave_max_f32(umax);
     emax = wave_max_f32(emax);
+    l1max = wave_max_f32(l1max);
     if (lane == 0) {
         red[wave][0] = amax;
         red[wave][1] = umax;
         red[wave][2] = emax;
+        red[wave][3] = l1max;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         const int q = threadIdx.x;
         rng[(size_t)block * 4 + q] = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
     }
-    if (threadIdx.x == 3) rng[(size_t)block * 4 + 3] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
@@ -342,22 +364,36 @@ __device__ __forceinline__ float relu(float x) { return __int_as_float(max(__flo
 // with everything in asm read half-written accumulators).
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// CL: the low plane's ReLU as the `clamp` bit of the instruction that forms it.  lo = h - hi lies in [0, ulp(hi)) for
+// h >= 0 and in (-ulp(hi), 0] for h < 0 (hi truncates towards zero), and clamp cuts to [0, 1]: exact whenever ulp(hi) <= 1,
+// i.e. |h| < 2048 - which the launch guarantees through a bound on |H| (ap_mode) before it picks this variant.
+template <bool CL>
 __device__ __forceinline__ f16x8 split_relu4(f32x4 h) {
     const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
     const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
     unsigned l01, l23;
-    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(l01), "=&v"(l23)
-        : "v"(h01), "v"(h23), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
     const i16x2 z = {0, 0};
     const unsigned a = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, h01), z));
     const unsigned b = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, h23), z));
-    const unsigned c = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l01), z));
-    const unsigned d = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l23), z));
-    return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
+    if constexpr (CL) {
+        asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0] clamp\n\t"
+            "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0] clamp\n\t"
+            "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\t"
+            "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp"
+            : "=&v"(l01), "=&v"(l23)
+            : "v"(h01), "v"(h23), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+        return __builtin_bit_cast(f16x8, u32x4{a, b, l01, l23});
+    } else {
+        asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(l01), "=&v"(l23)
+            : "v"(h01), "v"(h23), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+        const unsigned c = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l01), z));
+        const unsigned d = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l23), z));
+        return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
+    }
 }
 
 // Exact fp32 evaluation of the rectangle [r0, r1) x [c0, c1), one pair per wave iteration, for inputs outside the f16
@@ -433,23 +469,29 @@ __device__ __forceinline__ ApConsts ap_consts(const DevWeights& w, int l15, int 
 }
 
 // max |A'|, max |u|, max |e2| partials -> can every f16 the launch forms be represented?
-__device__ __forceinline__ void ap_range(const float* __restrict__ rng, int nrng, int lane, float& am, float& um, float& em) {
+__device__ __forceinline__ void ap_range(const float* __restrict__ rng, int nrng, int lane, float& am, float& um, float& em,
+                                         float& l1) {
     for (int i = lane; i < nrng; i += 64) {
         const float4 v = *reinterpret_cast<const float4*>(rng + (size_t)i * 4);
         am = fmaxf(am, v.x);
         um = fmaxf(um, v.y);
         em = fmaxf(em, v.z);
+        l1 = fmaxf(l1, v.w);
     }
 }
-__device__ __forceinline__ bool ap_fast(float am, float um, float em) {
+// 0: exact fp32 per-pair path (an f16 of the launch could overflow); 1: the f16-plane path; 2: the same with the low
+// plane's ReLU folded into its conversion (split_relu4<true>): |H[t]| <= |u[t]| + sum_j |A'[t][j]| max|e2| < 1024
+__device__ __forceinline__ int ap_mode(float am, float um, float em, float l1) {
     am = wave_max_f32(am);
     um = wave_max_f32(um);
     em = wave_max_f32(em);
-    return (am < AP_F16_SAFE) && (em < AP_F16_SAFE) && (um + 32.f * am * em < AP_F16_SAFE);
+    l1 = wave_max_f32(l1);
+    if (!((am < AP_F16_SAFE) && (em < AP_F16_SAFE) && (um + 32.f * am * em < AP_F16_SAFE))) return 0;
+    return (um + l1 * em < 1024.f) ? 2 : 1;
 }
 
 // the work items [it0, it1) of one R x M rectangle
-template <int NI, int VAR>
+template <int NI, int VAR, bool CL>
 __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k, const bool fast, int R, int M,
                                          const unsigned short* __restrict__ Ab, const unsigned short* __restrict__ Cb,
                                          const float* __restrict__ ur, const float* __restrict__ prow,
@@ -524,7 +566,7 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
                     }
                     if (VAR & 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4(h[i]);
+                    for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4<CL>(h[i]);
                     if (VAR & 8) __builtin_amdgcn_s_setprio(1);
                     if (VAR & 16) {
 #pragma unroll
@@ -594,9 +636,9 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeig
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g = lane >> 4;
     // ---- can every f16 this launch forms be represented?  |A'|, |e2| and |H| <= |u| + 32 max|A'| max|e2|
-    float am = 0.f, um = 0.f, em = 0.f;
-    ap_range(rng, nrng, lane, am, um, em);
-    const bool fast = ap_fast(am, um, em);
+    float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;
+    ap_range(rng, nrng, lane, am, um, em, l1);
+    const int mode = ap_mode(am, um, em, l1);
     const ApConsts k = ap_consts(w, l15, g);
     // work items = (row group of AP_ROWS, column chunk of AP_COLS), row-major; every workgroup takes a contiguous,
     // equally long range (the grid is sized to one resident slot per workgroup, so there is no second,
@@ -609,7 +651,10 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeig
     const unsigned nwg = gridDim.x;
     const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
-    ap_items<NI, VAR>(w, k, fast, R, M, Ab, Cb, ur, prow, pcol, score, ld, it0, it1);
+    if (mode == 2)
+        ap_items<NI, VAR, true>(w, k, true, R, M, Ab, Cb, ur, prow, pcol, score, ld, it0, it1);
+    else
+        ap_items<NI, VAR, false>(w, k, mode != 0, R, M, Ab, Cb, ur, prow, pcol, score, ld, it0, it1);
 }
 
 // the same for several rectangles: the work items of all jobs form one row-major list that the workgroups split evenly
@@ -627,10 +672,13 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const D
         const int lo = max(g0, jobs.item0[j]) - jobs.item0[j], hi = min(g1, jobs.item0[j + 1]) - jobs.item0[j];
         if (lo >= hi) continue;
         const ApJob& q = jobs.job[j];
-        float am = 0.f, um = 0.f, em = 0.f;                  // the f16 range question is answered per rectangle, like
-        ap_range(q.rng, q.nrng, lane, am, um, em);           // a call of its own would
-        const bool fast = ap_fast(am, um, em);
-        ap_items<NI, 0>(w, k, fast, q.R, q.M, q.Ab, q.Cb, q.ur, q.rows, q.cols, q.score, q.ld, lo, hi);
+        float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;        // the f16 range question is answered per rectangle, like
+        ap_range(q.rng, q.nrng, lane, am, um, em, l1);       // a call of its own would
+        const int mode = ap_mode(am, um, em, l1);
+        if (mode == 2)
+            ap_items<NI, 0, true>(w, k, true, q.R, q.M, q.Ab, q.Cb, q.ur, q.rows, q.cols, q.score, q.ld, lo, hi);
+        else
+            ap_items<NI, 0, false>(w, k, mode != 0, q.R, q.M, q.Ab, q.Cb, q.ur, q.rows, q.cols, q.score, q.ld, lo, hi);
     }
 }
 
