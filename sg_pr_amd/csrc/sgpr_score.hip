@@ -450,20 +450,29 @@ __device__ __forceinline__ void slow_tile(const DevWeights& w, const float* __re
 // per-wave constants of the tail: the head's weights in the lane layout of the MFMA results
 struct ApConsts {
     f16x8 w1hi, w1lo;
-    float4 b1v, w2v;
+    float4 b1v, side;
     float nb2;
 };
 
+// The head's weight w2[o] is folded into layer 2 (row o of W1 and b1[o] scaled by it - in fp32, before the planes are
+// cut), so that the accumulator holds q''[o] = w2[o] (b1[o] + W1[o].H) and the pair's term w2[o] relu(q[o]) is q''[o]
+// clamped to its own side of zero: max(q'', 0) for w2 > 0, min(q'', 0) for w2 < 0 = ONE v_med3_f32 against
+// (0, side[o]), side = +inf / -inf - instead of an integer maximum and a multiply-add per value.
 __device__ __forceinline__ ApConsts ap_consts(const DevWeights& w, int l15, int g) {
     ApConsts c;
-    const float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);   // W1[o = l15][t = 4g..4g+3]
+    const float s = w.fc2_w[l15];                                                      // the A operand's row is o = l15
+    float4 w1v = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);         // W1[o = l15][t = 4g..4g+3]
+    w1v = make_float4(s * w1v.x, s * w1v.y, s * w1v.z, s * w1v.w);
     const _Float16 wh0 = (_Float16)w1v.x, wh1 = (_Float16)w1v.y, wh2 = (_Float16)w1v.z, wh3 = (_Float16)w1v.w;
     const _Float16 z16 = (_Float16)0.f;
     c.w1hi = f16x8{wh0, wh1, wh2, wh3, wh0, wh1, wh2, wh3};                      // meets H's hi and lo planes
     c.w1lo = f16x8{(_Float16)(w1v.x - (float)wh0), (_Float16)(w1v.y - (float)wh1), (_Float16)(w1v.z - (float)wh2),
                         (_Float16)(w1v.w - (float)wh3), z16, z16, z16, z16};            // meets the hi plane only
-    c.b1v = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
-    c.w2v = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
+    const float4 b1 = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);              // the accumulator's rows are o = 4g + r
+    const float4 w2 = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
+    c.b1v = make_float4(w2.x * b1.x, w2.y * b1.y, w2.z * b1.z, w2.w * b1.w);
+    c.side = make_float4(w2.x < 0.f ? -INFINITY : INFINITY, w2.y < 0.f ? -INFINITY : INFINITY,
+                         w2.z < 0.f ? -INFINITY : INFINITY, w2.w < 0.f ? -INFINITY : INFINITY);
     c.nb2 = -w.fc2_b[0] * 1.4426950408889634f;
     return c;
 }
@@ -500,7 +509,7 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
-    const float4 b1v = k.b1v, w2v = k.w2v;
+    const float4 b1v = k.b1v, side = k.side;
     const float kL2E = 1.4426950408889634f;
     const float nb2 = k.nb2;
     const int ncc = (M + AP_COLS - 1) / AP_COLS;
@@ -587,10 +596,9 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
                             zb[b][r0 + i] = q[i][0];
                             continue;
                         }
-                        float z = w2v.x * relu(q[i][0]);
-                        z = fmaf(w2v.y, relu(q[i][1]), z);
-                        z = fmaf(w2v.z, relu(q[i][2]), z);
-                        zb[b][r0 + i] = fmaf(w2v.w, relu(q[i][3]), z);   // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
+                        const float t0 = __builtin_amdgcn_fmed3f(q[i][0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[i][1], 0.f, side.y);
+                        const float t2 = __builtin_amdgcn_fmed3f(q[i][2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[i][3], 0.f, side.w);
+                        zb[b][r0 + i] = (t0 + t1) + (t2 + t3);           // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
                     }
                 }
                 bh = nbh;
