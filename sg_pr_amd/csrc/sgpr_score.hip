@@ -178,6 +178,7 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
                                               float* __restrict__ ur, float* __restrict__ rng,
                                               unsigned short* __restrict__ Cb, const int block) {
     __shared__ float red[4][4];
+    __shared__ __attribute__((aligned(16))) unsigned short stage[16 * 2 * 4 * 8 * 8];   // [graph][plane][j >> 3][t & 7][j & 7]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
@@ -232,9 +233,11 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
                     l1r[r] += fabsf(a);
                     _Float16 h, l;
                     split2_f16(a, h, l);
-                    unsigned short* dst = Ab + ((size_t)g * 2 * 64 + (j >> 3) * 16 + t) * 8 + (j & 7);
+                    // staged through LDS in the operand layout: the lanes hold one f16 each of a 16-byte operand unit
+                    // (8 consecutive j of one (graph, plane, t)); 2-byte global stores cost the kernel a quarter of its time
+                    unsigned short* dst = stage + (((4 * lq + r) * 2 * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
                     dst[0] = __builtin_bit_cast(unsigned short, h);
-                    dst[64 * 8] = __builtin_bit_cast(unsigned short, l);
+                    dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
                 }
             }
             if (q & 1) {
@@ -248,6 +251,16 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
                     l1max = fmaxf(l1max, v);
                 }
             }
+        }
+    }
+    if (g0 < R) {
+        __syncthreads();
+        // 16 graphs x 2 planes x 4 (j >> 3) x 8 t of this half = 1024 units of 16 bytes, 8 consecutive t contiguous in memory
+        for (int u = threadIdx.x; u < 16 * 2 * 4 * 8; u += 256) {
+            const int tl = u & 7, jb = (u >> 3) & 3, pl = (u >> 5) & 1, gi = u >> 6;
+            if (g0 + gi < R)
+                *reinterpret_cast<uint4*>(Ab + (((size_t)(g0 + gi) * 2 + pl) * 64 + jb * 16 + half * 8 + tl) * 8) =
+                    *reinterpret_cast<const uint4*>(stage + (size_t)u * 8);
         }
     }
     // block term of the row graphs and the column operands: one graph per wave pass
