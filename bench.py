@@ -399,7 +399,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value comes from
         # the committed rocprofv3 --pmc passes of the same workload (profiles/pmc_hbm_latest.json) and is reported only
         # while that profile was taken from exactly these kernel sources
-        traffic, traffic_tail, issue = None, None, None
+        traffic, traffic_tail, issue, issue_tail = None, None, None, None
         try:
             with open(os.path.join(REPO, "profiles", "pmc_hbm_latest.json")) as f:
                 pmc = json.load(f)
@@ -426,6 +426,21 @@ def main():
                 pt = pmc.get("sgpr::score_all_pairs_kernel")
                 if pt and a.graphs == 4541:
                     traffic_tail = (2 * pt["FETCH_SIZE_KiB"] + pt["WRITE_SIZE_KiB"]) * 1024.0
+                    tc = pmc.get("tail_kernel_counters")
+                    if tc and tc.get("SQ_ACTIVE_INST_VALU") and tail_ms:
+                        # what binds the tail is instruction issue too (vector and f16 matrix instructions do not overlap
+                        # at throughput); the HBM figure above is what SURVEY 8d prices it against.  The
+                        # event-timed call holds the prep kernel as well: the SIMD-cycles are an upper bound, the
+                        # fraction a lower one (the kernel alone: profiles/rNN_kernel_stats.txt)
+                        simd_cycles_t = tail_ms * 1e-3 * SHADER_CLOCK_HZ * 4 * eng_cus
+                        busy_t = 4.0 * tc["SQ_ACTIVE_INST_VALU"]
+                        issue_tail = {"bound": "valu_issue", "achieved": busy_t, "peak": simd_cycles_t, "unit": "SIMD-cycles",
+                                      "frac": busy_t / simd_cycles_t,
+                                      "instructions_per_launch": {k_: tc.get(k_) for k_ in (
+                                          "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM")},
+                                      "mfma_busy_cycles": tc.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                                      "note": "score_all_pairs_kernel counters from the committed --pmc passes of these "
+                                              "sources; time = the event-timed tail call (prep + tail kernels) of this run"}
         except (OSError, KeyError, ValueError):
             pass
         res = {
@@ -468,7 +483,7 @@ def main():
                                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                     "traffic": traffic_tail, "launch_ms": tail_ms, "rows_per_call": rows_per_call,
                                     "mean_cols": cols, "bytes_per_call_algorithmic": tb,
-                                    "calls_per_step": tail_calls_per_step}
+                                    "calls_per_step": tail_calls_per_step, "issue": issue_tail}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.model, host_inputs[0][0], host_inputs[0][1], n, k, a.cpu_seconds,
                                                allpairs_job)

@@ -113,6 +113,14 @@ for shape in shapes:
                 ins["kernel"] = kname
     if ins:
         (hbm if shape == "kitti00" else hbm.setdefault(shape, {}))["embed_kernel_counters"] = ins
+    tail = {}
+    for name in ("sq1_", "sq2_"):
+        for kname, d in pmc(name + shape).items():
+            if "score_all_pairs_kernel" in kname:
+                tail.update({c: round(v) for c, v in d.items()})
+                tail["kernel"] = kname
+    if tail and shape == "kitti00":
+        hbm["tail_kernel_counters"] = tail
 json.dump(hbm, open(os.path.join(dst, "pmc_hbm_latest.json"), "w"), indent=2)
 if pmc_only:
     print("pmc_hbm_latest.json written for source hash", hbm["source_hash"])
