@@ -898,6 +898,15 @@ def test_all_pairs_f16_range_guard(eng, oracle_sd):
     print("tail vs float64: all-pairs (f16 planes) %.3g, pair list (fp32) %.3g" % (err_m, err_l))
     assert err_m <= 3e-6 and err_l <= 3e-6
     assert 0.02 < m.mean() < 0.98           # not saturated: the comparison means something
+    # the plane path has two forms, chosen per launch from a bound on |H| (sgpr_score.hip ap_mode): below 1024 the low
+    # plane's ReLU rides on its conversion, above it is a packed maximum - 0.25 x is on the first side for certain, 2 x on
+    # the second; both must be the same function
+    for scale in (0.25, 2.0):
+        m2, l2 = both(scale)
+        ref2 = _tail_float64(oracle_sd, rows_np * np.float32(scale), cols_np * np.float32(scale))
+        tol = 3e-6 * max(1.0, scale * scale)            # the hidden layer is bilinear in the inputs
+        print("scale %g: all-pairs %.3g, pair list %.3g" % (scale, np.abs(m2 - ref2).max(), np.abs(l2 - ref2).max()))
+        assert np.abs(m2 - ref2).max() <= tol and np.abs(l2 - ref2).max() <= tol, scale
     m, lst = both(400.0)                    # |A'| |e2| bound far beyond 65504: exact path, same arithmetic as the list
     np.testing.assert_array_equal(m, lst)
     m, lst = both(1e-4)                     # tiny inputs: subnormal lo planes
