@@ -338,7 +338,12 @@ def main():
     # what `value` excludes by contract: host <-> device transfers (SURVEY.md 8d counts them in its metric)
     end_to_end = None
     if allpairs_job and world == 1 and not a.no_end_to_end:
-        pinned = [(torch.from_numpy(c).pin_memory(), torch.from_numpy(l).pin_memory()) for c, l, _ in host_inputs]
+        # the graphs cross PCIe as the ragged store (sgpr_embed_ragged: 13 bytes per real node, no padding slots); the
+        # launch order and node_cap are properties of the data set, computed once and kept on the device
+        ragged = [eng.to_ragged(c, l) for c, l, _ in host_inputs]
+        pinned = [tuple(torch.from_numpy(x).pin_memory() for x in r) for r in ragged]
+        rag_plan = [eng.ragged_order(r[2], n, k) for r in ragged]
+        h2d_bytes = sum(x.nbytes for r in ragged for x in r)
         host_out = [torch.empty(j["m"], j["m"], dtype=torch.float32).pin_memory() for j in jobs]
         xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
         reps = max(3, min(20, a.steps))
@@ -348,11 +353,11 @@ def main():
         dev_out = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
 
         def e2e(consumer):
-            for j, (pc, pl), ho, do, pz in zip(jobs, pinned, host_out, dev_out, xz):
-                dc, dl = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True)
+            for j, (pc, pl, po), (order_r, cap_r), ho, do, pz in zip(jobs, pinned, rag_plan, host_out, dev_out, xz):
+                dc, dl, do_ = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True), po.to(dev, non_blocking=True)
+                pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=cap_r, order=order_r if a.embed_mode == "ordered" else None)[0]
                 if consumer == "d2h":
                     # the matrix leaves in row blocks: block i crosses PCIe on the copy stream while block i + 1 is scored
-                    pooled = j["scorer"].embed_fn(dc, dl)
                     m = j["m"]
                     for q in range(pieces):
                         r0, r1 = m * q // pieces, m * (q + 1) // pieces
@@ -364,7 +369,7 @@ def main():
                             ho[r0:r1].copy_(do[r0:r1], non_blocking=True)
                 else:
                     from sg_pr_amd import metrics
-                    mat = j["scorer"].run(dc, dl)
+                    mat = model.score_all_pairs(pooled, pooled, out=do)
                     metrics.f1_max_device(eng, mat, pose_xz=pz)
             torch.cuda.synchronize()
 
@@ -376,11 +381,11 @@ def main():
                 e2e(consumer)
             te = (time.perf_counter() - t0) / reps
             end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
-        end_to_end["note"] = ("per step: H2D of the packed graphs from pinned host memory (%.1f MB) + the step + either "
+        end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB) + the step + either "
                               "the D2H copy of the score matrices into pinned memory (%.1f MB, in %d row blocks whose copies "
                               "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "
                               "engine call with 64 bytes crossing PCIe (`device_f1`); %d repetitions"
-                              % (sum(c.nbytes + l.nbytes for c, l, _ in host_inputs) / 1e6, units * 4 / 1e6, pieces, reps))
+                              % (h2d_bytes / 1e6, units * 4 / 1e6, pieces, reps))
         ev_embed.clear()
         ev_tail.clear()
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 4
+#define SGPR_ABI_VERSION 5
 
 enum {
     SGPR_OK = 0,
@@ -119,6 +119,18 @@ int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_
 int sgpr_embed_ordered(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
                        int k, const int32_t* d_order, int n_order, float* d_pooled, float* d_att, float* d_emb,
                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* sgpr_embed_ordered over a RAGGED graph store: only the real nodes of a graph are in memory -
+ *   d_centers [S,3] f32, d_labels [S] i8 (0 .. num_labels-1), d_offsets [G+1] i64: graph g owns nodes
+ *   [d_offsets[g], d_offsets[g+1]) -
+ * and the zero padding up to N = node_num slots that transfer_to_torch appends (sg_net.py:258-272) is made in
+ * registers by the kernel.  13 bytes per real node instead of 16 per slot (KITTI-like graphs: 2.8x fewer bytes to hold
+ * and to move across PCIe); results are bit-identical to sgpr_embed on the padded arrays.  d_order may be NULL
+ * (n_order ignored: all G graphs in index order).  A graph with more than N nodes gets a NaN pooled vector and
+ * sgpr_check_status returns SGPR_E_NODES.  Outputs (d_att [G,N], d_emb [G,N,F3]) keep the padded shape. */
+int sgpr_embed_ragged(const sgpr_handle* h, const float* d_centers, const int8_t* d_labels, const int64_t* d_offsets,
+                      int G, int N, int node_cap, int k, const int32_t* d_order, int n_order, float* d_pooled,
+                      float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Same as sgpr_embed, taking the reference's dense tensor `features` [G, 3+L, N] f32
  * (data["features_1"], sg_net.py:119) - the sem block may hold any values. */

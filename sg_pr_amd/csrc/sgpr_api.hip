@@ -378,7 +378,7 @@ size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
 static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int node_cap, void* ws, size_t ws_bytes,
                         void* stream, int total_graphs = -1) {   // total_graphs: G when a.ids lists a subset
     if (h && a.G == 0) return SGPR_OK;
-    if (!h || !a.pooled || (!a.dense && (!a.centers || !a.labels))) {
+    if (!h || !a.pooled || (!a.dense && (!a.centers || (!a.labels && !(a.rag_off && a.rag_lab))))) {
         set_error("sgpr_embed: NULL argument");
         return SGPR_E_INVALID;
     }
@@ -454,6 +454,27 @@ int sgpr_embed_ordered(const sgpr_handle* h, const float* d_centers, const int32
     a.labels = d_labels;
     a.ids = d_order;
     a.G = n_order;
+    a.pooled = d_pooled;
+    a.att = d_att;
+    a.emb = d_emb;
+    return embed_common(h, a, N, k, node_cap, d_workspace, workspace_bytes, stream, G);
+}
+
+int sgpr_embed_ragged(const sgpr_handle* h, const float* d_centers, const int8_t* d_labels, const int64_t* d_offsets,
+                      int G, int N, int node_cap, int k, const int32_t* d_order, int n_order, float* d_pooled,
+                      float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (G < 0 || n_order < 0 || n_order > G || (n_order > 0 && !d_order) || (G > 0 && !d_offsets)) {
+        set_error("sgpr_embed_ragged: order list of " + std::to_string(n_order) + " entries for " + std::to_string(G) +
+                  " graphs, or no offsets");
+        return SGPR_E_INVALID;
+    }
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.centers = d_centers;
+    a.rag_lab = reinterpret_cast<const signed char*>(d_labels);
+    a.rag_off = reinterpret_cast<const long long*>(d_offsets);
+    a.ids = d_order;
+    a.G = d_order ? n_order : G;
     a.pooled = d_pooled;
     a.att = d_att;
     a.emb = d_emb;
@@ -718,6 +739,10 @@ int sgpr_check_status(const sgpr_handle* h, void* stream) {
         if (flag & 4) {
             set_error("internal: a semantic wave of the split embed launch did not deliver (pooled vector set to NaN)");
             return SGPR_E_HIP;
+        }
+        if (flag & 8) {
+            set_error("a graph of the ragged store holds more nodes than node_num slots, or its offsets decrease (its pooled vector is NaN)");
+            return SGPR_E_NODES;
         }
         if (flag & 2) {
             set_error("a graph needed more slots than the node_cap passed to sgpr_embed_capped (its pooled vector is NaN)");

@@ -1631,6 +1631,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     float sem[kLabels];
 #pragma unroll
     for (int c = 0; c < kLabels; ++c) sem[c] = 0.f;
+    // ragged store: a graph with more nodes than slots is an error of the caller, reported like a broken promise
+    const bool rag_bad = kp.a.rag_off && !kp.a.dense &&
+                         (kp.a.rag_off[g + 1] - kp.a.rag_off[g] < 0 || kp.a.rag_off[g + 1] - kp.a.rag_off[g] > NS);
     if (tid < NS) {
         if (kp.a.dense) {
             const bool second = kp.a.dense2 && g >= kp.a.g_split;
@@ -1652,11 +1655,26 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             }
             mylab = (ones == 1 && zeros == kLabels - 1) ? which : (zeros == kLabels ? -1 : -3);
         } else {
-            const float* c3 = kp.a.centers + ((size_t)g * NS + tid) * 3;
-            fx = c3[0];
-            fy = c3[1];
-            fz = c3[2];
-            const int lab = kp.a.labels[(size_t)g * NS + tid];
+            int lab = -1;
+            if (kp.a.rag_off) {
+                // ragged store: only the graph's real nodes are in memory; the zero padding of transfer_to_torch
+                // (sg_net.py:258-272) up to node_num slots is made here
+                const long long o0 = kp.a.rag_off[g];
+                const long long cnt = kp.a.rag_off[g + 1] - o0;
+                if (!rag_bad && tid < cnt) {
+                    const float* c3 = kp.a.centers + (size_t)(o0 + tid) * 3;
+                    fx = c3[0];
+                    fy = c3[1];
+                    fz = c3[2];
+                    lab = kp.a.rag_lab[o0 + tid];
+                }
+            } else {
+                const float* c3 = kp.a.centers + ((size_t)g * NS + tid) * 3;
+                fx = c3[0];
+                fy = c3[1];
+                fz = c3[2];
+                lab = kp.a.labels[(size_t)g * NS + tid];
+            }
             if (lab < -1 || lab >= kLabels) atomicOr(kp.a.status, 1);
             mylab = lab;
 #pragma unroll
@@ -1700,9 +1718,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         wdup = (float)m / (float)c;
         __syncthreads();                        // red / D region is reused below
     }
-    if (N > p.NC || N > kp.a.promise) {          // more slots to process than the caller's node_cap promised: fail loudly
+    if (N > p.NC || N > kp.a.promise || rag_bad) {   // more slots to process than the caller's node_cap promised: fail loudly
         if (role == 1) return;                   // (reported by the graph's other workgroup)
-        if (tid == 0) atomicOr(kp.a.status, 2);
+        if (tid == 0) atomicOr(kp.a.status, rag_bad ? 8 : 2);
         if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
         if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
         return;

@@ -103,6 +103,8 @@ bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan, bool wide_rang
 struct EmbedArgs {
     const float* centers;   // packed input, or
     const int32_t* labels;
+    const long long* rag_off;       // ragged packed input (sgpr_embed_ragged): graph g owns nodes [rag_off[g], rag_off[g+1]) of
+    const signed char* rag_lab;     // centers [S][3] / rag_lab [S]; the N - count padding slots exist only in registers
     const float* dense;     // dense [G][3+L][N] input (centers/labels NULL)
     const int32_t* ids;     // optional [G] graph indices: workgroup b embeds graph ids[b] (sgpr_embed_ordered)
     const float* dense2;    // optional second dense tensor: graphs g >= g_split read dense2[g - g_split]

@@ -31,7 +31,7 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 
 # every symbol include/sgpr.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
-               "sgpr_embed_capped", "sgpr_embed_ordered",
+               "sgpr_embed_capped", "sgpr_embed_ordered", "sgpr_embed_ragged",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_score_all_pairs_multi_workspace_bytes", "sgpr_score_all_pairs_multi",
                "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
@@ -92,6 +92,8 @@ def load_library():
     lib.sgpr_embed_capped.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_ordered.restype = i32
     lib.sgpr_embed_ordered.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_embed_ragged.restype = i32
+    lib.sgpr_embed_ragged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_dense.restype = i32
     lib.sgpr_embed_dense.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_debug.restype = i32
@@ -330,6 +332,56 @@ class Engine:
             return pooled, att, emb
         rc = self.lib.sgpr_embed_capped(self._h, _ptr(centers), _ptr(labels), g, n, int(node_cap), k, _ptr(pooled),
                                         _ptr(att), _ptr(emb), _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        return pooled, att, emb
+
+    @staticmethod
+    def to_ragged(centers, labels):
+        """Padded arrays (centers [G,N,3], labels [G,N], -1 = pad, padding trailing) -> the ragged store of
+        sgpr_embed_ragged: (centers f32 [S,3], labels i8 [S], offsets i64 [G+1]) as numpy arrays."""
+        import numpy as np
+        c = np.asarray(centers, dtype=np.float32)
+        l = np.asarray(labels)
+        real = l >= 0
+        counts = real.sum(1)
+        if not (real == (np.arange(l.shape[1])[None, :] < counts[:, None])).all():
+            raise ValueError("to_ragged: padding slots (label -1) must trail the real nodes of every graph")
+        offsets = np.zeros(l.shape[0] + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        return np.ascontiguousarray(c[real]), np.ascontiguousarray(l[real].astype(np.int8)), offsets
+
+    def ragged_order(self, offsets, node_num, k):
+        """size_order for a ragged store: (largest-first launch order i32 device tensor, node_cap).  A graph of c nodes
+        in node_num slots has m = node_num - c padding slots, of which one is processed when m >= k (else all m)."""
+        off = torch.as_tensor(offsets).to(torch.int64).cpu()
+        cnt = off[1:] - off[:-1]
+        m = node_num - cnt
+        eff = cnt + torch.where((m >= k) & (m > 1), torch.ones_like(m), m)
+        if eff.numel() == 0:
+            return torch.empty(0, dtype=torch.int32, device=self.device), 0
+        order = torch.argsort(eff, descending=True, stable=True).to(torch.int32).to(self.device)
+        return order, int(eff.max().item())
+
+    def embed_ragged(self, centers, labels, offsets, node_num, k, want_att=False, want_emb=False, node_cap=0, order=None):
+        """Ragged store (to_ragged) -> pooled [G,32] (+ att [G,node_num], emb [G,node_num,32]); bit-identical to `embed`
+        on the padded arrays.  node_cap / order: see ragged_order."""
+        centers = self._dev(centers, torch.float32, "centers")
+        labels = self._dev(labels, torch.int8, "labels")
+        offsets = self._dev(offsets, torch.int64, "offsets")
+        g, n = offsets.numel() - 1, int(node_num)
+        assert centers.dim() == 2 and centers.shape[1] == 3 and labels.shape[0] == centers.shape[0], "centers [S,3], labels [S]"
+        pooled = torch.empty(g, F3, dtype=torch.float32, device=self.device)
+        att = torch.empty(g, n, dtype=torch.float32, device=self.device) if want_att else None
+        emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if want_emb else None
+        if g == 0:
+            return pooled, att, emb
+        ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
+        ws = self._ws(ws_bytes)
+        if order is not None:
+            order = self._dev(order, torch.int32, "order")
+        rc = self.lib.sgpr_embed_ragged(self._h, _ptr(centers), _ptr(labels), _ptr(offsets), g, n, int(node_cap), k,
+                                        _ptr(order), order.numel() if order is not None else 0, _ptr(pooled), _ptr(att),
+                                        _ptr(emb), _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
         return pooled, att, emb
 

@@ -1108,6 +1108,43 @@ def test_sequence_census_of_near_tie_neighbour_flips(eng, oracle, oracle_sd):
     assert (s - rs).abs().max().item() < SCORE_TOL
 
 
+def test_ragged_store_equals_padded_arrays(eng):
+    """sgpr_embed_ragged (only the real nodes in memory, the padding made in registers) is bit-identical to the padded
+    entry points: plain, with node_cap + launch order, with attention / embedding outputs, on graphs of 0 .. node_num
+    nodes; a graph with more nodes than slots is a loud error."""
+    from sg_pr_amd import synth
+    from sg_pr_amd.engine import SgprError
+    c, l, _, _ = synth.kitti_like_sequence(300, 100, seed=3)
+    l = l.copy()
+    c = c.copy()
+    l[7], c[7] = -1, 0.0                                  # an empty graph
+    l[9, :] = np.arange(100) % 12                         # a full one (no padding at all)
+    c[9] = np.random.default_rng(0).uniform(-40, 40, (100, 3)).astype(np.float32)
+    rc, rl, off = eng.to_ragged(c, l)
+    assert rc.shape[0] == off[-1] == (l >= 0).sum() and off[8] == off[7] and off[10] - off[9] == 100
+    ref_p, ref_a, ref_e = eng.embed(c, l, 10, want_att=True, want_emb=True)
+    p1, a1, e1 = eng.embed_ragged(rc, rl, off, 100, 10, want_att=True, want_emb=True)
+    assert torch.equal(p1, ref_p) and torch.equal(a1, ref_a) and torch.equal(e1, ref_e)
+    order, cap = eng.ragged_order(off, 100, 10)
+    order_p, cap_p = eng.size_order(c, l, 10)
+    assert cap == cap_p == 100 and torch.equal(order, order_p)
+    keep = np.setdiff1d(np.arange(300), [9])               # without the full graph the lean plan applies
+    rc2, rl2, off2 = eng.to_ragged(c[keep], l[keep])
+    order2, cap2 = eng.ragged_order(off2, 100, 10)
+    assert cap2 <= 64
+    p2 = eng.embed_ragged(rc2, rl2, off2, 100, 10, node_cap=cap2, order=order2)[0]
+    assert torch.equal(p2, ref_p[torch.from_numpy(keep).cuda()])
+    eng.check_status()
+    bad = off.copy()
+    bad[3:] += 120                                          # graph 2 now claims 120 + nodes: more than the 100 slots
+    big_c = np.concatenate((rc, np.zeros((120, 3), np.float32)))
+    big_l = np.concatenate((rl, np.zeros(120, np.int8)))
+    pb = eng.embed_ragged(big_c, big_l, bad, 100, 10)[0]
+    with pytest.raises(SgprError):
+        eng.check_status()
+    assert torch.isnan(pb[2]).all() and torch.equal(pb[:2], ref_p[:2])
+
+
 def test_generic_branch_graph_outside_f16_range(eng, oracle, oracle_sd):
     """The second pass (embed_redo_kernel) chains its two reasons: a graph that the lean plan hands over for the
     generic semantic branch (fewer than 17 processed slots) is embedded on the full f16 plan - and when THAT run leaves

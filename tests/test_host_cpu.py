@@ -642,3 +642,22 @@ def test_c_abi_links_from_plain_c(tmp_path):
     and links against libsgpr_hip.so (examples/sgpr_demo.c; it is RUN by the GPU suite)."""
     exe = _build_c_demo(tmp_path)
     assert os.path.exists(exe)
+
+
+def test_ragged_store_conversion_and_order():
+    """Engine.to_ragged / ragged_order are host logic: counts, offsets, the processed-slot rule of sgpr_embed_capped."""
+    from sg_pr_amd.engine import Engine
+    from sg_pr_amd import synth
+    c, l, _, _ = synth.kitti_like_sequence(50, 100, seed=1)
+    rc, rl, off = Engine.to_ragged(c, l)
+    counts = (l >= 0).sum(1)
+    assert off[0] == 0 and (np.diff(off) == counts).all() and rc.shape == (counts.sum(), 3) and rl.dtype == np.int8
+    for g in (0, 17, 49):
+        assert (rc[off[g]:off[g + 1]] == c[g, :counts[g]]).all() and (rl[off[g]:off[g + 1]] == l[g, :counts[g]]).all()
+    eff = Engine.processed_slots(c, l, 10).numpy()
+    m = 100 - counts
+    assert (eff == counts + np.where((m >= 10) & (m > 1), 1, m)).all()
+    bad = l.copy()
+    bad[3, 0] = -1                                              # a hole before real nodes
+    with pytest.raises(ValueError):
+        Engine.to_ragged(c, bad)
