@@ -46,6 +46,10 @@ constexpr int PXF = 272;      // bytes per row of X in the fp32 layout (64 ch + 
 // pairs128 33.3 vs 33.1 - the conflicts are real (SQ_LDS_BANK_CONFLICT: 39 % of them sit in the GEMM phase, 25 % in the
 // Gram phase) but the LDS array is only ~38 % busy and nothing waits on it: the smaller rows stay.
 constexpr int PXH = 272;
+#ifndef SGPR_LEAN_WAVES
+#define SGPR_LEAN_WAVES 4
+#endif
+constexpr int kLeanNT = 64 * SGPR_LEAN_WAVES;   // threads of a lean workgroup (4 waves = one per 16-row tile; experiments: 5)
 // X layout of a kernel instance (EmbedPlan::fmt)
 constexpr int FMT_F32 = 0;    // fp32 rows, split into three bf16 planes when loaded (fallback of plans too large for FMT_BF3)
 constexpr int FMT_BF3 = 1;    // three bf16 planes, written once per layer by the gather epilogue (fp32 range: the fallback
@@ -92,7 +96,7 @@ __host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_pa
     p.xplanes = 1;
     p.fmt = FMT_H2;
     p.rowb = PXH;
-    p.nt = 256;
+    p.nt = kLeanNT;
     p.offX = 0;
     p.offRed = 0;
     p.offPark = rows * PXH;
@@ -1414,7 +1418,7 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
                 gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, 0);
                 group_sync<WAVE>();                                           // = the barrier inside gemm_cols
             } else {
-                gemm_layer<true, FMT, 3>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0);   // (lean: four waves)
+                gemm_layer<true, FMT, SGPR_LEAN_WAVES - 1>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0);   // (lean: four waves)
             }
         } else {
             gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, wave);
@@ -1590,7 +1594,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if constexpr (LEAN != 0) lean_fixed_layout(plan_local, DBG == 0, LEAN);
     const EmbedPlan& p = plan_local;
     float vmax = 0.f;                                    // FMT_H2: largest magnitude stored into the f16 planes
-    const int NT = LEAN != 0 ? 256 : (int)blockDim.x, NW = NT >> 6;   // 64 .. 512 threads (EmbedPlan::nt); lean: a constant
+    const int NT = LEAN != 0 ? kLeanNT : (int)blockDim.x, NW = NT >> 6;   // 64 .. 512 threads (EmbedPlan::nt); lean: a constant
     unsigned char* X = smem + p.offX;                    // [NP][XROW]: bf16 planes (or fp32 rows) / in-place fp32 b
     constexpr int XROW = xrow<FMT>();
     float* A = reinterpret_cast<float*>(smem + p.offA);
@@ -1872,9 +1876,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 gram_xyz_direct<FMT>(X, D, p.pitchD, N, NP, rc0, rows_chunk, tid, NT);
             } else if (p.overlap) {
                 if (k64)
-                    gram_tiles_sym<4, FMT, !LEAN, (LEAN != 0 ? 4 : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<4, FMT, !LEAN, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
                 else
-                    gram_tiles_sym<1, FMT, !LEAN, (LEAN != 0 ? 4 : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
+                    gram_tiles_sym<1, FMT, !LEAN, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
                 const int nti = rows_chunk >> 4;
                 for (int tile = wave; tile < nti * nrt; tile += NW) {
@@ -1907,7 +1911,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? 4 : 0)>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
+        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
@@ -2142,7 +2146,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
 }
 
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
-__global__ __launch_bounds__(LEAN ? 256 : NT_MAX, LEAN ? (DBG == 0 ? (LEAN == 48 ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
+__global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? (LEAN == 48 ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
     // (ONE call site: two inlined copies of embed_graph would double the kernel's footprint in the instruction cache)
     int slot = (int)blockIdx.x, role = 0;
     if constexpr (LEAN != 0 && DBG == 0) {
