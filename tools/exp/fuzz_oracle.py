@@ -19,9 +19,15 @@ for trial in range(40):
     c, l, _ = synth.make_graphs(g, n, lo, hi, int(rng.integers(1 << 30)), kitti_like=bool(rng.integers(2)))
     dense = torch.from_numpy(synth.dense_features(c, l))
     rp, ra, _ = oracle.embed(osd, dense, k)
-    for mode in ("packed", "dense", "lean"):
+    for mode in ("packed", "dense", "lean", "ragged"):
         if mode == "packed":
             p, a, _ = eng.embed(c, l, k, want_att=True)
+        elif mode == "ragged":
+            rc_, rl_, off_ = eng.to_ragged(c, l)
+            order_r, cap_r = eng.ragged_order(off_, n, k)
+            p, a, _ = eng.embed_ragged(rc_, rl_, off_, n, k, want_att=True, node_cap=cap_r, order=order_r)
+            p0 = eng.embed(c, l, k)[0]
+            assert torch.equal(p, p0), "ragged store differs from the padded arrays (n=%d k=%d)" % (n, k)
         elif mode == "dense":
             p, a, _ = eng.embed_dense(dense, k, want_att=True)
         else:
@@ -42,4 +48,4 @@ for trial in range(40):
             flips += 1
             print("att deviation %.2e (n=%d k=%d lo=%d mode=%s) score dev %.2e" % (da, n, k, lo, mode, d))
 eng.check_status()
-print("40 shapes x 3 entry points: max |dscore| all-pairs %.3e / pair-list %.3e, max |datt| %.3e, shapes with |datt| > 1e-4: %d" % (worst, worst_list, worst_att, flips))
+print("40 shapes x 4 entry points: max |dscore| all-pairs %.3e / pair-list %.3e, max |datt| %.3e, shapes with |datt| > 1e-4: %d" % (worst, worst_list, worst_att, flips))
