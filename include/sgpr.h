@@ -320,6 +320,13 @@ void sgpr_debug_set_profile_buffer(sgpr_handle* h, void* d_counters);
  * results).  0 (default) = normal. */
 void sgpr_debug_set_skip_mask(sgpr_handle* h, int mask);
 
+/* 1: the handle's weights run on the default datapath (two f16 planes per matrix operand); 0: the checkpoint's folded
+ * weights (or the super-node tables made from them) leave the f16 range, and every launch uses the wide-range
+ * instance (three bf16 planes / fp32 rows).  Decided once, at sgpr_create.  (Weights BELOW f16's normal range keep an
+ * absolute 2^-25 in the planes: harmless - the shipped checkpoints hold whole channels of 1e-30 .. 1e-7 behind dead
+ * BatchNorm scales.) */
+int sgpr_debug_uses_f16_planes(const sgpr_handle* h);
+
 const char* sgpr_last_error(void);
 int sgpr_abi_version(void);
 

@@ -717,6 +717,8 @@ void sgpr_debug_set_skip_mask(sgpr_handle* h, int mask) {
     if (h) h->dbg_skip = mask;
 }
 
+int sgpr_debug_uses_f16_planes(const sgpr_handle* h) { return (h && h->f16_weights) ? 1 : 0; }
+
 void sgpr_debug_set_profile_buffer(sgpr_handle* h, void* d_counters) {
     if (h) h->dbg_prof = static_cast<unsigned long long*>(d_counters);
 }

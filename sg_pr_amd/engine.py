@@ -39,7 +39,8 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_f1_max_workspace_bytes", "sgpr_f1_max", "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
                "sgpr_cluster_workspace_bytes", "sgpr_cluster_scan", "sgpr_graph_edges",
-               "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_last_error", "sgpr_abi_version"]
+               "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_debug_uses_f16_planes", "sgpr_last_error",
+               "sgpr_abi_version"]
 
 
 # struct sgpr_rank_group of include/sgpr.h
@@ -146,6 +147,8 @@ def load_library():
     lib.sgpr_graph_edges.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, sz, vp]
     lib.sgpr_debug_set_skip_mask.restype = None
     lib.sgpr_debug_set_skip_mask.argtypes = [vp, i32]
+    lib.sgpr_debug_uses_f16_planes.restype = i32
+    lib.sgpr_debug_uses_f16_planes.argtypes = [vp]
     lib.sgpr_debug_set_profile_buffer.restype = None
     lib.sgpr_debug_set_profile_buffer.argtypes = [vp, vp]
     lib.sgpr_last_error.restype = ctypes.c_char_p
@@ -265,6 +268,10 @@ class Engine:
         """Synchronises the stream and raises SgprError if a launch since the last check saw a label outside
         [-1, num_labels) (the reference raises KeyError, sg_net.py:277) or a graph that broke its node_cap promise."""
         self._check(self.lib.sgpr_check_status(self._h, self._stream()))
+
+    def uses_f16_planes(self):
+        """True: the default two-plane f16 datapath serves this checkpoint; False: the wide-range instance throughout."""
+        return bool(self.lib.sgpr_debug_uses_f16_planes(self._h))
 
     def set_skip_mask(self, mask):
         """Debug / ablation only (include/sgpr.h)."""

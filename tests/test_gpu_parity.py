@@ -956,6 +956,7 @@ def test_all_release_checkpoints(release_state_dicts, golden_dir):
     for name, sd in release_state_dicts.items():
         e = engine.Engine(sd, device=0)
         try:
+            assert e.uses_f16_planes(), name          # in range, and no row of tiny weights that the planes would starve
             s9, _, _ = e.forward_dense(feats[i], feats[j], 10)
             pooled, _, _ = e.embed(g["syn_centers"], g["syn_labels"], 10)
             ss = e.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous())
@@ -966,6 +967,32 @@ def test_all_release_checkpoints(release_state_dicts, golden_dir):
         finally:
             e.close()
     print("18 release checkpoints: worst max|dscore| =", worst)
+
+
+def test_weights_outside_the_f16_range_take_the_wide_range_instance(oracle, ckpt_path):
+    """A checkpoint whose folded weights exceed the f16 range is served by the wide-range instance throughout (decided at
+    sgpr_create) and still follows the oracle; the 19 shipped checkpoints all run on the two-plane f16 datapath
+    (test_all_release_checkpoints) although they hold whole channels of 1e-30 .. 1e-7 weights behind dead BatchNorm scales -
+    the planes keep an absolute 2^-25 of those, which is all such a channel can matter."""
+    from sg_pr_amd import engine, synth
+    sd = {k: v.clone() for k, v in torch.load(ckpt_path, map_location="cpu").items()}
+    key = [k for k in sd if k.endswith("dgcnn_s_conv2.0.weight")][0]
+    pre = key[: -len("0.weight")]
+    fold = sd[pre + "1.weight"] / torch.sqrt(sd[pre + "1.running_var"] + 1e-5)          # eval BatchNorm's scale per channel
+    mag = fold.abs() * sd[key].flatten(1).abs().amax(1)
+    ch = int(mag.argmax())                                # a live channel (the checkpoint has dead ones)
+    sd[key][ch] *= 2e5 / float(mag[ch])                   # its folded weights now reach 2e5: beyond f16's 65504
+    osd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    c, l, _ = synth.make_graphs(6, 100, 30, 60, 4, kitti_like=True)
+    ref = oracle.embed(osd, torch.from_numpy(synth.dense_features(c, l)), 10)[0]
+    e = engine.Engine(sd, device=0)
+    try:
+        assert not e.uses_f16_planes()
+        p = e.embed(c, l, 10)[0].cpu()
+    finally:
+        e.close()
+    assert torch.isfinite(p).all()
+    assert ((p - ref).abs() <= 1e-4 + 1e-4 * ref.abs()).all()
 
 
 def test_device_roc_auc(eng):
