@@ -16,14 +16,18 @@
 //    v_mfma_f32_16x16x32_bf16, or fp32 rows split on load).  The fp32 MFMA blocks the VALU of its SIMD for 32 cycles
 //    per instruction and is several times slower per product.
 //  * kNN: Gram matrix X.X^T (upper triangle only when the whole key matrix fits in LDS), ranking key
-//    |x_j|^2 - 2 x_i.x_j (= the reference's -pairwise_distance up to the row constant |x_i|^2), then an exact
-//    k-smallest selection per row: register sorting networks + butterfly merges, deterministic lowest-index tie-break.
+//    |x_j|^2 - 2 x_i.x_j (= the reference's -pairwise_distance up to the row constant |x_i|^2) - except in the
+//    coordinate layer, whose keys restate the reference's fp32 arithmetic operation for operation on the vector ALU
+//    (gram_xyz_direct: bit-identical neighbour sets there) -, then an exact k-smallest selection per row: register
+//    sorting networks + butterfly merges, deterministic lowest-index tie-break.
 //  * trailing duplicate (padding) slots collapse to one representative; with packed input the whole semantic branch
 //    runs on 13 label super-nodes (embed_kernel, "semantic branch on label super-nodes").
 //  * one workgroup per graph, 128..512 threads chosen by the host plan (make_embed_plan): graphs of <= 64 processed
-//    slots run on the lean instance - one fixed 39 424-byte LDS layout (30 208 bytes for <= 48 slots), 88 VGPRs, no
-//    scratch: four (five) 4-wave (3-wave) workgroups per CU; everything between the input read and the pooled vector
-//    lives in LDS / registers.
+//    slots run on the lean instance - one fixed 39 424-byte LDS layout (30 208 bytes for <= 48 slots), 91 (79) VGPRs,
+//    no scratch: four (five) 4-wave workgroups per CU, limited by LDS; everything between the input read and the
+//    pooled vector lives in LDS / registers.
+//  * input: padded arrays, the reference's dense tensors, or a ragged store whose padding is made in registers
+//    (sgpr_embed_ragged).
 #include <math.h>
 
 #include <atomic>
@@ -1581,7 +1585,7 @@ int launch_sem_tables(const DevWeights& w, float* d_table, float* d_vmax, hipStr
 
 // DBG = true: the instrumented build used by sgpr_embed_debug / the profiling and ablation hooks; the
 // production instance carries none of that code.
-// LEAN (64 / 48): the instance of the fixed lean layouts - 256 / 192 threads, four / five workgroups per CU (88 VGPRs)
+// LEAN (64 / 48): the instance of the fixed lean layouts - kLeanNT = 256 threads, four / five workgroups per CU (91 / 79 VGPRs)
 // KC: K as a compile-time constant (10, the reference's, in the lean production instances; 0 = read from the plan): the
 // K-derived loop bounds and predicates of every phase fold away
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps

@@ -454,8 +454,10 @@ __device__ __forceinline__ void slow_tile(const DevWeights& w, const float* __re
 //   layer 2  G[o][c] = relu(b1[o] + sum_t W1[o][t] H[t][c])   two f16 MFMAs: H is consumed straight from the
 //            accumulator layout (lane group g holds t = 4g..4g+3), split into two f16 planes; the K slots
 //            8g..8g+3 / 8g+4..8g+7 carry hi / lo, the A operand is W1 laid out to match
-//   head     z[c] = b2 + sum_o w2[o] G[o][c]  (4 FMAs per lane), then per super-block a lane-swap transpose-reduce over
-//            the 4 lane groups leaves lane (g, l15) with row g, columns 4 l15 .. 4 l15 + 3: sigmoid, one 16-byte store.
+//   head     z[c] = b2 + sum_o w2[o] G[o][c]: w2 is folded into layer 2 (ap_consts), so a lane's four terms are four
+//            v_med3_f32 of the accumulator against its own side of zero and three adds; then per super-block a lane-swap
+//            transpose-reduce over the 4 lane groups leaves lane (g, l15) with row g, columns 4 l15 .. 4 l15 + 3:
+//            sigmoid, one 16-byte store.
 // OCC = resident workgroups per CU the instance is compiled for; NI = row graphs whose dependent MFMA -> vector ->
 // MFMA -> vector chains are interleaved in program order (1, 2 or 4); VAR = timing experiments only (tools/probes):
 // bit 1 drops the stores, bit 2 the operand loads of the next block, bit 4 (16) the matrix instructions, bit 5 (32) the
