@@ -78,6 +78,73 @@ def agree_on_error(err, like=None, group=None):
         raise err
 
 
+class RaggedGraphs:
+    """A sequence of graphs as the ragged store of `sgpr_embed_ragged` (include/sgpr.h): centers f32 [S,3] and labels
+    i8 [S] wherever the caller keeps them (device tensors for the GPU path), offsets i64 [G+1] on the HOST - slicing by
+    graph range, which the sharding below does, needs them there.  Takes the place of the (centers [G,N,3], labels
+    [G,N]) pair wherever this module and `SG.embed` accept graphs: pass it as `centers` with `labels=None`."""
+
+    def __init__(self, centers, labels, offsets, node_num):
+        self.centers, self.labels = centers, labels
+        self.offsets = torch.as_tensor(offsets).to(torch.int64).cpu()
+        self.node_num = int(node_num)
+        if self.offsets.numel() < 1 or int(self.offsets[-1] - self.offsets[0]) != int(labels.shape[0]) or \
+                centers.shape[0] != labels.shape[0]:
+            raise ValueError("RaggedGraphs: offsets [G+1] must span the %d stored nodes" % int(labels.shape[0]))
+
+    @classmethod
+    def from_padded(cls, centers, labels, device=None):
+        """(centers [G,N,3], labels [G,N], -1 = trailing pad) -> RaggedGraphs (tensors moved to `device` when given)."""
+        from .engine import Engine
+        import numpy as np
+        c = centers.cpu().numpy() if isinstance(centers, torch.Tensor) else np.asarray(centers)
+        l = labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+        rc, rl, off = Engine.to_ragged(c, l)
+        tc, tl = torch.from_numpy(rc), torch.from_numpy(rl)
+        if device is not None:
+            tc, tl = tc.to(device), tl.to(device)
+        return cls(tc, tl, off, l.shape[1])
+
+    def __len__(self):
+        return self.offsets.numel() - 1
+
+    @property
+    def shape(self):                                   # (graphs, slots): what `labels.shape` is for padded arrays
+        return (len(self), self.node_num)
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise TypeError("RaggedGraphs are sliced by contiguous graph ranges")
+        lo, hi, _ = sl.indices(len(self))
+        hi = max(hi, lo)
+        a, b = int(self.offsets[lo]), int(self.offsets[hi])
+        base = int(self.offsets[0])
+        return RaggedGraphs(self.centers[a - base:b - base], self.labels[a - base:b - base], self.offsets[lo:hi + 1],
+                            self.node_num)
+
+    @staticmethod
+    def cat(parts):
+        """Concatenation in graph order (SequenceSet: this rank's shards of several sequences as one launch)."""
+        parts = list(parts)
+        if len({p.node_num for p in parts}) != 1:
+            raise ValueError("RaggedGraphs.cat: sequences of different node_num")
+        offs, at = [torch.zeros(1, dtype=torch.int64)], 0
+        for p in parts:
+            rel = p.offsets - p.offsets[0]
+            offs.append(rel[1:] + at)
+            at += int(rel[-1])
+        return RaggedGraphs(torch.cat([p.centers for p in parts]), torch.cat([p.labels for p in parts]), torch.cat(offs),
+                            parts[0].node_num)
+
+
+def _graph_count(centers, labels):
+    return len(centers) if isinstance(centers, RaggedGraphs) else labels.shape[0]
+
+
+def _graph_slice(centers, labels, lo, hi):
+    return (centers[lo:hi], None) if isinstance(centers, RaggedGraphs) else (centers[lo:hi], labels[lo:hi])
+
+
 class AllPairsScorer:
     """embed_fn(centers[g0:g1], labels[g0:g1]) -> pooled [g, F];  score_fn(rows, cols) -> [R, M].
 
@@ -122,10 +189,10 @@ class AllPairsScorer:
         """Embed this rank's shard and all_gather: every rank returns pooled [M, F].  `local`: the shard's pooled vectors
         when they were embedded already (SequenceSet embeds the shards of several sequences with one launch)."""
         world, rank = self._world()
-        m = labels.shape[0]
+        m = _graph_count(centers, labels)
         lo, hi = shard_bounds(m, world, rank)
         if local is None:
-            local = self.embed_fn(centers[lo:hi], labels[lo:hi])
+            local = self.embed_fn(*_graph_slice(centers, labels, lo, hi))
         assert local.shape[0] == hi - lo
         if world == 1:
             return local
@@ -308,14 +375,18 @@ class SequenceSet:
     bit-identical to per-sequence runs."""
 
     def __init__(self, scorer, sequences, batch_tails=True):
-        """sequences: list of (centers [M,N,3], labels [M,N]) tensors."""
+        """sequences: list of (centers [M,N,3], labels [M,N]) tensors, or of (RaggedGraphs, None) - one kind per set."""
         self.scorer = scorer
         self.batch_tails = batch_tails
         self.sequences = list(sequences)
         world, rank = scorer._world()
-        self.bounds = [shard_bounds(l.shape[0], world, rank) for _, l in self.sequences]
-        self.centers = torch.cat([c[lo:hi] for (c, _), (lo, hi) in zip(self.sequences, self.bounds)], dim=0)
-        self.labels = torch.cat([l[lo:hi] for (_, l), (lo, hi) in zip(self.sequences, self.bounds)], dim=0)
+        self.bounds = [shard_bounds(_graph_count(c, l), world, rank) for c, l in self.sequences]
+        if self.sequences and isinstance(self.sequences[0][0], RaggedGraphs):
+            self.centers = RaggedGraphs.cat([c[lo:hi] for (c, _), (lo, hi) in zip(self.sequences, self.bounds)])
+            self.labels = None
+        else:
+            self.centers = torch.cat([c[lo:hi] for (c, _), (lo, hi) in zip(self.sequences, self.bounds)], dim=0)
+            self.labels = torch.cat([l[lo:hi] for (_, l), (lo, hi) in zip(self.sequences, self.bounds)], dim=0)
 
     def run(self, embed_fn=None, gather=True, outs=None, chunks=4):
         """embed_fn(centers, labels) -> pooled of the concatenated shards (default: the scorer's).  Returns one result

@@ -41,12 +41,13 @@ class PackedSequence:
     def node_num(self):
         return self.labels.shape[1]
 
-    def ragged(self):
-        """The sequence as the ragged store of sgpr_embed_ragged / Engine.embed_ragged: (centers f32 [S,3], labels i8
-        [S], offsets i64 [M+1]) - only the real nodes, 13 bytes each instead of 16 per slot (what to keep resident for
-        a whole data set, and what to move across PCIe)."""
-        from .engine import Engine
-        return Engine.to_ragged(self.centers, self.labels)
+    def ragged(self, device=None):
+        """The sequence as the ragged store of sgpr_embed_ragged: an `allpairs.RaggedGraphs` (centers f32 [S,3], labels
+        i8 [S], host offsets i64 [M+1]) - only the real nodes, 13 bytes each instead of 16 per slot: what to keep
+        resident for a whole data set and what to move across PCIe.  Accepted wherever graphs are
+        (`SG.embed(rag, None)`, `AllPairsScorer.run(rag, None)`, `SequenceSet`)."""
+        from .allpairs import RaggedGraphs
+        return RaggedGraphs.from_padded(self.centers, self.labels, device=device)
 
     def save(self, path):
         np.savez_compressed(path, centers=self.centers, labels=self.labels, poses=self.poses,

@@ -108,6 +108,14 @@ class SG(torch.nn.Module):
         results are needed - the evaluation entry points (forward_packed, eval_batch_pair, eval_batch.score_pair_list,
         graph_store.evaluate_all_pairs) do."""
         eng = self.engine()
+        from .allpairs import RaggedGraphs
+        if isinstance(centers, RaggedGraphs):
+            # the ragged store (sgpr_embed_ragged): its offsets live on the host, so the launch plan costs no synchronisation
+            rag = centers
+            if node_cap is None and order is None and len(rag):
+                order, node_cap = eng.ragged_order(rag.offsets, rag.node_num, int(self.args.K))
+            return eng.embed_ragged(rag.centers, rag.labels, rag.offsets - rag.offsets[0], rag.node_num, int(self.args.K),
+                                    want_att=want_att, want_emb=want_emb, node_cap=node_cap or 0, order=order)
         if node_cap is None and order is None:
             if not (isinstance(labels, torch.Tensor) and labels.is_cuda) and len(labels):
                 order, node_cap = eng.size_order(centers, labels, int(self.args.K))

@@ -1172,6 +1172,29 @@ def test_ragged_store_equals_padded_arrays(eng):
     assert torch.isnan(pb[2]).all() and torch.equal(pb[:2], ref_p[:2])
 
 
+def test_scorer_on_a_ragged_store_equals_padded_arrays(ckpt_path):
+    """allpairs.RaggedGraphs through SG.embed, AllPairsScorer.run and SequenceSet.run: the matrices of the padded arrays
+    bit for bit (the launch plan - node_cap, largest-first order - comes from the store's host-side offsets)."""
+    from sg_pr_amd import allpairs, sg_net, synth
+    from sg_pr_amd.parser_sg import sgpr_args
+    args = sgpr_args()
+    args.model = ckpt_path
+    trainer = sg_net.SGTrainer(args, False)
+    scorer = allpairs.AllPairsScorer(model=trainer.model)
+    seqs = [synth.kitti_like_sequence(m, 100, seed)[:2] for seed, m in ((6, 203), (7, 77))]
+    dev = torch.device("cuda", 0)
+    padded = [(torch.from_numpy(c).to(dev), torch.from_numpy(l).to(dev)) for c, l in seqs]
+    ragged = [(allpairs.RaggedGraphs.from_padded(c, l, device=dev), None) for c, l in seqs]
+    ref = [scorer.run(c, l) for c, l in padded]
+    got = [scorer.run(r, None) for r, _ in ragged]
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    many = allpairs.SequenceSet(scorer, ragged).run()
+    for a, b in zip(ref, many):
+        assert torch.equal(a, b)
+    trainer.model.engine().check_status()
+
+
 def test_generic_branch_graph_outside_f16_range(eng, oracle, oracle_sd):
     """The second pass (embed_redo_kernel) chains its two reasons: a graph that the lean plan hands over for the
     generic semantic branch (fewer than 17 processed slots) is embedded on the full f16 plan - and when THAT run leaves

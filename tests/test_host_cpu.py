@@ -298,11 +298,32 @@ def _allpairs_worker(rank, world, port, golden, out_dir):
             return torch.empty(0, 32)
         return oracle.embed(sd, torch.from_numpy(synth.dense_features(c, l)), 10)[0]
 
-    scorer = allpairs.AllPairsScorer(embed_fn=embed_fn, score_fn=lambda r, c: oracle.score_all_pairs(sd, r, c))
+    def padded_of(rag):                                      # a ragged shard back as the padded arrays embed_fn takes
+        n = rag.node_num
+        c = np.zeros((len(rag), n, 3), np.float32)
+        l = -np.ones((len(rag), n), np.int32)
+        off = (rag.offsets - rag.offsets[0]).numpy()
+        for g in range(len(rag)):
+            c[g, :off[g + 1] - off[g]] = rag.centers[off[g]:off[g + 1]].numpy()
+            l[g, :off[g + 1] - off[g]] = rag.labels[off[g]:off[g + 1]].numpy()
+        return c, l
+
+    def embed_any(c, l):
+        return embed_fn(*padded_of(c)) if isinstance(c, allpairs.RaggedGraphs) else embed_fn(c, l)
+
+    scorer = allpairs.AllPairsScorer(embed_fn=embed_any, score_fn=lambda r, c: oracle.score_all_pairs(sd, r, c))
+    # the same job from the ragged store (sgpr_embed_ragged's format): sharded by graph ranges like the padded arrays
+    rag = allpairs.RaggedGraphs.from_padded(centers, labels)
+    assert len(rag) == 11 and rag.shape == (11, 100) and len(rag[3:7]) == 4 and len(rag[9:]) == 2
+    rag_full = scorer.run(rag, None, chunks=1)
+    rag_set = allpairs.SequenceSet(scorer, [(rag, None), (rag[:5], None)]).run(chunks=1)
     full = scorer.run(centers, labels)                       # chunks = 4: pieces shipped while the next one is scored
     plain = scorer.run(centers, labels, chunks=1)            # the plain form: one block, one gather
     if rank == 0:
         torch.testing.assert_close(full, plain, rtol=0, atol=2e-6)   # torch-CPU matmuls are not batch-invariant
+        torch.testing.assert_close(rag_full, plain, rtol=0, atol=2e-6)
+        torch.testing.assert_close(rag_set[0], plain, rtol=0, atol=2e-6)
+        assert rag_set[1].shape == (5, 5)
         torch.save(full, os.path.join(out_dir, "w%d.pt" % world))
     # several sequences as one job (allpairs.SequenceSet): the shards of both embedded by one call, matrices as before
     tc, tl = torch.from_numpy(centers), torch.from_numpy(labels)
@@ -661,3 +682,23 @@ def test_ragged_store_conversion_and_order():
     bad[3, 0] = -1                                              # a hole before real nodes
     with pytest.raises(ValueError):
         Engine.to_ragged(c, bad)
+
+
+def test_ragged_graphs_container():
+    """allpairs.RaggedGraphs: slicing by graph range, concatenation, round trip through Engine.to_ragged."""
+    from sg_pr_amd import allpairs, synth
+    c, l, _, _ = synth.kitti_like_sequence(20, 100, seed=2)
+    rag = allpairs.RaggedGraphs.from_padded(c, l)
+    counts = (l >= 0).sum(1)
+    assert len(rag) == 20 and int(rag.offsets[-1]) == counts.sum()
+    part = rag[4:9]
+    assert len(part) == 5 and int(part.offsets[-1] - part.offsets[0]) == counts[4:9].sum()
+    assert torch.equal(part.centers, rag.centers[int(rag.offsets[4]):int(rag.offsets[9])])
+    again = allpairs.RaggedGraphs.cat([rag[:4], part, rag[9:]])
+    assert torch.equal(again.centers, rag.centers) and torch.equal(again.labels, rag.labels)
+    assert torch.equal(again.offsets, rag.offsets)
+    assert len(rag[7:7]) == 0 and len(allpairs.RaggedGraphs.cat([rag[7:7], rag[:2]])) == 2
+    with pytest.raises(TypeError):
+        rag[::2]
+    with pytest.raises(ValueError):
+        allpairs.RaggedGraphs(rag.centers, rag.labels, rag.offsets[:-1], 100)
