@@ -79,6 +79,79 @@ def kitti_like_sequence(num_graphs=4541, node_num=100, seed=0):
     return centers, labels, n_real, poses
 
 
+def world_sequence(num_graphs=4541, node_num=100, seed=0, sensor_range=50.0, center_noise=0.15, dropout=0.12,
+                   density=0.0062, region=60.0, mix_alpha=3.0):
+    """A KITTI-00-sized sequence whose graphs come from ONE world, so that revisits look alike and the
+    precision-recall curve of the score matrix means something (`kitti_like_sequence` draws every graph
+    independently of its pose: its F1-max is chance).
+
+    The world is a fixed set of landmarks (label from the shipped-graph histogram, position uniform over the
+    trajectory's bounding box + sensor_range, height in [-2, 1] like the shipped graphs).  The vehicle drives a
+    planar random walk at 1 m per frame; the last third re-drives the first third (lateral offset ~0.5 m, heading
+    within a few degrees).  Frame t sees the landmarks within `sensor_range` of its pose, in the sensor frame
+    (x forward, y left, z up: the frame the shipped graphs' centres are in), each one dropped with probability
+    `dropout` and its centre jittered by N(0, center_noise) m - what a per-frame clustering does to a real
+    object.  At most node_num - 40 nodes are kept (nearest first), i.e. >= 40 padded slots: the tie regime stays
+    the reference's deterministic one.  Nodes are listed label-ascending like the shipped graphs.
+    Returns (centers f32 [G,N,3], labels i32 [G,N], n_real i32 [G], poses f64 [G,12]) - the KITTI 3x4 pose with
+    the heading as a rotation about the camera's y axis; utils.py:36 reads entries 3 (x) and 11 (z)."""
+    rng = np.random.default_rng(seed + 104729)
+    G = int(num_graphs)
+    heading = np.cumsum(rng.normal(0.0, 0.05, size=G))
+    xz = np.cumsum(np.stack([np.cos(heading), np.sin(heading)], axis=1), axis=0)
+    third = G // 3
+    if third > 0:
+        xz[-third:] = xz[:third] + rng.normal(0.0, 0.5, size=(third, 2))
+        heading[-third:] = heading[:third] + rng.normal(0.0, 0.03, size=third)
+    lo, hi = xz.min(0) - sensor_range, xz.max(0) + sensor_range
+    n_land = max(int(density * float(np.prod(hi - lo))), 1)
+    land_xz = rng.uniform(lo, hi, size=(n_land, 2))
+    land_h = rng.uniform(-2.0, 1.0, size=n_land)
+    # places differ: every `region` x `region` m cell of the world has its own label mix (a Dirichlet draw around the
+    # shipped-graph histogram) - a street of buildings and fences here, vegetation and trunks there
+    reg = np.floor((land_xz - lo) / region).astype(np.int64)
+    nreg = reg.max(0) + 1
+    mix = rng.dirichlet(_KITTI_LABEL_P * mix_alpha + 1e-3, size=int(nreg[0] * nreg[1]))
+    cum = np.cumsum(mix[reg[:, 0] * nreg[1] + reg[:, 1]], axis=1)
+    land_lab = np.minimum((rng.random(n_land)[:, None] > cum).sum(1), NUM_LABELS - 1)
+    # landmarks nowhere near the trajectory are never seen: drop them before the per-frame search
+    cell = np.floor(xz / sensor_range).astype(np.int64)
+    near = set()
+    for dx in (-1, 0, 1):
+        for dz in (-1, 0, 1):
+            near.update(map(tuple, cell + (dx, dz)))
+    keep = np.fromiter((tuple(c) in near for c in np.floor(land_xz / sensor_range).astype(np.int64)), bool, n_land)
+    land_xz, land_h, land_lab = land_xz[keep], land_h[keep], land_lab[keep]
+    max_real = max(node_num - 40, 1)
+    centers = np.zeros((G, node_num, 3), dtype=np.float32)
+    labels = -np.ones((G, node_num), dtype=np.int32)
+    n_real = np.zeros(G, dtype=np.int32)
+    for t in range(G):
+        d = land_xz - xz[t]
+        r2 = (d * d).sum(1)
+        seen = np.flatnonzero(r2 <= sensor_range * sensor_range)
+        seen = seen[rng.random(seen.size) >= dropout]
+        if seen.size > max_real:
+            seen = seen[np.argsort(r2[seen], kind="stable")[:max_real]]
+        c, s = np.cos(heading[t]), np.sin(heading[t])
+        fwd = d[seen, 0] * c + d[seen, 1] * s
+        left = -d[seen, 0] * s + d[seen, 1] * c
+        pts = np.stack([fwd, left, land_h[seen]], axis=1) + rng.normal(0.0, center_noise, size=(seen.size, 3))
+        order = np.argsort(land_lab[seen], kind="stable")
+        n = seen.size
+        centers[t, :n] = pts[order]
+        labels[t, :n] = land_lab[seen][order]
+        n_real[t] = n
+    poses = np.zeros((G, 12), dtype=np.float64)
+    poses[:, 0] = poses[:, 10] = np.cos(heading)
+    poses[:, 2] = np.sin(heading)
+    poses[:, 8] = -np.sin(heading)
+    poses[:, 5] = 1.0
+    poses[:, 3] = xz[:, 0]
+    poses[:, 11] = xz[:, 1]
+    return centers, labels, n_real, poses
+
+
 def dense_features(centers, labels, num_labels=NUM_LABELS):
     """Packed (centers, labels) -> the reference's dense `B x (3+L) x N` float32
     tensor (sg_net.py:274-298): xyz rows then a one-hot block, all-zero for -1."""

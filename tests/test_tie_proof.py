@@ -1,0 +1,79 @@
+"""CPU tests of the tie-proof machinery (tests/tie_proof.py) and of the world-consistent sequence generator: the proof
+must accept a genuine near-tie, and must REJECT a wrongly chosen neighbour and an upstream numerical error."""
+import numpy as np
+import torch
+
+import tie_proof
+from sg_pr_amd import synth
+
+
+def _trace_pair(oracle, oracle_sd, feats, k=10):
+    sd64 = {key: (v.double() if v.is_floating_point() else v) for key, v in oracle_sd.items()}
+    return tie_proof.oracle_trace(oracle, oracle_sd, feats, k), tie_proof.oracle_trace(oracle, sd64, feats.double(), k)
+
+
+def test_world_sequence_is_consistent_and_in_the_deterministic_regime():
+    c, l, n, poses = synth.world_sequence(300, 100, seed=3)
+    c2, l2, _, p2 = synth.world_sequence(300, 100, seed=3)
+    assert np.array_equal(c, c2) and np.array_equal(l, l2) and np.array_equal(poses, p2)
+    assert c.dtype == np.float32 and l.dtype == np.int32 and poses.shape == (300, 12)
+    assert n.min() >= 10 and n.max() <= 60                       # >= 40 padded slots: ties only between padding
+    assert ((l >= 0).sum(1) == n).all() and (l[:, 60:] == -1).all() and (c[:, 60:] == 0).all()
+    for g in (0, 150, 299):
+        assert (np.diff(l[g, :n[g]]) >= 0).all()                  # label-ascending like the shipped graphs
+    # a revisit sees the same landmarks: the last third re-drives the first third
+    a, b = 10, 200 + 10
+    xz = poses[:, [3, 11]]
+    assert np.linalg.norm(xz[a] - xz[b]) < 3.0
+    assert abs(int(n[a]) - int(n[b])) <= 15
+    ha, hb = np.bincount(l[a, :n[a]], minlength=12), np.bincount(l[b, :n[b]], minlength=12)
+    far = 100
+    hf = np.bincount(l[far, :n[far]], minlength=12)
+    assert np.abs(ha - hb).sum() < np.abs(ha - hf).sum() + 12
+
+
+def test_identical_traces_are_proven_without_flips(oracle, oracle_sd):
+    c, l, _, _ = synth.world_sequence(4, 100, seed=0)
+    f = torch.from_numpy(synth.dense_features(c[:1], l[:1]))
+    x, knn = tie_proof.oracle_trace(oracle, oracle_sd, f, 10)
+    rep = tie_proof.prove_ties(x, knn, x, knn)
+    assert rep["proven"] and not rep["flips"]
+
+
+def test_a_wrong_neighbour_is_not_a_tie(oracle, oracle_sd):
+    """Negative control: swap one genuinely chosen neighbour of a real node for a node farther away."""
+    c, l, _, _ = synth.world_sequence(4, 100, seed=0)
+    f = torch.from_numpy(synth.dense_features(c[:1], l[:1]))
+    x, knn = tie_proof.oracle_trace(oracle, oracle_sd, f, 10)
+    for li in (1, 2):                                            # the 64-channel coordinate layers
+        bad = [k.copy() for k in knn]
+        d2 = ((x[li][0][None, :] - x[li]) ** 2).sum(1)
+        order = np.argsort(d2, kind="stable")
+        far = [j for j in order[10:] if d2[j] > d2[order[9]] + 1e-3][0]
+        row0 = bad[li][0]
+        pos = np.flatnonzero(row0 == order[9])
+        row0[pos[0] if pos.size else 0] = far
+        rep = tie_proof.prove_ties(x, knn, x, bad)
+        assert not rep["proven"] and "not a tie" in rep["reason"], rep
+
+
+def test_an_upstream_numerical_error_is_not_a_tie(oracle, oracle_sd):
+    c, l, _, _ = synth.world_sequence(4, 100, seed=0)
+    f = torch.from_numpy(synth.dense_features(c[:1], l[:1]))
+    x, knn = tie_proof.oracle_trace(oracle, oracle_sd, f, 10)
+    xb = [v.copy() for v in x]
+    xb[1] = xb[1] + 1e-3
+    rep = tie_proof.prove_ties(x, knn, xb, knn)
+    assert not rep["proven"] and "inputs differ" in rep["reason"]
+
+
+def test_float64_oracle_flips_only_proven_ties(oracle, oracle_sd):
+    """The same model evaluated in float64 is an implementation of the reference that is not its BLAS: wherever its
+    embedding leaves the fp32 oracle's, the proof must find a near-tie (graph 595 of the world sequence is one)."""
+    c, l, _, _ = synth.world_sequence(4541, 100, seed=0)
+    f = torch.from_numpy(synth.dense_features(c[595:596], l[595:596]))
+    (xo, ko), (xh, kh) = _trace_pair(oracle, oracle_sd, f)
+    rep = tie_proof.prove_ties(xo, ko, xh, kh)
+    assert rep["proven"] and rep["flips"], rep
+    assert max(fl["ratio"] for fl in rep["flips"]) < 1.0
+    assert all(fl["gap"] < 1e-5 for fl in rep["flips"])
