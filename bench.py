@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - graph-pairs/sec of the SG_PR hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kitti00|kitti5seq|pairs128|stress]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kitti00|kitti5seq|pairlist|pairs128|stress]
 
 `--gpus N` with N > 1 and no torch.distributed environment: this script re-launches itself as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU, backend
@@ -23,6 +23,12 @@ this rank's shard (fused kNN/EdgeConv/attention kernel), exchange the pooled vec
 the matrix (NTN + head), gather the matrix on rank 0.  N > 1: the M graphs / M rows are sharded across ranks; the
 matrix is fixed, so `scaling` is "strong".  `end_to_end` adds what `value` excludes by contract: the H2D copy of the
 packed graphs and either the D2H copy of the matrix or its device-side consumer (F1-max from threshold counts).
+
+`pairlist`: the reference's OWN loop shape (eval_batch.py:30-36 walks a pair list, utils.py:61-70) on its own evaluation
+lists for KITTI 02 / 05 / 06 / 08 (tests/golden/pair_lists_3_20.npz: the index pairs of the reference's
+data_process/pair_list/pair_list_3_20_*.npy - 184 133 listed pairs over 12 584 graphs, ~15 per row graph), in a seeded
+shuffled order like the reference's files; graphs = synthetic KITTI-like sequences of those lengths.  One step = every
+graph embedded once + the listed pairs scored by sgpr_score_pair_list (grouped by row graph, matrix cores).
 
 Other workloads (parity-test shapes, not the headline): `pairs128` (config 2: 128 pairs, N=64, k=10, faithful
 per-pair forward) and `stress` (config 5: 1024 pairs, N=256, k=20).
@@ -83,7 +89,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prewarm", type=float, default=1.5,
                     help="seconds of untimed steps before the warmup (GPU clock ramp), 0 disables")
-    ap.add_argument("--workload", default="kitti00", choices=["kitti00", "kitti5seq", "pairs128", "stress"])
+    ap.add_argument("--workload", default="kitti00", choices=["kitti00", "kitti5seq", "pairlist", "pairs128", "stress"])
     ap.add_argument("--graphs", type=int, default=4541, help="M for the kitti00 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -100,8 +106,9 @@ def parse():
                     help="kitti00: a directory of real graph JSONs (e.g. $SG_PR_DATA/graphs_sk/00) packed once through "
                          "sg_pr_amd.graph_store.pack_directory instead of the synthetic sequence; the line then says "
                          "\"data\": \"real\" and M is the number of graphs found")
-    ap.add_argument("--event-stride", type=int, default=8,
-                    help="HIP events (roofline kernel durations) around every n-th embed / tail call of the timed region")
+    ap.add_argument("--kernel-reps", type=int, default=32,
+                    help="launches per kernel of the untimed duration pass that follows the timed region (HIP events "
+                         "around that many back-to-back embed calls, then tail calls; the timed region carries no events)")
     ap.add_argument("--d2h-pieces", type=int, default=4,
                     help="end_to_end.d2h: row blocks whose device-to-host copy overlaps the scoring of the next one")
     return ap.parse_args()
@@ -168,6 +175,10 @@ def main():
         seqs = list(KITTI_FRAMES.items())
         wl_name = ("config 4: KITTI 00+02+05+06+08-sized all-pairs matrices back to back (synthetic KITTI-like graphs), "
                    "M=" + "/".join(str(m) for _, m in seqs) + ", node_num=100, K=10")
+    elif a.workload == "pairlist":
+        n, k = 100, 10
+        wl_name = ("the reference's evaluation pair lists for KITTI 02+05+06+08 (pair_list_3_20_*.npy index pairs, seeded "
+                   "shuffle) over synthetic KITTI-like graphs: embed every graph once + sgpr_score_pair_list, node_num=100, K=10")
     elif a.workload == "pairs128":
         n, k = 64, 10
         wl_name = "config 2: 128 synthetic pairs per GPU, node_num=64, K=10, faithful per-pair forward"
@@ -182,31 +193,20 @@ def main():
     eng = model.engine()
     eng_cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
-    class _Events(list):            # (start, stop) event pairs + how many calls there were (recorded or not)
-        calls = 0
-
-        def clear(self):
-            super().clear()
-            self.calls = 0
-    ev_embed, ev_tail = _Events(), _Events()      # around the embed launch / the all-pairs tail launches
+    # Kernel durations for the roofline objects come from an UNTIMED pass after the timed region (kernel_ms below): an
+    # event record between two launches idles the stream for ~5 us, so the timed region carries none.
+    calls = {"embed": 0, "tail": 0}      # engine calls per kind during the timed region (launches per step)
+    dur_calls = {}                       # kind -> zero-argument callable that enqueues ONE such call (duration pass)
     graphs_per_step = 0             # graphs this rank embeds per step
     n_eff_all = []                  # processed slots of those graphs (algorithmic FLOPs)
     host_inputs = []                # (centers, labels) numpy, for the transfer-inclusive runs and the CPU baseline
+    host_pairs, plan, plan_ms = None, None, None
+    host_prep_ms = 0.0              # one-off host cost of node_cap / launch order (and the pair plan): data-set properties
 
-    def timed(events, fn):
-        # An event record between two launches leaves the stream idle for ~5 us (r03 kernel trace: 10 us between the
-        # embed call's last kernel and the tail call's first one, 0 between the kernels of one call), so only every
-        # --event-stride-th call of the timed region carries events: the kernel durations are averages over those.
+    def counted(kind, fn):
         def wrapped(*x, **kw):
-            events.calls += 1
-            if (events.calls - 1) % max(a.event_stride, 1):
-                return fn(*x, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*x, **kw)
-            e1.record()
-            events.append((e0, e1))
-            return r
+            calls[kind] += 1
+            return fn(*x, **kw)
         return wrapped
 
     if allpairs_job:
@@ -228,11 +228,14 @@ def main():
                 centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=si)
             host_inputs.append((centers, labels, poses))
             lo, hi = allpairs.shard_bounds(m, world, rank)
+            t_h = time.perf_counter()
             node_cap = eng.node_cap_of(centers, labels, k)   # dataset property (the graph store knows its node counts)
             order = eng.size_order(centers[lo:hi], labels[lo:hi], k)[0] if a.embed_mode == "ordered" else None
+            torch.cuda.synchronize()
+            host_prep_ms += (time.perf_counter() - t_h) * 1e3
             scorer = allpairs.AllPairsScorer(model=model)
-            scorer.embed_fn = timed(ev_embed, lambda c, l, cap=node_cap, o=order: eng.embed(c, l, k, node_cap=cap, order=o)[0])
-            scorer.score_fn = timed(ev_tail, model.score_all_pairs)
+            scorer.embed_fn = counted("embed", lambda c, l, cap=node_cap, o=order: eng.embed(c, l, k, node_cap=cap, order=o)[0])
+            scorer.score_fn = counted("tail", model.score_all_pairs)
             full_out = (torch.empty(m, m, dtype=torch.float32, device=dev)
                         if (world > 1 and rank == 0 and not a.no_gather) else None)
             jobs.append({"name": name, "m": m, "scorer": scorer, "out": full_out, "node_cap": node_cap,
@@ -246,9 +249,12 @@ def main():
             # several sequences: this rank's shards of all of them are embedded by ONE launch (allpairs.SequenceSet)
             seqset = allpairs.SequenceSet(jobs[0]["scorer"], [(j["d_centers"], j["d_labels"]) for j in jobs],
                                           batch_tails=not a.per_sequence_tails)
-            eng.score_all_pairs_multi = timed(ev_tail, eng.score_all_pairs_multi)   # (the batched tails' launches)
+            eng.score_all_pairs_multi = counted("tail", eng.score_all_pairs_multi)   # (the batched tails' launches)
+            t_h = time.perf_counter()
             set_order = (eng.size_order(seqset.centers, seqset.labels, k)[0] if a.embed_mode == "ordered" else None)
-            set_embed = timed(ev_embed, lambda c, l: eng.embed(c, l, k, node_cap=node_cap_report, order=set_order)[0])
+            torch.cuda.synchronize()
+            host_prep_ms += (time.perf_counter() - t_h) * 1e3
+            set_embed = counted("embed", lambda c, l: eng.embed(c, l, k, node_cap=node_cap_report, order=set_order)[0])
 
         def step(gather=not a.no_gather):
             if seqset is not None:
@@ -257,6 +263,76 @@ def main():
             for j in jobs:
                 out = j["scorer"].run(j["d_centers"], j["d_labels"], gather=gather, out=j["out"], chunks=a.chunks)
             return out
+
+        # one embed call / one tail call exactly as the step issues them (this rank's shard), for the duration pass
+        if seqset is not None:
+            dur_calls["embed"] = lambda: set_embed(seqset.centers, seqset.labels)
+        else:
+            j0 = jobs[0]
+            lo0, hi0 = allpairs.shard_bounds(j0["m"], world, rank)
+            dur_calls["embed"] = lambda: j0["scorer"].embed_fn(j0["d_centers"][lo0:hi0], j0["d_labels"][lo0:hi0])
+        if seqset is not None and not a.per_sequence_tails and world == 1:
+            _pl = [eng.embed(j["d_centers"], j["d_labels"], k)[0] for j in jobs]
+            _outs = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
+            dur_calls["tail"] = lambda: eng.score_all_pairs_multi([(p_, p_, o_) for p_, o_ in zip(_pl, _outs)])
+        else:
+            j0 = jobs[0]
+            lo0, hi0 = allpairs.shard_bounds(j0["m"], world, rank)
+            _p0 = eng.embed(j0["d_centers"], j0["d_labels"], k)[0]
+            _o0 = torch.empty(hi0 - lo0, j0["m"], dtype=torch.float32, device=dev)
+            _r0 = _p0[lo0:hi0].contiguous()
+            dur_calls["tail"] = lambda: j0["scorer"].score_fn(_r0, _p0, out=_o0)
+    elif a.workload == "pairlist":
+        fx = np.load(os.path.join(REPO, "tests", "golden", "pair_lists_3_20.npz"))
+        seqs, parts_c, parts_l, parts_i, parts_j, base = [], [], [], [], [], 0
+        for si, name in enumerate(("02", "05", "06", "08")):
+            ij = fx["seq_" + name].astype(np.int64)
+            m = int(ij.max()) + 1
+            c, l, _, _ = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=10 + si)
+            parts_c.append(c)
+            parts_l.append(l)
+            parts_i.append(ij[:, 0] + base)
+            parts_j.append(ij[:, 1] + base)
+            seqs.append((name, m))
+            base += m
+        centers, labels = np.concatenate(parts_c), np.concatenate(parts_l)
+        li, lj = np.concatenate(parts_i), np.concatenate(parts_j)
+        perm = np.random.default_rng(2024).permutation(li.size)       # the reference's files are in shuffled order
+        li, lj = li[perm].astype(np.int32), lj[perm].astype(np.int32)
+        lo, hi = allpairs.shard_bounds(li.size, world, rank)          # pair-list mode shards the LIST
+        li, lj = li[lo:hi], lj[lo:hi]
+        host_inputs.append((centers, labels, None))
+        host_pairs = (li, lj)
+        m = centers.shape[0]
+        units = int(sum(fx["seq_" + nm].shape[0] for nm, _ in seqs))
+        used = np.unique(np.concatenate((li, lj)))                    # a rank embeds only the graphs its pairs name
+        remap = np.full(m, -1, dtype=np.int32)
+        remap[used] = np.arange(used.size, dtype=np.int32)
+        d_centers, d_labels = torch.from_numpy(centers[used]).to(dev), torch.from_numpy(labels[used]).to(dev)
+        t_h = time.perf_counter()
+        node_cap_report = eng.node_cap_of(centers[used], labels[used], k)
+        order = eng.size_order(centers[used], labels[used], k)[0] if a.embed_mode == "ordered" else None
+        torch.cuda.synchronize()
+        host_prep_ms += (time.perf_counter() - t_h) * 1e3
+        t_h = time.perf_counter()
+        plan = eng.pair_plan(remap[li], remap[lj], used.size, used.size)
+        plan_ms = (time.perf_counter() - t_h) * 1e3
+        graphs_per_step = int(used.size)
+        n_eff_all.append(synth.effective_nodes(centers[used], labels[used], k))
+        embed_t = counted("embed", lambda: eng.embed(d_centers, d_labels, k, node_cap=node_cap_report, order=order)[0])
+        _pooled0 = embed_t()
+        _score0 = torch.empty(plan.P, dtype=torch.float32, device=dev)
+        tail_t = counted("tail", lambda pooled: eng.score_pair_list(pooled, pooled, plan, out=_score0))
+        dur_calls["embed"] = embed_t
+        dur_calls["tail"] = lambda: tail_t(_pooled0)
+        _d_i, _d_j = torch.from_numpy(remap[li]).to(dev), torch.from_numpy(remap[lj]).to(dev)
+        dur_calls["tail_one_wave_per_pair"] = lambda: eng.score_pairs(_pooled0, _pooled0, _d_i, _d_j, out=_score0)
+
+        def step(gather=True):
+            sc = tail_t(embed_t())
+            if world > 1 and gather:
+                sc = allpairs.all_gather_varlen(sc, None)[0]
+            return sc
     else:
         centers, labels, _ = (synth.config2_pairs(seed=0) if a.workload == "pairs128" else synth.config5_pairs(seed=0))
         host_inputs.append((centers, labels, None))
@@ -266,11 +342,15 @@ def main():
         d_centers, d_labels = torch.from_numpy(centers).to(dev), torch.from_numpy(labels).to(dev)
         cc = torch.cat((d_centers[0::2], d_centers[1::2])).contiguous()
         ll = torch.cat((d_labels[0::2], d_labels[1::2])).contiguous()
+        t_h = time.perf_counter()
         node_cap_report = eng.node_cap_of(centers, labels, k)
         order = eng.size_order(cc, ll, k)[0] if a.embed_mode == "ordered" else None
+        torch.cuda.synchronize()
+        host_prep_ms += (time.perf_counter() - t_h) * 1e3
         graphs_per_step = m
         n_eff_all.append(synth.effective_nodes(centers, labels, k))
-        embed_t = timed(ev_embed, lambda: eng.embed(cc, ll, k, node_cap=node_cap_report, order=order)[0])
+        embed_t = counted("embed", lambda: eng.embed(cc, ll, k, node_cap=node_cap_report, order=order)[0])
+        dur_calls["embed"] = embed_t
 
         def step(gather=True):
             pooled = embed_t()
@@ -316,14 +396,40 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    ev_embed.clear()
-    ev_tail.clear()
+    calls["embed"] = calls["tail"] = 0
     dt = timed_steps(a.steps, step)
-    launches_per_step = max(1, round(ev_embed.calls / max(a.steps, 1)))
-    embed_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in ev_embed])) / max(len(ev_embed), 1)
-    launches_timed = len(ev_embed)
-    tail_ms = (float(np.sum([e0.elapsed_time(e1) for e0, e1 in ev_tail])) / max(len(ev_tail), 1)) if ev_tail else None
-    tail_calls_per_step = ev_tail.calls / max(a.steps, 1)
+    launches_per_step = max(1, round(calls["embed"] / max(a.steps, 1)))
+    tail_calls_per_step = calls["tail"] / max(a.steps, 1)
+
+    def kernel_ms(fn, reps):
+        """Average duration of one engine call from HIP events around `reps` back-to-back calls on the launch stream
+        (torch's current stream is the stream the engine launches on): no event between the calls, no idle gaps."""
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    launches_timed = max(16, a.kernel_reps)
+    embed_ms = kernel_ms(dur_calls["embed"], launches_timed)
+    tail_ms = kernel_ms(dur_calls["tail"], launches_timed) if "tail" in dur_calls else None
+    one_wave_ms = kernel_ms(dur_calls["tail_one_wave_per_pair"], 16) if "tail_one_wave_per_pair" in dur_calls else None
+    step_ms = dt / a.steps * 1e3
+    kernels_ms = embed_ms * launches_per_step + (tail_ms or 0.0) * tail_calls_per_step
+    # the kernels of a step cannot take longer than the step (back-to-back launches of ONE kernel lack only the
+    # dependencies between different kernels, which cost time, never save it); 5 % for clock / box noise
+    durations_consistent = bool(world > 1 or kernels_ms <= 1.05 * step_ms)
+    if not durations_consistent:
+        embed_ms = kernel_ms(dur_calls["embed"], launches_timed)          # once more before saying so
+        tail_ms = kernel_ms(dur_calls["tail"], launches_timed) if "tail" in dur_calls else None
+        kernels_ms = embed_ms * launches_per_step + (tail_ms or 0.0) * tail_calls_per_step
+        durations_consistent = bool(kernels_ms <= 1.05 * step_ms)
+    assert world > 1 or kernels_ms <= 1.25 * step_ms, \
+        "kernel durations (%.4f ms) exceed the timed step (%.4f ms): the duration pass is broken" % (kernels_ms, step_ms)
 
     # N > 1, extra information (not `value`): the same K steps with the matrix left sharded by rows - what the
     # device-side consumers (F1-max counts, top-k retrieval) work on; isolates the cost of the gather to rank 0
@@ -386,8 +492,6 @@ def main():
                               "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "
                               "engine call with 64 bytes crossing PCIe (`device_f1`); %d repetitions"
                               % (h2d_bytes / 1e6, units * 4 / 1e6, pieces, reps))
-        ev_embed.clear()
-        ev_tail.clear()
 
     if rank == 0:
         value = units * a.steps / dt
@@ -451,16 +555,22 @@ def main():
         res = {
             "metric": "graph-pairs/sec", "value": value, "unit": "graph-pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if allpairs_job else "weak",
+            "higher_is_better": True, "scaling": "strong" if (allpairs_job or a.workload == "pairlist") else "weak",
             "vs_baseline": None, "dtype": "f32 (2xf16-plane operands on the matrix cores, fp32 accumulate; fp32 vector math)",
             "data": data_kind,
             "config": {"workload": wl_name, "graphs": int(sum(mm for _, mm in seqs)) if allpairs_job else int(m),
                        "node_num": n, "K": k, "pairs_per_step": int(units), "node_cap": int(node_cap_report),
                        "embed_launch_order": "largest graph first" if a.embed_mode == "ordered" else "as stored",
-                       "parallelism": "row-sharded x%d" % world, "backend": backend if world > 1 else None,
+                       "parallelism": ("list-sharded x%d" if a.workload == "pairlist" else "row-sharded x%d") % world, "backend": backend if world > 1 else None,
                        "gather_to_rank0": (not a.no_gather) if allpairs_job else None,
                        "gather_chunks": a.chunks if (allpairs_job and world > 1) else None,
-                       "checkpoint": "tests/golden/model.pth"},
+                       "checkpoint": "tests/golden/model.pth",
+                       "host_prep_ms_once": host_prep_ms,
+                       "host_prep_note": "node_cap + largest-first launch order, computed once per data set outside "
+                                         "the timed step (and outside end_to_end)"},
+            "kernel_durations": {"embed_call_ms": embed_ms, "tail_call_ms": tail_ms, "sum_per_step_ms": kernels_ms,
+                                 "ms_per_step": step_ms, "consistent": durations_consistent,
+                                 "launches_timed": launches_timed},
             "sharded_output": sharded,
             "end_to_end": end_to_end,
             "roofline": {"kernel": "sgpr::embed_kernel", "bound": "valu",
@@ -468,7 +578,8 @@ def main():
                                        "matrix pipe is ~8 % busy and HBM ~0.5 % - priced against the fp32 vector peak",
                          "achieved": ach_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP32_PEAK_TFLOPS, "traffic": traffic, "issue": issue, "launch_ms": embed_ms, "launches_timed": launches_timed,
-                         "event_stride": a.event_stride,
+                         "timing": "HIP events around %d back-to-back calls after the timed region (embed_kernel + its "
+                                   "second-pass dispatcher)" % launches_timed,
                          "graphs_per_launch": g / launches_per_step, "launches_per_step": launches_per_step,
                          "flops_per_launch_algorithmic": flops, "mean_nodes_processed": float(np.mean(n_eff)),
                          "dense_equivalent_tflops": flops_dense / (embed_ms * 1e-3) / 1e12,
@@ -476,7 +587,21 @@ def main():
                          "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_graph": embed_bytes_per_graph(n)}},
         }
-        if tail_ms is not None:
+        if a.workload == "pairlist":
+            # the grouped pair-list tail (ntn_prep_list + score_pair_list kernels of one call): algorithmic bytes = the
+            # pooled vectors of the graphs read once + per listed pair its two indices, its output position and its score
+            tb = graphs_per_step * 128 * 2 + plan.P * 16
+            res["pairlist"] = {"pairs": int(plan.P), "graphs_embedded": int(graphs_per_step), "distinct_row_graphs": plan.n_rows,
+                               "work_items": plan.n_items, "embed_call_ms": embed_ms, "tail_call_ms": tail_ms,
+                               "tail_one_wave_per_pair_ms": one_wave_ms,
+                               "tail_below_embed": bool(tail_ms < embed_ms),
+                               "plan_build_ms_once": plan_ms,
+                               "hbm": {"achieved": tb / (tail_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": tb / (tail_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_call_algorithmic": tb},
+                               "note": "kernels: sgpr::ntn_prep_list_kernel + sgpr::score_pair_list_kernel (grouped by row "
+                                       "graph, 16 listed columns per MFMA group) against sgpr::score_pairs_kernel (one wave "
+                                       "per pair) on the same list; the call is launch-latency bound at this size"}
+        elif tail_ms is not None:
             # all-pairs tail (ntn_prep + score_all_pairs kernels of one call): the HBM-write-bound piece -
             # algorithmic bytes = the scores written + the pooled vectors read
             rows_per_call = sum(allpairs.shard_bounds(mm, world, 0)[1] for _, mm in seqs) / max(tail_calls_per_step, 1)
@@ -491,7 +616,7 @@ def main():
                                     "calls_per_step": tail_calls_per_step, "issue": issue_tail}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.model, host_inputs[0][0], host_inputs[0][1], n, k, a.cpu_seconds,
-                                               allpairs_job)
+                                               allpairs_job, pairs=host_pairs if a.workload == "pairlist" else None)
         print(json.dumps(res))
         sys.stdout.flush()
     if world > 1:
@@ -509,7 +634,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job):
+def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job, pairs=None):
     """The oracle (faithful torch-CPU restatement of the reference forward: both graphs of
     every pair embedded, materialised edge tensors) timed on the host cores over a bounded
     sample of pairs drawn from the same workload."""
@@ -523,8 +648,12 @@ def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job):
     m = centers.shape[0]
 
     def batch():
-        i = rng.integers(0, m, size=bsz)
-        j = rng.integers(0, m, size=bsz)
+        if pairs is not None:                 # the listed pairs themselves, in list order (eval_batch.py:30-36)
+            at = int(rng.integers(0, max(len(pairs[0]) - bsz, 1)))
+            i, j = pairs[0][at:at + bsz], pairs[1][at:at + bsz]
+        else:
+            i = rng.integers(0, m, size=bsz)
+            j = rng.integers(0, m, size=bsz)
         f1 = torch.from_numpy(synth.dense_features(centers[i], labels[i]))
         f2 = torch.from_numpy(synth.dense_features(centers[j], labels[j]))
         return f1, f2

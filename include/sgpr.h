@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 5
+#define SGPR_ABI_VERSION 6
 
 enum {
     SGPR_OK = 0,
@@ -150,6 +150,30 @@ int sgpr_embed_debug(const sgpr_handle* h, const float* d_centers, const int32_t
  *   (d_pooled1[idx1 ? idx1[p] : p], d_pooled2[idx2 ? idx2[p] : p]); idx may be NULL. */
 int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t* d_idx1,
                      const float* d_pooled2, const int32_t* d_idx2, int64_t P, float* d_score, void* stream);
+
+/* The same tail for a pair LIST grouped by row graph - the shape of the reference's own evaluation loop
+ * (eval_batch.py:30-36 walks `<seq>.txt`, utils.py:61-70: 10^4 - 10^5 listed pairs over 10^3 graphs, ~15 per row graph).
+ * sgpr_score_pairs spends a whole wave and a 64 KB weight read on every pair; here the bilinear form is hoisted per
+ * DISTINCT row graph and the listed columns of a row go through the matrix cores 16 at a time, exactly like a row of
+ * the dense rectangle: the scores are bit-identical to sgpr_score_all_pairs' entries at the listed (row, column).
+ *
+ * sgpr_pair_plan (HOST memory in and out, no GPU work): groups pair p = (idx1[p], idx2[p]), 0 <= idx1 < R, 0 <= idx2 < M,
+ * P < 2^31, by row graph (stable: a row's pairs keep their list order) and cuts every row's pairs into work items of
+ * <= 16.  h_plan receives int32 words
+ *     row_ids [n_rows] | item_row [n_items] | item_begin [n_items + 1] | cols [P] | pos [P]
+ * (distinct row graphs ascending; per item its row as an index into row_ids and its first pair in cols / pos; per pair
+ * its column graph and its position in the caller's list).  sgpr_pair_plan_ints(P, R) bounds the words needed;
+ * *plan_ints returns the words written.  An index out of range -> SGPR_E_INVALID.  Build it once per list (like a launch
+ * order), copy it to the device, reuse it for every call.
+ * sgpr_score_pair_list: d_score[p] = SG-tail(d_pooled_rows[idx1[p]], d_pooled_cols[idx2[p]]) for the P pairs of the plan
+ * (d_plan: the plan words in DEVICE memory).  Workspace: sgpr_score_pair_list_workspace_bytes(h, n_rows, M). */
+size_t sgpr_pair_plan_ints(int64_t P, int R);
+int sgpr_pair_plan(const int32_t* h_idx1, const int32_t* h_idx2, int64_t P, int R, int M, int32_t* h_plan,
+                   size_t plan_capacity_ints, size_t* plan_ints, int32_t* n_rows, int32_t* n_items);
+size_t sgpr_score_pair_list_workspace_bytes(const sgpr_handle* h, int n_rows, int M);
+int sgpr_score_pair_list(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols, int M,
+                         const int32_t* d_plan, int n_rows, int n_items, int64_t P, float* d_score, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* Dense all-pairs form of the same tail: score[r, c] = SG-tail(rows[r], cols[c])
  * (the NTN is asymmetric, layers_batch.py:77-83, so the full rectangle is computed).

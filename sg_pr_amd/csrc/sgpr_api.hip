@@ -519,6 +519,95 @@ int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t
     return launch_score_pairs(h, d_pooled1, d_idx1, d_pooled2, d_idx2, P, d_score, static_cast<hipStream_t>(stream));
 }
 
+size_t sgpr_pair_plan_ints(int64_t P, int R) {
+    if (P < 0 || R < 0) return 0;
+    const int64_t rows = P < R ? P : R;                       // distinct row graphs at most
+    const int64_t items = P / 16 + rows;                      // sum over rows of ceil(count / 16) at most
+    return (size_t)(rows + items + (items + 1) + 2 * P);
+}
+
+int sgpr_pair_plan(const int32_t* h_idx1, const int32_t* h_idx2, int64_t P, int R, int M, int32_t* h_plan,
+                   size_t plan_capacity_ints, size_t* plan_ints, int32_t* n_rows, int32_t* n_items) {
+    if (P < 0 || P >= 0x7fffffffLL || R < 0 || M < 0 || (P > 0 && (!h_idx1 || !h_idx2)) || !plan_ints || !n_rows || !n_items) {
+        set_error("sgpr_pair_plan: NULL argument, negative count or 2^31 pairs or more");
+        return SGPR_E_INVALID;
+    }
+    std::vector<int32_t> count((size_t)R + 1, 0);
+    for (int64_t p = 0; p < P; ++p) {
+        const int32_t a = h_idx1[p], b = h_idx2[p];
+        if (a < 0 || a >= R || b < 0 || b >= M) {
+            set_error("sgpr_pair_plan: pair " + std::to_string(p) + " = (" + std::to_string(a) + ", " + std::to_string(b) +
+                      ") outside [0, " + std::to_string(R) + ") x [0, " + std::to_string(M) + ")");
+            return SGPR_E_INVALID;
+        }
+        ++count[a];
+    }
+    int64_t nr = 0, ni = 0;
+    for (int r = 0; r < R; ++r)
+        if (count[r]) {
+            ++nr;
+            ni += (count[r] + 15) / 16;
+        }
+    const size_t need = (size_t)(nr + ni + (ni + 1) + 2 * P);
+    *plan_ints = need;
+    *n_rows = (int32_t)nr;
+    *n_items = (int32_t)ni;
+    if (!h_plan || plan_capacity_ints < need) {
+        if (!h_plan && plan_capacity_ints == 0) return SGPR_OK;           // size query
+        set_error("sgpr_pair_plan: plan needs " + std::to_string(need) + " int32 words");
+        return SGPR_E_WORKSPACE;
+    }
+    int32_t* row_ids = h_plan;
+    int32_t* item_row = row_ids + nr;
+    int32_t* item_beg = item_row + ni;
+    int32_t* cols = item_beg + ni + 1;
+    int32_t* pos = cols + P;
+    std::vector<int32_t> cursor((size_t)R + 1, 0);
+    int32_t at = 0, cr = 0, it = 0;
+    for (int r = 0; r < R; ++r) {
+        cursor[r] = at;
+        if (!count[r]) continue;
+        row_ids[cr] = r;
+        for (int32_t c0 = 0; c0 < count[r]; c0 += 16) {
+            item_row[it] = cr;
+            item_beg[it++] = at + c0;
+        }
+        at += count[r];
+        ++cr;
+    }
+    item_beg[it] = (int32_t)P;
+    for (int64_t p = 0; p < P; ++p) {
+        const int32_t w = cursor[h_idx1[p]]++;
+        cols[w] = h_idx2[p];
+        pos[w] = (int32_t)p;
+    }
+    return SGPR_OK;
+}
+
+size_t sgpr_score_pair_list_workspace_bytes(const sgpr_handle* h, int n_rows, int M) {
+    if (!h || n_rows < 0 || M < 0) return 0;
+    return score_pair_list_ws_bytes(n_rows, M);
+}
+
+int sgpr_score_pair_list(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols, int M,
+                         const int32_t* d_plan, int n_rows, int n_items, int64_t P, float* d_score, void* d_workspace,
+                         size_t workspace_bytes, void* stream) {
+    if (!h || R < 0 || M < 0 || P < 0 || P >= 0x7fffffffLL || n_rows < 0 || n_rows > R || n_items < 0 ||
+        (P > 0 && (!d_pooled_rows || !d_pooled_cols || !d_plan || !d_score || n_rows == 0 || n_items == 0 || n_items > P))) {
+        set_error("sgpr_score_pair_list: NULL argument, negative count or a plan that does not fit (P, R)");
+        return SGPR_E_INVALID;
+    }
+    if (P == 0) return SGPR_OK;
+    const size_t need = score_pair_list_ws_bytes(n_rows, M);
+    if (!d_workspace || workspace_bytes < need) {
+        set_error("sgpr_score_pair_list: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    DeviceGuard guard(h->device);
+    return launch_score_pair_list(h, d_pooled_rows, d_pooled_cols, M, d_plan, n_rows, n_items, P, d_score, d_workspace,
+                                  static_cast<hipStream_t>(stream));
+}
+
 size_t sgpr_score_all_pairs_workspace_bytes(const sgpr_handle* h, int R, int M) {
     if (!h || R < 0 || M < 0) return 0;
     return score_all_pairs_ws_bytes(R, M);

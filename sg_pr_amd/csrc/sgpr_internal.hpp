@@ -141,6 +141,9 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
                            int64_t ld, void* ws, hipStream_t stream);
 size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs);
 int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs, void* ws, hipStream_t stream);
+size_t score_pair_list_ws_bytes(int NR, int M);
+int launch_score_pair_list(const sgpr_handle* h, const float* rows, const float* cols, int M, const int32_t* plan,
+                           int NR, int NI, int64_t P, float* score, void* ws, hipStream_t stream);
 int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,
                float* out, hipStream_t stream);
 int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);

@@ -173,10 +173,14 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
 // instead of once per graph - plus the column half of the block term, split into two f16 planes on the way out, and
 // u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
+// LIST (pair-list mode, score_pair_list_kernel): the R row graphs are rows[row_ids[0 .. R)] (the distinct row graphs of
+// the list, gathered) and the column operands are laid out per graph, Cb [M][2 planes][32] f16, instead of per super-block.
+template <bool LIST>
 __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* __restrict__ rows, int R,
                                               const float* __restrict__ cols, int M, unsigned short* __restrict__ Ab,
                                               float* __restrict__ ur, float* __restrict__ rng,
-                                              unsigned short* __restrict__ Cb, const int block) {
+                                              unsigned short* __restrict__ Cb, const int block,
+                                              const int32_t* __restrict__ row_ids = nullptr) {
     __shared__ float red[4][4];
     __shared__ __attribute__((aligned(16))) unsigned short stage[16 * 2 * 4 * 8 * 8];   // [graph][plane][j >> 3][t & 7][j & 7]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -186,7 +190,8 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     float amax = 0.f, umax = 0.f, emax = 0.f, l1max = 0.f;       // l1max: max over (graph, t) of sum_j |A'[t][j]|
     if (g0 < R) {
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
-        const float* e = rows + (size_t)min(g0 + l15, R - 1) * F + 4 * lq;
+        const int ga = min(g0 + l15, R - 1);
+        const float* e = rows + (size_t)(LIST ? row_ids[ga] : ga) * F + 4 * lq;
         const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
         // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
         // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
@@ -267,7 +272,7 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     for (int gi = half * 8 + wave * 2; gi < half * 8 + wave * 2 + 2; ++gi) {
         const int g = g0 + gi;
         if (g < R) {
-            const float* e1 = rows + (size_t)g * F;
+            const float* e1 = rows + (size_t)(LIST ? row_ids[g] : g) * F;
             float s = 0.f;
             for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
             s += __shfl_xor(s, 16);
@@ -276,16 +281,22 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
             umax = fmaxf(umax, fabsf(s));
             if (lq == 0) ur[(size_t)g * T + l15] = s;
         }
-        const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
+        const int msb = LIST ? M : (M + AP_SB - 1) / AP_SB * AP_SB;
         if (g < msb && lane < F) {                          // the column operand itself, two f16 planes (zeros past M)
             const float x = g < M ? cols[(size_t)g * F + lane] : 0.f;
             emax = fmaxf(emax, fabsf(x));
             _Float16 h, l;
             split2_f16(x, h, l);
-            const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
-            unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
-            dst[0] = __builtin_bit_cast(unsigned short, h);
-            dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+            if (LIST) {
+                unsigned short* dst = Cb + (size_t)g * (2 * F) + lane;
+                dst[0] = __builtin_bit_cast(unsigned short, h);
+                dst[F] = __builtin_bit_cast(unsigned short, l);
+            } else {
+                const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
+                unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
+                dst[0] = __builtin_bit_cast(unsigned short, h);
+                dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+            }
         }
     }
     // NaN inputs: fmaxf drops them, so fold an explicit "not finite" marker in (infinity fails every bound)
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
                                                        const float* __restrict__ cols, int M,
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                        float* __restrict__ rng, unsigned short* __restrict__ Cb) {
-    ntn_prep_body(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
+    ntn_prep_body<false>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
 }
 
 // several independent rectangles in one launch (sgpr_score_all_pairs_multi): job j owns the prep workgroups
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(256) void ntn_prep_multi_kernel(const DevWeights w,
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
     const ApJob& q = jobs.job[j];
-    ntn_prep_body(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j]);
+    ntn_prep_body<false>(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j]);
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
@@ -411,38 +422,42 @@ __device__ __forceinline__ f16x8 split_relu4(f32x4 h) {
 
 // Exact fp32 evaluation of the rectangle [r0, r1) x [c0, c1), one pair per wave iteration, for inputs outside the f16
 // range.  Deliberately rolled loops: it shares the kernel with the hot loop and must not cost it registers.
+__device__ __forceinline__ float slow_pair(const DevWeights& w, const float* __restrict__ e1, const float* __restrict__ e2) {
+    const int lane = threadIdx.x & 63, t = lane & 15, q = lane >> 4;
+    float s = 0.f;
+#pragma unroll 1
+    for (int j = 8 * q; j < 8 * q + 8; ++j) {                     // this lane group's quarter of the 32 j
+        float v = 0.f;
+#pragma unroll 1
+        for (int i = 0; i < F; ++i) v = fmaf(e1[i], w.ntn_w[i * (F * T) + j * T + t], v);
+        s = fmaf(v, e2[j], s);
+    }
+#pragma unroll 1
+    for (int m = 16 * q; m < 16 * q + 16; ++m) s = fmaf(w.ntn_wb[t * 2 * F + m], m < F ? e1[m] : e2[m - F], s);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float h = fmaxf(s + w.ntn_bias[t], 0.f);
+    float gacc = w.fc1_b[t];
+#pragma unroll 1
+    for (int tt = 0; tt < T; ++tt) gacc = fmaf(w.fc1_w[t * T + tt], __shfl(h, tt), gacc);
+    float z = fmaxf(gacc, 0.f) * w.fc2_w[t];
+    z += __shfl_xor(z, 1);
+    z += __shfl_xor(z, 2);
+    z += __shfl_xor(z, 4);
+    z += __shfl_xor(z, 8);
+    return 1.f / (1.f + expf(-(z + w.fc2_b[0])));
+}
+
 __device__ __forceinline__ void slow_tile(const DevWeights& w, const float* __restrict__ prow,
                                           const float* __restrict__ pcol, int r0, int r1, int c0, int c1,
                                           float* __restrict__ score, int64_t ld) {
-    const int lane = threadIdx.x & 63, t = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63;
 #pragma unroll 1
     for (int r = r0; r < r1; ++r)
 #pragma unroll 1
         for (int c = c0; c < c1; ++c) {
-            const float* e1 = prow + (size_t)r * F;
-            const float* e2 = pcol + (size_t)c * F;
-            float s = 0.f;
-#pragma unroll 1
-            for (int j = 8 * q; j < 8 * q + 8; ++j) {                     // this lane group's quarter of the 32 j
-                float v = 0.f;
-#pragma unroll 1
-                for (int i = 0; i < F; ++i) v = fmaf(e1[i], w.ntn_w[i * (F * T) + j * T + t], v);
-                s = fmaf(v, e2[j], s);
-            }
-#pragma unroll 1
-            for (int m = 16 * q; m < 16 * q + 16; ++m) s = fmaf(w.ntn_wb[t * 2 * F + m], m < F ? e1[m] : e2[m - F], s);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            const float h = fmaxf(s + w.ntn_bias[t], 0.f);
-            float gacc = w.fc1_b[t];
-#pragma unroll 1
-            for (int tt = 0; tt < T; ++tt) gacc = fmaf(w.fc1_w[t * T + tt], __shfl(h, tt), gacc);
-            float z = fmaxf(gacc, 0.f) * w.fc2_w[t];
-            z += __shfl_xor(z, 1);
-            z += __shfl_xor(z, 2);
-            z += __shfl_xor(z, 4);
-            z += __shfl_xor(z, 8);
-            if (lane == 0) score[(size_t)r * ld + c] = 1.f / (1.f + expf(-(z + w.fc2_b[0])));
+            const float sc = slow_pair(w, prow + (size_t)r * F, pcol + (size_t)c * F);
+            if (lane == 0) score[(size_t)r * ld + c] = sc;
         }
 }
 
@@ -780,6 +795,156 @@ int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_j
     hipLaunchKernelGGL((score_all_pairs_multi_kernel<AP_OCC, AP_NI>), dim3(grid), dim3(256), 0, stream, h->w, a);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_multi_kernel launch");
+    return SGPR_OK;
+}
+
+// ------------------------------------------------------------------ grouped pair list (sgpr_score_pair_list)
+// The reference's own evaluation loop walks a pair LIST (eval_batch.py:30-36: ~15 listed pairs per row graph, 10^4-10^5
+// pairs over 10^3 graphs).  The list arrives grouped by row graph (sgpr_pair_plan, host): work item = (row graph, up to 16
+// of its listed columns).  ntn_prep hoists A'_r / u_r for the DISTINCT row graphs and the two-plane copies of the column
+// graphs exactly as for the dense rectangle; a wave then takes FOUR items at a time through the all-pairs inner loop -
+// layer 1 (3 MFMAs), split, layer 2 (2 MFMAs), head - with the columns gathered by index, and the lane-swap
+// transpose-reduce that gives lane group g the four rows of one item in the dense kernel gives it item g here.  Every
+// instruction and operand of a pair is the one score_all_pairs_kernel would use for that (row, column): the scores are
+// bit-identical to the dense matrix's entries.  Against score_pairs_kernel (one wave per pair, the 64 KB NTN weight
+// re-read per pair): ~430 VALU + 290 VMEM instructions per pair there, ~3 + 0.5 here.
+// workspace:  ur [NR][T] f32 | rng [2 groups][4] f32 | Ab [NR][2][64][8] f16 | Cg [M][2][32] f16
+static inline int pl_prep_groups(int NR, int M) { return ((NR > M ? NR : M) + 15) / 16; }
+
+size_t score_pair_list_ws_bytes(int NR, int M) {
+    return (size_t)NR * T * sizeof(float) + (size_t)2 * pl_prep_groups(NR, M) * 4 * sizeof(float) +
+           (size_t)NR * 2 * 64 * 8 * sizeof(unsigned short) + (size_t)M * 2 * F * sizeof(unsigned short);
+}
+
+__global__ __launch_bounds__(256) void ntn_prep_list_kernel(const DevWeights w, const float* __restrict__ rows,
+                                                            const int32_t* __restrict__ row_ids, int NR,
+                                                            const float* __restrict__ cols, int M,
+                                                            unsigned short* __restrict__ Ab, float* __restrict__ ur,
+                                                            float* __restrict__ rng, unsigned short* __restrict__ Cg) {
+    ntn_prep_body<true>(w, rows, NR, cols, M, Ab, ur, rng, Cg, (int)blockIdx.x, row_ids);
+}
+
+struct PairPlan {                 // device views into the plan buffer (sgpr.h, sgpr_pair_plan)
+    const int32_t* row_ids;       // [NR]          distinct row graphs, ascending
+    const int32_t* item_row;      // [NI]          compact row (index into row_ids) of every work item
+    const int32_t* item_beg;      // [NI + 1]      first listed pair of the item in cols / pos (an item holds <= 16)
+    const int32_t* cols;          // [P]           column graph of every listed pair, grouped by row graph
+    const int32_t* pos;           // [P]           position of that pair in the caller's list = where its score goes
+    int NR, NI;
+};
+
+template <bool CL>
+__device__ __forceinline__ void pl_items(const DevWeights& w, const ApConsts& k, const bool fast, const PairPlan pl,
+                                         const unsigned short* __restrict__ Ab, const unsigned short* __restrict__ Cg,
+                                         const float* __restrict__ ur, const float* __restrict__ prow,
+                                         const float* __restrict__ pcol, float* __restrict__ score) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+    const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
+    const float4 b1v = k.b1v, side = k.side;
+    const float kL2E = 1.4426950408889634f;
+    const float nb2 = k.nb2;
+    const int nquad = (pl.NI + 3) >> 2;
+    const int wave0 = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
+    for (int q4 = wave0; q4 < nquad; q4 += nwaves) {
+        if (!fast) {        // inputs outside the f16 range: exact fp32 arithmetic, one pair per wave step
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int item = 4 * q4 + i;
+                if (item >= pl.NI) break;
+                const int beg = pl.item_beg[item], end = pl.item_beg[item + 1];
+                const float* e1 = prow + (size_t)pl.row_ids[pl.item_row[item]] * F;
+#pragma unroll 1
+                for (int p = beg; p < end; ++p) {
+                    const float sc = slow_pair(w, e1, pcol + (size_t)pl.cols[p] * F);
+                    if (lane == 0) score[pl.pos[p]] = sc;
+                }
+            }
+            continue;
+        }
+        float zb[4];
+        int my_beg = 0, my_cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = min(4 * q4 + i, pl.NI - 1);
+            const int beg = pl.item_beg[item];
+            const int cnt = (4 * q4 + i < pl.NI) ? pl.item_beg[item + 1] - beg : 0;
+            if (i == g) {
+                my_beg = beg;
+                my_cnt = cnt;
+            }
+            const int r = pl.item_row[item];
+            const int c = pl.cols[beg + min(l15, max(cnt, 1) - 1)];             // slots past the item's end repeat its last pair
+            const unsigned short* ap = Ab + ((size_t)r * 2 * 64 + lane) * 8;      // A'_r[t = l15][8g .. 8g+7]
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ap);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ap + 64 * 8);
+            const float4 u = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+            const unsigned short* cp = Cg + (size_t)c * (2 * F) + 8 * g;          // e2_c[8g .. 8g+7], column = MFMA column l15
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(cp);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(cp + F);
+            f32x4 h = mfma_f16(al, bh, f32x4{u.x, u.y, u.z, u.w});
+            h = mfma_f16(ah, bl, h);
+            h = mfma_f16(ah, bh, h);
+            const f16x8 hb = split_relu4<CL>(h);
+            f32x4 q = mfma_f16(w1lo, hb, f32x4{b1v.x, b1v.y, b1v.z, b1v.w});
+            q = mfma_f16(w1hi, hb, q);
+            const float t0 = __builtin_amdgcn_fmed3f(q[0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[1], 0.f, side.y);
+            const float t2 = __builtin_amdgcn_fmed3f(q[2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[3], 0.f, side.w);
+            zb[i] = (t0 + t1) + (t2 + t3);
+        }
+        const float p02 = swap32_add(zb[0], zb[2]);
+        const float p13 = swap32_add(zb[1], zb[3]);
+        const float zsel = swap16_add(p02, p13);             // lane group g: item g of the quad, its pair l15
+        const float sc = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
+        if (l15 < my_cnt) score[pl.pos[my_beg + l15]] = sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void score_pair_list_kernel(const DevWeights w, const PairPlan pl,
+                                                              const unsigned short* __restrict__ Ab,
+                                                              const unsigned short* __restrict__ Cg,
+                                                              const float* __restrict__ ur,
+                                                              const float* __restrict__ rng, int nrng,
+                                                              const float* __restrict__ prow,
+                                                              const float* __restrict__ pcol,
+                                                              float* __restrict__ score) {
+    const int lane = threadIdx.x & 63;
+    float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;
+    ap_range(rng, nrng, lane, am, um, em, l1);
+    const int mode = ap_mode(am, um, em, l1);
+    const ApConsts k = ap_consts(w, lane & 15, lane >> 4);
+    if (mode == 2)
+        pl_items<true>(w, k, true, pl, Ab, Cg, ur, prow, pcol, score);
+    else
+        pl_items<false>(w, k, mode != 0, pl, Ab, Cg, ur, prow, pcol, score);
+}
+
+int launch_score_pair_list(const sgpr_handle* h, const float* rows, const float* cols, int M, const int32_t* plan,
+                           int NR, int NI, int64_t P, float* score, void* ws, hipStream_t stream) {
+    if (P == 0 || NI == 0) return SGPR_OK;
+    PairPlan pl;
+    pl.row_ids = plan;
+    pl.item_row = pl.row_ids + NR;
+    pl.item_beg = pl.item_row + NI;
+    pl.cols = pl.item_beg + NI + 1;
+    pl.pos = pl.cols + P;
+    pl.NR = NR;
+    pl.NI = NI;
+    const int nrng = 2 * pl_prep_groups(NR, M);
+    float* ur = static_cast<float*>(ws);
+    float* rng = ur + (size_t)NR * T;
+    unsigned short* Ab = reinterpret_cast<unsigned short*>(rng + (size_t)nrng * 4);
+    unsigned short* Cg = Ab + (size_t)NR * 2 * 64 * 8;
+    hipLaunchKernelGGL(ntn_prep_list_kernel, dim3(nrng), dim3(256), 0, stream, h->w, rows, pl.row_ids, NR, cols, M, Ab, ur,
+                       rng, Cg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "ntn_prep_list_kernel launch");
+    const int64_t wgs = ((int64_t)(NI + 3) / 4 + 3) / 4;          // one quad of items per wave, four waves per workgroup
+    const int64_t slots = (int64_t)h->num_cus * 8;
+    const unsigned grid = (unsigned)(wgs < slots ? wgs : slots);
+    hipLaunchKernelGGL(score_pair_list_kernel, dim3(grid), dim3(256), 0, stream, h->w, pl, Ab, Cg, ur, rng, nrng, rows, cols,
+                       score);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "score_pair_list_kernel launch");
     return SGPR_OK;
 }
 

@@ -32,7 +32,8 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 # every symbol include/sgpr.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_capped", "sgpr_embed_ordered", "sgpr_embed_ragged",
-               "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_score_all_pairs_workspace_bytes",
+               "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_pair_plan_ints", "sgpr_pair_plan",
+               "sgpr_score_pair_list_workspace_bytes", "sgpr_score_pair_list", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_score_all_pairs_multi_workspace_bytes", "sgpr_score_all_pairs_multi",
                "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
                "sgpr_pair_positives", "sgpr_pair_threshold_counts_workspace_bytes", "sgpr_pair_threshold_counts",
@@ -79,6 +80,18 @@ def load_library():
                           "(there is no CPU fallback)" % path)
     lib = ctypes.CDLL(path)
     vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    # first thing: a library built from other sources than the header this binding follows must say so before any
+    # missing symbol raises an AttributeError
+    want = _build.header_abi_version()
+    try:
+        lib.sgpr_abi_version.restype = i32
+        lib.sgpr_abi_version.argtypes = []
+        have = lib.sgpr_abi_version()
+    except AttributeError:
+        have = None
+    if have != want:
+        raise ImportError("%s reports C-ABI version %s, include/sgpr.h declares %d: rebuild it "
+                          "(`python -m sg_pr_amd._build --force`)" % (path, have, want))
     lib.sgpr_weights_count.restype = sz
     lib.sgpr_weights_count.argtypes = [ctypes.POINTER(SgprDims)]
     lib.sgpr_create.restype = i32
@@ -101,6 +114,15 @@ def load_library():
     lib.sgpr_embed_debug.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.sgpr_score_pairs.restype = i32
     lib.sgpr_score_pairs.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
+    lib.sgpr_pair_plan_ints.restype = sz
+    lib.sgpr_pair_plan_ints.argtypes = [i64, i32]
+    lib.sgpr_pair_plan.restype = i32
+    lib.sgpr_pair_plan.argtypes = [vp, vp, i64, i32, i32, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(i32),
+                                   ctypes.POINTER(i32)]
+    lib.sgpr_score_pair_list_workspace_bytes.restype = sz
+    lib.sgpr_score_pair_list_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.sgpr_score_pair_list.restype = i32
+    lib.sgpr_score_pair_list.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, sz, vp]
     lib.sgpr_score_all_pairs_workspace_bytes.restype = sz
     lib.sgpr_score_all_pairs_workspace_bytes.argtypes = [vp, i32, i32]
     lib.sgpr_score_all_pairs.restype = i32
@@ -153,12 +175,6 @@ def load_library():
     lib.sgpr_debug_set_profile_buffer.argtypes = [vp, vp]
     lib.sgpr_last_error.restype = ctypes.c_char_p
     lib.sgpr_last_error.argtypes = []
-    lib.sgpr_abi_version.restype = i32
-    lib.sgpr_abi_version.argtypes = []
-    want = _build.header_abi_version()
-    if lib.sgpr_abi_version() != want:     # a library built from other sources than the header this binding follows
-        raise ImportError("%s reports C-ABI version %d, include/sgpr.h declares %d: rebuild it "
-                          "(`python -m sg_pr_amd._build --force`)" % (path, lib.sgpr_abi_version(), want))
     _lib = lib
     return lib
 
@@ -350,6 +366,10 @@ class Engine:
         c = np.asarray(centers, dtype=np.float32)
         l = np.asarray(labels)
         real = l >= 0
+        if real.any() and int(l[real].max()) >= NUM_LABELS:
+            # an int8 cast would wrap 256 + c into the valid class c: refuse like the padded path and the reference do
+            # (KeyError, sg_net.py:277)
+            raise ValueError("to_ragged: label %d outside [0, %d)" % (int(l[real].max()), NUM_LABELS))
         counts = real.sum(1)
         if not (real == (np.arange(l.shape[1])[None, :] < counts[:, None])).all():
             raise ValueError("to_ragged: padding slots (label -1) must trail the real nodes of every graph")
@@ -423,6 +443,32 @@ class Engine:
         score = out if out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
         rc = self.lib.sgpr_score_pairs(self._h, _ptr(pooled1), _ptr(idx1), _ptr(pooled2), _ptr(idx2), n, _ptr(score),
                                        self._stream())
+        self._check(rc)
+        return score
+
+    def pair_plan(self, idx1, idx2, num_rows, num_cols):
+        """Group a pair list by row graph for score_pair_list (sgpr_pair_plan; host work, once per list - like a launch
+        order).  idx1 / idx2: integer arrays on the host (pair p = (idx1[p], idx2[p])).  Returns a PairPlan."""
+        return PairPlan(self, idx1, idx2, num_rows, num_cols)
+
+    def score_pair_list(self, pooled_rows, pooled_cols, plan, out=None):
+        """score[p] = SG-tail(pooled_rows[idx1[p]], pooled_cols[idx2[p]]) for the pairs of `plan` (sgpr_score_pair_list):
+        the bilinear form hoisted per distinct row graph, a row's listed columns through the matrix cores 16 at a time;
+        bit-identical to score_all_pairs' entries at the listed indices."""
+        rows = self._dev(pooled_rows, torch.float32, "pooled_rows")
+        cols = self._dev(pooled_cols, torch.float32, "pooled_cols")
+        if rows.shape[0] != plan.num_rows or cols.shape[0] != plan.num_cols:
+            raise ValueError("plan was built for %d x %d graphs, got %d x %d"
+                             % (plan.num_rows, plan.num_cols, rows.shape[0], cols.shape[0]))
+        score = out if out is not None else torch.empty(plan.P, dtype=torch.float32, device=self.device)
+        assert score.numel() == plan.P and score.is_contiguous()
+        if plan.P == 0:
+            return score
+        ws_bytes = self.lib.sgpr_score_pair_list_workspace_bytes(self._h, plan.n_rows, plan.num_cols)
+        ws = self._ws(ws_bytes)
+        rc = self.lib.sgpr_score_pair_list(self._h, _ptr(rows), plan.num_rows, _ptr(cols), plan.num_cols, _ptr(plan.words),
+                                           plan.n_rows, plan.n_items, plan.P, _ptr(score), _ptr(ws), ws_bytes,
+                                           self._stream())
         self._check(rc)
         return score
 
@@ -585,6 +631,29 @@ class Engine:
         if want_att:
             return score, att[0], att[1]
         return score, None, None
+
+
+class PairPlan:
+    """A pair list grouped by row graph (include/sgpr.h, sgpr_pair_plan): built on the host once, kept on the device."""
+
+    def __init__(self, engine, idx1, idx2, num_rows, num_cols):
+        i1 = np.ascontiguousarray(np.asarray(idx1).reshape(-1), dtype=np.int32)
+        i2 = np.ascontiguousarray(np.asarray(idx2).reshape(-1), dtype=np.int32)
+        if i1.size != i2.size:
+            raise ValueError("pair sides differ in length: %d vs %d" % (i1.size, i2.size))
+        lib = engine.lib
+        self.P, self.num_rows, self.num_cols = int(i1.size), int(num_rows), int(num_cols)
+        cap = int(lib.sgpr_pair_plan_ints(self.P, self.num_rows))
+        words = np.empty(max(cap, 1), dtype=np.int32)
+        used, nr, ni = ctypes.c_size_t(), ctypes.c_int32(), ctypes.c_int32()
+        rc = lib.sgpr_pair_plan(i1.ctypes.data_as(ctypes.c_void_p), i2.ctypes.data_as(ctypes.c_void_p), self.P,
+                                self.num_rows, self.num_cols, words.ctypes.data_as(ctypes.c_void_p), words.size,
+                                ctypes.byref(used), ctypes.byref(nr), ctypes.byref(ni))
+        if rc != SGPR_OK:
+            raise SgprError(rc, lib.sgpr_last_error().decode())
+        self.n_rows, self.n_items = int(nr.value), int(ni.value)
+        self.host_words = words[:int(used.value)]
+        self.words = torch.from_numpy(self.host_words.copy()).to(engine.device)
 
 
 # ---------------------------------------------------------------------- handle-free entry points (stand-alone modules)

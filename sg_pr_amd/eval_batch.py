@@ -67,7 +67,7 @@ def score_pair_list(trainer, graph_pairs, group=None):
                                 for s in range(0, len(paths), chunk)])
             pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib)).reshape(-1)
         model.engine().check_status()      # bad labels / broken node_cap promises are errors, not silent NaNs
-    except (KeyError, OSError, ValueError, RuntimeError) as e:
+    except Exception as e:       # any rank-local failure must reach the agreement below, or the other ranks hang in it
         if world == 1:
             raise
         err = e

@@ -122,9 +122,20 @@ class SG(torch.nn.Module):
         return eng.embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb,
                          node_cap=node_cap or 0, order=order)
 
+    GROUPED_MIN_PAIRS = 2048     # below this the one-wave-per-pair kernel's single launch wins
+
     def score_pooled(self, pooled_1, pooled_2, idx_1=None, idx_2=None):
-        """NTN + head on pooled vectors (optionally gathered through index lists)."""
-        return self.engine().score_pairs(pooled_1, pooled_2, idx_1, idx_2)
+        """NTN + head on pooled vectors (optionally gathered through index lists).  A list of GROUPED_MIN_PAIRS pairs
+        or more over shared graphs - the reference's evaluation loop, eval_batch.py:30-36 - is grouped by row graph
+        once on the host and scored by sgpr_score_pair_list (matrix cores, bilinear form hoisted per distinct row
+        graph); shorter lists and un-indexed sides take sgpr_score_pairs (one wave per pair, exact fp32)."""
+        eng = self.engine()
+        if idx_1 is not None and idx_2 is not None and len(idx_1) >= self.GROUPED_MIN_PAIRS:
+            i1 = idx_1.cpu().numpy() if isinstance(idx_1, torch.Tensor) else np.asarray(idx_1)
+            i2 = idx_2.cpu().numpy() if isinstance(idx_2, torch.Tensor) else np.asarray(idx_2)
+            plan = eng.pair_plan(i1, i2, pooled_1.shape[0], pooled_2.shape[0])
+            return eng.score_pair_list(pooled_1, pooled_2, plan)
+        return eng.score_pairs(pooled_1, pooled_2, idx_1, idx_2)
 
     def score_all_pairs(self, pooled_rows, pooled_cols, out=None):
         return self.engine().score_all_pairs(pooled_rows, pooled_cols, out=out)

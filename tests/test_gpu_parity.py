@@ -1335,3 +1335,82 @@ def test_f16_planes_against_wide_range_on_the_shipped_graphs(eng, golden_dir):
     assert dp <= 2e-5 and da <= 2e-6 and ds <= 5e-6
     np.testing.assert_allclose(s16.reshape(-1), g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
     np.testing.assert_allclose(sw.reshape(-1), g["scores"], rtol=0, atol=GOLDEN_SCORE_TOL)
+
+
+def _listed(eng, pooled_r, pooled_c, i1, i2):
+    plan = eng.pair_plan(i1, i2, pooled_r.shape[0], pooled_c.shape[0])
+    return eng.score_pair_list(pooled_r, pooled_c, plan), plan
+
+
+def test_grouped_pair_list_is_bitwise_the_dense_matrix(eng):
+    """sgpr_score_pair_list (the reference's loop shape, eval_batch.py:30-36: a pair LIST grouped by row graph) against
+    the dense rectangle: every listed score is bit for bit the matrix entry at (row, column), for rows with 1, 15, 16,
+    17 and 40 listed pairs, absent rows, repeated pairs, a rectangular job and a one-pair list; the one-wave-per-pair
+    kernel (exact fp32) agrees to rounding."""
+    from sg_pr_amd import synth
+    c, l, _ = synth.make_graphs(300, 100, 25, 60, seed=5, kitti_like=True)
+    pooled = eng.embed(c, l, 10)[0]
+    dense = eng.score_all_pairs(pooled, pooled)
+    rng = np.random.default_rng(11)
+    i1, i2 = [], []
+    for row, cnt in ((0, 1), (3, 15), (4, 16), (7, 17), (299, 40), (150, 33), (151, 2)):
+        i1 += [row] * cnt
+        i2 += rng.integers(0, 300, cnt).tolist()
+    i1 += [7, 7, 7]
+    i2 += [5, 5, 5]                                             # repeated pairs
+    extra = rng.integers(0, 300, (4000, 2))
+    i1, i2 = np.array(i1 + extra[:, 0].tolist()), np.array(i2 + extra[:, 1].tolist())
+    perm = rng.permutation(i1.size)
+    i1, i2 = i1[perm], i2[perm]
+    got, plan = _listed(eng, pooled, pooled, i1, i2)
+    assert plan.P == i1.size and plan.n_rows == np.unique(i1).size
+    want = dense[torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()]
+    assert torch.equal(got, want)
+    one_wave = eng.score_pairs(pooled, pooled, torch.from_numpy(i1.astype(np.int32)), torch.from_numpy(i2.astype(np.int32)))
+    assert (got - one_wave).abs().max().item() < 3e-6
+    # rectangular: rows and columns from different graph sets
+    rect = eng.score_all_pairs(pooled[:37].contiguous(), pooled[100:].contiguous())
+    j1, j2 = rng.integers(0, 37, 777), rng.integers(0, 200, 777)
+    got2, _ = _listed(eng, pooled[:37].contiguous(), pooled[100:].contiguous(), j1, j2)
+    assert torch.equal(got2, rect[torch.from_numpy(j1).cuda(), torch.from_numpy(j2).cuda()])
+    one, _ = _listed(eng, pooled, pooled, [299], [0])
+    assert torch.equal(one, dense[299, 0:1])
+    empty, _ = _listed(eng, pooled, pooled, [], [])
+    assert empty.numel() == 0
+    # inputs outside the f16 range take the exact fp32 path inside the same kernel - like the dense kernel does
+    big = pooled * 400.0
+    dense_big = eng.score_all_pairs(big, big)
+    got_big, _ = _listed(eng, big, big, i1, i2)
+    assert torch.equal(got_big, dense_big[torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()])
+    # errors: an index outside the graphs, a plan for other sizes
+    from sg_pr_amd.engine import SgprError
+    with pytest.raises(SgprError):
+        eng.pair_plan([0, 300], [0, 0], 300, 300)
+    with pytest.raises(ValueError):
+        eng.score_pair_list(pooled[:10].contiguous(), pooled, plan)
+
+
+def test_reference_pair_lists_full_size(eng, golden_dir, ckpt_path):
+    """The reference's own evaluation lists (data_process/pair_list/pair_list_3_20_{02,05,06,08}.npy, index pairs kept as
+    tests/golden/pair_lists_3_20.npz) at full size over KITTI-like graphs: grouped scores == dense matrix entries bit
+    for bit, and SG.score_pooled routes lists of this size through the grouped kernel."""
+    from sg_pr_amd import synth, sg_net
+    from sg_pr_amd.parser_sg import sgpr_args
+    fx = np.load(os.path.join(golden_dir, "pair_lists_3_20.npz"))
+    args = sgpr_args()
+    args.model = ckpt_path
+    model = sg_net.SGTrainer(args, False).model
+    for si, name in enumerate(("06", "02")):
+        ij = fx["seq_" + name].astype(np.int64)
+        m = int(ij.max()) + 1
+        assert (name, m, ij.shape[0]) in (("06", 1101, 8299), ("02", 4661, 71226))
+        c, l, _, _ = synth.kitti_like_sequence(m, 100, seed=20 + si)
+        pooled = eng.embed(c, l, 10)[0]
+        perm = np.random.default_rng(si).permutation(ij.shape[0])
+        i1, i2 = ij[perm, 0], ij[perm, 1]
+        got, plan = _listed(eng, pooled, pooled, i1, i2)
+        assert plan.n_rows == np.unique(i1).size and plan.n_items >= plan.n_rows
+        dense = eng.score_all_pairs(pooled, pooled)
+        assert torch.equal(got, dense[torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()])
+        via_model = model.score_pooled(pooled, pooled, torch.from_numpy(i1.astype(np.int32)), torch.from_numpy(i2.astype(np.int32)))
+        assert torch.equal(via_model, got)

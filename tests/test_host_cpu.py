@@ -702,3 +702,47 @@ def test_ragged_graphs_container():
         rag[::2]
     with pytest.raises(ValueError):
         allpairs.RaggedGraphs(rag.centers, rag.labels, rag.offsets[:-1], 100)
+
+
+def test_pair_plan_groups_a_list_by_row_graph():
+    """sgpr_pair_plan (host half of sgpr_score_pair_list; no GPU work): distinct row graphs ascending, work items of <= 16
+    pairs that never cross a row graph, a stable order inside a row, every pair placed exactly once; the reference's
+    own list for KITTI 06 (tests/golden/pair_lists_3_20.npz) gives 1101 row graphs."""
+    import ctypes
+    from sg_pr_amd import engine
+
+    class Host:            # the plan needs the library, not a GPU
+        lib, device = engine.load_library(), "cpu"
+
+    def check(i1, i2, r, m):
+        pl = engine.PairPlan(Host, i1, i2, r, m)
+        w, nr, ni, p = pl.host_words, pl.n_rows, pl.n_items, len(i1)
+        assert w.size == nr + ni + ni + 1 + 2 * p <= Host.lib.sgpr_pair_plan_ints(p, r)
+        row_ids, item_row, item_beg = w[:nr], w[nr:nr + ni], w[nr + ni:nr + 2 * ni + 1]
+        cols, pos = w[nr + 2 * ni + 1:nr + 2 * ni + 1 + p], w[nr + 2 * ni + 1 + p:]
+        assert np.array_equal(row_ids, np.unique(i1))
+        assert item_beg[0] == 0 and item_beg[-1] == p
+        assert (np.diff(item_beg) > 0).all() and (np.diff(item_beg) <= 16).all()
+        assert ni == sum(-(-c // 16) for c in np.bincount(i1)[np.unique(i1)])
+        for it in range(ni):
+            ps = pos[item_beg[it]:item_beg[it + 1]]
+            assert (np.asarray(i1)[ps] == row_ids[item_row[it]]).all()
+            assert np.array_equal(np.asarray(i2)[ps], cols[item_beg[it]:item_beg[it + 1]])
+            assert (np.diff(ps) > 0).all()                          # list order kept inside a row graph
+        assert np.array_equal(np.sort(pos), np.arange(p))
+        return pl
+
+    rng = np.random.default_rng(0)
+    check(rng.integers(0, 50, 1000), rng.integers(0, 70, 1000), 50, 70)
+    check(np.zeros(33, dtype=np.int64), np.arange(33), 1, 33)       # one row graph, three items
+    fx = np.load(os.path.join(REPO, "tests", "golden", "pair_lists_3_20.npz"))
+    ij = fx["seq_06"].astype(np.int64)
+    pl = check(ij[:, 0], ij[:, 1], 1101, 1101)
+    assert pl.n_rows == 1101 and pl.P == 8299
+    empty = engine.PairPlan(Host, [], [], 5, 5)
+    assert empty.P == 0 and empty.n_rows == 0 and empty.n_items == 0
+    for bad in (([5], [0]), ([0], [7]), ([-1], [0])):
+        with pytest.raises(engine.SgprError, match="outside"):
+            engine.PairPlan(Host, bad[0], bad[1], 5, 7)
+    with pytest.raises(ValueError):
+        engine.PairPlan(Host, [0, 1], [0], 5, 7)
