@@ -355,18 +355,32 @@ static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wid
 // workspace of an embed launch over G graphs of N slots:  redo flags [G] (one byte per launch slot, written by the f16
 // instance, read by the wide-range second pass) | parked first-branch output [G][round16(N)][32] f32 when N > 128
 // (sized for the uncapped plan: the second pass never uses a node_cap)
-static size_t embed_flag_bytes(int G) { return ((size_t)G + 255) & ~(size_t)255; }
+// (+ one word at the end of the flag region: EmbedArgs::redo_count)
+static size_t embed_flag_bytes(int G) { return ((size_t)G + 8 + 255) & ~(size_t)255; }
+static unsigned* embed_redo_count(unsigned char* flags, int G) {
+    return reinterpret_cast<unsigned*>(flags + embed_flag_bytes(G) - 8);
+}
 static size_t embed_park_bytes(int G, int N) {
     return ((N > 128 ? (size_t)G * ((N + 15) / 16 * 16) * 32 * sizeof(float) : 0) + 255) & ~(size_t)255;
 }
-// ... | split launch (sgpr_internal.hpp, EmbedArgs::sem_tab): one 64-bit flag + 16 rows of 32 floats per launch slot
-static size_t embed_sem_bytes(int G) { return (size_t)G * (sizeof(unsigned long long) + 16 * 32 * sizeof(float)); }
-static size_t embed_ws_bytes(int G, int N) { return embed_flag_bytes(G) + embed_park_bytes(G, N) + embed_sem_bytes(G); }
+// ... | split launch (sgpr_internal.hpp, EmbedArgs::sem_tab): one 64-bit flag (the flag array rounded up to 16 bytes: the
+// rows behind it are read and written as float4) + 16 rows of 32 floats per launch slot; a split launch has at most
+// num_cus / 2 graphs (launch_embed), so the region is sized for that many slots, not for G
+constexpr int kMaxSplitGraphs = 128;     // MI355X: 256 CUs / 2 (a handle-independent bound: workspace queries need no device)
+static int embed_sem_slots(const sgpr_handle*, int G) { return G < kMaxSplitGraphs ? G : kMaxSplitGraphs; }
+static size_t embed_sem_flag_bytes(int slots) { return ((size_t)slots * sizeof(unsigned long long) + 15) & ~(size_t)15; }
+static size_t embed_sem_bytes(const sgpr_handle* h, int G) {
+    const int slots = embed_sem_slots(h, G);
+    return embed_sem_flag_bytes(slots) + (size_t)slots * 16 * 32 * sizeof(float);
+}
+static size_t embed_ws_bytes(const sgpr_handle* h, int G, int N) {
+    return embed_flag_bytes(G) + embed_park_bytes(G, N) + embed_sem_bytes(h, G);
+}
 
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
     EmbedPlan p;
     if (!h || G < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
-    return embed_ws_bytes(G, N);
+    return embed_ws_bytes(h, G, N);
 }
 
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
@@ -392,16 +406,18 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     if (rc != SGPR_OK) return rc;
     // graphs are addressed by their own index: an ordered launch needs rows for all of them
     const int gtot = total_graphs < 0 ? a.G : total_graphs;
-    const size_t need = embed_ws_bytes(gtot, N);
+    const size_t need = embed_ws_bytes(h, gtot, N);
     if (!ws || ws_bytes < need) {
         set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required (sgpr_embed_workspace_bytes)");
         return SGPR_E_WORKSPACE;
     }
     a.redo = static_cast<unsigned char*>(ws);
+    a.redo_count = embed_redo_count(a.redo, gtot);
     a.park_ws = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot));
     unsigned char* sem = static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot) + embed_park_bytes(gtot, N);
-    a.sem_flag = reinterpret_cast<unsigned long long*>(sem);               // indexed by launch slot (< a.G <= gtot)
-    a.sem_tab = reinterpret_cast<float*>(sem + (size_t)gtot * sizeof(unsigned long long));
+    a.sem_flag = reinterpret_cast<unsigned long long*>(sem);               // indexed by launch slot (< a.G <= num_cus / 2)
+    a.sem_tab = reinterpret_cast<float*>(sem + embed_sem_flag_bytes(embed_sem_slots(h, gtot)));
+    if (a.G > kMaxSplitGraphs) a.sem_tab = nullptr;                        // (no split launch: the region holds fewer than G slots)
 #if !SGPR_SPLIT_SEM
     a.sem_tab = nullptr;                                                   // (A/B builds: the unsplit launch)
 #endif
@@ -669,7 +685,7 @@ int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pair
 size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k) {
     EmbedPlan p;
     if (!h || B < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
-    return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(2 * B, N);
+    return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(h, 2 * B, N);
 }
 
 int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const float* d_features_2, int B, int N,
@@ -697,6 +713,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     a.G = 2 * B;
     a.pooled = pooled;
     a.redo = reinterpret_cast<unsigned char*>(pooled + (size_t)2 * B * kF3);
+    a.redo_count = embed_redo_count(a.redo, 2 * B);      // (the per-side launches below share the word: tokens differ)
     a.park_ws = reinterpret_cast<float*>(a.redo + embed_flag_bytes(2 * B));
     a.status = h->d_status;
     a.prof = h->dbg_prof;

@@ -1490,14 +1490,24 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
 // ------------------------------------------------------------------ split launch (few graphs: the latency regime)
 // The two branches of dgcnn_conv_pass are independent until conv_end (sg_net.py:81-104).  When a launch has at most half
 // as many graphs as the GPU has CUs, every graph gets TWO workgroups, each on a CU of its own: workgroup s < G runs the
-// input phase and the xyz branch, meets the rows of the other half before conv_end and finishes the graph (role 2);
-// workgroup G + s runs the input phase and the semantic branch (role 1) and publishes the 16 sem3 rows through global
-// memory (sem_tab[s] + sem_flag[s] = token(s)).  All 2 G workgroups are resident at once, so the waiting side cannot
-// starve the producing side; should a flag nevertheless not arrive, the waiting workgroup gives up loudly (status bit 4,
-// NaN pooled vector) instead of hanging.  With more graphs the halves would share CUs, which costs each more than the
+// input phase and the semantic branch (role 1) and publishes the 16 sem3 rows through global memory (sem_tab[s] +
+// sem_flag[s] = token(s)); workgroup G + s runs the input phase and the xyz branch, meets the rows of the other half
+// before conv_end and finishes the graph (role 2).  The producers own the lower block indices, so a waiting workgroup is
+// never dispatched ahead of its producer; on an idle GPU all 2 G workgroups are resident at once.  Should a flag
+// nevertheless not arrive in time (another stream or process holding CUs), the waiting workgroup hands its graph to the
+// second pass (request_redo) instead of hanging or failing.  With more graphs the halves would share CUs, which costs each more than the
 // split saves (launch_embed), and in the throughput regime the kernel's time is its instruction count: every workgroup
 // does both branches (role 0).  Measured and dropped on the way here: the semantic branch of EVERY launch on single
 // waves ("semantic waves", 4 graphs per leading workgroup): the same instructions at lower parallelism, 197 -> 303 us.
+// A launch slot's second-pass request (EmbedArgs::redo: 1 wide-range instance, 2 full f16 plan) - and, with any request,
+// this launch's token in redo_count: the second pass reads that ONE word and returns when no workgroup stored it, so
+// the (normal) empty pass costs a launch and a load instead of a scan of every flag.  The word is never reset: a token
+// belongs to one launch (launch_embed's counter), whatever the workspace held before is some other value.
+__device__ __forceinline__ void request_redo(const EmbedArgs& a, int slot, unsigned char why) {
+    a.redo[slot] = why;
+    if (why && a.redo_count) __hip_atomic_store(a.redo_count, a.sem_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __host__ __device__ __forceinline__ unsigned long long sem_token(unsigned epoch, int slot) {
     return ((unsigned long long)epoch << 32) | (unsigned)(slot + 1);   // (bit 31: an f16 overflow in the branch)
 }
@@ -1781,7 +1791,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         if (!fast && (p.small_park || role == 1)) {
             // this plan parks only the super-node rows: the graph takes the generic branch in the second pass
             // (split launch: decided and reported by the graph's xyz workgroup, which takes the same decision)
-            if (tid == 0 && kp.a.redo && role != 1) kp.a.redo[launch_slot] = 2;
+            if (tid == 0 && kp.a.redo && role != 1) request_redo(kp.a, launch_slot, 2);
             return;
         }
         if (fast) {
@@ -2020,10 +2030,17 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         __syncthreads();
         const int st = *met;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows were published before the flag
-        if (st == 0) {       // never expected (all 2 G workgroups are resident): fail loudly instead of hanging or guessing
-            if (tid == 0) atomicOr(kp.a.status, 4);
-            if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
-            if (kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
+        if (st == 0) {
+            // The producer did not arrive in time: HIP promises neither co-residency nor forward progress between the
+            // workgroups of a launch, and with another stream or process on the device the producers may still be
+            // waiting for a CU.  Not an error: the graph is handed to the second pass (full plan, both branches in one
+            // workgroup); without a second pass (no workspace flag) it stays a loud failure.
+            if (kp.a.redo) {
+                if (tid == 0) request_redo(kp.a, launch_slot, 2);
+            } else {
+                if (tid == 0) atomicOr(kp.a.status, 4);
+                if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
+            }
             return;
         }
         if (st == 2 && tid == 0) vmax = INFINITY;            // the branch left the f16 range: this graph goes to the second pass
@@ -2140,7 +2157,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         kp.a.pooled[(size_t)g * 32 + tid] = s;
     }
     // a graph whose activations left the f16 range is embedded again by the wide-range instance (embed_redo_kernel)
-    if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = *ovflag ? 1 : 0;
+    if (FMT == FMT_H2 && kp.a.redo && tid == 0) request_redo(kp.a, launch_slot, *ovflag ? 1 : 0);
     SGPR_PROF(7)
 #undef SGPR_PROF
     if (prof && lane == 0) {
@@ -2154,9 +2171,9 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? (LEAN =
     // (ONE call site: two inlined copies of embed_graph would double the kernel's footprint in the instruction cache)
     int slot = (int)blockIdx.x, role = 0;
     if constexpr (LEAN != 0 && DBG == 0) {
-        if (kp.a.sem_tab) {            // split launch: workgroups [0, G) xyz halves (the critical path starts first),
-            role = slot >= kp.a.G ? 1 : 2;                        // [G, 2 G) semantic halves
-            slot -= role == 1 ? kp.a.G : 0;
+        if (kp.a.sem_tab) {            // split launch: workgroups [0, G) semantic halves - the PRODUCERS are dispatched
+            role = slot >= kp.a.G ? 2 : 1;                        // first, a waiting xyz half [G, 2 G) never holds a CU its
+            slot -= role == 2 ? kp.a.G : 0;                       // own producer still needs
         }
     }
     embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role);
@@ -2169,6 +2186,9 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? (LEAN =
 template <int KP, int FMTW>
 __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // nothing requested by the first pass (every launch on real data): one load, done
+    if (kp.a.redo_count &&
+        __hip_atomic_load(kp.a.redo_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kp.a.sem_epoch) return;
     // this workgroup's contiguous range of launch slots, 64 flags at a time: wave 0 reads them with one load and hands
     // the ballots to the other waves through the first bytes of LDS (one dependent load per slot made the empty pass
     // cost 23 us); the masks then live in registers, so embed_graph is free to overwrite LDS
@@ -2271,12 +2291,13 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     // call, 128 graphs 38.1 -> 34.6, 256 graphs 37.9 -> 44.2); the caller reserved sem_tab / sem_flag in the workspace
     const bool can_split = plan.fmt == FMT_H2 && plan.lean && !a.dense && !a.dbg_layers && !a.dbg_knn && !a.prof &&
                            !(a.skip & ~8192) && a.sem_tab && a.sem_flag && 2 * a.G <= h->num_cus;
-    if (can_split) {
-        static std::atomic<unsigned> epoch{0u};
+    {
+        static std::atomic<unsigned> epoch{0u};                    // this launch's token (split-launch flags, redo_count)
         unsigned e = ++epoch;
         if (e == 0u) e = ++epoch;
         kp.a.sem_epoch = e;
-    } else {
+    }
+    if (!can_split) {
         kp.a.sem_tab = nullptr;
         kp.a.sem_flag = nullptr;
     }

@@ -117,11 +117,12 @@ struct EmbedArgs {
     int32_t* dbg_knn;
     float* park_ws;         // [G][NP][32] when !park_in_lds
     unsigned char* redo;    // [launch slots] written by the f16 instance: 1 = the graph left the f16 range -> embed_redo_kernel
+    unsigned* redo_count;   // one word: receives sem_epoch when any slot asks for the second pass (else untouched)
     // split launch (sgpr_embed.hip): workgroup G + s publishes the 16 sem3 rows of launch slot s in sem_tab[s][16][32]
     // and sem_flag[s] = token(s); workgroup s picks them up before conv_end.  sem_tab == NULL: the unsplit launch
     float* sem_tab;
     unsigned long long* sem_flag;
-    unsigned sem_epoch;         // distinguishes this launch's flags from whatever the workspace held before
+    unsigned sem_epoch;         // this launch's token: distinguishes its flags / redo_count from whatever the workspace held
     int32_t* status;
     unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
     int promise;                // the caller's node_cap (or N): checked even when the plan ignores it

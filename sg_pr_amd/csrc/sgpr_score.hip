@@ -508,23 +508,38 @@ __device__ __forceinline__ ApConsts ap_consts(const DevWeights& w, int l15, int 
 }
 
 // max |A'|, max |u|, max |e2| partials -> can every f16 the launch forms be represented?
-__device__ __forceinline__ void ap_range(const float* __restrict__ rng, int nrng, int lane, float& am, float& um, float& em,
-                                         float& l1) {
-    for (int i = lane; i < nrng; i += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(rng + (size_t)i * 4);
-        am = fmaxf(am, v.x);
-        um = fmaxf(um, v.y);
-        em = fmaxf(em, v.z);
-        l1 = fmaxf(l1, v.w);
+// The whole workgroup reads the partials, four independent 16-byte loads per thread and round (a wave reading them alone,
+// one dependent load per loop trip, spent ~0.7 us per 64 partials before its first matrix instruction: 6 us of the
+// KITTI-00 tail, 25 us of a 12 k-graph pair list); the waves' maxima meet in LDS.  Every wave returns the same values.
+__device__ __forceinline__ void ap_range(const float* __restrict__ rng, int nrng, float& am, float& um, float& em, float& l1) {
+    __shared__ float4 part[4];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < nrng; i += 4 * 256) {
+        const float4 v0 = *reinterpret_cast<const float4*>(rng + (size_t)i * 4);
+        const float4 v1 = i + 256 < nrng ? *reinterpret_cast<const float4*>(rng + (size_t)(i + 256) * 4) : z;
+        const float4 v2 = i + 512 < nrng ? *reinterpret_cast<const float4*>(rng + (size_t)(i + 512) * 4) : z;
+        const float4 v3 = i + 768 < nrng ? *reinterpret_cast<const float4*>(rng + (size_t)(i + 768) * 4) : z;
+        am = fmaxf(fmaxf(am, v0.x), fmaxf(fmaxf(v1.x, v2.x), v3.x));
+        um = fmaxf(fmaxf(um, v0.y), fmaxf(fmaxf(v1.y, v2.y), v3.y));
+        em = fmaxf(fmaxf(em, v0.z), fmaxf(fmaxf(v1.z, v2.z), v3.z));
+        l1 = fmaxf(fmaxf(l1, v0.w), fmaxf(fmaxf(v1.w, v2.w), v3.w));
     }
-}
-// 0: exact fp32 per-pair path (an f16 of the launch could overflow); 1: the f16-plane path; 2: the same with the low
-// plane's ReLU folded into its conversion (split_relu4<true>): |H[t]| <= |u[t]| + sum_j |A'[t][j]| max|e2| < 1024
-__device__ __forceinline__ int ap_mode(float am, float um, float em, float l1) {
     am = wave_max_f32(am);
     um = wave_max_f32(um);
     em = wave_max_f32(em);
     l1 = wave_max_f32(l1);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = make_float4(am, um, em, l1);
+    __syncthreads();
+    const float4 p0 = part[0], p1 = part[1], p2 = part[2], p3 = part[3];
+    am = fmaxf(fmaxf(p0.x, p1.x), fmaxf(p2.x, p3.x));
+    um = fmaxf(fmaxf(p0.y, p1.y), fmaxf(p2.y, p3.y));
+    em = fmaxf(fmaxf(p0.z, p1.z), fmaxf(p2.z, p3.z));
+    l1 = fmaxf(fmaxf(p0.w, p1.w), fmaxf(p2.w, p3.w));
+    __syncthreads();                                      // (the multi-job kernel calls this once per rectangle)
+}
+// 0: exact fp32 per-pair path (an f16 of the launch could overflow); 1: the f16-plane path; 2: the same with the low
+// plane's ReLU folded into its conversion (split_relu4<true>): |H[t]| <= |u[t]| + sum_j |A'[t][j]| max|e2| < 1024
+__device__ __forceinline__ int ap_mode(float am, float um, float em, float l1) {
     if (!((am < AP_F16_SAFE) && (em < AP_F16_SAFE) && (um + 32.f * am * em < AP_F16_SAFE))) return 0;
     return (um + l1 * em < 1024.f) ? 2 : 1;
 }
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_kernel(const DevWeig
     const int l15 = lane & 15, g = lane >> 4;
     // ---- can every f16 this launch forms be represented?  |A'|, |e2| and |H| <= |u| + 32 max|A'| max|e2|
     float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;
-    ap_range(rng, nrng, lane, am, um, em, l1);
+    ap_range(rng, nrng, am, um, em, l1);
     const int mode = ap_mode(am, um, em, l1);
     const ApConsts k = ap_consts(w, l15, g);
     // work items = (row group of AP_ROWS, column chunk of AP_COLS), row-major; every workgroup takes a contiguous,
@@ -711,7 +726,7 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const D
         if (lo >= hi) continue;
         const ApJob& q = jobs.job[j];
         float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;        // the f16 range question is answered per rectangle, like
-        ap_range(q.rng, q.nrng, lane, am, um, em, l1);       // a call of its own would
+        ap_range(q.rng, q.nrng, am, um, em, l1);             // a call of its own would
         const int mode = ap_mode(am, um, em, l1);
         if (mode == 2)
             ap_items<NI, 0, true>(w, k, true, q.R, q.M, q.Ab, q.Cb, q.ur, q.rows, q.cols, q.score, q.ld, lo, hi);
@@ -909,7 +924,7 @@ __global__ __launch_bounds__(256) void score_pair_list_kernel(const DevWeights w
                                                               float* __restrict__ score) {
     const int lane = threadIdx.x & 63;
     float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;
-    ap_range(rng, nrng, lane, am, um, em, l1);
+    ap_range(rng, nrng, am, um, em, l1);
     const int mode = ap_mode(am, um, em, l1);
     const ApConsts k = ap_consts(w, lane & 15, lane >> 4);
     if (mode == 2)

@@ -46,10 +46,14 @@ def test_lds_plans():
         assert 0 < b <= 160 * 1024, (n, k, b)
     assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 0      # > SGPR_MAX_NODES
     assert lib.sgpr_embed_lds_bytes(h, 8, 10) == 0        # K > node_num
-    # one redo flag per launch slot (rounded to 256 B) + the parked first-branch block for node_num > 128
-    sem = lambda g: g * (8 + 16 * 32 * 4)          # split launch: one flag + 16 sem3 rows per launch slot
+    # one redo flag per launch slot + the second pass's request word (rounded to 256 B) + the parked first-branch block
+    # for node_num > 128 + the split launch's region: one flag (the array rounded to 16 B) + 16 sem3 rows per launch slot,
+    # for at most 128 slots (a split launch has at most half as many graphs as the GPU has CUs)
+    sem = lambda g: (min(g, 128) * 8 + 15) // 16 * 16 + min(g, 128) * 16 * 32 * 4
     assert lib.sgpr_embed_workspace_bytes(h, 10, 100, 10) == 256 + sem(10)
+    assert lib.sgpr_embed_workspace_bytes(h, 250, 100, 10) == 512 + sem(250)      # 250 flags + 8 bytes > 256
     assert lib.sgpr_embed_workspace_bytes(h, 300, 100, 10) == 512 + sem(300)
+    assert lib.sgpr_embed_workspace_bytes(h, 100000, 100, 10) == (100008 + 255) // 256 * 256 + sem(128)
     assert lib.sgpr_embed_workspace_bytes(h, 10, 256, 20) == 256 + 10 * 256 * 32 * 4 + sem(10)
 
 
