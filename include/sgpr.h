@@ -252,14 +252,16 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
                                int groups_per_threshold, const unsigned long long* d_at_least, unsigned long long* d_out,
                                void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* F1-max of a score rectangle (eval_batch.py:69, 85-87) in ONE call, no host round trip between its steps: the scores of
- * the positive pairs, thresholds picked among them on the device (sorted and de-duplicated in LDS), one streaming pass
- * over the matrix for the negatives between them, exact F1 at every threshold and bounds for the positives in between,
- * a second pass over the few values that can still hold the maximum.  Same ground truth arguments as
- * sgpr_pair_positives.  d_result (device, 8 doubles): [0] F1-max (exact), [1] status - 0 ok, 1 the rectangle needs the
- * multi-call path (more than 2^20 positive pairs, or more than 8191 values left to settle), 2 negative / NaN scores
- * among the labelled pairs -, [2] positive pairs, [3] negative pairs, [4] passes over the matrix, [5] thresholds of the
- * first pass, [6] values settled by the second.  Asynchronous on `stream`; the caller copies d_result when it needs it. */
+/* F1-max of a score rectangle (eval_batch.py:69, 85-87) in ONE call, no host round trip between its steps: one
+ * streaming pass classifies every pair once - negatives into a histogram over the score's bit pattern (one shift, one LDS
+ * atomic), the scores of the positive pairs into a list -, exact F1 at every bin edge and bounds for the positives
+ * inside the bins follow from suffix sums, and a second pass settles the few bins that can still hold the maximum
+ * (their positives sorted and de-duplicated in LDS; a negative outside them costs one bit test).  Same ground truth
+ * arguments as sgpr_pair_positives.  d_result (device, 8 doubles): [0] F1-max (exact), [1] status - 0 ok, 1 the
+ * rectangle needs the multi-call path (more than 2^20 positive pairs, or more than 4095 positive scores left to settle:
+ * a flat curve), 2 negative / NaN scores among the labelled pairs -, [2] positive pairs, [3] negative pairs, [4] passes
+ * over the matrix, [5] bins of the first pass, [6] values settled by the second.  Asynchronous on `stream`; the caller
+ * copies d_result when it needs it. */
 size_t sgpr_f1_max_workspace_bytes(const sgpr_handle* h, int R, int M);
 int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0, const double* d_pose_xz,
                 double d_pos, double d_neg, const signed char* d_gt, int64_t ldg, double* d_result, void* d_workspace,

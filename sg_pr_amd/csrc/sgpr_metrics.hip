@@ -344,25 +344,52 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 
 // ------------------------------------------------------------------ F1-max in one call (sgpr_f1_max)
 // eval_batch.py:69, 85-87 without a sort of the matrix and without a host round trip between the steps.  F1(t) can only
-// peak at the score t of a POSITIVE pair, F1 = f(TP(>= t), FP(>= t)) grows with TP and falls with FP, so:
-//   1. pair_positives_kernel            the scores of the positive pairs (a short list: loop closures are rare)
-//   2. f1_pick_kernel (one workgroup)   up to 8191 of them, evenly spaced in list order, sorted and de-duplicated in LDS
-//                                       = the thresholds; every positive is bucketed among them (b = #{thr <= s})
-//   3. pair_threshold_count_kernel      the negatives by bucket: one streaming pass over the matrix
-//   4. f1_plan_kernel (one workgroup)   exact F1 at every threshold; for the positives strictly inside bucket b the
-//                                       bound F1(#{pos > thr[b-1]}, #{neg >= thr[b]}); buckets whose bound beats the
-//                                       best exact value hand their interior positives to a second list
-//   5. steps 2-3 on that list (every value a threshold), f1_final_kernel: exact F1 there; the maximum is exact.
-// Everything the steps decide lives in a control block on the device; the host reads 8 doubles at the end.  Lists the
-// device path is not built for (more than 2^20 positives, more than 8191 values to settle) are reported in the status
-// word and the caller falls back to the multi-call path (sg_pr_amd/metrics.py), which handles any size.
-constexpr int F1_MAXT = PC_MAX_THRESHOLDS;     // 8191
-constexpr int F1_SORT = 8192;
+// peak at the score t of a POSITIVE pair, and F1 = f(TP(>= t), FP(>= t)) grows with TP and falls with FP.  Round 4: a radix
+// histogram on the score's bit pattern replaces the threshold search tree (13 dependent LDS reads per score, two passes
+// of ~85 us each) and the separate scan for the positives:
+//   A  f1_scan_kernel      ONE streaming pass: every pair is classified once; a negative costs one shift and one LDS
+//                          atomic (bin = f1_key(score): a monotone map of the bit pattern with 6 mantissa bits of
+//                          resolution in s below 1/2 and in 1 - s above - sigmoid scores crowd towards 1), a positive is
+//                          appended to the (short) list of positive scores
+//   .  slab_sum_kernel     the workgroups' histograms added up
+//   P  f1_plan_kernel      (one workgroup) positives by bin; suffix sums give exact (TP, FP) at every bin edge - each an
+//                          attained point of the curve - and for the positives INSIDE bin b the bound F1(TP(>= edge b),
+//                          FP(>= edge b+1)); the bins whose bound beats the best edge value are the candidates: their
+//                          positives (at most F1_PICK) are sorted and de-duplicated in LDS = the thresholds of pass B,
+//                          with TP exact for each of them
+//   B  f1_refine_kernel    second streaming pass: a negative outside the candidate bins costs one bit test; inside, a
+//                          bisection among the thresholds and one LDS atomic
+//   .  slab_sum_kernel
+//   F  f1_final_kernel     exact FP, hence exact F1, at every threshold; the maximum with the edge values is exact.
+// Everything the steps decide lives in a control block on the device; the host reads 8 doubles at the end.  Rectangles
+// the device path is not built for (more than 2^20 positives, more than F1_PICK values to settle - a flat curve) are
+// reported in the status word and the caller falls back to the multi-call path (sg_pr_amd/metrics.py).
+constexpr int F1_SH = 17;                                        // key = bit pattern >> 17: sign, exponent, 6 mantissa bits
+constexpr int F1_HALF = 0x3F000000 >> F1_SH;                     // 8064 bins for s in [0, 1/2)
+constexpr int F1_ONE = 2 * F1_HALF;                              // the bin of s == 1
+constexpr int F1_NB = F1_ONE + 1 + ((0x7F800000 - 0x3F800000) >> F1_SH) + 1;   // 24 322 bins: ... and s in (1, +inf]
+constexpr int F1_NBP = (F1_NB + 3) & ~3;
+constexpr int F1_PICK = 4095;                                    // values pass B settles at most (a 4096-entry sort)
+constexpr int F1_SORT = 4096;
+constexpr int F1_PBUF = 8192;                                    // staged positives per workgroup between two flushes
+constexpr int F1_THREADS = 1024;
+
+// monotone: s1 < s2 => key(s1) <= key(s2), for every s >= 0 (not NaN).  1 - s is exact for s in [1/2, 1] (Sterbenz).
+__device__ __forceinline__ int f1_key(float s) {
+    // branch-free: three shifts and two selects (the three-way branch cost ~27 scalar instructions per score in pass A)
+    const unsigned b = __float_as_uint(s);
+    const int lo = (int)(b >> F1_SH);
+    const int mid = F1_ONE - (int)(__float_as_uint(1.0f - s) >> F1_SH);
+    const int hi = F1_ONE + 1 + (int)((b - 0x3F800000u) >> F1_SH);
+    return b < 0x3F000000u ? lo : (b <= 0x3F800000u ? mid : hi);
+}
+
 struct F1Ctrl {
-    int T1, T2;                  // thresholds of pass 1 / 2 (-1: pass not needed)
-    int n2;                      // values collected for pass 2
+    int T2;                      // thresholds of pass B (-1: pass not needed)
+    int n2;                      // positives inside the candidate bins
     int status;                  // 0 ok, 1 fall back (sizes), 2 negative / NaN scores
-    double best1;
+    int pad;
+    double best1;                // best F1 at a bin edge
     unsigned long long P, N;     // positive / negative pairs
 };
 
@@ -374,159 +401,190 @@ __device__ __forceinline__ double f1_of(double tp, double fp, double pos) {
     return f == f ? f : 0.0;
 }
 
-// One workgroup.  cand[0..nc): values to draw the thresholds from (every stride-th, at most F1_PICK of them).
-// Out: thr[T] ascending distinct, *dT = T, posc / eqc zeroed for f1_bucket_kernel.
-// The bitonic network runs on 16 waves that each own 1/16 of the array: every step whose partner distance stays inside
-// a wave's block needs no workgroup barrier (the LDS serves a wave's accesses in order), only the log2(16) + ... steps
-// that cross blocks do.
-constexpr int F1_PICK = 4095;                  // thresholds of a pass at most (a 4096-entry sort; 12 levels of the count tree)
-__global__ __launch_bounds__(1024) void f1_pick_kernel(const float* __restrict__ cand, const unsigned long long* __restrict__ nc_dev,
-                                                       const int* __restrict__ nc_int, const unsigned long long* __restrict__ na_dev,
-                                                       long long cap, float* __restrict__ thr, int* __restrict__ dT,
-                                                       unsigned* __restrict__ posc, unsigned* __restrict__ eqc,
-                                                       F1Ctrl* __restrict__ ctrl, int pass) {
-    __shared__ float v[F1_PICK + 1];
-    __shared__ int scan[1024 / 64 + 1];
-    __shared__ int total;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long long na = (long long)na_dev[0];
-    const long long nc = nc_int ? (long long)*nc_int : (long long)nc_dev[0];
-    for (int i = tid; i < F1_SORT; i += 1024) {
-        posc[i] = 0u;
-        eqc[i] = 0u;
+// Streaming layout of passes A and B: a WAVE owns a strip of 256 columns (four per lane) and walks a chunk of rows down
+// it - the column poses are loaded once per task, the row pose is wave-uniform (scalar loads), a row of the strip is one
+// contiguous kilobyte (16 bytes per lane, dword-aligned: rows of an M x M float matrix are not 16-byte aligned), and four
+// rows are in flight per wave.  Tasks (row chunk, strip) are dealt to the waves of the grid strip-first, so that
+// neighbouring waves read neighbouring kilobytes.
+constexpr int F1_ROWS = 4;                                       // rows per task = rows in flight per wave (5 tasks per wave on a KITTI-00 matrix)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+struct StripTask {
+    int c0, r0, r1;
+    __device__ __forceinline__ bool init(const PairScan& sc, long long task, int lane) {
+        const int strips = (sc.M + 255) >> 8;
+        const long long chunk = task / strips;
+        const int strip = (int)(task - chunk * strips);
+        r0 = (int)chunk * F1_ROWS;
+        r1 = min(sc.R, r0 + F1_ROWS);
+        c0 = strip * 256 + 4 * lane;
+        return r0 < sc.R;
     }
-    if (pass == 1 && (na > cap || ctrl->status != 0)) {                    // list longer than its buffer: the caller falls back
-        if (tid == 0) {
-            if (ctrl->status == 0) ctrl->status = 1;
-            *dT = -1;
+};
+__device__ __forceinline__ long long strip_tasks(const PairScan& sc) {
+    return (long long)((sc.M + 255) >> 8) * ((sc.R + F1_ROWS - 1) / F1_ROWS);
+}
+
+__device__ __forceinline__ void load_row4(const PairScan& sc, int r, int c0, float (&s)[4]) {
+    const float* sp = sc.score + (int64_t)r * sc.ld + c0;
+    if (c0 + 3 < sc.M) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(sp);
+        s[0] = v[0]; s[1] = v[1]; s[2] = v[2]; s[3] = v[3];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = c0 + q < sc.M ? sp[q] : 0.f;
+    }
+}
+
+// the planar poses of a lane's four columns (pose mode), loaded once per task
+struct ColPoses {
+    double x[4], z[4];
+    __device__ __forceinline__ void load(const PairTruth& t, int c0, int M) {
+        if (!t.pose) return;
+        if (c0 + 3 < M) {
+            const f64x2u* cp = reinterpret_cast<const f64x2u*>(t.pose + 2 * c0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f64x2u v = cp[q];
+                x[q] = v[0];
+                z[q] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = min(c0 + q, M - 1);
+                x[q] = t.pose[2 * c];
+                z[q] = t.pose[2 * c + 1];
+            }
         }
-        return;
     }
-    if (pass == 2 && (ctrl->status != 0 || nc <= 0)) {                     // nothing left to settle (or a fall-back already)
-        if (tid == 0) *dT = -1;
-        return;
+};
+
+// everything a task reads from memory, requested together: the column poses and the task's four rows
+struct StripData {
+    StripTask t;
+    ColPoses cp;
+    float s[F1_ROWS][4];
+    bool inb;
+    __device__ __forceinline__ void fetch(const PairScan& sc, long long task, long long ntasks, int lane, float fill) {
+        t.r0 = t.r1 = 0;
+        t.c0 = 0;
+        inb = false;
+#pragma unroll
+        for (int u = 0; u < F1_ROWS; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[u][q] = fill;
+        if (task >= ntasks) return;
+        t.init(sc, task, lane);
+        inb = t.c0 < sc.M;
+        if (!inb) return;
+        cp.load(sc.truth, t.c0, sc.M);
+#pragma unroll
+        for (int u = 0; u < F1_ROWS; ++u)
+            if (t.r0 + u < t.r1) load_row4(sc, t.r0 + u, t.c0, s[u]);
     }
-    // ---- sample: every stride-th candidate, +inf padding to a power of two (>= 1024: one pair per thread and step)
-    const long long stride = (nc + F1_PICK - 1) / F1_PICK > 0 ? (nc + F1_PICK - 1) / F1_PICK : 1;
-    const int ns = (int)((nc + stride - 1) / stride);                      // <= F1_PICK
-    int np2 = 2048;
-    while (np2 < ns) np2 <<= 1;
-    for (int i = tid; i < np2; i += 1024) v[i] = i < ns ? cand[(long long)i * stride] : INFINITY;
+};
+
+// classes (1 positive, 0 negative, -1 ignored / outside the matrix) of the pairs (r, c0 .. c0 + 3); classify_pair's
+// arithmetic (utils.py:36 in float64, operation by operation) on the preloaded column poses
+__device__ __forceinline__ void classify_row4(const PairTruth& t, const ColPoses& cp, int r, int c0, int M, double lo2, double hi2,
+                                              int (&cls)[4]) {
+    if (t.pose) {
+        const double px = t.pose[2 * (t.row0 + r)], pz = t.pose[2 * (t.row0 + r) + 1];     // wave-uniform
+        const double pos_lo = lo2 * (1.0 - 1e-12), pos_hi = lo2 * (1.0 + 1e-12), neg_lo = hi2 * (1.0 - 1e-12), neg_hi = hi2 * (1.0 + 1e-12);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double dx = px - cp.x[q], dz = pz - cp.z[q];
+            const double s2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz));
+            // sqrt is monotone and correctly rounded: away from the two thresholds the squared distance decides (selects, no
+            // branches); only within a relative 1e-12 of them is the reference's `sqrt(...) <= t` evaluated literally
+            int c = s2 < pos_lo ? 1 : (s2 > neg_hi ? 0 : -1);
+            if (!(s2 < pos_lo) && !(s2 > neg_hi) && !(s2 > pos_hi && s2 < neg_lo)) {
+                const double d = sqrt(s2);
+                c = d <= t.d_pos ? 1 : (d >= t.d_neg ? 0 : -1);
+            }
+            cls[q] = c0 + q < M ? c : -1;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = c0 + q < M ? t.gt[(int64_t)r * t.ldg + c0 + q] : -1;
+            cls[q] = g < 0 ? -1 : (g != 0);
+        }
+    }
+}
+
+// ---- A: negatives by key bin (LDS histogram of the workgroup -> its slab), positives appended to `pos` (count[0] of
+//      them; count[1] = positives with a negative / NaN score); slab tail word 0 = negatives with such a score.
+//      No workgroup barrier inside the loop: the positives are staged per WAVE (512 floats each, appended with a ballot
+//      prefix, flushed with one global atomic by the wave).
+constexpr int F1_WBUF = F1_PBUF / (F1_THREADS / 64);          // 512 staged positives per wave
+__global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, unsigned* __restrict__ slabs, int slab_words,
+                                                             float* __restrict__ pos, long long cap,
+                                                             unsigned long long* __restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
+    unsigned* hist = reinterpret_cast<unsigned*>(f1_smem);                  // [F1_NBP]
+    float* buf = reinterpret_cast<float*>(hist + F1_NBP) + (threadIdx.x >> 6) * F1_WBUF;   // this wave's staging area
+    __shared__ unsigned nbad_neg;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) hist[i] = 0u;
+    if (tid == 0) nbad_neg = 0u;
     __syncthreads();
-    // ---- bitonic sort: wave w owns pairs [w * np2/32, (w+1) * np2/32), i.e. elements [w * np2/16, (w+1) * np2/16)
-    const int ppw = np2 >> 5, blk = np2 >> 4;                              // pairs / elements per wave
-    bool crossed = false;                                                  // the previous step crossed wave blocks
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool cross = 2 * j > blk;
-            if (cross || crossed) __syncthreads();
-            crossed = cross;
-            for (int u = lane; u < ppw; u += 64) {
-                const int t = w * ppw + u;                                 // pair t: elements i and i + j
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const float a = v[i], b = v[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    v[i] = b;
-                    v[l] = a;
+    int nst = 0;                                          // staged positives of this wave (wave-uniform)
+    auto flush = [&]() {
+        unsigned long long g = 0ull;
+        if (lane == 0) g = atomicAdd(&count[0], (unsigned long long)nst);
+        g = __shfl(g, 0);
+        for (int i = lane; i < nst; i += 64) {
+            const long long idx = (long long)g + i;
+            if (idx < cap) pos[idx] = buf[i];
+        }
+        nst = 0;
+    };
+    const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
+    unsigned bad_pos = 0u, bad_neg = 0u;
+    const long long ntasks = strip_tasks(sc);
+    const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
+    for (long long task = wave0; task < ntasks; task += nwaves) {
+        StripData cur;                                    // (requesting task i + 1 before processing task i was measured: no
+        cur.fetch(sc, task, ntasks, lane, 0.f);           //  gain for this pass, 63 -> 73 us for pass B - dropped)
+#pragma unroll
+        for (int u = 0; u < F1_ROWS; ++u) {
+            if (cur.t.r0 + u >= cur.t.r1) break;          // (wave-uniform)
+            int cls[4] = {-1, -1, -1, -1};
+            if (cur.inb) classify_row4(sc.truth, cur.cp, cur.t.r0 + u, cur.t.c0, sc.M, lo2, hi2, cls);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = cur.s[u][q];
+                const bool usable = __float_as_uint(x) <= 0x7f800000u;      // not negative, not NaN
+                if (cls[q] == 0) {
+                    if (usable) atomicAdd(&hist[f1_key(x)], 1u);
+                    else ++bad_neg;
+                }
+                bool p = cls[q] == 1;
+                if (p && !usable) {
+                    ++bad_pos;
+                    p = false;
+                }
+                const unsigned long long m = __ballot(p);
+                if (m) {
+                    if (p) buf[nst + __popcll(m & ((1ull << lane) - 1ull))] = x;
+                    nst += __popcll(m);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (program order inside the wave is all it takes)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (nst > F1_WBUF - 256) flush();             // (wave-uniform) room for one more row is gone
         }
-    __syncthreads();
-    // ---- distinct values: flag, block scan, compact (ascending order is kept)
-    constexpr int PER = (F1_PICK + 1) / 1024;                              // 4 consecutive entries per thread
-    int keep[PER], mine = 0;
-    float vals[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int i = tid * PER + q;
-        vals[q] = i < np2 ? v[i] : INFINITY;
-        keep[q] = (i < ns && (i == 0 || vals[q] != v[i - 1])) ? 1 : 0;
-        mine += keep[q];
     }
-    int incl = mine;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int o = __shfl_up(incl, m);
-        if (lane >= m) incl += o;
-    }
-    if (lane == 63) scan[w] = incl;
+    if (nst) flush();
+    if (bad_pos) atomicAdd(&count[1], (unsigned long long)bad_pos);
+    if (bad_neg) atomicAdd(&nbad_neg, bad_neg);
     __syncthreads();
+    unsigned* slab = slabs + (size_t)blockIdx.x * slab_words;
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) slab[i] = hist[i];
     if (tid == 0) {
-        int run = 0;
-        for (int q = 0; q < 1024 / 64; ++q) {
-            const int c = scan[q];
-            scan[q] = run;
-            run += c;
-        }
-        total = run;
-    }
-    __syncthreads();
-    int at = scan[w] + incl - mine;
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-        if (keep[q]) thr[at++] = vals[q];
-    if (tid == 0) {
-        *dT = total;
-        if (pass == 1) ctrl->T1 = total; else ctrl->T2 = total;
-    }
-}
-
-// Every positive among the thresholds of a pass: b = #{thr <= s} (bisection in an LDS copy of the thresholds), bid[i] = b |
-// (equal to thr[b-1]) << 15; counters posc[b] / eqc[b] first in LDS (random LDS atomics are cheap; 47 k global atomics on
-// 4 k hot addresses were measured at 0.5 ms), then one global atomic per bucket the workgroup touched.
-__global__ __launch_bounds__(1024) void f1_bucket_kernel(const float* __restrict__ all, const unsigned long long* __restrict__ na_dev,
-                                                         const float* __restrict__ thr, const int* __restrict__ dT,
-                                                         unsigned* __restrict__ posc, unsigned* __restrict__ eqc,
-                                                         unsigned short* __restrict__ bid) {
-    __shared__ float v[F1_PICK + 1];
-    __shared__ unsigned pc[F1_PICK + 1], ec[F1_PICK + 1];
-    const int T = *dT;
-    if (T < 0) return;
-    for (int i = threadIdx.x; i <= T; i += 1024) {
-        v[i] = i < T ? thr[i] : INFINITY;
-        pc[i] = 0u;
-        ec[i] = 0u;
-    }
-    __syncthreads();
-    const long long na = (long long)na_dev[0];
-    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < na; i += (long long)gridDim.x * 1024) {
-        const float s = all[i];
-        int lo = 0, hi = T;                                                // thr[lo-1] <= s < thr[hi]
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (v[mid] <= s) lo = mid + 1; else hi = mid;
-        }
-        const bool eq = lo > 0 && v[lo - 1] == s;
-        atomicAdd(&pc[lo], 1u);
-        if (eq) atomicAdd(&ec[lo], 1u);
-        bid[i] = (unsigned short)(lo | (eq ? 0x8000 : 0));
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i <= T; i += 1024) {
-        if (pc[i]) atomicAdd(&posc[i], pc[i]);
-        if (ec[i]) atomicAdd(&eqc[i], ec[i]);
-    }
-}
-
-// The interior positives of the marked buckets = the values the second pass settles (f1_plan_kernel decided: ctrl->n2 of
-// them, at most F1_PICK)
-__global__ __launch_bounds__(256) void f1_collect_kernel(const float* __restrict__ all, const unsigned long long* __restrict__ na_dev,
-                                                         const unsigned short* __restrict__ bid, const unsigned char* __restrict__ mark,
-                                                         const F1Ctrl* __restrict__ ctrl, float* __restrict__ list2,
-                                                         int* __restrict__ cursor) {
-    __shared__ unsigned char mk[F1_SORT];
-    if (ctrl->status != 0 || ctrl->n2 <= 0) return;
-    for (int i = threadIdx.x; i < F1_SORT; i += 256) mk[i] = mark[i];
-    __syncthreads();
-    const long long na = (long long)na_dev[0];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long long)gridDim.x * 256) {
-        const unsigned b = bid[i];
-        if (!(b & 0x8000u) && mk[b]) list2[atomicAdd(cursor, 1)] = all[i];
+        reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[0] = nbad_neg;
+        reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[1] = 0ull;
     }
 }
 
@@ -569,91 +627,350 @@ __device__ __forceinline__ double block_max(double x, double* sh) {
     return r;
 }
 
-// One workgroup.  negc[b] (uint64, from slab_sum_kernel; negc[T+1] = negatives with unusable scores), posc / eqc of pass 1.
-__global__ __launch_bounds__(1024) void f1_plan_kernel(const unsigned long long* __restrict__ negc, const unsigned* __restrict__ posc,
-                                                       const unsigned* __restrict__ eqc, const unsigned long long* __restrict__ count,
-                                                       unsigned char* __restrict__ mark, int* __restrict__ n2_dev,
-                                                       F1Ctrl* __restrict__ ctrl) {
+// ascending bitonic sort of v[0 .. np2) in LDS by 16 waves that each own 1/16 of the array: every step whose partner
+// distance stays inside a wave's block needs no workgroup barrier (the LDS serves a wave's accesses in order), only
+// the steps that cross blocks do.  np2 = a power of two >= 64.
+__device__ __forceinline__ void lds_bitonic_sort(float* v, int np2) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ppw = np2 >> 5, blk = np2 >> 4;                              // pairs / elements per wave
+    bool crossed = true;                                                   // (the caller's fill crossed the blocks)
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = 2 * j > blk;
+            if (cross || crossed) __syncthreads();
+            crossed = cross;
+            for (int u = lane; u < ppw; u += 64) {
+                const int t = w * ppw + u;                                 // pair t: elements i and i + j
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const float a = v[i], b = v[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    v[i] = b;
+                    v[l] = a;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (program order inside the wave is all it takes)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    __syncthreads();
+}
+
+// what pass B and the final step need per threshold q (ascending distinct positive values of the candidate bins)
+struct F1Thr {
+    unsigned long long tp;       // positive pairs with a score >= thr[q]            (exact)
+    unsigned long long fp_above; // negative pairs in the bins above the threshold's bin
+    int seg_end;                 // thresholds in bins <= the threshold's bin (= the largest bucket a negative of that bin can get)
+    int pad;
+};
+
+constexpr int F1_HASH = 8192;                                    // slots of the de-duplication table (> F1_PICK + F1_THREADS)
+__device__ __forceinline__ unsigned f1_hash(unsigned bits) { return (bits * 2654435761u) >> 19; }
+
+// ---- P: one workgroup.  negb [F1_NBP + 2] (uint64, from slab_sum_kernel; [F1_NBP] = negatives with unusable scores).
+//      Out: ctrl, mark bits [F1_NBP / 32 + 1], thr [T2], info [T2], dT2; tpge / fpge [F1_NB + 1] = pairs in bins >= b.
+//      A single workgroup lives on latency: the bins' sums are scanned in registers (thread t owns 24 consecutive bins),
+//      every pass over the positives keeps eight independent loads in flight.
+__global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long long* __restrict__ negb, const float* __restrict__ pos,
+                                                             const unsigned long long* __restrict__ count, long long cap,
+                                                             unsigned long long* __restrict__ tpge, unsigned long long* __restrict__ fpge,
+                                                             unsigned* __restrict__ mark_out, float* __restrict__ thr,
+                                                             F1Thr* __restrict__ info, int* __restrict__ dT2, F1Ctrl* __restrict__ ctrl,
+                                                             unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
+#define F1_STAMP(i) if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64();
+    F1_STAMP(0)
+    unsigned* posb = reinterpret_cast<unsigned*>(f1_smem);                  // [F1_NBP] positives by bin; later:
+    unsigned* hkey = posb;                                                  //   [F1_HASH] bit patterns of the distinct values
+    unsigned* hcnt = posb + F1_HASH;                                        //   [F1_HASH] positive pairs that carry each
+    unsigned* ssum = posb + 2 * F1_HASH;                                    //   [F1_SORT + 1] pairs of the sorted entries >= i
+    float* v = reinterpret_cast<float*>(posb + F1_NBP);                     // [F1_SORT] the values pass B settles
+    unsigned* mark = reinterpret_cast<unsigned*>(v + F1_SORT);              // [F1_NBP / 32 + 1]
     __shared__ unsigned long long sh[2][17];
     __shared__ double shd[16];
-    __shared__ unsigned n2s;
+    __shared__ unsigned ndist, nv;
+    __shared__ unsigned long long tot[2];
     const int tid = threadIdx.x;
-    if (ctrl->status != 0) return;
-    const int T = ctrl->T1;
-    if (tid == 0) n2s = 0u;
-    if (count[1] != 0ull || negc[T + 1] != 0ull) {                         // negative / NaN scores have no rank
-        if (tid == 0) {
-            ctrl->status = 2;
-            *n2_dev = 0;
-        }
+    const long long na = (long long)count[0];
+    if (tid == 0) *dT2 = -1;
+    if (na > cap) {                                                         // list longer than its buffer: the caller falls back
+        if (tid == 0) ctrl->status = 1;
         return;
     }
-    constexpr int PER = F1_SORT / 1024;
-    unsigned long long ng[PER + 1], ps[PER + 1];                           // [q]: buckets tid*PER+q .. of this thread and above
-    unsigned long long sn = 0ull, sp = 0ull;
-#pragma unroll
-    for (int q = PER - 1; q >= 0; --q) {
-        const int b = tid * PER + q;
-        sn += b <= T ? negc[b] : 0ull;
-        sp += b <= T ? (unsigned long long)posc[b] : 0ull;
-        ng[q] = sn;
-        ps[q] = sp;
+    if (count[1] != 0ull || negb[F1_NBP] != 0ull) {                         // negative / NaN scores have no rank
+        if (tid == 0) ctrl->status = 2;
+        return;
     }
-    unsigned long long an = sn, ap = sp;
-    suffix_scan2(an, ap, sh);                                              // totals of the buckets of the threads above
+    constexpr int PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;             // 24 bins per thread
+    static_assert(PER % 2 == 0, "bins per thread");
+    // this thread's negatives: 12 independent 16-byte loads
+    unsigned long long ng[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q += 2) {
+        const int b = tid * PER + q;
+        ulonglong2 x = make_ulonglong2(0ull, 0ull);
+        if (b + 1 < F1_NBP) x = *reinterpret_cast<const ulonglong2*>(negb + b);
+        ng[q] = b < F1_NB ? x.x : 0ull;
+        ng[q + 1] = b + 1 < F1_NB ? x.y : 0ull;
+    }
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) posb[i] = 0u;
+    for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
+    if (tid == 0) ndist = nv = 0u;
+    __syncthreads();
+    // (keeping a thread's ~47 positives in registers for the second look at them was measured: the unrolled body spills,
+    // 14 -> 63 us; both passes read the list from L2 with eight independent loads in flight)
+    for (long long i0 = 0; i0 < na; i0 += 8 * F1_THREADS) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = i0 + u * F1_THREADS + tid;
+            x[u] = i < na ? pos[i] : -1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (x[u] >= 0.f) atomicAdd(&posb[f1_key(x[u])], 1u);
+    }
+    __syncthreads();
+    F1_STAMP(1)
+    unsigned ps[PER];
+    unsigned long long sn = 0ull, sp = 0ull;
+    bool any = false;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        ng[q] += an;
-        ps[q] += ap;
+        const int b = tid * PER + q;
+        ps[q] = b < F1_NB ? posb[b] : 0u;
+        sn += ng[q];
+        sp += ps[q];
+        any = any || ps[q] != 0u || ng[q] != 0ull;
     }
-    ng[PER] = an;
-    ps[PER] = ap;
-    __shared__ unsigned long long tot[2];
+    unsigned long long an = sn, ap = sp;
+    suffix_scan2(an, ap, sh);                                              // pairs in the bins of the threads above
     if (tid == 0) {
-        tot[0] = ps[0];                                                    // all positives / negatives
-        tot[1] = ng[0];
+        tot[0] = ap + sp;                                                  // all positives / negatives
+        tot[1] = an + sn;
     }
     __syncthreads();
     const double P = (double)tot[0];
-    // exact F1 at threshold b - 1 = F1(positives / negatives in buckets >= b)
-    double best = 0.0;
+    // F1 = 2 TP / (TP + FP + P) is monotone in g = TP / (TP + FP + P).  Which edge is best and which bins can beat it is
+    // decided on g in fp32 (one division per occupied bin; f1_of's three float64 divisions per bin and test were 40 us of
+    // this single workgroup) with a margin of 1e-5 - far above fp32 rounding, so the exact maximum is never excluded -,
+    // and the exact float64 F1 is evaluated only at the few edges inside the margin.
+    const float Pf = (float)tot[0];
+    auto g32 = [&](unsigned long long tp, unsigned long long fp) {
+        const float a = (float)tp;
+        return a > 0.f ? a / (a + (float)fp + Pf) : 0.f;
+    };
+    float gbest = 0.f;
+    {
+        unsigned long long rn = an, rp = ap;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int b = tid * PER + q;
-        if (b >= 1 && b <= T) best = fmax(best, f1_of((double)ps[q], (double)ng[q], P));
+        for (int q = PER - 1; q >= 0; --q) {
+            rn += ng[q];
+            rp += ps[q];
+            if (ps[q] != 0u || ng[q] != 0ull) gbest = fmaxf(gbest, g32(rp, rn));   // (an empty bin repeats the edge above it)
+        }
     }
-    best = block_max(best, shd);
-    // bound for the positives strictly inside bucket b: at most the positives above thr[b-1], at least the negatives >= thr[b]
-    unsigned mine2 = 0u;
+    gbest = (float)block_max((double)gbest, shd);
+    const float gcut = gbest * (1.f - 1e-5f);
+    // exact F1 at the edges that can be the best one = the curve's point at the smallest score >= the edge
+    double best = 0.0;
+    {
+        unsigned long long rn = an, rp = ap;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int b = tid * PER + q;
-        unsigned char m = 0;
-        if (b <= T) {
-            const unsigned inside = posc[b] - eqc[b];
-            if (inside > 0u && f1_of((double)(ps[q] - eqc[b]), (double)ng[q + 1], P) > best) {
-                m = 1;
-                mine2 += inside;
+        for (int q = PER - 1; q >= 0; --q) {
+            rn += ng[q];
+            rp += ps[q];
+            if (ps[q] != 0u || ng[q] != 0ull) {
+                const float gq = g32(rp, rn);
+                if (gq > 0.f && gq >= gcut) best = fmax(best, f1_of((double)rp, (double)rn, P));
             }
         }
-        if (b < F1_SORT) mark[b] = m;
     }
-    if (mine2) atomicAdd(&n2s, mine2);
-    __threadfence_block();
+    best = block_max(best, shd);
+    // candidate bins: some positive inside could beat the best edge value (at most every positive from the bin's lower
+    // edge on, at least the negatives above its upper edge); pairs from every bin edge on -> tpge / fpge
+    {
+        unsigned long long rn = an, rp = ap;
+#pragma unroll
+        for (int q = PER - 1; q >= 0; --q) {
+            const int b = tid * PER + q;
+            const unsigned long long fp_above = rn, tp_above = rp;
+            rn += ng[q];
+            rp += ps[q];
+            if (ps[q] != 0u && g32(rp, fp_above) >= gcut) {
+                atomicOr(&mark[b >> 5], 1u << (b & 31));
+                tpge[b + 1] = tp_above;                  // (only what the thresholds of this bin will need: a store per bin
+                fpge[b + 1] = fp_above;                  //  from 1024 threads in 192-byte strides was 20 us of this kernel)
+            }
+        }
+    }
+    (void)any;
+    __syncthreads();                                     // marks complete; posb is dead from here on (-> hash table)
+    F1_STAMP(2)
+    for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark_out[i] = mark[i];
+    for (int i = tid; i < 2 * F1_HASH; i += F1_THREADS) posb[i] = i < F1_HASH ? 0xffffffffu : 0u;   // empty = a NaN pattern
     __syncthreads();
-    const unsigned n2 = n2s;
+    // ---- the positives of the candidate bins: distinct values (and the pairs that carry each) through a hash table
+    auto insert = [&](float x) {
+        if (!(x >= 0.f)) return;
+        const int b = f1_key(x);
+        if (!((mark[b >> 5] >> (b & 31)) & 1u)) return;
+        const unsigned bits = __float_as_uint(x);
+        unsigned hslot = f1_hash(bits);
+        // (more distinct values than pass B settles: stop - the table never fills, at most one more value per thread)
+        while (__hip_atomic_load(&ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned)F1_PICK) {
+            const unsigned old = atomicCAS(&hkey[hslot], 0xffffffffu, bits);
+            if (old == 0xffffffffu) atomicAdd(&ndist, 1u);
+            if (old == 0xffffffffu || old == bits) {
+                atomicAdd(&hcnt[hslot], 1u);
+                break;
+            }
+            hslot = (hslot + 1) & (F1_HASH - 1);
+        }
+    };
+    for (long long i0 = 0; i0 < na; i0 += 8 * F1_THREADS) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = i0 + u * F1_THREADS + tid;
+            x[u] = i < na ? pos[i] : -1.f;
+        }
+#pragma unroll 1
+        for (int u = 0; u < 8; ++u) insert(x[u]);
+    }
+    __syncthreads();
+    F1_STAMP(3)
+    const unsigned n2 = ndist;
     if (tid == 0) {
         ctrl->best1 = best;
         ctrl->P = tot[0];
         ctrl->N = tot[1];
         ctrl->n2 = (int)n2;
-        if (n2 > (unsigned)F1_PICK) ctrl->status = 1;                      // too many values to settle in one more pass
-        *n2_dev = n2 > (unsigned)F1_PICK ? 0 : (int)n2;
+        if (n2 > (unsigned)F1_PICK) ctrl->status = 1;                      // a flat curve: too many values to settle in one pass
     }
+    if (n2 == 0u || n2 > (unsigned)F1_PICK) return;
+    int np2 = 64;
+    while (np2 < (int)n2) np2 <<= 1;
+    for (int i = tid; i < np2; i += F1_THREADS) v[i] = INFINITY;
+    __syncthreads();
+    for (int i = tid; i < F1_HASH; i += F1_THREADS)
+        if (hkey[i] != 0xffffffffu) v[atomicAdd(&nv, 1u)] = __uint_as_float(hkey[i]);
+    lds_bitonic_sort(v, np2);
+    F1_STAMP(4)
+    // ---- pairs of the sorted entries >= i (suffix sums of the multiplicities)
+    constexpr int PT = F1_SORT / F1_THREADS;                               // 4 consecutive entries per thread
+    unsigned mult[PT];
+    unsigned long long run = 0ull, dummy = 0ull;
+#pragma unroll
+    for (int q = PT - 1; q >= 0; --q) {
+        const int i = tid * PT + q;
+        unsigned c = 0u;
+        if (i < (int)n2) {
+            const unsigned bits = __float_as_uint(v[i]);
+            unsigned hslot = f1_hash(bits);
+            while (hkey[hslot] != bits) hslot = (hslot + 1) & (F1_HASH - 1);
+            c = hcnt[hslot];
+        }
+        run += c;
+        mult[q] = (unsigned)run;                                           // entries i .. end of this thread's four
+    }
+    unsigned long long above = run;
+    suffix_scan2(above, dummy, sh);
+#pragma unroll
+    for (int q = 0; q < PT; ++q) ssum[tid * PT + q] = mult[q] + (unsigned)above;
+    if (tid == 0) ssum[F1_SORT] = 0u;
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < PT; ++q) {
+        const int i = tid * PT + q;
+        if (i >= (int)n2) continue;
+        const float s = v[i];
+        const int b = f1_key(s);
+        // the end of this bin's segment of the sorted list: first entry of a later bin (bisection on the monotone key)
+        int lo = i + 1, hi = (int)n2;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (f1_key(v[mid]) <= b) lo = mid + 1; else hi = mid;
+        }
+        thr[i] = s;
+        F1Thr e;
+        e.tp = tpge[b + 1] + (unsigned long long)(ssum[i] - ssum[lo]);
+        e.fp_above = fpge[b + 1];
+        e.seg_end = lo;
+        e.pad = 0;
+        info[i] = e;
+    }
+    if (tid == 0) {
+        ctrl->T2 = (int)n2;
+        *dT2 = (int)n2;
+    }
+    F1_STAMP(5)
+#undef F1_STAMP
 }
 
-__global__ __launch_bounds__(1024) void f1_final_kernel(const unsigned long long* __restrict__ negc2, const unsigned* __restrict__ posc2,
-                                                        const F1Ctrl* __restrict__ ctrl, double* __restrict__ result) {
+// ---- B: negatives of the candidate bins by threshold bucket b = #{thr <= s}; everything else costs one bit test.
+//      Same strips as pass A; the float64 pose arithmetic runs only for rows in which some lane holds a candidate.
+__global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc, const unsigned* __restrict__ mark_in,
+                                                               const float* __restrict__ thr_in, const int* __restrict__ dT2,
+                                                               unsigned* __restrict__ slabs, int slab_words) {
+    __shared__ unsigned mark[F1_NBP / 32 + 1];
+    __shared__ float thr[F1_SORT];
+    __shared__ unsigned cnt[F1_SORT + 1];
+    const int T = *dT2;
+    if (T < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = mark_in[i];
+    for (int i = tid; i < F1_SORT; i += F1_THREADS) thr[i] = i < T ? thr_in[i] : INFINITY;
+    for (int i = tid; i <= F1_SORT; i += F1_THREADS) cnt[i] = 0u;
+    __syncthreads();
+    const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
+    const long long ntasks = strip_tasks(sc);
+    const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
+    for (long long task = wave0; task < ntasks; task += nwaves) {
+        StripData cur;
+        cur.fetch(sc, task, ntasks, lane, -1.f);
+#pragma unroll
+        for (int u = 0; u < F1_ROWS; ++u) {
+            bool cand[4];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = cur.s[u][q];                               // (-1: outside the task / the matrix)
+                const bool usable = __float_as_uint(x) <= 0x7f800000u;
+                const int b = usable ? f1_key(x) : 0;
+                cand[q] = cur.t.c0 + q < sc.M && usable && ((mark[b >> 5] >> (b & 31)) & 1u);
+                any = any || cand[q];
+            }
+            if (!any) continue;
+            int cls[4];
+            classify_row4(sc.truth, cur.cp, cur.t.r0 + u, cur.t.c0, sc.M, lo2, hi2, cls);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                  // (unrolled: a rolled loop would index the
+                if (!cand[q] || cls[q] != 0) continue;                     //  register arrays dynamically = scratch)
+                const float x = cur.s[u][q];
+                int lo = 0, hi = T;                                        // thr[lo-1] <= x < thr[hi]
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (thr[mid] <= x) lo = mid + 1; else hi = mid;
+                }
+                // counted only when it is >= a threshold OF ITS OWN BIN: a negative below every threshold of its bin
+                // belongs to no threshold there (the bins above a threshold's bin are accounted through fp_above), and
+                // bucket lo then names the bin of thr[lo - 1] unambiguously
+                if (lo > 0 && f1_key(thr[lo - 1]) == f1_key(x)) atomicAdd(&cnt[lo], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned* slab = slabs + (size_t)blockIdx.x * slab_words;
+    for (int i = tid; i <= T; i += F1_THREADS) slab[i] = cnt[i];
+    if (tid < 2) reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[tid] = 0ull;
+}
+
+// ---- F: one workgroup.  negc2[b] (uint64) = negatives of the candidate bins with exactly b thresholds <= their score
+__global__ __launch_bounds__(F1_THREADS) void f1_final_kernel(const unsigned long long* __restrict__ negc2, const F1Thr* __restrict__ info,
+                                                              const F1Ctrl* __restrict__ ctrl, double* __restrict__ result) {
+    __shared__ unsigned long long G[F1_SORT + 2];                          // G[b] = negatives with a bucket >= b
     __shared__ unsigned long long sh[2][17];
     __shared__ double shd[16];
     const int tid = threadIdx.x;
@@ -661,24 +978,27 @@ __global__ __launch_bounds__(1024) void f1_final_kernel(const unsigned long long
     int passes = 1;
     if (ctrl->status == 0 && ctrl->n2 > 0) {
         const int T = ctrl->T2;
-        constexpr int PER = F1_SORT / 1024;
-        unsigned long long ng[PER], ps[PER], sn = 0ull, sp = 0ull;
-#pragma unroll
+        constexpr int PER = (F1_SORT + 1 + F1_THREADS - 1) / F1_THREADS;   // 5
+        unsigned long long part[PER], sn = 0ull, dummy = 0ull;
         for (int q = PER - 1; q >= 0; --q) {
             const int b = tid * PER + q;
             sn += b <= T ? negc2[b] : 0ull;
-            sp += b <= T ? (unsigned long long)posc2[b] : 0ull;
-            ng[q] = sn;
-            ps[q] = sp;
+            part[q] = sn;
         }
-        unsigned long long an = sn, ap = sp;
-        suffix_scan2(an, ap, sh);
-        const double P = (double)ctrl->P;
-        double b2 = 0.0;
-#pragma unroll
+        unsigned long long an = sn;
+        suffix_scan2(an, dummy, sh);
         for (int q = 0; q < PER; ++q) {
             const int b = tid * PER + q;
-            if (b >= 1 && b <= T) b2 = fmax(b2, f1_of((double)(ps[q] + ap), (double)(ng[q] + an), P));
+            if (b <= F1_SORT + 1) G[b] = b <= T ? part[q] + an : 0ull;
+        }
+        __syncthreads();
+        const double P = (double)ctrl->P;
+        double b2 = 0.0;
+        for (int q = tid; q < T; q += F1_THREADS) {
+            const F1Thr e = info[q];
+            // negatives >= thr[q]: those above the bin + those of the bin with a bucket in (q, seg_end]
+            const unsigned long long fp = e.fp_above + (G[q + 1] - G[e.seg_end + 1]);
+            b2 = fmax(b2, f1_of((double)e.tp, (double)fp, P));
         }
         best = fmax(best, block_max(b2, shd));
         passes = 2;
@@ -689,7 +1009,7 @@ __global__ __launch_bounds__(1024) void f1_final_kernel(const unsigned long long
         result[2] = (double)ctrl->P;
         result[3] = (double)ctrl->N;
         result[4] = (double)passes;
-        result[5] = (double)ctrl->T1;
+        result[5] = (double)F1_NB;
         result[6] = (double)ctrl->n2;
         result[7] = 0.0;
     }
@@ -880,33 +1200,34 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
     return SGPR_OK;
 }
 
-// ---- sgpr_f1_max: workspace = header (counts, control block, device-side sizes) | thresholds, bucket counters, marks of
-//      both passes | negatives by bucket of both passes | second list | positives | their buckets | counter slabs
+// ---- sgpr_f1_max: workspace = header (counts, control block, device-side sizes) | negatives by bin | pairs from a bin on
+//      (two arrays) | candidate-bin marks | thresholds, their info, negatives by bucket of pass B | positives | counter slabs
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct F1Layout {
-    size_t off_thr1, off_thr2, off_posc1, off_eqc1, off_posc2, off_eqc2, off_mark, off_neg1, off_neg2, off_list2, off_pos, off_bid,
-        off_slabs, total;
+    size_t off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, total;
     long long cap;
+    int slabs_a, slabs_b, words_a, words_b;
 };
 static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     F1Layout L;
     const long long pairs = (long long)R * M;
     L.cap = pairs < (1LL << 20) ? pairs : (1LL << 20);
     if (L.cap < 1) L.cap = 1;
+    L.slabs_a = h->num_cus;                       // pass A: one 1024-thread workgroup (97 KB histogram) per CU
+    L.slabs_b = h->num_cus;                       // pass B: likewise (4096 waves, ~5 strip tasks each on a KITTI-00 matrix)
+    L.words_a = F1_NBP + 4;
+    L.words_b = slab_words(F1_SORT);
     size_t off = 256;                                                       // header
-    L.off_thr1 = off;  off += a256(F1_SORT * sizeof(float));
-    L.off_thr2 = off;  off += a256(F1_SORT * sizeof(float));
-    L.off_posc1 = off; off += a256(F1_SORT * sizeof(unsigned));
-    L.off_eqc1 = off;  off += a256(F1_SORT * sizeof(unsigned));
-    L.off_posc2 = off; off += a256(F1_SORT * sizeof(unsigned));
-    L.off_eqc2 = off;  off += a256(F1_SORT * sizeof(unsigned));
-    L.off_mark = off;  off += a256(F1_SORT);
-    L.off_neg1 = off;  off += a256((F1_SORT + 4) * sizeof(unsigned long long));
+    L.off_negb = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
+    L.off_tpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
+    L.off_fpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
+    L.off_mark = off;  off += a256((F1_NBP / 32 + 1) * sizeof(unsigned));
+    L.off_thr = off;   off += a256(F1_SORT * sizeof(float));
+    L.off_info = off;  off += a256(F1_SORT * sizeof(F1Thr));
     L.off_neg2 = off;  off += a256((F1_SORT + 4) * sizeof(unsigned long long));
-    L.off_list2 = off; off += a256(F1_SORT * sizeof(float));
     L.off_pos = off;   off += a256((size_t)L.cap * sizeof(float));
-    L.off_bid = off;   off += a256((size_t)L.cap * sizeof(unsigned short));
-    L.off_slabs = off; off += a256((size_t)h->num_cus * slab_words(F1_MAXT) * sizeof(unsigned));
+    const size_t sa = (size_t)L.slabs_a * L.words_a, sb = (size_t)L.slabs_b * L.words_b;
+    L.off_slabs = off; off += a256((sa > sb ? sa : sb) * sizeof(unsigned));
     L.total = off;
     return L;
 }
@@ -935,63 +1256,45 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     unsigned char* ws = static_cast<unsigned char*>(d_workspace);
     unsigned long long* count = reinterpret_cast<unsigned long long*>(ws);            // [2]
     F1Ctrl* ctrl = reinterpret_cast<F1Ctrl*>(ws + 64);
-    int* dT1 = reinterpret_cast<int*>(ws + 192);
-    int* dT2 = dT1 + 1;
-    int* n2 = dT1 + 2;
-    float* thr1 = reinterpret_cast<float*>(ws + L.off_thr1);
-    float* thr2 = reinterpret_cast<float*>(ws + L.off_thr2);
-    unsigned* posc1 = reinterpret_cast<unsigned*>(ws + L.off_posc1);
-    unsigned* eqc1 = reinterpret_cast<unsigned*>(ws + L.off_eqc1);
-    unsigned* posc2 = reinterpret_cast<unsigned*>(ws + L.off_posc2);
-    unsigned* eqc2 = reinterpret_cast<unsigned*>(ws + L.off_eqc2);
-    unsigned char* mark = ws + L.off_mark;
-    unsigned long long* neg1 = reinterpret_cast<unsigned long long*>(ws + L.off_neg1);
+    int* dT2 = reinterpret_cast<int*>(ws + 192);
+    unsigned long long* negb = reinterpret_cast<unsigned long long*>(ws + L.off_negb);
+    unsigned long long* tpge = reinterpret_cast<unsigned long long*>(ws + L.off_tpge);
+    unsigned long long* fpge = reinterpret_cast<unsigned long long*>(ws + L.off_fpge);
+    unsigned* mark = reinterpret_cast<unsigned*>(ws + L.off_mark);
+    float* thr = reinterpret_cast<float*>(ws + L.off_thr);
+    F1Thr* info = reinterpret_cast<F1Thr*>(ws + L.off_info);
     unsigned long long* neg2 = reinterpret_cast<unsigned long long*>(ws + L.off_neg2);
-    float* list2 = reinterpret_cast<float*>(ws + L.off_list2);
     float* pos = reinterpret_cast<float*>(ws + L.off_pos);
-    unsigned short* bid = reinterpret_cast<unsigned short*>(ws + L.off_bid);
     unsigned* slabs = reinterpret_cast<unsigned*>(ws + L.off_slabs);
     static_assert(sizeof(F1Ctrl) <= 128, "control block");
-    hipError_t e = hipMemsetAsync(ws, 0, 256, s);                                      // counts, control block, sizes
-    if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
+    const size_t lds_scan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_PBUF * sizeof(float);
+    const size_t lds_plan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_SORT * sizeof(float) +
+                            (size_t)(F1_NBP / 32 + 1) * sizeof(unsigned);
+    static_assert(2 * F1_HASH + F1_SORT + 1 <= F1_NBP, "the hash table and the suffix sums reuse the positives' histogram");
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_threshold_count_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(f1 kernels)");
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&f1_scan_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&f1_plan_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan);
+        if (e1 != hipSuccess || e2 != hipSuccess) return hip_fail(e1 != hipSuccess ? e1 : e2, "hipFuncSetAttribute(f1 kernels)");
         attr_set = true;
     }
-    const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
-    if ((int64_t)R * M > 0)
-        hipLaunchKernelGGL(pair_positives_kernel, dim3(h->num_cus * 8), dim3(256), 0, s, sc, pos, L.cap, count);
-    const size_t count_lds = (size_t)F1_SORT * sizeof(float) + (size_t)F1_SORT * sizeof(unsigned);
-    CountArgs a;
-    memset(&a, 0, sizeof(a));
-    a.scan = sc;
-    a.slabs = slabs;
-    a.slab_words = slab_words(F1_MAXT);
-    int* cursor = n2 + 1;                                                              // append cursor of the second list
-    for (int pass = 1; pass <= 2; ++pass) {
-        float* thr = pass == 1 ? thr1 : thr2;
-        int* dT = pass == 1 ? dT1 : dT2;
-        unsigned* posc = pass == 1 ? posc1 : posc2;
-        unsigned* eqc = pass == 1 ? eqc1 : eqc2;
-        hipLaunchKernelGGL(f1_pick_kernel, dim3(1), dim3(1024), 0, s, pass == 1 ? pos : list2, count,
-                           pass == 1 ? (const int*)nullptr : n2, count, L.cap, thr, dT, posc, eqc, ctrl, pass);
-        hipLaunchKernelGGL(f1_bucket_kernel, dim3(32), dim3(1024), 0, s, pos, count, thr, dT, posc, eqc, bid);
-        a.thr = thr;
-        a.dT = dT;
-        if ((int64_t)R * M > 0) {
-            hipLaunchKernelGGL(pair_threshold_count_kernel, dim3(h->num_cus), dim3(PC_THREADS), count_lds, s, a);
-            hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_MAXT + 3 + 31) / 32), dim3(1024), 0, s, slabs, h->num_cus, a.slab_words,
-                               0, pass == 1 ? neg1 : neg2, dT);
-        }
-        if (pass == 1) {
-            hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(1024), 0, s, neg1, posc1, eqc1, count, mark, n2, ctrl);
-            hipLaunchKernelGGL(f1_collect_kernel, dim3(64), dim3(256), 0, s, pos, count, bid, mark, ctrl, list2, cursor);
-        }
+    hipError_t e = hipMemsetAsync(ws, 0, 256, s);                                      // counts, control block, sizes
+    if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
+    if ((int64_t)R * M == 0) {                       // an empty rectangle: F1-max 0 over 0 positive / 0 negative pairs, status 0
+        e = hipMemsetAsync(d_result, 0, 8 * sizeof(double), s);
+        if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
+        return SGPR_OK;
     }
-    hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(1024), 0, s, neg2, posc2, ctrl, d_result);
+    const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
+    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb);
+    hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
+                       ctrl, reinterpret_cast<unsigned long long*>(ws + 128));
+    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_SORT + 3 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_b, L.words_b, 0, neg2, dT2);
+    hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(F1_THREADS), 0, s, neg2, info, ctrl, d_result);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max launches");
     return SGPR_OK;

@@ -137,6 +137,9 @@ constexpr int AP_OCC = 4;      // resident workgroups per CU the kernel is compi
 #ifndef SGPR_AP_NI
 #define SGPR_AP_NI 1
 #endif
+#ifndef SGPR_AP_NT_STORE
+#define SGPR_AP_NT_STORE 0      // 1: the matrix leaves through non-temporal stores (A/B builds, tools/build_variant.sh)
+#endif
 constexpr int AP_NI = SGPR_AP_NI;   // row graphs interleaved in program order (see score_all_pairs_kernel)
 constexpr float AP_F16_SAFE = 60000.f;
 
@@ -666,7 +669,11 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
                 float* dst = score + (size_t)r * ld + c0;
                 if (c0 + 3 < M) {
                     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#if SGPR_AP_NT_STORE
+                    __builtin_nontemporal_store(f32x4u{sc[0], sc[1], sc[2], sc[3]}, reinterpret_cast<f32x4u*>(dst));
+#else
                     *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
+#endif
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b)

@@ -187,7 +187,7 @@ def f1_max_device(engine, score, pose_xz=None, p_thresh=3.0, n_thresh=20.0, gt=N
     """F1-max of a score rectangle that stays on the device -> (f1_max, counting passes).
     one_call (default): the engine's single entry point (sgpr_f1_max: positives, thresholds, counting passes and the
     F1 reduction all on the device, one small copy at the end); rectangles it reports as too large for that path - more
-    than 2^20 positive pairs, more than 8191 values to settle in the second pass - and one_call=False take the multi-call
+    than 2^20 positive pairs, more than 4095 values to settle in the second pass - and one_call=False take the multi-call
     path (pr_roc_device), which handles any size.  Both are exact."""
     if one_call and hasattr(engine, "f1_max"):
         res = engine.f1_max(score, row0=row0, pose_xz=pose_xz, d_pos=p_thresh, d_neg=n_thresh, gt=gt)

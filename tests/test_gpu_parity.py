@@ -1134,11 +1134,13 @@ def test_full_sequence_parity_with_tie_proofs(eng, oracle, oracle_sd):
     assert r["scores"] == 4541 * 4541
     assert r["scores_off_clean"] == 0 and r["score_max_clean"] < SCORE_TOL       # every score between agreeing graphs
     assert r["flagged"].size <= 4541 // 100                                       # ties are rare events, not a regime
-    # F1-max: a proven tie moves at most the 2 x 4541 scores of its graph; the curve's maximum moves accordingly.
-    # SURVEY 8d's 1e-6 presumes score parity everywhere; with k proven-tie graphs the gate is k rows + columns of pairs
-    # changing side at the best threshold, i.e. <= 2 k M / (TP + FP + P) in F1 - far below the 1e-3 gated here.
+    # F1-max.  SURVEY 8d's |dF1| <= 1e-6 presumes score parity everywhere; it does not hold on the full matrix (observed
+    # 3.6e-6): the proven-tie graphs move the 2 x 4541 scores of their rows and columns (by up to 5e-2), and scores that
+    # agree to 2.5e-5 can still trade places across the best threshold.  What holds, with a 10 x margin: 5e-5 on the
+    # full matrix - the curve itself is far from chance (F1-max 0.146 against a positive rate of 0.2 %).
     assert r["f1_oracle"] > 0.1, "the sequence's PR curve is at chance: %r" % r["f1_oracle"]
-    assert abs(r["f1_hip"] - r["f1_oracle"]) <= 1e-3
+    assert abs(r["f1_hip"] - r["f1_oracle"]) <= 5e-5
+    assert abs(r["f1_hip_clean"] - r["f1_oracle_clean"]) <= 5e-5
     # the device F1-max (one engine call) on the HIP matrix = the sorted host computation on the same matrix
     pooled = r["pooled"]
     from sg_pr_amd import metrics
@@ -1414,3 +1416,45 @@ def test_reference_pair_lists_full_size(eng, golden_dir, ckpt_path):
         assert torch.equal(got, dense[torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()])
         via_model = model.score_pooled(pooled, pooled, torch.from_numpy(i1.astype(np.int32)), torch.from_numpy(i2.astype(np.int32)))
         assert torch.equal(via_model, got)
+
+
+def test_f1_max_bit_pattern_bins_at_their_edges(eng):
+    """sgpr_f1_max bins the negatives by the score's bit pattern (f1_key: 6 mantissa bits of s below 1/2, of 1 - s above,
+    of s again beyond 1).  Scores ON the seams of that map - 0, subnormals, 1/2, 1, the neighbours of each, values beyond
+    1, +inf - and whole matrices squeezed into one or two bins must still give the sorted host computation exactly."""
+    from sg_pr_amd import metrics
+    rng = np.random.default_rng(99)
+    one = np.float32(1.0)
+    special = np.array([0.0, 1e-45, 1e-40, 1.1754944e-38, 1e-20, 0.25, np.nextafter(np.float32(0.5), np.float32(0)), 0.5,
+                        np.nextafter(np.float32(0.5), one), 0.75, 1 - 2.0 ** -7, 1 - 2.0 ** -20, np.nextafter(one, np.float32(0)),
+                        1.0, np.nextafter(one, np.float32(2)), 1.5, 2.0, 1e10, 3e38, np.inf], dtype=np.float32)
+
+    def check(sc, lab, what, may_fall_back=False):
+        dev = torch.from_numpy(sc).cuda()
+        res = eng.f1_max(dev, gt=torch.from_numpy(lab))
+        keep = lab.ravel() >= 0
+        want = metrics.f1_max(lab.ravel()[keep], sc.ravel()[keep])
+        # status 1 = "more than 4095 distinct positive scores left to settle": legitimate when thousands of distinct
+        # positive values share a few bins; metrics.f1_max_device then takes the multi-call path
+        assert res[1] == 0 or (may_fall_back and res[1] == 1), (what, res.tolist())
+        if res[1] == 0:
+            assert abs(res[0] - want) < 1e-12, (what, res.tolist(), want)
+            assert res[2] == int((lab == 1).sum()) and res[3] == int((lab == 0).sum()), (what, res.tolist())
+        assert abs(metrics.f1_max_device(eng, dev, gt=torch.from_numpy(lab))[0] - want) < 1e-12, what
+
+    for rows, cols in ((64, 257), (200, 200)):
+        lab = rng.integers(-1, 2, size=(rows, cols)).astype(np.int8)
+        check(special[rng.integers(0, special.size, size=(rows, cols))], lab, "special values")
+        # a sigmoid's crowd near 1: 1 - 10^-u, u uniform in [0, 7]; positives a little higher than negatives
+        u = rng.uniform(0, 7, size=(rows, cols)) + 0.3 * (lab == 1)
+        check((1.0 - 10.0 ** -u).astype(np.float32), lab, "crowd near 1")
+        # everything inside ONE bin (64 consecutive bit patterns share the top bits), and inside two neighbours
+        base = np.float32(0.8125).view(np.uint32)
+        check((base + rng.integers(0, 64, size=(rows, cols)).astype(np.uint32)).view(np.float32), lab, "one bin")
+        check((base + rng.integers(0, 2 ** 17 + 64, size=(rows, cols)).astype(np.uint32)).view(np.float32), lab, "few bins",
+              may_fall_back=True)
+    # rare positives with scores spread over the whole range among 10^6 negatives (the loop-closure shape)
+    sc = rng.random((1000, 1000), dtype=np.float32) ** 3
+    lab = (rng.random((1000, 1000)) < 0.002).astype(np.int8)
+    sc[lab == 1] = np.sqrt(sc[lab == 1])
+    check(sc, lab, "rare positives")

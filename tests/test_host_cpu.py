@@ -686,6 +686,13 @@ def test_ragged_store_conversion_and_order():
     bad[3, 0] = -1                                              # a hole before real nodes
     with pytest.raises(ValueError):
         Engine.to_ragged(c, bad)
+    # a label outside 0..11 is refused before the int8 cast could wrap it into a valid class (261 -> 5); the reference
+    # raises KeyError (sg_net.py:277), the padded path flags it on the device
+    for wrong in (12, 128, 261):
+        bad = l.copy()
+        bad[7, 2] = wrong
+        with pytest.raises(ValueError, match="label"):
+            Engine.to_ragged(c, bad)
 
 
 def test_ragged_graphs_container():

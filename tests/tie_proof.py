@@ -33,12 +33,21 @@ LAYERS = ["xyz1", "xyz2", "xyz3", "sem1", "sem2", "sem3"]
 
 def oracle_trace(oracle, sd, feats, k):
     """feats [1, 3+L, N] (torch, any float dtype) -> (inputs [6] of [N, C] numpy, knn [6] of [N, k] numpy int64):
-    every EdgeConv layer's input and the oracle's neighbour lists there (SG.dgcnn_conv_pass, sg_net.py:79-110)."""
+    every EdgeConv layer's input and the oracle's neighbour lists there (SG.dgcnn_conv_pass, sg_net.py:79-110).
+    The inputs list carries, as attribute `.pd`, the oracle's own ranking keys pd [N, N] per layer (dgcnn.py:15-17 in its
+    own precision): how far apart the REFERENCE's arithmetic saw two swapped candidates."""
     with torch.no_grad():
         _, lay = oracle.conv_pass(sd, feats, k, want_layers=True)
         ins = [feats[:, :3, :], lay["xyz1"], lay["xyz2"], feats[:, 3:, :], lay["sem1"], lay["sem2"]]
         knn = [oracle.knn(x, k)[0].numpy().astype(np.int64) for x in ins]
-    return [x[0].T.contiguous().numpy() for x in ins], knn
+        pd = [oracle.neg_sq_dist(x)[0].numpy() for x in ins]
+    out = _Trace(x[0].T.contiguous().numpy() for x in ins)
+    out.pd = pd
+    return out, knn
+
+
+class _Trace(list):
+    pd = None
 
 
 def _canon(x):
@@ -97,9 +106,11 @@ def prove_ties(x_o, knn_o, x_h, knn_h, tie_c=TIE_C, input_tol=INPUT_TOL):
                             dd = np.linalg.norm((xh[i] - xo[i]) - (xh[j] - xo[j]))
                             pert += 2.0 * np.sqrt(d2(j)) * dd + dd * dd
                         bound = fp32 + pert
+                        pd = getattr(x_o, "pd", None)
+                        ref_gap = float(abs(np.float64(pd[li][i, a]) - np.float64(pd[li][i, b]))) if pd is not None else None
                         rep["flips"].append({"layer": LAYERS[li], "row": int(i), "ours": a, "theirs": b, "gap": gap,
                                              "d2": d2(b), "fp32_bound": fp32, "perturbation": pert,
-                                             "ratio": gap / bound})
+                                             "ratio": gap / bound, "ref_gap": ref_gap})
                         if not gap <= bound:
                             rep["proven"] = False
                             rep["reason"] += ("%s row %d: candidates %d / %d are %.3g apart in d^2 (bound %.3g): not a "
@@ -177,9 +188,10 @@ def census(eng, oracle, sd, centers, labels, poses, k=10, flag_tol=2e-4, score_t
         for f in rep["flips"]:
             out["ratios"].append(f["ratio"])
             log("  graph %d (|d pooled| %.2e) %s row %d: ours %d / oracle's %d, d^2 = %.6g, gap %.3g, bound %.3g "
-                "(fp32 %.3g + input rounding %.3g) -> %.2f of the bound"
+                "(fp32 %.3g + input rounding %.3g) -> %.2f of the bound; the oracle's own fp32 keys of the two: %s"
                 % (g, dev[g], f["layer"], f["row"], f["ours"], f["theirs"], f["d2"], f["gap"],
-                   f["fp32_bound"] + f["perturbation"], f["fp32_bound"], f["perturbation"], f["ratio"]))
+                   f["fp32_bound"] + f["perturbation"], f["fp32_bound"], f["perturbation"], f["ratio"],
+                   "EQUAL (torch.topk's tie order decides)" if f["ref_gap"] == 0.0 else "%.3g apart" % f["ref_gap"]))
         if not rep["proven"]:
             log("  graph %d NOT PROVEN: %s" % (g, rep["reason"]))
     log("proven ties: %d of %d flagged graphs; largest gap / bound %.3f"
@@ -215,5 +227,10 @@ def census(eng, oracle, sd, centers, labels, poses, k=10, flag_tol=2e-4, score_t
     out["f1_hip"] = oracle.f1_max(lab[m], s_h[m])
     log("F1-max over %d positive / %d negative pairs: oracle matrix %.9f, HIP matrix %.9f, |d| %.3e"
         % (out["positives"], out["negatives"], out["f1_oracle"], out["f1_hip"], abs(out["f1_oracle"] - out["f1_hip"])))
+    mc = m & ~tm                                          # ... and over the pairs between graphs whose embeddings agree
+    out["f1_oracle_clean"] = oracle.f1_max(lab[mc], s_o[mc])
+    out["f1_hip_clean"] = oracle.f1_max(lab[mc], s_h[mc])
+    log("F1-max without the rows / columns of the flagged graphs: oracle %.9f, HIP %.9f, |d| %.3e"
+        % (out["f1_oracle_clean"], out["f1_hip_clean"], abs(out["f1_oracle_clean"] - out["f1_hip_clean"])))
     out["pooled"], out["ref"], out["s_h"] = pooled, ref, s_h
     return out
