@@ -443,9 +443,30 @@ __device__ __forceinline__ void xzero(unsigned char* row, int ch) {
 }
 
 // ------------------------------------------------------------------ selection helpers
-// v_med3_f32 as an exact, canonicalisation-free min / max (keys are never NaN)
+__device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f32, defined with the gather)
+// Exact min / max of two keys (never NaN) as ONE instruction each.  The builtins (fminf, fmed3 with an infinite bound,
+// which the optimizer folds back into it) first canonicalise every operand that does not come out of an arithmetic
+// instruction - a v_max x, x behind each LDS read and each DPP move: 78 such instructions in the lean instance, most of
+// them in the selection's merges.  Operands come from LDS reads, DPP moves or other minima / maxima, never straight
+// from an MFMA (whose wait states the compiler would not insert in front of inline asm).
+#ifndef SGPR_ASM_MINMAX
+#define SGPR_ASM_MINMAX 1
+#endif
+#if SGPR_ASM_MINMAX
+__device__ __forceinline__ float kmin(float a, float b) {
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float kmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#else
 __device__ __forceinline__ float kmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
 __device__ __forceinline__ float kmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+#endif
 
 __device__ __forceinline__ void cswap(float& a, float& b) {
     const float lo = kmin(a, b);
@@ -676,16 +697,29 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
         bitonic_merge<KP>(L);                                            \
         _Pragma("unroll") for (int s = KEEP; s < KP; ++s) L[s] = INFINITY; \
     }
+    float tau;                                       // the k-th smallest key of the row
+    bool have_tau = false;
     SGPR_MERGE_ROUND(1)
-    SGPR_MERGE_ROUND(2)
-    SGPR_MERGE_ROUND(4)
-    SGPR_MERGE_ROUND(8)
-    SGPR_MERGE_ROUND(16)
-    SGPR_MERGE_ROUND(32)
+    if constexpr (PC == 4 && KEEP == 10) {
+        // LAST round of the lean instances (four lanes per row): only the K-th smallest key is needed, not the merged list.
+        // min(L[s], O[K-1-s]), s < K, ARE the K smallest of the two lists (as a set): their maximum is that key - five
+        // v_max3 instead of the ~15 comparators of the merge network that feed entry K-1
+        float mn[10];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) mn[s] = kmin(L[s], lane_xor(L[9 - s], 2));
+        tau = max3(max3(max3(mn[0], mn[1], mn[2]), max3(mn[3], mn[4], mn[5]), max3(mn[6], mn[7], mn[8])), mn[9], mn[9]);
+        have_tau = true;
+    } else {
+        SGPR_MERGE_ROUND(2)
+        SGPR_MERGE_ROUND(4)
+        SGPR_MERGE_ROUND(8)
+        SGPR_MERGE_ROUND(16)
+        SGPR_MERGE_ROUND(32)
+    }
 #undef SGPR_MERGE_ROUND
     SEL_STAMP(2)
-    float tau;                                       // the k-th smallest key of the row
-    if (KEEP == 10 || k == 10) {
+    if (have_tau) {
+    } else if (KEEP == 10 || k == 10) {
         tau = L[9];
     } else if (KP == 32 && (KEEP == 20 || k == 20)) {
         tau = L[KP == 32 ? 19 : 0];
@@ -1290,17 +1324,37 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return d;
 }
 
-__device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const uint32_t* __restrict__ nwa,
-                                            const uint32_t* __restrict__ nwb, int k, float4& ma, float4& mb) {
+#ifndef SGPR_GATHER_U16
+#define SGPR_GATHER_U16 0     // 1: neighbour offsets as sixteen-bit LDS reads - the load-store vectorizer fuses the pair back into a 32-bit read + unpack (measured: no ds_read_u16 is emitted), so the plain form stays
+#endif
+__device__ __forceinline__ void nbr_pair(const unsigned short* __restrict__ nw, int q, bool odd, int& a0, int& a1) {
+#if SGPR_GATHER_U16
+    // the offsets come out of the LDS pipe ready to use: the vector ALU is what this kernel is short of
+    // (the second pointer goes through an opaque copy: the load-store vectorizer would otherwise fuse the pair back into one
+    // 32-bit read + v_and / v_bfe)
+    const unsigned short *p0 = nw + 2 * q, *p1 = nw + 2 * q + 1;
+    asm("" : "+v"(p0));
+    asm("" : "+v"(p1));
+    a0 = *p0;
+    a1 = odd ? (int)*p1 : a0;
+#else
+    const uint32_t w = reinterpret_cast<const uint32_t*>(nw)[q];
+    a0 = w & 0xffffu;
+    a1 = odd ? (int)(w >> 16) : a0;
+#endif
+}
+
+__device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const unsigned short* __restrict__ nwa,
+                                            const unsigned short* __restrict__ nwb, int k, float4& ma, float4& mb) {
     ma = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     mb = ma;
     const int kw = (k + 1) >> 1;
 #pragma unroll 5
     for (int q = 0; q < kw; ++q) {
-        const uint32_t wa = nwa[q], wb = nwb[q];
         const bool odd = 2 * q + 1 < k;
-        const int a0 = wa & 0xffffu, a1 = odd ? (int)(wa >> 16) : a0;
-        const int b0 = wb & 0xffffu, b1 = odd ? (int)(wb >> 16) : b0;
+        int a0, a1, b0, b1;
+        nbr_pair(nwa, q, odd, a0, a1);
+        nbr_pair(nwb, q, odd, b0, b1);
         const float4 va0 = *reinterpret_cast<const float4*>(A4 + a0);
         const float4 va1 = *reinterpret_cast<const float4*>(A4 + a1);
         const float4 vb0 = *reinterpret_cast<const float4*>(A4 + b0);
@@ -1317,14 +1371,14 @@ __device__ __forceinline__ void gather_max2(const float* __restrict__ A4, const 
 }
 
 // one row (the last, unpaired group of a wave)
-__device__ __forceinline__ void gather_max1(const float* __restrict__ A4, const uint32_t* __restrict__ nwa, int k, float4& ma) {
+__device__ __forceinline__ void gather_max1(const float* __restrict__ A4, const unsigned short* __restrict__ nwa, int k, float4& ma) {
     ma = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     const int kw = (k + 1) >> 1;
 #pragma unroll 5
     for (int q = 0; q < kw; ++q) {
-        const uint32_t wa = nwa[q];
         const bool odd = 2 * q + 1 < k;
-        const int a0 = wa & 0xffffu, a1 = odd ? (int)(wa >> 16) : a0;
+        int a0, a1;
+        nbr_pair(nwa, q, odd, a0, a1);
         const float4 va0 = *reinterpret_cast<const float4*>(A4 + a0);
         const float4 va1 = *reinterpret_cast<const float4*>(A4 + a1);
         ma.x = max3(ma.x, va0.x, va1.x);
@@ -1947,10 +2001,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 const int ra = min(ia, N - 1), rb = TWO ? min(ib, N - 1) : ra;   // padded rows: compute a real row
                 float4 ma, mb;
                 if constexpr (TWO) {
-                    gather_max2(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch),
-                                reinterpret_cast<const uint32_t*>(nbr + rb * p.kpitch), k, ma, mb);
+                    gather_max2(A + c4, nbr + ra * p.kpitch, nbr + rb * p.kpitch, k, ma, mb);
                 } else {
-                    gather_max1(A + c4, reinterpret_cast<const uint32_t*>(nbr + ra * p.kpitch), k, ma);
+                    gather_max1(A + c4, nbr + ra * p.kpitch, k, ma);
                     mb = ma;
                 }
                 // padded rows (>= N) inside a partly real group simply keep a copy of row N-1: they are never candidates

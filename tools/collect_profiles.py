@@ -63,6 +63,13 @@ if not pmc_only:
     kernel_stats("kt_stress", tag + "_stress_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload stress --no-cpu-baseline --steps 50")
     kernel_stats("kt_pairs128", tag + "_pairs128_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairs128 --no-cpu-baseline --steps 50")
     kernel_stats("kt_consumers", tag + "_consumers_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_f1.py 3")
+    kernel_stats("kt_pairlist", tag + "_pairlist_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairlist --no-cpu-baseline --steps 50")
+    for kind in ("kitti", "world"):
+        f = os.path.join(src, "f1_phases_%s.log" % kind)
+        if os.path.exists(f):
+            with open(os.path.join(dst, tag + "_f1_phases_%s.txt" % kind), "w") as o:
+                o.write("# python tools/f1_phases.py %s  (sgpr_f1_max on a KITTI-00-sized matrix)\n" % kind)
+                o.write("".join(l for l in open(f) if "amdgpu.ids" not in l))
     if os.path.exists(os.path.join(src, "consumers.log")):
         with open(os.path.join(dst, tag + "_consumers.txt"), "w") as o:
             o.write("# python tools/run_f1.py 10 check  (KITTI-00-sized matrix of the bench, device F1-max / ROC area)\n")
@@ -70,7 +77,7 @@ if not pmc_only:
     cons = {}
     for nm in ("sq_consumers", "FETCH_SIZE_consumers", "WRITE_SIZE_consumers"):
         for kname, d in pmc(nm).items():
-            if "pair_" in kname or "slab" in kname:
+            if "pair_" in kname or "slab" in kname or "f1_" in kname:
                 cons.setdefault(kname, {}).update(d)
     if cons:
         with open(os.path.join(dst, tag + "_consumers_pmc.txt"), "w") as o:
@@ -81,7 +88,8 @@ if not pmc_only:
         print(open(os.path.join(dst, tag + "_consumers_pmc.txt")).read())
     for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
                       ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
-                      ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json")):
+                      ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json"),
+                      ("bench_pairlist.json", "_pairlist_bench.json")):
         bench_line(name, tag + out)
 
 hbm = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python "

@@ -5,6 +5,7 @@
 #   stress / pairs128 (BASELINE configs 5 / 2): bench line, kernel stats, HBM + LDS counters
 #   kitti5seq (config 4) and a 2-rank gloo run of the N > 1 path on one GPU: bench lines
 #   the matrix consumers (device F1-max / ROC area): wall times and kernel stats
+#   pairlist (the reference's evaluation lists): bench line + kernel stats; sgpr_f1_max per call + plan-kernel phases
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
@@ -26,6 +27,9 @@ for w in stress pairs128; do
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_$w -- python $R/bench.py --workload $w --no-cpu-baseline --steps 50 > $O/kt_$w.log 2>&1 </dev/null
 done
 timeout 300 python $R/bench.py --workload kitti5seq --no-cpu-baseline --steps 50 > $O/bench_kitti5seq.json 2> $O/bench_kitti5seq.err </dev/null
+# the reference's own loop shape: its evaluation pair lists (index-pair fixture), embed once + grouped tail, with a CPU baseline
+timeout 300 python $R/bench.py --workload pairlist --steps 100 > $O/bench_pairlist.json 2> $O/bench_pairlist.err </dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_pairlist -- python $R/bench.py --workload pairlist --no-cpu-baseline --steps 50 > $O/kt_pairlist.log 2>&1 </dev/null
 SGPR_BENCH_BACKEND=gloo timeout 300 python $R/bench.py --gpus 2 --steps 50 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err </dev/null
 python - <<PY || { echo "REFRESH FAILED: bench line without roofline.traffic (PMC profile and sources differ)"; exit 1; }
 import json
@@ -34,6 +38,8 @@ assert r["roofline"]["traffic"] is not None and r["roofline"].get("issue"), r["r
 print("bench line carries traffic", r["roofline"]["traffic"], "and issue", r["roofline"]["issue"]["frac"])
 PY
 timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
+timeout 200 python $R/tools/f1_phases.py kitti > $O/f1_phases_kitti.log 2>&1 </dev/null
+timeout 200 python $R/tools/f1_phases.py world > $O/f1_phases_world.log 2>&1 </dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_consumers -- python $R/tools/run_f1.py 3 > $O/kt_consumers.log 2>&1 </dev/null
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O -o sq_consumers -- python $R/tools/run_f1.py 1 > $O/sq_consumers.log 2>&1 </dev/null
 for c in FETCH_SIZE WRITE_SIZE; do timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o ${c}_consumers -- python $R/tools/run_f1.py 1 > $O/${c}_consumers.log 2>&1 </dev/null; done
