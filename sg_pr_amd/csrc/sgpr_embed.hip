@@ -1508,8 +1508,9 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             group_sync<WAVE>();
         }
         const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
+        const int lsh = cout == 64 ? 4 : 3;                                // (a shift, not an integer division by lpr)
         for (int t = tid; t < 16 * lpr; t += NT) {
-            const int l = t / lpr, c4 = (t & (lpr - 1)) * 4;
+            const int l = t >> lsh, c4 = (t & (lpr - 1)) * 4;
             int mask = vmask[l];                                           // a few labels per row: walk the set bits
             float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             while (mask) {
@@ -1986,8 +1987,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         // ---- gather-max over the k neighbours: cout/4 lanes per row, 4 channels (16 B) per lane
         {
             const int lpr = cout >> 2;                   // lanes per row: 16 or 8
-            const int rpw = 64 / lpr;                    // rows per wave-iteration: 4 or 8
-            const int c4 = (lane & (lpr - 1)) * 4, sub = lane / lpr;
+            const int lsh = cout == 64 ? 4 : 3;          // log2(lpr): shifts, not integer divisions (a division by a run-time
+            const int rpw = 64 >> lsh;                   //   value is a ~30-instruction sequence: -2 % of the launch)
+            const int c4 = (lane & (lpr - 1)) * 4, sub = lane >> lsh;
             const bool want_norm = (L != 2 && L != 5);
             float* dbg = dbg_layers ? dbg_layers + ((size_t)g * 6 + Ldump) * NS * 64 : nullptr;
             const int rstep = NW * rpw;
@@ -2055,7 +2057,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             // rows of the skipped all-padding groups: zero planes (finite operands for the next layer's matrix phases)
             if (L != 2 && !(skip & 8)) {
                 constexpr int QW = (FMT == FMT_BF3 ? 384 : 256) / 16;        // 16-byte pieces per row
-                const int nq = (N + rpw - 1) / rpw * rpw;
+                const int nq = (N + rpw - 1) & ~(rpw - 1);
                 for (int e = tid; e < (NP - nq) * QW; e += NT)
                     *reinterpret_cast<uint4*>(X + (nq + e / QW) * XROW + (e % QW) * 16) = make_uint4(0u, 0u, 0u, 0u);
             }
