@@ -68,6 +68,41 @@ int main(int argc, char** argv) {
 
     float* score = (float*)malloc((size_t)G * G * 4);
     CHECK_HIP(hipMemcpy(score, d_score, (size_t)G * G * 4, hipMemcpyDeviceToHost));
+
+    /* the reference's own loop shape (eval_batch.py:30-36): a pair LIST, grouped by row graph once on the host
+     * (sgpr_pair_plan) and scored by sgpr_score_pair_list - every listed score must be the dense matrix's entry, bit for bit */
+    const int64_t P = (int64_t)G * 5;
+    int32_t* i1 = (int32_t*)malloc((size_t)P * 4);
+    int32_t* i2 = (int32_t*)malloc((size_t)P * 4);
+    uint32_t lcg = 12345u;
+    for (int64_t p = 0; p < P; ++p) {
+        lcg = lcg * 1664525u + 1013904223u;
+        i1[p] = (int32_t)((lcg >> 8) % (uint32_t)G);
+        lcg = lcg * 1664525u + 1013904223u;
+        i2[p] = (int32_t)((lcg >> 8) % (uint32_t)G);
+    }
+    const size_t cap = sgpr_pair_plan_ints(P, G);
+    int32_t* plan = (int32_t*)malloc(cap * 4 + 4);
+    size_t used = 0;
+    int32_t n_rows = 0, n_items = 0;
+    CHECK_SGPR(sgpr_pair_plan(i1, i2, P, G, G, plan, cap, &used, &n_rows, &n_items));
+    int32_t* d_plan;
+    float* d_list;
+    void* d_ws3 = NULL;
+    const size_t ws3 = sgpr_score_pair_list_workspace_bytes(h, n_rows, G);
+    CHECK_HIP(hipMalloc((void**)&d_plan, used * 4 + 4));
+    CHECK_HIP(hipMalloc((void**)&d_list, (size_t)P * 4 + 4));
+    if (ws3) CHECK_HIP(hipMalloc(&d_ws3, ws3));
+    CHECK_HIP(hipMemcpy(d_plan, plan, used * 4, hipMemcpyHostToDevice));
+    CHECK_SGPR(sgpr_score_pair_list(h, d_pooled, G, d_pooled, G, d_plan, n_rows, n_items, P, d_list, d_ws3, ws3, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    float* listed = (float*)malloc((size_t)P * 4 + 4);
+    CHECK_HIP(hipMemcpy(listed, d_list, (size_t)P * 4, hipMemcpyDeviceToHost));
+    int64_t differ = 0;
+    for (int64_t p = 0; p < P; ++p) differ += listed[p] != score[(size_t)i1[p] * G + i2[p]];
+    printf("pair list: %lld pairs over %d row graphs in %d work items, %lld differ from the dense matrix\n", (long long)P, n_rows,
+           n_items, (long long)differ);
+    if (differ) return 4;
     FILE* out = fopen(argv[3], "wb");
     if (!out || fwrite(score, 4, (size_t)G * G, out) != (size_t)G * G) { fprintf(stderr, "cannot write %s\n", argv[3]); return 1; }
     fclose(out);

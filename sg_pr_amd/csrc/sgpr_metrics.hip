@@ -704,7 +704,24 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     }
     constexpr int PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;             // 24 bins per thread
     static_assert(PER % 2 == 0, "bins per thread");
-    // this thread's negatives: 12 independent 16-byte loads
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) posb[i] = 0u;
+    for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
+    if (tid == 0) ndist = nv = 0u;
+    __syncthreads();
+    // (keeping a thread's ~47 positives in registers for the second look at them was measured: the unrolled body spills,
+    // 14 -> 63 us; both passes read the list from L2 with sixteen / eight independent loads in flight)
+    for (long long i0 = 0; i0 < na; i0 += 16 * F1_THREADS) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const long long i = i0 + u * F1_THREADS + tid;
+            x[u] = i < na ? pos[i] : -1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (x[u] >= 0.f) atomicAdd(&posb[f1_key(x[u])], 1u);
+    }
+    // this thread's negatives: 12 independent 16-byte loads (requested only now: 48 registers the list passes need)
     unsigned long long ng[PER];
 #pragma unroll
     for (int q = 0; q < PER; q += 2) {
@@ -713,23 +730,6 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         if (b + 1 < F1_NBP) x = *reinterpret_cast<const ulonglong2*>(negb + b);
         ng[q] = b < F1_NB ? x.x : 0ull;
         ng[q + 1] = b + 1 < F1_NB ? x.y : 0ull;
-    }
-    for (int i = tid; i < F1_NBP; i += F1_THREADS) posb[i] = 0u;
-    for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
-    if (tid == 0) ndist = nv = 0u;
-    __syncthreads();
-    // (keeping a thread's ~47 positives in registers for the second look at them was measured: the unrolled body spills,
-    // 14 -> 63 us; both passes read the list from L2 with eight independent loads in flight)
-    for (long long i0 = 0; i0 < na; i0 += 8 * F1_THREADS) {
-        float x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long long i = i0 + u * F1_THREADS + tid;
-            x[u] = i < na ? pos[i] : -1.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (x[u] >= 0.f) atomicAdd(&posb[f1_key(x[u])], 1u);
     }
     __syncthreads();
     F1_STAMP(1)
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     const float Pf = (float)tot[0];
     auto g32 = [&](unsigned long long tp, unsigned long long fp) {
         const float a = (float)tp;
-        return a > 0.f ? a / (a + (float)fp + Pf) : 0.f;
+        return a > 0.f ? a * __builtin_amdgcn_rcpf(a + (float)fp + Pf) : 0.f;     // (1 ulp: the margin below is 1e-5)
     };
     float gbest = 0.f;
     {
@@ -829,15 +829,15 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
             hslot = (hslot + 1) & (F1_HASH - 1);
         }
     };
-    for (long long i0 = 0; i0 < na; i0 += 8 * F1_THREADS) {
-        float x[8];
+    for (long long i0 = 0; i0 < na; i0 += 16 * F1_THREADS) {
+        float x[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const long long i = i0 + u * F1_THREADS + tid;
             x[u] = i < na ? pos[i] : -1.f;
         }
-#pragma unroll 1
-        for (int u = 0; u < 8; ++u) insert(x[u]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) insert(x[u]);
     }
     __syncthreads();
     F1_STAMP(3)

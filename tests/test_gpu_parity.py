@@ -611,6 +611,7 @@ def test_c_demo_matches_engine(tmp_path, eng, ckpt_path):
     out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "g.bin"), str(tmp_path / "s.f32")],
                          check=True, capture_output=True, text=True).stdout
     assert "scored 37 x 37" in out
+    assert "pair list: 185 pairs" in out and ", 0 differ from the dense matrix" in out        # sgpr_pair_plan + sgpr_score_pair_list
     got = np.fromfile(tmp_path / "s.f32", dtype=np.float32).reshape(37, 37)
     pooled = eng.embed(centers, labels, 10)[0]
     np.testing.assert_array_equal(got, eng.score_all_pairs(pooled, pooled).cpu().numpy())
