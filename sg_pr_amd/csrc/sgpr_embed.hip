@@ -449,6 +449,10 @@ __device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f
 // instruction - a v_max x, x behind each LDS read and each DPP move: 78 such instructions in the lean instance, most of
 // them in the selection's merges.  Operands come from LDS reads, DPP moves or other minima / maxima, never straight
 // from an MFMA (whose wait states the compiler would not insert in front of inline asm).
+#ifndef SGPR_EXP_DOUBLE
+#define SGPR_EXP_DOUBLE 0     // timing experiments only (tools/build_variant.sh): run an idempotent phase TWICE - the launch's time
+#endif                        // difference is what the phase costs, with valid results (1 counting selection, 2 selection, 4 Gram
+                              // tiles, 8 super-node branch, 16 coordinate-layer keys)
 #ifndef SGPR_ASM_MINMAX
 #define SGPR_ASM_MINMAX 1
 #endif
@@ -1499,6 +1503,15 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             const unsigned okey = ord_u32(key);                            // (-0 == +0; +inf for labels the graph lacks)
             before = count_before<1>(okey, (unsigned)cj | ((unsigned)j << 16),
                                      ((unsigned long long)okey << 32) | ((unsigned)j << 16), before);
+#if SGPR_EXP_DOUBLE & 1
+            {
+                unsigned ok2 = okey;
+                asm volatile("" : "+v"(ok2));
+                const int b2 = count_before<1>(ok2, (unsigned)cj | ((unsigned)j << 16),
+                                               ((unsigned long long)ok2 << 32) | ((unsigned)j << 16), 0);
+                before = min(before, b2);
+            }
+#endif
             const unsigned long long inc = __ballot(cj > 0 && before < k0);
             if (j == 0) vmask[l] = (int)((inc >> (lane & 48)) & 0xffffull);
         }
@@ -1867,6 +1880,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 }
                 __syncthreads();
                 supernode_branch<FMT, LEAN, false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
+#if SGPR_EXP_DOUBLE & 8
+                __syncthreads();
+                supernode_branch<FMT, LEAN, false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
+#endif
             }
             L0 = 3;
             if (LEAN != 0 && DBG == 0 && role == 1) {
@@ -1943,10 +1960,18 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             if (skip & 4) {
             } else if (L == 3) {
                 gram_xyz_direct<FMT>(X, D, p.pitchD, N, NP, rc0, rows_chunk, tid, NT);
+#if SGPR_EXP_DOUBLE & 16
+                __syncthreads();
+                gram_xyz_direct<FMT>(X, D, p.pitchD, N, NP, rc0, rows_chunk, tid, NT);
+#endif
             } else if (p.overlap) {
-                if (k64)
+                if (k64) {
                     gram_tiles_sym<4, FMT, !LEAN, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
-                else
+#if SGPR_EXP_DOUBLE & 4
+                    __syncthreads();
+                    gram_tiles_sym<4, FMT, !LEAN, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
+#endif
+                } else
                     gram_tiles_sym<1, FMT, !LEAN, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, xx, D, p.pitchD, N, nrt, wave);
             } else {
                 const int nti = rows_chunk >> 4;
@@ -1968,6 +1993,12 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     unsigned long long* const sp = (DBG == 2 && prof_buf && (skip & 128)) ? prof_buf + 8 : nullptr;
                     if (KP == 16 && k == 10)
                         select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+#if SGPR_EXP_DOUBLE & 2
+                    if (KP == 16 && k == 10) {
+                        __syncthreads();
+                        select_phase<KP, LEAN ? 16 : CAP, (KP == 16 ? 10 : KP), (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
+                    }
+#endif
                     else if (KP == 32 && k == 20)
                         select_phase<KP, LEAN ? 16 : CAP, (KP == 32 ? 20 : KP), (LEAN != 0 ? 4 : 0)>(p, N, NP, P, seg, k, one_rep, D, rc0, rows_chunk, nbr, dbg_knn, sp);
                     else
