@@ -934,6 +934,211 @@ __device__ __forceinline__ void select_phase(const EmbedPlan& p, int n, int np, 
 #undef SEL_STAMP
 }
 
+// ------------------------------------------------------------------ lean production instances: keys straight from the accumulators
+// "Owned rows": wave w owns the 16 rows of row tile w.  It computes the Gram tiles of its rows against EVERY candidate
+// tile with the candidates as the A operand and its rows as the B operand, so that the accumulator of lane (l15, lq)
+// holds the keys of row 16 w + l15 for candidates 16 tj + 4 lq + r (r = 0..3): after nrt tiles the lane has the <= 16
+// candidates the selection works on IN REGISTERS - no key matrix in LDS (8 stores + 4 loads per lane and layer), no
+// barrier between the Gram phase and the selection, no upper-triangle bookkeeping; the matrix cores (9 % busy) do
+// nrt^2 tiles instead of nrt (nrt + 1) / 2.  The four lanes of a row sit 16 lanes apart, so the butterfly merges
+// exchange through ds_bpermute (the LDS pipe, not the vector ALU this kernel is short of) instead of DPP.
+// Bit-identical keys: a key of the resident path comes from tile16(a = lower tile, b = higher tile), whose correction
+// chain adds lo(a).hi(b) before hi(a).lo(b); here the operands are (candidates, rows), so a candidate tile at or above
+// the row tile takes the chain in the other order (tile16_swapped), one below it the standard one.
+#ifndef SGPR_OWNED_SELECT
+#define SGPR_OWNED_SELECT 1
+#endif
+
+template <int FMT>
+__device__ __forceinline__ f32x4 tile16_swapped(const FragT<FMT> (&a)[2], const FragT<FMT> (&b)[2]) {
+    static_assert(FMT == FMT_H2, "lean instances run on the f16 planes");
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        lo = mfma_h(a[st].h, b[st].l, lo);           // = lo(row) . hi(candidate) of tile16(rows, candidates) ...
+        lo = mfma_h(a[st].l, b[st].h, lo);           // ... then hi(row) . lo(candidate)
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) hi = mfma_h(a[st].h, b[st].h, hi);
+    return hi + lo;
+}
+
+// candidate index of bit u of a lane's mask: tile u >> 2, lane group lq, element u & 3
+__device__ __forceinline__ int owned_cand(int u, int lq) { return 16 * (u >> 2) + 4 * lq + (u & 3); }
+
+__device__ __forceinline__ void emit_owned(unsigned take, int lq, int pitchA, unsigned short* __restrict__ out, int& pos) {
+    while (take) {
+        const int u = __ffs(take) - 1;
+        take &= take - 1;
+        out[pos++] = (unsigned short)(owned_cand(u, lq) * pitchA);
+    }
+}
+
+// coord: the coordinate layer (keys = the reference's fp32 arithmetic, gram_xyz_direct's operations on the same operands);
+// a run-time flag, so that the sorting networks behind the keys exist once in the instance (instruction cache)
+template <int FMT>
+__device__ __forceinline__ void select_owned(const EmbedPlan& p, const int n, const int nrt, const bool one_rep,
+                                             const unsigned char* __restrict__ X, const float* __restrict__ xx,
+                                             unsigned short* __restrict__ nbr, const int wave, const bool coord) {
+    constexpr int K = 10, KP = 16, XR = xrow<FMT>();
+    if (wave >= nrt) return;                         // no rows of the graph in this wave's tile
+    const int lane = phase_tid() & 63, l15 = lane & 15, lq = lane >> 4;
+    const int i = 16 * wave + l15;
+    const bool active = i < n;
+    // the representative of >= K identical trailing slots (select_phase): its key, picked up while its tile goes by
+    const int jr = n - 1, tr = jr >> 4, rr = jr & 3, lqr = (jr >> 2) & 3;
+    float d[16], krep_part = 0.f;
+    if (coord) {
+        const float4 ci = *reinterpret_cast<const float4*>(X + i * XR + (XR - 16));
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            if (tj < nrt) {                          // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 cj = *reinterpret_cast<const float4*>(X + (16 * tj + 4 * lq + r) * XR + (XR - 16));
+                    const float dot = fmaf(ci.z, cj.z, fmaf(ci.y, cj.y, __fmul_rn(ci.x, cj.x)));
+                    const float t = fmaf(2.f, dot, -cj.w);
+                    key[r] = __fsub_rn(ci.w, t);     // (+inf for an empty slot: its |x|^2 is)
+                }
+                if (tj == tr) krep_part = rr == 0 ? key[0] : (rr == 1 ? key[1] : (rr == 2 ? key[2] : key[3]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[4 * tj + r] = key[r];
+        }
+    } else {
+        FragT<FMT> b[2];
+        xload<4, FMT>(X + i * XR, lq, b);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            if (tj < nrt) {                          // wave-uniform
+                FragT<FMT> a[2];
+                xload<4, FMT>(X + (16 * tj + l15) * XR, lq, a);
+                const f32x4 g = tj >= wave ? tile16_swapped<FMT>(a, b) : tile16<4, FMT>(a, b);
+                const int jb = 16 * tj + 4 * lq;
+                const float4 xj = *reinterpret_cast<const float4*>(xx + jb);
+                key[0] = fmaf(-2.f, g[0], jb + 0 < n ? xj.x : INFINITY);
+                key[1] = fmaf(-2.f, g[1], jb + 1 < n ? xj.y : INFINITY);
+                key[2] = fmaf(-2.f, g[2], jb + 2 < n ? xj.z : INFINITY);
+                key[3] = fmaf(-2.f, g[3], jb + 3 < n ? xj.w : INFINITY);
+                if (tj == tr) krep_part = rr == 0 ? key[0] : (rr == 1 ? key[1] : (rr == 2 ? key[2] : key[3]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[4 * tj + r] = key[r];
+        }
+    }
+    // ---- this lane's K smallest (ascending), then the butterfly over the row's four lanes (16 and 32 lanes away)
+    float L[KP];
+    list_from_32<KP, K, 0, 16>(d, 4 * nrt, L);
+    {
+        float o[KP];
+#pragma unroll
+        for (int s = 0; s < KP; ++s) o[s] = (KP - 1 - s < K) ? __shfl_xor(L[KP - 1 - s], 16) : INFINITY;
+#pragma unroll
+        for (int s = 0; s < KP; ++s) L[s] = s < K ? ((KP - 1 - s < K) ? kmin(L[s], o[s]) : L[s]) : o[s];
+        bitonic_merge<KP>(L);
+    }
+    float tau;                                       // the K-th smallest key of the row
+    {
+        float mn[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) mn[s] = kmin(L[s], __shfl_xor(L[K - 1 - s], 32));
+        tau = max3(max3(max3(mn[0], mn[1], mn[2]), max3(mn[3], mn[4], mn[5]), max3(mn[6], mn[7], mn[8])), mn[9], mn[9]);
+    }
+    unsigned short* out = nbr + i * p.kpitch;
+    bool dup_cut = false;
+    if (one_rep) {
+        const float krep = __shfl(krep_part, l15 + 16 * lqr);
+        if (krep < tau) {
+            tau = krep;
+            dup_cut = true;
+        }
+        if (active) {
+            const unsigned short rep = (unsigned short)(jr * p.pitchA);
+            for (int q = lq; q < K; q += 4) out[q] = rep;
+        }
+    }
+    // ---- the common case: exactly K keys at or below tau (or the representative's cut) -> one mask, a prefix, emission
+    unsigned gt = 0u;
+#pragma unroll
+    for (int u = 15; u >= 0; --u) gt = __builtin_amdgcn_alignbit(gt, __float_as_uint(tau - d[u]), 31);
+    const unsigned le = ~gt & 0xffffu;
+    const int n_le = __popc(le);
+    int incl = n_le;                                 // inclusive prefix over the row's lanes (lq order)
+    {
+        const int t1 = __shfl_up(incl, 16);
+        incl += lq >= 1 ? t1 : 0;
+        const int t2 = __shfl_up(incl, 32);
+        incl += lq >= 2 ? t2 : 0;
+    }
+    const int total_le = __shfl(incl, 48 + l15);
+    if (__ballot(active && !(dup_cut || total_le == K)) == 0ull) {
+        if (active) {
+            int pos = incl - n_le;
+            emit_owned(le, lq, p.pitchA, out, pos);
+        }
+        return;
+    }
+    // ---- ties across the cut (identical nodes, kept padding copies): the whole wave takes the general path.  Everything
+    //      below tau, then the first T candidates AT tau in candidate-index order = (tile, lane group, element) order
+    unsigned lt = 0u, gtm = 0u;
+#pragma unroll
+    for (int u = 15; u >= 0; --u) {
+        lt = __builtin_amdgcn_alignbit(lt, __float_as_uint(d[u] - tau), 31);
+        gtm = __builtin_amdgcn_alignbit(gtm, __float_as_uint(tau - d[u]), 31);
+    }
+    lt &= 0xffffu;
+    unsigned eq = ~(lt | gtm) & 0xffffu;             // (inf - inf is a positive NaN: an empty slot at an infinite tau is "equal")
+    if (dup_cut) {                                   // everything at or below the representative's key, no tie limit
+        lt |= eq;
+        eq = 0u;
+    }
+    const int n_less = __popc(lt);
+    int less_incl = n_less;
+    {
+        const int t1 = __shfl_up(less_incl, 16);
+        less_incl += lq >= 1 ? t1 : 0;
+        const int t2 = __shfl_up(less_incl, 32);
+        less_incl += lq >= 2 ? t2 : 0;
+    }
+    const int total_less = __shfl(less_incl, 48 + l15);
+    const int T = dup_cut ? 0 : K - total_less;      // ties to accept
+    // ties per tile of every lane of the row: one byte per tile
+    const unsigned mine = (unsigned)__popc(eq & 0xfu) | ((unsigned)__popc(eq & 0xf0u) << 8) |
+                          ((unsigned)__popc(eq & 0xf00u) << 16) | ((unsigned)__popc(eq & 0xf000u) << 24);
+    unsigned pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pk[q] = (unsigned)__shfl((int)mine, 16 * q + l15);
+    if (active) {
+        int pos = less_incl - n_less;
+        emit_owned(lt, lq, p.pitchA, out, pos);
+        int before = 0;                              // ties in the tiles before the current one
+#pragma unroll 1
+        for (int tj = 0; tj < 4; ++tj) {             // (rolled: this path is rare, the instance's code size is not)
+            int ahead = 0, own = 0, all = 0;         // ties of this tile in the lane groups before mine / in mine / in all four
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = (int)((pk[q] >> (8 * tj)) & 0xffu);
+                all += e;
+                ahead += q < lq ? e : 0;
+                own = q == lq ? e : own;
+            }
+            const int start = before + ahead;
+            const int take_n = max(0, min(own, T - start));
+            unsigned bits = (eq >> (4 * tj)) & 0xfu, keep = 0u;
+            for (int c = 0; c < take_n; ++c) {
+                const unsigned low = bits & (0u - bits);
+                keep |= low;
+                bits ^= low;
+            }
+            int tpos = total_less + min(start, T);
+            emit_owned(keep << (4 * tj), lq, p.pitchA, out, tpos);
+            before += all;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ selection by value bisection (wave per row)
 // wave64 min / max of a u32 (result uniform)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
@@ -1955,7 +2160,14 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         int32_t* dbg_knn = dbg_knn_all ? dbg_knn_all + ((size_t)g * 6 + Ldump) * NS * p.k : nullptr;
         // ---- kNN keys (Gram on MFMA) -> selection, one chunk of rows at a time (a single chunk, upper-triangular
         //      tiles mirrored, when the whole key matrix is resident)
-        for (int rc0 = 0; rc0 < NP; rc0 += p.RC) {
+        constexpr bool kOwned = SGPR_OWNED_SELECT != 0 && LEAN != 0 && DBG == 0 && FMT == FMT_H2 && KC == 10;
+        if constexpr (kOwned) {
+            // lean production instances: keys in registers, selection right behind them, no barrier until the GEMMs' own
+            // (A is written only by the GEMM phase and nothing reads it here; b replaces X behind gemm_cols' barrier, which
+            // every wave reaches after its selection)
+            select_owned<FMT>(p, N, nrt, one_rep, X, xx, nbr, wave, L == 3);
+        }
+        for (int rc0 = 0; !kOwned && rc0 < NP; rc0 += p.RC) {
             const int rows_chunk = min(p.RC, NP - rc0);
             if (skip & 4) {
             } else if (L == 3) {
