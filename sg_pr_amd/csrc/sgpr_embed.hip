@@ -109,6 +109,9 @@ __host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_pa
     p.offA = p.offIdx + rows * 16 * 2;
     p.offD = p.offA;
     p.lds_bytes = p.offA + rows * 68 * 4;
+#if SGPR_EXP_LDS32      // timing experiment only (results invalid): the 64-row layout cut to 32 KB = five workgroups per CU
+    if (p.lds_bytes > 32768) p.lds_bytes = 32768;
+#endif
 }
 
 static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_park = false, int min_nt = 0) {
@@ -2465,7 +2468,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
 }
 
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
-__global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? (LEAN == 48 ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
+#ifndef SGPR_EXP_LDS32
+#define SGPR_EXP_LDS32 0
+#endif
+__global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN == 48 || SGPR_EXP_LDS32) ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
     // (ONE call site: two inlined copies of embed_graph would double the kernel's footprint in the instruction cache)
     int slot = (int)blockIdx.x, role = 0;
     if constexpr (LEAN != 0 && DBG == 0) {
