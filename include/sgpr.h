@@ -39,7 +39,7 @@ extern "C" {
 enum {
     SGPR_OK = 0,
     SGPR_E_INVALID = -1,   /* NULL pointer / negative count                                   */
-    SGPR_E_DIMS = -2,      /* architecture not supported by the kernels (see sgpr_dims)       */
+    SGPR_E_DIMS = -2,      /* architecture larger than the kernels are built for (see sgpr_dims) */
     SGPR_E_NODES = -3,     /* node_num outside [k, SGPR_MAX_NODES], or a graph exceeded node_cap      */
     SGPR_E_K = -4,         /* K outside [1, SGPR_MAX_K] or K > node_num                        */
     SGPR_E_LABEL = -5,     /* a label outside [-1, num_labels) was seen (sgpr_check_status)    */
@@ -56,7 +56,12 @@ typedef struct sgpr_handle sgpr_handle;
 /* Architecture hyper-parameters = the `arch:` block of the reference's
  * config.yml (parser_sg.py:12-18) + number_of_labels (sg_net.py:201-203).
  * The HIP kernels are written for the architecture of every shipped
- * checkpoint: {12, 64, 64, 32, 16, 16}; anything else -> SGPR_E_DIMS. */
+ * checkpoint, {12, 64, 64, 32, 16, 16}, and serve every architecture that is
+ * no larger in any of the six: sgpr_create embeds its tensors into the built
+ * shapes with zero weights for the channels it does not have, which is exact
+ * (device buffers keep the built widths: pooled [G, 32], emb [G, N, 32], the
+ * missing channels are 0; dense features are [G, 3 + num_labels, N]).  A
+ * larger architecture -> SGPR_E_DIMS. */
 typedef struct sgpr_dims {
     int32_t num_labels;
     int32_t filters_1;

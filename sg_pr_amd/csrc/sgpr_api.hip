@@ -20,8 +20,17 @@ int hip_fail(hipError_t e, const char* what) {
     return SGPR_E_HIP;
 }
 
+// The kernels are written for {12, 64, 64, 32, 16, 16}.  A SMALLER architecture is served exactly by the same kernels:
+// its tensors are embedded into the built shapes with zero weights (and neutral BatchNorm statistics) for the channels
+// it does not have - a channel whose weights are all zero stays 0 through conv / BN / LeakyReLU, adds 0 to every
+// distance, every sum and every maximum partner, and a zero tensor / bottleneck neuron contributes 0 to the score.
 static bool dims_supported(const sgpr_dims* d) {
-    return d && d->num_labels == kLabels && d->filters_1 == kF1 && d->filters_2 == kF2 && d->filters_3 == kF3 &&
+    return d && d->num_labels >= 1 && d->num_labels <= kLabels && d->filters_1 >= 1 && d->filters_1 <= kF1 &&
+           d->filters_2 >= 1 && d->filters_2 <= kF2 && d->filters_3 >= 1 && d->filters_3 <= kF3 &&
+           d->tensor_neurons >= 1 && d->tensor_neurons <= kT && d->bottle_neck_neurons >= 1 && d->bottle_neck_neurons <= kB;
+}
+static bool dims_full(const sgpr_dims* d) {
+    return d->num_labels == kLabels && d->filters_1 == kF1 && d->filters_2 == kF2 && d->filters_3 == kF3 &&
            d->tensor_neurons == kT && d->bottle_neck_neurons == kB;
 }
 
@@ -38,6 +47,67 @@ static void block_shapes(const sgpr_dims* d, BlockShape out[7]) {
     out[4] = {d->filters_3, 2 * d->filters_2};
     out[5] = {d->filters_3, 2 * d->filters_2};
     out[6] = {d->filters_3, 2 * d->filters_3};
+}
+
+static size_t weights_count(const sgpr_dims* d);
+// the blob of a smaller architecture `d` scattered into the built architecture's blob layout
+static std::vector<float> pad_blob(const float* src, const sgpr_dims* d) {
+    const sgpr_dims full = {kLabels, kF1, kF2, kF3, kT, kB};
+    BlockShape bs[7], bf[7];
+    block_shapes(d, bs);
+    block_shapes(&full, bf);
+    std::vector<float> out(weights_count(&full), 0.f);
+    float* dst = out.data();
+    for (int b = 0; b < 7; ++b) {
+        const int co = bs[b].cout, ci = bs[b].cin2 / 2, CO = bf[b].cout, CI = bf[b].cin2 / 2;
+        // weight [cout][2 cin]: the (x_j - x_i) half and the x_i half keep their places in the wider halves (conv_end:
+        // the xyz3 half and the sem3 half of cat(xyz3, sem3))
+        for (int c = 0; c < co; ++c)
+            for (int i = 0; i < ci; ++i) {
+                dst[(size_t)c * 2 * CI + i] = src[(size_t)c * 2 * ci + i];
+                dst[(size_t)c * 2 * CI + CI + i] = src[(size_t)c * 2 * ci + ci + i];
+            }
+        src += (size_t)co * 2 * ci;
+        dst += (size_t)CO * 2 * CI;
+        const float neutral[4] = {1.f, 0.f, 0.f, 1.f};          // gamma, beta, running_mean, running_var
+        for (int v = 0; v < 4; ++v) {
+            for (int c = 0; c < CO; ++c) dst[c] = c < co ? src[c] : neutral[v];
+            src += co;
+            dst += CO;
+        }
+    }
+    const int f = d->filters_3, t = d->tensor_neurons, bn = d->bottle_neck_neurons;
+    for (int i = 0; i < f; ++i)                                  // attention.weight_matrix [F3][F3]
+        for (int j = 0; j < f; ++j) dst[(size_t)i * kF3 + j] = src[(size_t)i * f + j];
+    src += (size_t)f * f;
+    dst += (size_t)kF3 * kF3;
+    for (int i = 0; i < f; ++i)                                  // tensor_network.weight_matrix [F3][F3][T]
+        for (int j = 0; j < f; ++j)
+            for (int q = 0; q < t; ++q) dst[((size_t)i * kF3 + j) * kT + q] = src[((size_t)i * f + j) * t + q];
+    src += (size_t)f * f * t;
+    dst += (size_t)kF3 * kF3 * kT;
+    for (int q = 0; q < t; ++q)                                  // weight_matrix_block [T][2 F3]
+        for (int j = 0; j < f; ++j) {
+            dst[(size_t)q * 2 * kF3 + j] = src[(size_t)q * 2 * f + j];
+            dst[(size_t)q * 2 * kF3 + kF3 + j] = src[(size_t)q * 2 * f + f + j];
+        }
+    src += (size_t)t * 2 * f;
+    dst += (size_t)kT * 2 * kF3;
+    for (int q = 0; q < t; ++q) dst[q] = src[q];                 // tensor_network.bias [T]
+    src += t;
+    dst += kT;
+    for (int o = 0; o < bn; ++o)                                 // fully_connected_first.weight [B][T]
+        for (int q = 0; q < t; ++q) dst[(size_t)o * kT + q] = src[(size_t)o * t + q];
+    src += (size_t)bn * t;
+    dst += (size_t)kB * kT;
+    for (int o = 0; o < bn; ++o) dst[o] = src[o];                // fully_connected_first.bias [B]
+    src += bn;
+    dst += kB;
+    for (int o = 0; o < bn; ++o) dst[o] = src[o];                // scoring_layer.weight [1][B]
+    src += bn;
+    dst += kB;
+    dst[0] = src[0];                                             // scoring_layer.bias
+    return out;
 }
 
 static size_t weights_count(const sgpr_dims* d) {
@@ -92,13 +162,23 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         return SGPR_E_INVALID;
     }
     if (!dims_supported(dims)) {
-        set_error("sgpr_create: only the architecture {labels 12, filters 64/64/32, tensor 16, bottleneck 16} is built");
+        set_error("sgpr_create: the kernels are built for {labels 12, filters 64/64/32, tensor 16, bottleneck 16} and serve "
+                  "every architecture that is no larger in any of the six; this one is larger");
         return SGPR_E_DIMS;
     }
     if (n_floats != weights_count(dims)) {
         set_error("sgpr_create: weights blob has " + std::to_string(n_floats) + " floats, expected " +
                   std::to_string(weights_count(dims)));
         return SGPR_E_BLOB;
+    }
+    const sgpr_dims user_dims = *dims;
+    const sgpr_dims full_dims = {kLabels, kF1, kF2, kF3, kT, kB};
+    std::vector<float> padded;
+    if (!dims_full(dims)) {                  // a smaller architecture inside the built one (dims_supported)
+        padded = pad_blob(weights, dims);
+        weights = padded.data();
+        n_floats = padded.size();
+        dims = &full_dims;
     }
     BlockShape bs[7];
     block_shapes(dims, bs);
@@ -242,7 +322,7 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
     sgpr_handle* h = new sgpr_handle();
     memset(h, 0, sizeof(*h));
     h->device = device;
-    h->dims = *dims;
+    h->dims = user_dims;            // (what the caller loaded; the kernels run on the built shapes)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
@@ -424,6 +504,7 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     a.status = h->d_status;
     a.prof = h->dbg_prof;
     a.skip = h->dbg_skip;
+    a.num_labels = h->dims.num_labels;
     DeviceGuard guard(h->device);
     return launch_embed(h, plan, a, static_cast<hipStream_t>(stream));
 }
@@ -718,6 +799,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
     a.status = h->d_status;
     a.prof = h->dbg_prof;
     a.skip = h->dbg_skip;
+    a.num_labels = h->dims.num_labels;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d_att1 && d_att2 && d_att2 == d_att1 + (size_t)B * N) {

@@ -1931,13 +1931,14 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if (tid < NS) {
         if (kp.a.dense) {
             const bool second = kp.a.dense2 && g >= kp.a.g_split;
+            const int nl = kp.a.num_labels;               // (a smaller architecture's tensors have fewer label channels)
             const float* dn = (second ? kp.a.dense2 : kp.a.dense) +
-                              (size_t)(second ? g - kp.a.g_split : g) * (3 + kLabels) * NS + tid;
+                              (size_t)(second ? g - kp.a.g_split : g) * (3 + nl) * NS + tid;
             fx = dn[0];
             fy = dn[NS];
             fz = dn[2 * NS];
 #pragma unroll
-            for (int c = 0; c < kLabels; ++c) sem[c] = dn[(size_t)(3 + c) * NS];
+            for (int c = 0; c < kLabels; ++c) sem[c] = c < nl ? dn[(size_t)(3 + c) * NS] : 0.f;
             // the reference's own tensors (transfer_to_torch, sg_net.py:274-298) are one-hot rows / all-zero padding:
             // recover the label so that the super-node branch below applies; anything else runs the generic branch
             int ones = 0, zeros = 0, which = -1;
@@ -1969,7 +1970,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 fz = c3[2];
                 lab = kp.a.labels[(size_t)g * NS + tid];
             }
-            if (lab < -1 || lab >= kLabels) atomicOr(kp.a.status, 1);
+            if (lab < -1 || lab >= kp.a.num_labels) {
+                atomicOr(kp.a.status, 1);
+                lab = -1;                                 // (flagged; embedded like padding, never as another class)
+            }
             mylab = lab;
 #pragma unroll
             for (int c = 0; c < kLabels; ++c) sem[c] = (lab == c) ? 1.f : 0.f;

@@ -109,6 +109,8 @@ struct EmbedArgs {
     const int32_t* ids;     // optional [G] graph indices: workgroup b embeds graph ids[b] (sgpr_embed_ordered)
     const float* dense2;    // optional second dense tensor: graphs g >= g_split read dense2[g - g_split]
     int g_split;
+    int num_labels;         // label classes of the loaded checkpoint (<= kLabels): dense tensors have 3 + num_labels channels,
+                            // a packed label outside [-1, num_labels) is an error (the reference raises KeyError, sg_net.py:277)
     int G;
     float* pooled;
     float* att;

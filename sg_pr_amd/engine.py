@@ -212,6 +212,10 @@ class Engine:
                                "there is no CPU fallback")
         self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
         self.dims = dims if dims is not None else default_dims()
+        # The kernels run on the built shapes (32 pooled features, 12 label channels ...); a smaller architecture is served
+        # by zero-padding its tensors at sgpr_create.  Device buffers keep the built widths (pooled [G, 32]: the channels
+        # the checkpoint does not have are exactly 0); node embeddings are cut to filters_3 where they leave the engine.
+        self.f3 = int(self.dims.filters_3)
         if isinstance(state_dict, (np.ndarray, torch.Tensor)):          # already the flat fp32 blob (sg_pr_amd.ops)
             blob = np.ascontiguousarray(torch.as_tensor(state_dict).detach().cpu().numpy(), dtype=np.float32).ravel()
         else:
@@ -249,6 +253,10 @@ class Engine:
         if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
             t = t.to(device=self.device, dtype=dtype).contiguous()
         return t
+
+    def _cut(self, emb):
+        """node embeddings [.., 32] -> [.., filters_3] (a view; identity for the shipped architecture)"""
+        return emb if emb is None or self.f3 == F3 else emb[..., :self.f3]
 
     def _ws(self, nbytes):
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
@@ -343,33 +351,33 @@ class Engine:
             rc = self.lib.sgpr_embed_debug(self._h, _ptr(centers), _ptr(labels), g, n, k, _ptr(pooled), _ptr(att),
                                            _ptr(emb), _ptr(layers), _ptr(knn), _ptr(ws), ws_bytes, self._stream())
             self._check(rc)
-            return pooled, att, emb, layers, knn
+            return pooled, att, self._cut(emb), layers, knn
         if g == 0:
-            return pooled, att, emb
+            return pooled, att, self._cut(emb)
         if order is not None:
             order = self._dev(order, torch.int32, "order")
             rc = self.lib.sgpr_embed_ordered(self._h, _ptr(centers), _ptr(labels), g, n, int(node_cap), k, _ptr(order),
                                              order.numel(), _ptr(pooled), _ptr(att), _ptr(emb), _ptr(ws), ws_bytes,
                                              self._stream())
             self._check(rc)
-            return pooled, att, emb
+            return pooled, att, self._cut(emb)
         rc = self.lib.sgpr_embed_capped(self._h, _ptr(centers), _ptr(labels), g, n, int(node_cap), k, _ptr(pooled),
                                         _ptr(att), _ptr(emb), _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
-        return pooled, att, emb
+        return pooled, att, self._cut(emb)
 
     @staticmethod
-    def to_ragged(centers, labels):
+    def to_ragged(centers, labels, num_labels=NUM_LABELS):
         """Padded arrays (centers [G,N,3], labels [G,N], -1 = pad, padding trailing) -> the ragged store of
         sgpr_embed_ragged: (centers f32 [S,3], labels i8 [S], offsets i64 [G+1]) as numpy arrays."""
         import numpy as np
         c = np.asarray(centers, dtype=np.float32)
         l = np.asarray(labels)
         real = l >= 0
-        if real.any() and int(l[real].max()) >= NUM_LABELS:
+        if real.any() and int(l[real].max()) >= num_labels:
             # an int8 cast would wrap 256 + c into the valid class c: refuse like the padded path and the reference do
             # (KeyError, sg_net.py:277)
-            raise ValueError("to_ragged: label %d outside [0, %d)" % (int(l[real].max()), NUM_LABELS))
+            raise ValueError("to_ragged: label %d outside [0, %d)" % (int(l[real].max()), num_labels))
         counts = real.sum(1)
         if not (real == (np.arange(l.shape[1])[None, :] < counts[:, None])).all():
             raise ValueError("to_ragged: padding slots (label -1) must trail the real nodes of every graph")
@@ -410,7 +418,7 @@ class Engine:
                                         _ptr(order), order.numel() if order is not None else 0, _ptr(pooled), _ptr(att),
                                         _ptr(emb), _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
-        return pooled, att, emb
+        return pooled, att, self._cut(emb)
 
     def embed_dense(self, features, k, want_att=False, want_emb=False):
         """features [G, 3+L, N] f32 (the reference's dense layout) -> pooled (+ att, emb)."""
@@ -426,7 +434,7 @@ class Engine:
         rc = self.lib.sgpr_embed_dense(self._h, _ptr(features), g, n, k, _ptr(pooled), _ptr(att), _ptr(emb), _ptr(ws),
                                        ws_bytes, self._stream())
         self._check(rc)
-        return pooled, att, emb
+        return pooled, att, self._cut(emb)
 
     # ------------------------------------------------------------------ pair-coupled half
     def score_pairs(self, pooled1, pooled2, idx1=None, idx2=None, out=None):
@@ -704,13 +712,16 @@ def attention_pool(weight, emb):
     emb = _gpu_f32(emb, "embedding")
     weight = _gpu_f32(weight, "weight_matrix").to(emb.device)
     b, n, f = emb.shape
-    if f != F3 or tuple(weight.shape) != (F3, F3):
-        raise ValueError("attention_pool is built for filters_3 = %d" % F3)
+    if f > F3 or tuple(weight.shape) != (f, f):
+        raise ValueError("attention_pool is built for filters_3 <= %d" % F3)
+    if f < F3:          # a smaller width is the built one with zero channels (exactly: zeros add nothing to any sum)
+        emb = torch.nn.functional.pad(emb, (0, F3 - f))
+        weight = torch.nn.functional.pad(weight, (0, F3 - f, 0, F3 - f))
     rep = torch.empty(b, F3, dtype=torch.float32, device=emb.device)
     att = torch.empty(b, n, dtype=torch.float32, device=emb.device)
     with torch.cuda.device(emb.device):
         _raise_if(lib, lib.sgpr_attention_pool(_ptr(weight), _ptr(emb), b, n, _ptr(rep), _ptr(att), _stream_of(emb)))
-    return rep, att
+    return rep[:, :f], att
 
 
 def ntn(weight, weight_block, bias, e1, e2):
@@ -722,12 +733,20 @@ def ntn(weight, weight_block, bias, e1, e2):
     wb = _gpu_f32(weight_block, "weight_matrix_block").to(e1.device)
     bs = _gpu_f32(bias, "bias").to(e1.device).view(-1)
     b = e1.shape[0]
-    if e1.shape != (b, F3) or e2.shape != (b, F3) or tuple(w.shape) != (F3, F3, 16) or tuple(wb.shape) != (16, 2 * F3):
-        raise ValueError("ntn is built for filters_3 = 32, tensor_neurons = 16")
+    f, t = (int(w.shape[0]), int(w.shape[2])) if w.dim() == 3 else (-1, -1)
+    if (f < 1 or f > F3 or t < 1 or t > 16 or e1.shape != (b, f) or e2.shape != (b, f) or tuple(w.shape) != (f, f, t) or
+            tuple(wb.shape) != (t, 2 * f) or bs.numel() != t):
+        raise ValueError("ntn is built for filters_3 <= 32, tensor_neurons <= 16")
+    if f < F3 or t < 16:   # a smaller module is the built one with zero weights for what it does not have
+        pad = torch.nn.functional.pad
+        e1, e2 = pad(e1, (0, F3 - f)).contiguous(), pad(e2, (0, F3 - f)).contiguous()
+        w = pad(w, (0, 16 - t, 0, F3 - f, 0, F3 - f)).contiguous()
+        wb = pad(torch.cat((pad(wb[:, :f], (0, F3 - f)), pad(wb[:, f:], (0, F3 - f))), dim=1), (0, 0, 0, 16 - t)).contiguous()
+        bs = pad(bs, (0, 16 - t)).contiguous()
     out = torch.empty(b, 16, dtype=torch.float32, device=e1.device)
     with torch.cuda.device(e1.device):
         _raise_if(lib, lib.sgpr_ntn(_ptr(w), _ptr(wb), _ptr(bs), _ptr(e1), _ptr(e2), b, _ptr(out), _stream_of(e1)))
-    return out
+    return out[:, :t]
 
 
 def cluster_scan(points, labels, max_nodes=1024, want_point_node=False):

@@ -1459,3 +1459,82 @@ def test_f1_max_bit_pattern_bins_at_their_edges(eng):
     lab = (rng.random((1000, 1000)) < 0.002).astype(np.int8)
     sc[lab == 1] = np.sqrt(sc[lab == 1])
     check(sc, lab, "rare positives")
+
+
+def test_smaller_architectures_run_on_the_built_kernels(oracle):
+    """parser_sg.py:12-18 exposes filters_1/2/3, tensor_neurons and bottle_neck_neurons; the label count is a model
+    argument (sg_net.py:40-76).  Every architecture no larger than the built one {12, 64, 64, 32, 16, 16} in any of the six
+    is served by zero-padding its tensors at sgpr_create - exact, not approximate: randomly initialised models of three
+    such shapes (BatchNorm statistics randomised too) against the oracle, through the reference's own SG / state-dict API;
+    a larger one is refused with SGPR_E_DIMS."""
+    from sg_pr_amd import sg_net, synth
+    from sg_pr_amd.engine import SgprError
+    from sg_pr_amd.parser_sg import sgpr_args
+    rng = np.random.default_rng(5)
+    for labels, f1, f2, f3, t, bn in ((10, 32, 48, 16, 8, 8), (12, 64, 64, 32, 16, 16), (5, 17, 33, 9, 3, 5), (12, 64, 64, 32, 16, 1)):
+        args = sgpr_args()
+        args.filters_1, args.filters_2, args.filters_3, args.tensor_neurons, args.bottle_neck_neurons = f1, f2, f3, t, bn
+        args.node_num, args.K = 64, 10
+        torch.manual_seed(labels * 1000 + f1)
+        model = sg_net.SG(args, labels)
+        with torch.no_grad():
+            for name, buf in model.named_buffers():
+                if name.endswith("running_mean"):
+                    buf.copy_(torch.randn_like(buf) * 0.2)
+                if name.endswith("running_var"):
+                    buf.copy_(torch.rand_like(buf) + 0.5)
+            for name, prm in model.named_parameters():
+                if name.endswith(".1.weight"):
+                    prm.copy_(torch.rand_like(prm) + 0.5)
+                if name.endswith(".1.bias") or name in ("fully_connected_first.bias", "scoring_layer.bias"):
+                    prm.copy_(torch.randn_like(prm) * 0.2)
+        model.eval()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        c, l, _ = synth.make_graphs(24, 64, 20, 50, seed=labels)
+        l = np.where(l >= 0, l % labels, l).astype(np.int32)
+        for gi in range(l.shape[0]):                                  # keep the label-ascending node order of the generators
+            n = int((l[gi] >= 0).sum())
+            order = np.argsort(l[gi, :n], kind="stable")
+            l[gi, :n], c[gi, :n] = l[gi, :n][order], c[gi, :n][order]
+        feats = torch.from_numpy(synth.dense_features(c, l, num_labels=labels))
+        f_a, f_b = feats[:12], feats[12:]
+        want, wa1, wa2 = oracle.forward(sd, f_a, f_b, 10)
+        got, a1, a2 = model({"features_1": f_a, "features_2": f_b})
+        assert got.shape == (12,) and a1.shape == (12, 64, 1)
+        assert (got.cpu() - want).abs().max().item() < SCORE_TOL, (labels, f1, f2, f3, t, bn)
+        assert (a1.cpu() - wa1).abs().max().item() < 1e-4 and (a2.cpu() - wa2).abs().max().item() < 1e-4
+        emb = model.dgcnn_conv_pass(feats)
+        assert emb.shape == (24, 64, f3)
+        assert (emb.cpu() - oracle.conv_pass(sd, feats, 10)).abs().max().item() < 1e-4
+        # packed input and the all-pairs tail
+        pooled = model.embed(c, l)[0]
+        assert pooled.shape == (24, 32) and (f3 == 32 or float(pooled[:, f3:].abs().max()) == 0.0)
+        ref_pooled = oracle.embed(sd, feats, 10)[0]
+        assert (pooled[:, :f3].cpu() - ref_pooled).abs().max().item() < 2e-4
+        mat = model.score_all_pairs(pooled, pooled).cpu()
+        assert (mat - oracle.score_all_pairs(sd, ref_pooled, ref_pooled)).abs().max().item() < SCORE_TOL
+        # a label the model does not have is an error, as in the reference (KeyError, sg_net.py:277)
+        if labels < 12:
+            bad = l.copy()
+            bad[0, 0] = labels
+            model.embed(torch.from_numpy(c).cuda(), torch.from_numpy(bad).cuda())
+            with pytest.raises(SgprError):
+                model.engine().check_status()
+        # the stand-alone modules with this model's widths
+        from sg_pr_amd.layers_batch import AttentionModule, TenorNetworkModule
+        att_mod = AttentionModule(args).cuda()
+        att_mod.load_state_dict({"weight_matrix": sd["attention.weight_matrix"]})
+        e = torch.randn(3, 20, f3).cuda()
+        rep, sig = att_mod(e)
+        w_rep, w_sig = oracle.attention({"attention.weight_matrix": sd["attention.weight_matrix"]}, e.cpu())
+        assert rep.shape == (3, f3, 1) and (rep.cpu() - w_rep).abs().max().item() < 1e-4
+        ntn_mod = TenorNetworkModule(args).cuda()
+        ntn_mod.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("tensor_network.")})
+        e1, e2 = torch.randn(7, f3, 1).cuda(), torch.randn(7, f3, 1).cuda()
+        ntn = ntn_mod(e1, e2)
+        assert ntn.shape == (7, t, 1) and (ntn.cpu() - oracle.tensor_network(sd, e1.cpu(), e2.cpu())).abs().max().item() < 1e-4
+    args = sgpr_args()
+    args.filters_3 = 64                                               # larger than built
+    big = sg_net.SG(args, 12).eval()
+    with pytest.raises(SgprError, match="SGPR_E_DIMS"):
+        big.engine()
