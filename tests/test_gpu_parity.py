@@ -637,11 +637,33 @@ def _two_rank_worker(rank, world, port, ckpt, out_dir):
     plain = scorer.run(dc, dl, chunks=1)                                         # plain gather
     block = scorer.run(dc, dl, gather=False)
     f1 = scorer.f1_max(block, poses)
+    # pair-list mode (eval_batch.py:30-36) sharded over the ranks: 2600 listed pairs per rank -> the grouped kernel
+    from sg_pr_amd import eval_batch
+    pairs = [l.split() for l in open(os.path.join(out_dir, "pairs.txt")).read().splitlines()]
+    pred, gt = eval_batch.score_pair_list(trainer, pairs)
     if rank == 0:
         assert torch.equal(full, plain)
-        torch.save({"full": full.cpu(), "f1": f1}, os.path.join(out_dir, "two.pt"))
+        torch.save({"full": full.cpu(), "f1": f1, "pred": pred, "gt": gt}, os.path.join(out_dir, "two.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _write_graph_dir(tmp_path, n_graphs=120, n_pairs=5200, seed=4):
+    """graph JSONs (utils.py:21-38 format) 100 m apart + a shuffled pair list with repeated row graphs"""
+    import json
+    from sg_pr_amd import synth
+    centers, labels, n_real, _ = synth.kitti_like_sequence(n_graphs, 100, seed)
+    gdir = tmp_path / "graphs"
+    gdir.mkdir()
+    for g in range(n_graphs):
+        n = int(n_real[g])
+        pose = [1.0, 0.0, 0.0, 100.0 * g, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+        json.dump({"nodes": labels[g, :n].tolist(), "centers": centers[g, :n].astype(float).tolist(), "pose": pose},
+                  open(gdir / ("%d.json" % g), "w"))
+    rng = np.random.default_rng(seed)
+    ij = rng.integers(0, n_graphs, size=(n_pairs, 2))
+    (tmp_path / "pairs.txt").write_text("".join("%s %s\n" % (gdir / ("%d.json" % a), gdir / ("%d.json" % b)) for a, b in ij))
+    return [[str(gdir / ("%d.json" % a)), str(gdir / ("%d.json" % b))] for a, b in ij]
 
 
 @pytest.mark.timeout(600)
@@ -650,10 +672,11 @@ def test_two_ranks_on_one_gpu_bitwise_equal_one_rank(tmp_path, ckpt_path):
     plain gather) with two ranks on cuda:0: the gathered matrix is bit-identical to the single-process one and the
     sharded device F1-max equals the single-rank value.  (RCCL needs one GPU per rank; gloo ranks can share one.)"""
     import torch.multiprocessing as mp
-    from sg_pr_amd import synth, allpairs, sg_net
+    from sg_pr_amd import synth, allpairs, sg_net, eval_batch
     from sg_pr_amd.parser_sg import sgpr_args
+    pairs = _write_graph_dir(tmp_path)
     mp.spawn(_two_rank_worker, args=(2, 29641, ckpt_path, str(tmp_path)), nprocs=2, join=True)
-    two = torch.load(os.path.join(str(tmp_path), "two.pt"))
+    two = torch.load(os.path.join(str(tmp_path), "two.pt"), weights_only=False)
     args = sgpr_args()
     args.model = ckpt_path
     trainer = sg_net.SGTrainer(args, False)
@@ -662,6 +685,10 @@ def test_two_ranks_on_one_gpu_bitwise_equal_one_rank(tmp_path, ckpt_path):
     one = scorer.run(torch.from_numpy(centers).cuda(), torch.from_numpy(labels).cuda())
     assert torch.equal(one.cpu(), two["full"])
     assert scorer.f1_max(one, poses) == two["f1"]
+    # the sharded pair list == the single-process one, bit for bit (each rank grouped and scored its own 2600 pairs)
+    pred, gt = eval_batch.score_pair_list(trainer, pairs)
+    assert len(pred) == 5200 and np.array_equal(pred, two["pred"]) and np.array_equal(gt, two["gt"])
+    assert set(np.unique(gt)) == {0.0, 1.0}
 
 
 def test_sequence_set_equals_per_sequence_runs(ckpt_path):

@@ -89,7 +89,8 @@ if not pmc_only:
     for name, out in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
                       ("bench_stress.json", "_stress_bench.json"), ("bench_pairs128.json", "_pairs128_bench.json"),
                       ("bench_kitti5seq.json", "_kitti5seq_bench.json"), ("bench_gloo2.json", "_gloo2ranks_one_gpu_bench.json"),
-                      ("bench_pairlist.json", "_pairlist_bench.json")):
+                      ("bench_pairlist.json", "_pairlist_bench.json"),
+                      ("bench_gloo2_pairlist.json", "_gloo2ranks_one_gpu_pairlist_bench.json")):
         bench_line(name, tag + out)
 
 hbm = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python "

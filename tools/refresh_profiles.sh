@@ -31,6 +31,7 @@ timeout 300 python $R/bench.py --workload kitti5seq --no-cpu-baseline --steps 50
 timeout 300 python $R/bench.py --workload pairlist --steps 100 > $O/bench_pairlist.json 2> $O/bench_pairlist.err </dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_pairlist -- python $R/bench.py --workload pairlist --no-cpu-baseline --steps 50 > $O/kt_pairlist.log 2>&1 </dev/null
 SGPR_BENCH_BACKEND=gloo timeout 300 python $R/bench.py --gpus 2 --steps 50 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err </dev/null
+SGPR_BENCH_BACKEND=gloo timeout 300 python $R/bench.py --gpus 2 --workload pairlist --steps 50 --no-cpu-baseline > $O/bench_gloo2_pairlist.json 2> $O/bench_gloo2_pairlist.err </dev/null
 python - <<PY || { echo "REFRESH FAILED: bench line without roofline.traffic (PMC profile and sources differ)"; exit 1; }
 import json
 r = json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1])
