@@ -441,8 +441,9 @@ def main():
         tail_ms = kernel_ms(dur_calls["tail"], launches_timed) if "tail" in dur_calls else None
         kernels_ms = embed_ms * launches_per_step + (tail_ms or 0.0) * tail_calls_per_step
         durations_consistent = bool(kernels_ms <= 1.05 * step_ms)
-    assert world > 1 or kernels_ms <= 1.25 * step_ms, \
-        "kernel durations (%.4f ms) exceed the timed step (%.4f ms): the duration pass is broken" % (kernels_ms, step_ms)
+    if world == 1 and kernels_ms > 1.25 * step_ms:        # reported (`kernel_durations.consistent`), never fatal: the line
+        print("bench.py: kernel durations (%.4f ms) exceed the timed step (%.4f ms) - clock change between the two passes?"
+              % (kernels_ms, step_ms), file=sys.stderr)    # with `value` must come out whatever the duration pass saw
 
     # N > 1, extra information (not `value`): the same K steps with the matrix left sharded by rows - what the
     # device-side consumers (F1-max counts, top-k retrieval) work on; isolates the cost of the gather to rank 0
@@ -457,54 +458,57 @@ def main():
     # what `value` excludes by contract: host <-> device transfers (SURVEY.md 8d counts them in its metric)
     end_to_end = None
     if allpairs_job and world == 1 and not a.no_end_to_end:
-        # the graphs cross PCIe as the ragged store (sgpr_embed_ragged: 13 bytes per real node, no padding slots); the
-        # launch order and node_cap are properties of the data set, computed once and kept on the device
-        ragged = [eng.to_ragged(c, l) for c, l, _ in host_inputs]
-        pinned = [tuple(torch.from_numpy(x).pin_memory() for x in r) for r in ragged]
-        rag_plan = [eng.ragged_order(r[2], n, k) for r in ragged]
-        h2d_bytes = sum(x.nbytes for r in ragged for x in r)
-        host_out = [torch.empty(j["m"], j["m"], dtype=torch.float32).pin_memory() for j in jobs]
-        xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
-        reps = max(3, min(20, a.steps))
+        try:
+            # the graphs cross PCIe as the ragged store (sgpr_embed_ragged: 13 bytes per real node, no padding slots); the
+            # launch order and node_cap are properties of the data set, computed once and kept on the device
+            ragged = [eng.to_ragged(c, l) for c, l, _ in host_inputs]
+            pinned = [tuple(torch.from_numpy(x).pin_memory() for x in r) for r in ragged]
+            rag_plan = [eng.ragged_order(r[2], n, k) for r in ragged]
+            h2d_bytes = sum(x.nbytes for r in ragged for x in r)
+            host_out = [torch.empty(j["m"], j["m"], dtype=torch.float32).pin_memory() for j in jobs]
+            xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
+            reps = max(3, min(20, a.steps))
 
-        copy_stream = torch.cuda.Stream(device=dev)
-        pieces = max(1, a.d2h_pieces)
-        dev_out = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
+            copy_stream = torch.cuda.Stream(device=dev)
+            pieces = max(1, a.d2h_pieces)
+            dev_out = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
 
-        def e2e(consumer):
-            for j, (pc, pl, po), (order_r, cap_r), ho, do, pz in zip(jobs, pinned, rag_plan, host_out, dev_out, xz):
-                dc, dl, do_ = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True), po.to(dev, non_blocking=True)
-                pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=cap_r, order=order_r if a.embed_mode == "ordered" else None)[0]
-                if consumer == "d2h":
-                    # the matrix leaves in row blocks: block i crosses PCIe on the copy stream while block i + 1 is scored
-                    m = j["m"]
-                    for q in range(pieces):
-                        r0, r1 = m * q // pieces, m * (q + 1) // pieces
-                        model.score_all_pairs(pooled[r0:r1].contiguous(), pooled, out=do[r0:r1])
-                        ready = torch.cuda.Event()
-                        ready.record()
-                        copy_stream.wait_event(ready)
-                        with torch.cuda.stream(copy_stream):
-                            ho[r0:r1].copy_(do[r0:r1], non_blocking=True)
-                else:
-                    from sg_pr_amd import metrics
-                    mat = model.score_all_pairs(pooled, pooled, out=do)
-                    metrics.f1_max_device(eng, mat, pose_xz=pz)
-            torch.cuda.synchronize()
+            def e2e(consumer):
+                for j, (pc, pl, po), (order_r, cap_r), ho, do, pz in zip(jobs, pinned, rag_plan, host_out, dev_out, xz):
+                    dc, dl, do_ = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True), po.to(dev, non_blocking=True)
+                    pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=cap_r, order=order_r if a.embed_mode == "ordered" else None)[0]
+                    if consumer == "d2h":
+                        # the matrix leaves in row blocks: block i crosses PCIe on the copy stream while block i + 1 is scored
+                        m = j["m"]
+                        for q in range(pieces):
+                            r0, r1 = m * q // pieces, m * (q + 1) // pieces
+                            model.score_all_pairs(pooled[r0:r1].contiguous(), pooled, out=do[r0:r1])
+                            ready = torch.cuda.Event()
+                            ready.record()
+                            copy_stream.wait_event(ready)
+                            with torch.cuda.stream(copy_stream):
+                                ho[r0:r1].copy_(do[r0:r1], non_blocking=True)
+                    else:
+                        from sg_pr_amd import metrics
+                        mat = model.score_all_pairs(pooled, pooled, out=do)
+                        metrics.f1_max_device(eng, mat, pose_xz=pz)
+                torch.cuda.synchronize()
 
-        end_to_end = {}
-        for consumer in ("d2h", "device_f1"):
-            e2e(consumer)
-            t0 = time.perf_counter()
-            for _ in range(reps):
+            end_to_end = {}
+            for consumer in ("d2h", "device_f1"):
                 e2e(consumer)
-            te = (time.perf_counter() - t0) / reps
-            end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
-        end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB) + the step + either "
-                              "the D2H copy of the score matrices into pinned memory (%.1f MB, in %d row blocks whose copies "
-                              "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "
-                              "engine call with 64 bytes crossing PCIe (`device_f1`); %d repetitions"
-                              % (h2d_bytes / 1e6, units * 4 / 1e6, pieces, reps))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    e2e(consumer)
+                te = (time.perf_counter() - t0) / reps
+                end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
+            end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB) + the step + either "
+                                  "the D2H copy of the score matrices into pinned memory (%.1f MB, in %d row blocks whose copies "
+                                  "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "
+                                  "engine call with 64 bytes crossing PCIe (`device_f1`); %d repetitions"
+                                  % (h2d_bytes / 1e6, units * 4 / 1e6, pieces, reps))
+        except Exception as e:     # extra legs beside `value`: a failure here is reported, the contract line still comes out
+            end_to_end = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         value = units * a.steps / dt
@@ -633,8 +637,12 @@ def main():
                                     "mean_cols": cols, "bytes_per_call_algorithmic": tb,
                                     "calls_per_step": tail_calls_per_step, "issue": issue_tail}
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.model, host_inputs[0][0], host_inputs[0][1], n, k, a.cpu_seconds,
-                                               allpairs_job, pairs=host_pairs if a.workload == "pairlist" else None)
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.model, host_inputs[0][0], host_inputs[0][1], n, k, a.cpu_seconds,
+                                                   allpairs_job, pairs=host_pairs if a.workload == "pairlist" else None)
+            except Exception as e:      # the GPU measurement above stands whatever happens to the host-side comparison leg
+                res["cpu_baseline"] = {"value": None, "unit": "graph-pairs/s", "cores": 0, "kind": "port", "sample": "failed",
+                                       "error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(res))
         sys.stdout.flush()
     if world > 1:
