@@ -348,7 +348,9 @@ void sgpr_debug_set_profile_buffer(sgpr_handle* h, void* d_counters);
  * bit 2 the Gram phase, bit 3 the gather-max; bit 4 returns right after dispatch, bit 5 after the input fetch;
  * bit 8 = nothing skipped (just selects the profiling instance); bits 9/10/11 keep the GEMM phase but drop its weight
  * loads / its MFMAs / its inner barrier; bit 12 runs the generic first semantic layer instead of the label lookup (valid
- * results).  0 (default) = normal. */
+ * results); bit 13 forces the wide-range instance and bit 20 makes the producers of the split launch's odd slots
+ * withhold their flag, so that their graphs reach the second pass through the late-producer path (both: valid
+ * results, production kernels).  0 (default) = normal. */
 void sgpr_debug_set_skip_mask(sgpr_handle* h, int mask);
 
 /* 1: the handle's weights run on the default datapath (two f16 planes per matrix operand); 0: the checkpoint's folded

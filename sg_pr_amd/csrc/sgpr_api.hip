@@ -406,6 +406,9 @@ void sgpr_destroy(sgpr_handle* h) {
 #endif
 
 // wide: use the wide-range X layouts (bf16 planes / fp32 rows) instead of the default f16 planes
+// debug-mask bits that keep the production kernel instance: 8192 forces the wide-range instance, 1 << 20 makes the split
+// launch's odd producers withhold their flag (test hook for the late-producer hand-over to the second pass)
+static constexpr int kProductionSkipBits = 8192 | (1 << 20);
 static bool wide_range(const sgpr_handle* h) { return !h->f16_weights || (h->dbg_skip & 8192); }
 
 static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wide, bool small_park = false) {
@@ -481,7 +484,7 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     if (a.G <= h->num_cus) node_cap = 0;
     EmbedPlan plan;
     // production launches (no dumps, timers or ablation) of lean plans park only the super-node rows
-    const bool production = !a.dbg_layers && !a.dbg_knn && !h->dbg_prof && !(h->dbg_skip & ~8192);
+    const bool production = !a.dbg_layers && !a.dbg_knn && !h->dbg_prof && !(h->dbg_skip & ~kProductionSkipBits);
     int rc = check_nk(a.G, N, k, node_cap, &plan, wide_range(h), production);
     if (rc != SGPR_OK) return rc;
     // graphs are addressed by their own index: an ordered launch needs rows for all of them
@@ -777,7 +780,7 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
         return SGPR_E_INVALID;
     }
     EmbedPlan plan;
-    int rc = check_nk(2 * B, N, k, 0, &plan, wide_range(h), !h->dbg_prof && !(h->dbg_skip & ~8192));
+    int rc = check_nk(2 * B, N, k, 0, &plan, wide_range(h), !h->dbg_prof && !(h->dbg_skip & ~kProductionSkipBits));
     if (rc != SGPR_OK) return rc;
     const size_t need = sgpr_forward_workspace_bytes(h, B, N, k);
     if (!d_workspace || workspace_bytes < need) {

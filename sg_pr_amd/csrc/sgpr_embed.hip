@@ -2109,7 +2109,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 if (FMT == FMT_H2 && __ballot(!(vmax < kF16Safe)) != 0ull && lane == 0) atomicOr(ovf, 1);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __syncthreads();
-                if (tid == 0)
+                // (debug mask bit 20, tests only: the producers of odd launch slots withhold their flag - their consumers
+                //  must time out and hand the graph to the second pass)
+                if (tid == 0 && !((kp.a.skip & (1 << 20)) && (launch_slot & 1)))
                     __hip_atomic_store(kp.a.sem_flag + launch_slot,
                                        sem_token(kp.a.sem_epoch, launch_slot) | (*ovf ? 0x80000000ull : 0ull), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -2598,7 +2600,7 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     // (measured: two workgroups sharing a CU cost each other more than the split saves - 64 graphs 38.0 -> 31.7 us per
     // call, 128 graphs 38.1 -> 34.6, 256 graphs 37.9 -> 44.2); the caller reserved sem_tab / sem_flag in the workspace
     const bool can_split = plan.fmt == FMT_H2 && plan.lean && !a.dense && !a.dbg_layers && !a.dbg_knn && !a.prof &&
-                           !(a.skip & ~8192) && a.sem_tab && a.sem_flag && 2 * a.G <= h->num_cus;
+                           !(a.skip & ~(8192 | (1 << 20))) && a.sem_tab && a.sem_flag && 2 * a.G <= h->num_cus;
     {
         static std::atomic<unsigned> epoch{0u};                    // this launch's token (split-launch flags, redo_count)
         unsigned e = ++epoch;
@@ -2610,7 +2612,7 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
         kp.a.sem_flag = nullptr;
     }
     // layer / kNN dumps run on the roomy instance; timers and ablation keep the production occupancy
-    const int mode = (a.dbg_layers || a.dbg_knn) ? 2 : ((a.prof || (a.skip & ~8192)) ? 1 : 0);
+    const int mode = (a.dbg_layers || a.dbg_knn) ? 2 : ((a.prof || (a.skip & ~(8192 | (1 << 20)))) ? 1 : 0);
     int rc;
     if (plan.kp == 16)
         rc = mode == 2 ? launch_layout<16, 2>(plan, kp, stream)

@@ -1180,6 +1180,38 @@ def test_full_sequence_parity_with_tie_proofs(eng, oracle, oracle_sd):
             f.write("\n".join(lines) + "\n")
 
 
+@pytest.mark.timeout(300)
+def test_split_launch_late_producer_goes_to_the_second_pass(eng):
+    """Split launch (<= 128 graphs: a graph's two branches on two workgroups): a consumer whose producer's flag does not
+    arrive - HIP promises no co-residency between the workgroups of a launch - hands its graph to the second pass
+    instead of hanging or failing.  Debug bit 20 makes the producers of the odd launch slots withhold their flag: the
+    call takes the consumers' time-out (tens of milliseconds), reports no error, and every pooled vector is bit for bit the one of the
+    undisturbed call."""
+    from sg_pr_amd import synth
+    c, l, _ = synth.make_graphs(24, 64, 20, 50, seed=21, kitti_like=True)        # node_num 64: the lean plan splits
+    want, want_att, _ = eng.embed(c, l, 10, want_att=True)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.embed(c, l, 10, want_att=True)
+    torch.cuda.synchronize()
+    t_plain = time.perf_counter() - t0
+    eng.set_skip_mask(1 << 20)
+    try:
+        t0 = time.perf_counter()
+        got, got_att, _ = eng.embed(c, l, 10, want_att=True)
+        torch.cuda.synchronize()
+        t_late = time.perf_counter() - t0
+        eng.check_status()
+    finally:
+        eng.set_skip_mask(0)
+    assert torch.equal(got, want) and torch.equal(got_att, want_att)
+    # the hook really withheld flags: the call waited out the consumers' time-out (2^20 polls) instead of ~40 us
+    assert t_late > 5e-3 and t_late > 20 * t_plain, (t_plain, t_late)
+    again = eng.embed(c, l, 10)[0]                       # the request word of the disturbed launch does not linger
+    assert torch.equal(again, want)
+
+
 @pytest.mark.timeout(900)
 def test_random_shapes_deviate_only_through_proven_ties(eng, oracle, oracle_sd):
     """The same statement away from the KITTI shape: 40 random (node_num 17..256, K 1..32, node counts) batches of 8
