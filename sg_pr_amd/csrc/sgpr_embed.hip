@@ -34,6 +34,24 @@
 #include <type_traits>
 
 #include "sgpr_internal.hpp"
+#ifndef SGPR_EXP_BARRIERS
+#define SGPR_EXP_BARRIERS 1      // timing experiment only (tools/build_variant.sh): every workgroup barrier of this file N times -
+#endif                           // the launch's growth per extra copy is what its barriers cost (results stay valid)
+#if SGPR_EXP_BARRIERS > 1
+namespace sgpr {
+__device__ __forceinline__ void sync_n() {
+    __syncthreads();
+#pragma unroll
+    for (int i = 1; i < SGPR_EXP_BARRIERS; ++i) __builtin_amdgcn_s_barrier();
+}
+}
+#define __syncthreads() ::sgpr::sync_n_dispatch()
+namespace sgpr {
+#undef __syncthreads
+__device__ __forceinline__ void sync_n_dispatch() { sync_n(); }
+}
+#define __syncthreads() ::sgpr::sync_n_dispatch()
+#endif
 
 namespace sgpr {
 
