@@ -45,12 +45,7 @@ __device__ __forceinline__ void sync_n() {
     for (int i = 1; i < SGPR_EXP_BARRIERS; ++i) __builtin_amdgcn_s_barrier();
 }
 }
-#define __syncthreads() ::sgpr::sync_n_dispatch()
-namespace sgpr {
-#undef __syncthreads
-__device__ __forceinline__ void sync_n_dispatch() { sync_n(); }
-}
-#define __syncthreads() ::sgpr::sync_n_dispatch()
+#define __syncthreads() ::sgpr::sync_n()     // (after sync_n's own use of the real one)
 #endif
 
 namespace sgpr {
