@@ -171,7 +171,9 @@ int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t
  * *plan_ints returns the words written.  An index out of range -> SGPR_E_INVALID.  Build it once per list (like a launch
  * order), copy it to the device, reuse it for every call.
  * sgpr_score_pair_list: d_score[p] = SG-tail(d_pooled_rows[idx1[p]], d_pooled_cols[idx2[p]]) for the P pairs of the plan
- * (d_plan: the plan words in DEVICE memory).  Workspace: sgpr_score_pair_list_workspace_bytes(h, n_rows, M). */
+ * (d_plan: the plan words in DEVICE memory; R, M, n_rows, n_items and P are the values sgpr_pair_plan was given and
+ * returned - the kernels trust the plan's indices, as sgpr_score_pairs trusts idx1 / idx2).  Workspace:
+ * sgpr_score_pair_list_workspace_bytes(h, n_rows, M). */
 size_t sgpr_pair_plan_ints(int64_t P, int R);
 int sgpr_pair_plan(const int32_t* h_idx1, const int32_t* h_idx2, int64_t P, int R, int M, int32_t* h_plan,
                    size_t plan_capacity_ints, size_t* plan_ints, int32_t* n_rows, int32_t* n_items);
