@@ -406,7 +406,13 @@ __device__ __forceinline__ double f1_of(double tp, double fp, double pos) {
 // contiguous kilobyte (16 bytes per lane, dword-aligned: rows of an M x M float matrix are not 16-byte aligned), and four
 // rows are in flight per wave.  Tasks (row chunk, strip) are dealt to the waves of the grid strip-first, so that
 // neighbouring waves read neighbouring kilobytes.
-constexpr int F1_ROWS = 4;                                       // rows per task = rows in flight per wave (5 tasks per wave on a KITTI-00 matrix)
+#ifndef SGPR_F1_ROWS
+#define SGPR_F1_ROWS 4
+#endif
+#ifndef SGPR_F1_WGB
+#define SGPR_F1_WGB 2          // workgroups per CU of pass B (A/B builds)
+#endif
+constexpr int F1_ROWS = SGPR_F1_ROWS;                                       // rows per task = rows in flight per wave (5 tasks per wave on a KITTI-00 matrix)
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
 
@@ -466,23 +472,32 @@ struct StripData {
     StripTask t;
     ColPoses cp;
     float s[F1_ROWS][4];
+    unsigned cb[F1_ROWS];        // pass B: the class bytes pass A left for the rows (0xff = all four pairs ignored)
     bool inb;
-    __device__ __forceinline__ void fetch(const PairScan& sc, long long task, long long ntasks, int lane, float fill) {
+    // cls_in == nullptr: pass A (loads the column poses); else pass B (loads the rows' class bytes instead)
+    __device__ __forceinline__ void fetch(const PairScan& sc, long long task, long long ntasks, int lane, float fill,
+                                          const unsigned char* __restrict__ cls_in = nullptr) {
         t.r0 = t.r1 = 0;
         t.c0 = 0;
         inb = false;
 #pragma unroll
-        for (int u = 0; u < F1_ROWS; ++u)
+        for (int u = 0; u < F1_ROWS; ++u) {
+            cb[u] = 0xffu;
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[u][q] = fill;
+        }
         if (task >= ntasks) return;
         t.init(sc, task, lane);
         inb = t.c0 < sc.M;
         if (!inb) return;
-        cp.load(sc.truth, t.c0, sc.M);
+        if (!cls_in) cp.load(sc.truth, t.c0, sc.M);
+        const size_t cw = (size_t)(sc.M + 3) >> 2;
 #pragma unroll
         for (int u = 0; u < F1_ROWS; ++u)
-            if (t.r0 + u < t.r1) load_row4(sc, t.r0 + u, t.c0, s[u]);
+            if (t.r0 + u < t.r1) {
+                load_row4(sc, t.r0 + u, t.c0, s[u]);
+                if (cls_in) cb[u] = cls_in[(size_t)(t.r0 + u) * cw + (t.c0 >> 2)];
+            }
     }
 };
 
@@ -492,19 +507,40 @@ __device__ __forceinline__ void classify_row4(const PairTruth& t, const ColPoses
                                               int (&cls)[4]) {
     if (t.pose) {
         const double px = t.pose[2 * (t.row0 + r)], pz = t.pose[2 * (t.row0 + r) + 1];     // wave-uniform
-        const double pos_lo = lo2 * (1.0 - 1e-12), pos_hi = lo2 * (1.0 + 1e-12), neg_lo = hi2 * (1.0 - 1e-12), neg_hi = hi2 * (1.0 + 1e-12);
+        // Almost every pair lies far from both thresholds: the float64 differences, squared and summed in fp32 (relative error
+        // below 4 x 2^-24 = 2.4e-7), decide it when they clear a threshold by a relative 4e-6.  The float64 arithmetic of the
+        // reference (utils.py:36) runs for a wave only when one of its pairs is closer to a threshold than that (or not
+        // finite: every fp32 comparison is false) - the pass was bound by its float64 instructions (14.5 M vector
+        // instructions per KITTI-00 matrix), not by HBM.
+        const float plo = (float)(lo2 * (1.0 - 4e-6)), phi = (float)(lo2 * (1.0 + 4e-6));
+        const float nlo = (float)(hi2 * (1.0 - 4e-6)), nhi = (float)(hi2 * (1.0 + 4e-6));
+        double dxs[4], dzs[4];
+        bool open = false;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double dx = px - cp.x[q], dz = pz - cp.z[q];
-            const double s2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dz, dz));
-            // sqrt is monotone and correctly rounded: away from the two thresholds the squared distance decides (selects, no
-            // branches); only within a relative 1e-12 of them is the reference's `sqrt(...) <= t` evaluated literally
-            int c = s2 < pos_lo ? 1 : (s2 > neg_hi ? 0 : -1);
-            if (!(s2 < pos_lo) && !(s2 > neg_hi) && !(s2 > pos_hi && s2 < neg_lo)) {
-                const double d = sqrt(s2);
-                c = d <= t.d_pos ? 1 : (d >= t.d_neg ? 0 : -1);
-            }
+            dxs[q] = px - cp.x[q];
+            dzs[q] = pz - cp.z[q];
+            const float fx = (float)dxs[q], fz = (float)dzs[q];
+            const float s2f = fmaf(fx, fx, fz * fz);
+            const int c = s2f < plo ? 1 : (s2f > nhi ? 0 : ((s2f > phi && s2f < nlo) ? -1 : 2));
+            open = open || (c == 2 && c0 + q < M);
             cls[q] = c0 + q < M ? c : -1;
+        }
+        if (__ballot(open) != 0ull) {                                                      // (rare; wave-uniform branch)
+            const double pos_lo = lo2 * (1.0 - 1e-12), pos_hi = lo2 * (1.0 + 1e-12), neg_lo = hi2 * (1.0 - 1e-12), neg_hi = hi2 * (1.0 + 1e-12);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (cls[q] != 2) continue;
+                const double s2 = __dadd_rn(__dmul_rn(dxs[q], dxs[q]), __dmul_rn(dzs[q], dzs[q]));
+                // sqrt is monotone and correctly rounded: away from the two thresholds the squared distance decides; only
+                // within a relative 1e-12 of them is the reference's `sqrt(...) <= t` evaluated literally
+                int c = s2 < pos_lo ? 1 : (s2 > neg_hi ? 0 : -1);
+                if (!(s2 < pos_lo) && !(s2 > neg_hi) && !(s2 > pos_hi && s2 < neg_lo)) {
+                    const double d = sqrt(s2);
+                    c = d <= t.d_pos ? 1 : (d >= t.d_neg ? 0 : -1);
+                }
+                cls[q] = c;
+            }
         }
     } else {
 #pragma unroll
@@ -520,9 +556,12 @@ __device__ __forceinline__ void classify_row4(const PairTruth& t, const ColPoses
 //      No workgroup barrier inside the loop: the positives are staged per WAVE (512 floats each, appended with a ballot
 //      prefix, flushed with one global atomic by the wave).
 constexpr int F1_WBUF = F1_PBUF / (F1_THREADS / 64);          // 512 staged positives per wave
+//      The classes of a lane's four pairs leave as one byte (2 bits each: 0 negative, 1 positive, 3 ignored) into
+//      cls_out [R][(M + 3) / 4]: pass B reads that byte instead of repeating the pose arithmetic.
 __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, unsigned* __restrict__ slabs, int slab_words,
                                                              float* __restrict__ pos, long long cap,
-                                                             unsigned long long* __restrict__ count) {
+                                                             unsigned long long* __restrict__ count,
+                                                             unsigned char* __restrict__ cls_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
     unsigned* hist = reinterpret_cast<unsigned*>(f1_smem);                  // [F1_NBP]
     float* buf = reinterpret_cast<float*>(hist + F1_NBP) + (threadIdx.x >> 6) * F1_WBUF;   // this wave's staging area
@@ -543,6 +582,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
         nst = 0;
     };
     const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
+    const size_t cw = (size_t)(sc.M + 3) >> 2;            // class bytes per row
     unsigned bad_pos = 0u, bad_neg = 0u;
     const long long ntasks = strip_tasks(sc);
     const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
@@ -553,7 +593,11 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
         for (int u = 0; u < F1_ROWS; ++u) {
             if (cur.t.r0 + u >= cur.t.r1) break;          // (wave-uniform)
             int cls[4] = {-1, -1, -1, -1};
-            if (cur.inb) classify_row4(sc.truth, cur.cp, cur.t.r0 + u, cur.t.c0, sc.M, lo2, hi2, cls);
+            if (cur.inb) {
+                classify_row4(sc.truth, cur.cp, cur.t.r0 + u, cur.t.c0, sc.M, lo2, hi2, cls);
+                cls_out[(size_t)(cur.t.r0 + u) * cw + (cur.t.c0 >> 2)] =
+                    (unsigned char)((cls[0] & 3) | ((cls[1] & 3) << 2) | ((cls[2] & 3) << 4) | ((cls[3] & 3) << 6));
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float x = cur.s[u][q];
@@ -910,10 +954,11 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
 }
 
 // ---- B: negatives of the candidate bins by threshold bucket b = #{thr <= s}; everything else costs one bit test.
-//      Same strips as pass A; the float64 pose arithmetic runs only for rows in which some lane holds a candidate.
+//      Same strips as pass A; a pair's class comes from the byte pass A stored (no pose arithmetic here).
 __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc, const unsigned* __restrict__ mark_in,
                                                                const float* __restrict__ thr_in, const int* __restrict__ dT2,
-                                                               unsigned* __restrict__ slabs, int slab_words) {
+                                                               unsigned* __restrict__ slabs, int slab_words,
+                                                               const unsigned char* __restrict__ cls_in) {
     __shared__ unsigned mark[F1_NBP / 32 + 1];
     __shared__ float thr[F1_SORT];
     __shared__ unsigned cnt[F1_SORT + 1];
@@ -924,31 +969,21 @@ __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc
     for (int i = tid; i < F1_SORT; i += F1_THREADS) thr[i] = i < T ? thr_in[i] : INFINITY;
     for (int i = tid; i <= F1_SORT; i += F1_THREADS) cnt[i] = 0u;
     __syncthreads();
-    const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
     const long long ntasks = strip_tasks(sc);
     const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
     for (long long task = wave0; task < ntasks; task += nwaves) {
         StripData cur;
-        cur.fetch(sc, task, ntasks, lane, -1.f);
+        cur.fetch(sc, task, ntasks, lane, -1.f, cls_in);
 #pragma unroll
         for (int u = 0; u < F1_ROWS; ++u) {
-            bool cand[4];
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x = cur.s[u][q];                               // (-1: outside the task / the matrix)
-                const bool usable = __float_as_uint(x) <= 0x7f800000u;
-                const int b = usable ? f1_key(x) : 0;
-                cand[q] = cur.t.c0 + q < sc.M && usable && ((mark[b >> 5] >> (b & 31)) & 1u);
-                any = any || cand[q];
-            }
-            if (!any) continue;
-            int cls[4];
-            classify_row4(sc.truth, cur.cp, cur.t.r0 + u, cur.t.c0, sc.M, lo2, hi2, cls);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                                  // (unrolled: a rolled loop would index the
-                if (!cand[q] || cls[q] != 0) continue;                     //  register arrays dynamically = scratch)
+                                                                           //  register arrays dynamically = scratch)
+                if (((cur.cb[u] >> (2 * q)) & 3u) != 0u) continue;         // pass A's class: not a negative (or outside)
                 const float x = cur.s[u][q];
+                if (__float_as_uint(x) > 0x7f800000u) continue;
+                const int b = f1_key(x);
+                if (!((mark[b >> 5] >> (b & 31)) & 1u)) continue;          // not in a candidate bin: nothing to settle
                 int lo = 0, hi = T;                                        // thr[lo-1] <= x < thr[hi]
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
@@ -1204,7 +1239,7 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
 //      (two arrays) | candidate-bin marks | thresholds, their info, negatives by bucket of pass B | positives | counter slabs
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct F1Layout {
-    size_t off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, total;
+    size_t off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
     long long cap;
     int slabs_a, slabs_b, words_a, words_b;
 };
@@ -1214,7 +1249,7 @@ static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     L.cap = pairs < (1LL << 20) ? pairs : (1LL << 20);
     if (L.cap < 1) L.cap = 1;
     L.slabs_a = h->num_cus;                       // pass A: one 1024-thread workgroup (97 KB histogram) per CU
-    L.slabs_b = h->num_cus;                       // pass B: likewise (4096 waves, ~5 strip tasks each on a KITTI-00 matrix)
+    L.slabs_b = h->num_cus * SGPR_F1_WGB;                       // pass B: likewise (4096 waves, ~5 strip tasks each on a KITTI-00 matrix)
     L.words_a = F1_NBP + 4;
     L.words_b = slab_words(F1_SORT);
     size_t off = 256;                                                       // header
@@ -1228,6 +1263,7 @@ static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     L.off_pos = off;   off += a256((size_t)L.cap * sizeof(float));
     const size_t sa = (size_t)L.slabs_a * L.words_a, sb = (size_t)L.slabs_b * L.words_b;
     L.off_slabs = off; off += a256((sa > sb ? sa : sb) * sizeof(unsigned));
+    L.off_cls = off;   off += a256((size_t)R * (((size_t)M + 3) >> 2));     // one class byte per four pairs (pass A -> pass B)
     L.total = off;
     return L;
 }
@@ -1266,6 +1302,7 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     unsigned long long* neg2 = reinterpret_cast<unsigned long long*>(ws + L.off_neg2);
     float* pos = reinterpret_cast<float*>(ws + L.off_pos);
     unsigned* slabs = reinterpret_cast<unsigned*>(ws + L.off_slabs);
+    unsigned char* cls = ws + L.off_cls;
     static_assert(sizeof(F1Ctrl) <= 128, "control block");
     const size_t lds_scan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_PBUF * sizeof(float);
     const size_t lds_plan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_SORT * sizeof(float) +
@@ -1288,11 +1325,11 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
         return SGPR_OK;
     }
     const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
-    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count);
+    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count, cls);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb);
     hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
                        ctrl, reinterpret_cast<unsigned long long*>(ws + 128));
-    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b);
+    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b, cls);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_SORT + 3 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_b, L.words_b, 0, neg2, dT2);
     hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(F1_THREADS), 0, s, neg2, info, ctrl, d_result);
     e = hipGetLastError();
