@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "sgpr_internal.hpp"
+#include "sgpr_prep.hpp"
 #ifndef SGPR_EXP_BARRIERS
 #define SGPR_EXP_BARRIERS 1      // timing experiment only (tools/build_variant.sh): every workgroup barrier of this file N times -
 #endif                           // the launch's growth per extra copy is what its barriers cost (results stay valid)
@@ -471,6 +472,9 @@ __device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f
                               // tiles, 8 super-node branch, 16 coordinate-layer keys)
 #ifndef SGPR_ASM_MINMAX
 #define SGPR_ASM_MINMAX 1
+#endif
+#ifndef SGPR_SEM_STAGE
+#define SGPR_SEM_STAGE 1      // super-node branch, tabled layer 2: this graph's table rows staged in LDS / registers beside the keys
 #endif
 #if SGPR_ASM_MINMAX
 __device__ __forceinline__ float kmin(float a, float b) {
@@ -1707,6 +1711,7 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, wave);
             group_sync<WAVE>();
         }
+        float4 b2row = make_float4(0.f, 0.f, 0.f, 0.f);                  // tab2: this thread's piece of its row's b term
         for (int t = tid; t < 16 * 16; t += NT) {                          // row l = t >> 4, candidate j = t & 15
             const int l = t >> 4, j = t & 15;
             const int cj = j <= kLabels ? cnt[j] : 0;
@@ -1714,6 +1719,15 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             if (tab2) {
                 const int bl = (l >= kLabels || cnt[l] < k0) ? 1 : 0, bj = (j >= kLabels || cj < k0) ? 1 : 0;
                 if (cj > 0) key = fmaf(-2.f, w.sem_g[((bl * 2 + bj) * 16 + l) * 16 + j], w.sem_xx[bj * 16 + j]);
+                if constexpr (SGPR_SEM_STAGE) {
+                    // this graph's version of every table row, fetched in the same round trip as the keys: the a rows go to
+                    // A rows 0..15 (free until layer 3), where the gather below finds them like the generic path's - a
+                    // read of the table inside its data-dependent loop would be one L2 round trip per neighbour label
+                    const int c4 = j * 4;
+                    *reinterpret_cast<float4*>(A + l * pitchA + c4) =
+                        *reinterpret_cast<const float4*>(w.sem_a2 + ((bl ? 16 : 0) + l) * 64 + c4);
+                    if (NT >= 256) b2row = *reinterpret_cast<const float4*>(w.sem_b2 + ((bl ? 16 : 0) + l) * 64 + c4);
+                }
             } else if (cj > 0) {
                 key = Dv[l * pitchD + j];
             }
@@ -1750,7 +1764,8 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             while (mask) {
                 const int j = __builtin_ctz(mask);
                 mask &= mask - 1;
-                const float* arow = tab2 ? w.sem_a2 + (((j >= kLabels || cnt[j] < k0) ? 16 : 0) + j) * 64 : A + j * pitchA;
+                const float* arow = (tab2 && !SGPR_SEM_STAGE) ? w.sem_a2 + (((j >= kLabels || cnt[j] < k0) ? 16 : 0) + j) * 64
+                                                              : A + j * pitchA;
                 const float4 v = *reinterpret_cast<const float4*>(arow + c4);
                 m4.x = kmax(m4.x, v.x);
                 m4.y = kmax(m4.y, v.y);
@@ -1759,7 +1774,9 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
             }
             const float* brow = tab2 ? w.sem_b2 + (((l >= kLabels || cnt[l] < k0) ? 16 : 0) + l) * 64
                                      : reinterpret_cast<const float*>(X + l * XROW);
-            const float4 y = add_lrelu(m4, *reinterpret_cast<const float4*>(brow + c4), l <= kLabels);
+            // (tab2 on >= 256 threads: the piece was fetched with the keys - same (row, channels) per thread in both loops)
+            const float4 bv = (tab2 && SGPR_SEM_STAGE && NT >= 256) ? b2row : *reinterpret_cast<const float4*>(brow + c4);
+            const float4 y = add_lrelu(m4, bv, l <= kLabels);
             if (Lv == 1) {
                 xstore<FMT>(X + l * XROW, c4, y, vmax);
                 float sa = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
@@ -2486,6 +2503,45 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     }
 }
 
+// ------------------------------------------------------------------ tail operands in the embed epilogue
+// The all-pairs tail needs, per graph, A' = e1^T W + Wb[:, F:], u = Wb[:, :F] e1 + bias (as a row graph) and its pooled
+// vector in two f16 planes (as a column graph): sgpr_prep.hpp.  With a tail workspace the embed launch leaves them behind:
+// a workgroup that has finished its graph counts itself in at its group of 16 launch slots; the one that completes the
+// group prepares the 16 graphs with the code of ntn_prep_kernel (one fp32 MFMA GEMM per group: the 64 KB tensor crosses
+// L2 -> CU once per 16 graphs) - same instructions on the same operands, so the operands carry the bits the stand-alone
+// prep would produce.  The counter cell holds launch token << 32 | arrivals: whatever the workspace held before is another
+// launch's token (or garbage) and counts as zero.
+__device__ __forceinline__ void tail_prep_group(const KParams& kp, const int group, unsigned char* lds) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half)
+        ntn_prep_body<PREP_SLOTS>(kp.w, kp.a.pooled, kp.a.G, kp.a.pooled, kp.a.G, kp.a.tail_Ab, kp.a.tail_ur, kp.a.tail_rng,
+                                  kp.a.tail_Cb, 2 * group + half, kp.a.ids, lds);
+}
+
+__device__ __forceinline__ void tail_arrive(const KParams& kp, const int slot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* last = reinterpret_cast<int*>(smem);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this graph's pooled vector, before the count
+    __syncthreads();                                            // (also: embed_graph is done with LDS)
+    if (threadIdx.x == 0) {
+        const int group = slot >> 4;
+        const unsigned want = (unsigned)min(16, kp.a.G - 16 * group);
+        unsigned long long* cell = kp.a.tail_cnt + group;
+        unsigned long long old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), now;
+        do {
+            now = ((unsigned)(old >> 32) == kp.a.sem_epoch ? old : ((unsigned long long)kp.a.sem_epoch << 32)) + 1ull;
+        } while (!__hip_atomic_compare_exchange_strong(cell, &old, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+        *last = (unsigned)(now & 0xffffffffull) == want ? 1 : 0;
+    }
+    __syncthreads();
+    const bool mine = *last != 0;
+    __syncthreads();                                            // (`last` sits in the staging area)
+    if (!mine) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other 15 workgroups' pooled vectors
+    tail_prep_group(kp, slot >> 4, smem);
+}
+
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
 #ifndef SGPR_EXP_LDS32
 #define SGPR_EXP_LDS32 0
@@ -2500,6 +2556,8 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN 
         }
     }
     embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role);
+    // (every exit of embed_graph is workgroup-uniform and ends up here; the semantic half of a split launch owns no graph)
+    if (kp.a.tail_Ab && role != 1) tail_arrive(kp, slot);
 }
 
 // Second pass over the launch slots the f16 instance flagged (kp.a.redo):
@@ -2515,7 +2573,9 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
     // this workgroup's contiguous range of launch slots, 64 flags at a time: wave 0 reads them with one load and hands
     // the ballots to the other waves through the first bytes of LDS (one dependent load per slot made the empty pass
     // cost 23 us); the masks then live in registers, so embed_graph is free to overwrite LDS
-    const int per = (kp.a.G + gridDim.x - 1) / gridDim.x;
+    // (whole groups of 16 slots per workgroup: the tail operands of a group are prepared again by the workgroup that
+    //  re-embedded one of its graphs)
+    const int per = ((kp.a.G + gridDim.x - 1) / gridDim.x + 15) & ~15;
     const int b0 = blockIdx.x * per, b1 = min(kp.a.G, b0 + per);
     for (int base = b0; base < b1; base += 64) {
         if (threadIdx.x < 64) {
@@ -2530,6 +2590,7 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
         __syncthreads();
         unsigned long long wide = reinterpret_cast<const unsigned long long*>(smem)[0];
         unsigned long long full = reinterpret_cast<const unsigned long long*>(smem)[1];
+        const unsigned long long again = wide | full;         // slots whose pooled vector this pass replaces
         __syncthreads();
         // the graphs that need the generic semantic branch first: the full f16 plan resets the slot's flag and raises it
         // again (1) when an activation or a coordinate leaves the f16 range - such a slot joins the wide-range list
@@ -2547,6 +2608,18 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
             wide &= wide - 1;
             embed_graph<KP, 0, 0, FMTW>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot);
             __syncthreads();
+        }
+        if (kp.a.tail_Ab && again) {
+            // the first pass prepared these groups from pooled vectors that have just been replaced: once more
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q)
+                if ((again >> (16 * q)) & 0xffffull) {
+                    tail_prep_group(kp, (base >> 4) + q, smem);
+                    __syncthreads();
+                }
         }
     }
 }
@@ -2567,7 +2640,9 @@ static int launch_t(const KParams& kp, hipStream_t stream) {
     int rc = set_lds_limit(&embed_kernel<KP, DBG, LEAN, FMT, KC>, &attr_set);
     if (rc != SGPR_OK) return rc;
     const int grid = kp.a.G * ((LEAN != 0 && DBG == 0 && kp.a.sem_tab) ? 2 : 1);
-    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT, KC>), dim3(grid), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    // (the epilogue's tail prep stages its operands in the same dynamic LDS: tiny plans are rounded up to it)
+    const int lds = (kp.a.tail_Ab && kp.p.lds_bytes < kPrepLdsBytes) ? kPrepLdsBytes : kp.p.lds_bytes;
+    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT, KC>), dim3(grid), dim3(kp.p.nt), lds, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
@@ -2578,7 +2653,8 @@ static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
     static bool attr_set = false;
     int rc = set_lds_limit(&embed_redo_kernel<KP, FMT>, &attr_set);
     if (rc != SGPR_OK) return rc;
-    const int lds = kp.p.lds_bytes > kp.p2.lds_bytes ? kp.p.lds_bytes : kp.p2.lds_bytes;
+    int lds = kp.p.lds_bytes > kp.p2.lds_bytes ? kp.p.lds_bytes : kp.p2.lds_bytes;
+    if (kp.a.tail_Ab && lds < kPrepLdsBytes) lds = kPrepLdsBytes;
     hipLaunchKernelGGL((embed_redo_kernel<KP, FMT>), dim3(blocks), dim3(kp.p.nt), lds, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_redo_kernel launch");

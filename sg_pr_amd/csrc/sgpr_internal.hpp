@@ -120,13 +120,25 @@ struct EmbedArgs {
     float* park_ws;         // [G][NP][32] when !park_in_lds
     unsigned char* redo;    // [launch slots] written by the f16 instance: 1 = the graph left the f16 range -> embed_redo_kernel
     unsigned* redo_count;   // one word: receives sem_epoch when any slot asks for the second pass (else untouched)
-    // split launch (sgpr_embed.hip): workgroup G + s publishes the 16 sem3 rows of launch slot s in sem_tab[s][16][32]
-    // and sem_flag[s] = token(s); workgroup s picks them up before conv_end.  sem_tab == NULL: the unsplit launch
+    // split launch (sgpr_embed.hip): workgroup s < G (a PRODUCER: the semantic half of launch slot s) publishes the 16
+    // sem3 rows of the slot in sem_tab[s][16][32] and sem_flag[s] = token(s); workgroup G + s (the CONSUMER: the xyz half)
+    // picks them up before conv_end.  Producers own the lower block indices and are therefore dispatched first - the
+    // forward-progress argument of the hand-over (a waiting consumer never holds a CU its own producer still needs)
+    // depends on that order.  sem_tab == NULL: the unsplit launch
     float* sem_tab;
     unsigned long long* sem_flag;
     unsigned sem_epoch;         // this launch's token: distinguishes its flags / redo_count from whatever the workspace held
     int32_t* status;
     unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
+    // tail operands (sgpr_embed_ex with a tail workspace; sgpr_prep.hpp, PREP_SLOTS): the workgroup that completes a group
+    // of 16 launch slots (tail_cnt[slot >> 4] = launch token << 32 | arrivals) writes the all-pairs tail's row / column
+    // operands of the group's graphs at their graph indices - the square matrix over the G graphs of this call then needs
+    // no prep launch (sgpr_score_all_pairs_prepared).  tail_Ab == NULL: off
+    unsigned short* tail_Ab;
+    unsigned short* tail_Cb;
+    float* tail_ur;
+    float* tail_rng;
+    unsigned long long* tail_cnt;
     int promise;                // the caller's node_cap (or N): checked even when the plan ignores it
     int skip;                   // debug/ablation only (sgpr_debug_set_profile_buffer's companion): phases to skip
 };
@@ -142,6 +154,11 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 size_t score_all_pairs_ws_bytes(int R, int M);
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream);
+// the tail workspace of an embed call (score_all_pairs_ws_bytes(G, G) + the arrival counters) and its views
+size_t embed_tail_ws_bytes(int G);
+void embed_tail_views(void* ws, int G, EmbedArgs* a);
+int launch_score_all_pairs_prepared(const sgpr_handle* h, const float* pooled, int G, float* score, int64_t ld,
+                                    void* tail_ws, hipStream_t stream);
 size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs);
 int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs, void* ws, hipStream_t stream);
 size_t score_pair_list_ws_bytes(int NR, int M);

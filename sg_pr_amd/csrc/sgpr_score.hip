@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "sgpr_internal.hpp"
+#include "sgpr_prep.hpp"
 
 namespace sgpr {
 
@@ -131,7 +132,7 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 // matrix core (tools/probes/f16_split_probe.hip), so small values only lose what fp32 would lose as well.
 constexpr int AP_RW = 4;       // row graphs per wave: their A' operands (2 planes) stay in registers
 constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
-constexpr int AP_SB = 64;      // columns per super-block (4 MFMA column blocks)
+//        AP_SB = 64 (sgpr_prep.hpp): columns per super-block (4 MFMA column blocks)
 constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
 constexpr int AP_OCC = 4;      // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 #ifndef SGPR_AP_NI
@@ -172,159 +173,13 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return fmaxf(v, __shfl_xor(v, 32));
 }
 
-// 16 graphs per pair of workgroups.  Row graphs get A' (16 x 32 per graph) as ONE small GEMM per workgroup,
-// [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
-// instead of once per graph - plus the column half of the block term, split into two f16 planes on the way out, and
-// u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
-// LIST (pair-list mode, score_pair_list_kernel): the R row graphs are rows[row_ids[0 .. R)] (the distinct row graphs of
-// the list, gathered) and the column operands are laid out per graph, Cb [M][2 planes][32] f16, instead of per super-block.
-template <bool LIST>
-__device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* __restrict__ rows, int R,
-                                              const float* __restrict__ cols, int M, unsigned short* __restrict__ Ab,
-                                              float* __restrict__ ur, float* __restrict__ rng,
-                                              unsigned short* __restrict__ Cb, const int block,
-                                              const int32_t* __restrict__ row_ids = nullptr) {
-    __shared__ float red[4][4];
-    __shared__ __attribute__((aligned(16))) unsigned short stage[16 * 2 * 4 * 8 * 8];   // [graph][plane][j >> 3][t & 7][j & 7]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
-    const int g0 = (block >> 1) * 16, half = block & 1;
-    float amax = 0.f, umax = 0.f, emax = 0.f, l1max = 0.f;       // l1max: max over (graph, t) of sum_j |A'[t][j]|
-    if (g0 < R) {
-        // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
-        const int ga = min(g0 + l15, R - 1);
-        const float* e = rows + (size_t)(LIST ? row_ids[ga] : ga) * F + 4 * lq;
-        const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
-        // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
-        // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
-        float wv[4][8], wbv[4], l1r[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tile = half * 16 + wave * 4 + q;
-            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
-            const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                wv[q][s4] = wp[s4 * T * F];
-                wv[q][4 + s4] = wp[(16 + s4) * T * F];
-            }
-            wbv[q] = w.ntn_wb[t * 2 * F + F + j];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tile = half * 16 + wave * 4 + q;
-            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wv[q][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wv[q][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wv[q][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wv[q][3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wv[q][4], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wv[q][5], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wv[q][6], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wv[q][7], acc, 0, 0, 0);
-            // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
-            const float wbc = wbv[q];
-            // tiles q = 0, 1 (and 2, 3) are the two halves j < 16 / j >= 16 of the same t: a row of A' is the 16 lanes of
-            // a lane group in both of them
-            if ((q & 1) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) l1r[r] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int g = g0 + 4 * lq + r;
-                if (g < R) {
-                    const float a = acc[r] + wbc;
-                    amax = fmaxf(amax, fabsf(a));
-                    l1r[r] += fabsf(a);
-                    _Float16 h, l;
-                    split2_f16(a, h, l);
-                    // staged through LDS in the operand layout: the lanes hold one f16 each of a 16-byte operand unit
-                    // (8 consecutive j of one (graph, plane, t)); 2-byte global stores cost the kernel a quarter of its time
-                    unsigned short* dst = stage + (((4 * lq + r) * 2 * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
-                    dst[0] = __builtin_bit_cast(unsigned short, h);
-                    dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
-                }
-            }
-            if (q & 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = l1r[r];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
-                    l1max = fmaxf(l1max, v);
-                }
-            }
-        }
-    }
-    if (g0 < R) {
-        __syncthreads();
-        // 16 graphs x 2 planes x 4 (j >> 3) x 8 t of this half = 1024 units of 16 bytes, 8 consecutive t contiguous in memory
-        for (int u = threadIdx.x; u < 16 * 2 * 4 * 8; u += 256) {
-            const int tl = u & 7, jb = (u >> 3) & 3, pl = (u >> 5) & 1, gi = u >> 6;
-            if (g0 + gi < R)
-                *reinterpret_cast<uint4*>(Ab + (((size_t)(g0 + gi) * 2 + pl) * 64 + jb * 16 + half * 8 + tl) * 8) =
-                    *reinterpret_cast<const uint4*>(stage + (size_t)u * 8);
-        }
-    }
-    // block term of the row graphs and the column operands: one graph per wave pass
-    for (int gi = half * 8 + wave * 2; gi < half * 8 + wave * 2 + 2; ++gi) {
-        const int g = g0 + gi;
-        if (g < R) {
-            const float* e1 = rows + (size_t)(LIST ? row_ids[g] : g) * F;
-            float s = 0.f;
-            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            s += w.ntn_bias[l15];
-            umax = fmaxf(umax, fabsf(s));
-            if (lq == 0) ur[(size_t)g * T + l15] = s;
-        }
-        const int msb = LIST ? M : (M + AP_SB - 1) / AP_SB * AP_SB;
-        if (g < msb && lane < F) {                          // the column operand itself, two f16 planes (zeros past M)
-            const float x = g < M ? cols[(size_t)g * F + lane] : 0.f;
-            emax = fmaxf(emax, fabsf(x));
-            _Float16 h, l;
-            split2_f16(x, h, l);
-            if (LIST) {
-                unsigned short* dst = Cb + (size_t)g * (2 * F) + lane;
-                dst[0] = __builtin_bit_cast(unsigned short, h);
-                dst[F] = __builtin_bit_cast(unsigned short, l);
-            } else {
-                const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
-                unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
-                dst[0] = __builtin_bit_cast(unsigned short, h);
-                dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
-            }
-        }
-    }
-    // NaN inputs: fmaxf drops them, so fold an explicit "not finite" marker in (infinity fails every bound)
-    amax = wave_max_f32(amax);
-    umax = wave_max_f32(umax);
-    emax = wave_max_f32(emax);
-    l1max = wave_max_f32(l1max);
-    if (lane == 0) {
-        red[wave][0] = amax;
-        red[wave][1] = umax;
-        red[wave][2] = emax;
-        red[wave][3] = l1max;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int q = threadIdx.x;
-        rng[(size_t)block * 4 + q] = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
-    }
-}
-
+// (ntn_prep_body: sgpr_prep.hpp - shared with the embed kernels' epilogue)
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
                                                        const float* __restrict__ cols, int M,
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                        float* __restrict__ rng, unsigned short* __restrict__ Cb) {
-    ntn_prep_body<false>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kPrepLdsBytes];
+    ntn_prep_body<PREP_DENSE>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x, nullptr, lds);
 }
 
 // several independent rectangles in one launch (sgpr_score_all_pairs_multi): job j owns the prep workgroups
@@ -352,7 +207,8 @@ __global__ __launch_bounds__(256) void ntn_prep_multi_kernel(const DevWeights w,
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
     const ApJob& q = jobs.job[j];
-    ntn_prep_body<false>(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j]);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kPrepLdsBytes];
+    ntn_prep_body<PREP_DENSE>(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j], nullptr, lds);
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
@@ -767,6 +623,37 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// ---- operands left behind by an embed call (sgpr_embed.hip, tail_arrive): the workspace of launch_score_all_pairs for
+//      the square matrix over the call's G graphs, followed by the arrival counters (one 64-bit cell per 16 launch slots)
+size_t embed_tail_ws_bytes(int G) {
+    return align256(score_all_pairs_ws_bytes(G, G)) + (size_t)((G + 15) / 16) * sizeof(unsigned long long);
+}
+
+void embed_tail_views(void* ws, int G, EmbedArgs* a) {
+    const int nrng = 2 * ap_prep_groups(G, G);
+    a->tail_ur = static_cast<float*>(ws);
+    a->tail_rng = a->tail_ur + (size_t)G * T;
+    a->tail_Ab = reinterpret_cast<unsigned short*>(a->tail_rng + (size_t)nrng * 4);
+    a->tail_Cb = a->tail_Ab + (size_t)G * 2 * 64 * 8;
+    a->tail_cnt = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + align256(score_all_pairs_ws_bytes(G, G)));
+}
+
+int launch_score_all_pairs_prepared(const sgpr_handle* h, const float* pooled, int G, float* score, int64_t ld,
+                                    void* tail_ws, hipStream_t stream) {
+    if (G == 0) return SGPR_OK;
+    EmbedArgs v;
+    embed_tail_views(tail_ws, G, &v);
+    const int nrng = 2 * ((G + 15) / 16);                 // the partials the embed launch wrote: two per group of 16 slots
+    const int64_t items = (int64_t)((G + AP_COLS - 1) / AP_COLS) * ((G + AP_ROWS - 1) / AP_ROWS);
+    const int64_t slots = (int64_t)h->num_cus * AP_OCC;
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((score_all_pairs_kernel<AP_OCC, AP_NI, 0>), dim3(grid), dim3(256), 0, stream, h->w, G, G, v.tail_Ab, v.tail_Cb,
+                       v.tail_ur, v.tail_rng, nrng, pooled, pooled, score, ld);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
+    return SGPR_OK;
+}
+
 size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs) {
     size_t total = 0;
     for (int j = 0; j < n; ++j) total += align256(score_all_pairs_ws_bytes(jobs[j].R, jobs[j].M));
@@ -843,7 +730,8 @@ __global__ __launch_bounds__(256) void ntn_prep_list_kernel(const DevWeights w, 
                                                             const float* __restrict__ cols, int M,
                                                             unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                             float* __restrict__ rng, unsigned short* __restrict__ Cg) {
-    ntn_prep_body<true>(w, rows, NR, cols, M, Ab, ur, rng, Cg, (int)blockIdx.x, row_ids);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kPrepLdsBytes];
+    ntn_prep_body<PREP_LIST>(w, rows, NR, cols, M, Ab, ur, rng, Cg, (int)blockIdx.x, row_ids, lds);
 }
 
 struct PairPlan {                 // device views into the plan buffer (sgpr.h, sgpr_pair_plan)
