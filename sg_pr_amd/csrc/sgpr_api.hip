@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,23 @@ namespace sgpr {
 static thread_local std::string g_last_error;
 
 void set_error(const std::string& msg) { g_last_error = msg; }
+
+int raise_lds_limit(LdsLimitOnce* once, const void* kernel, int bytes, const char* what) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (once->done & bit)) return SGPR_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        int have = 0;
+        (void)hipDeviceGetAttribute(&have, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+        set_error(std::string(what) + ": the kernel needs " + std::to_string(bytes) + " bytes of LDS per workgroup, device " +
+                  std::to_string(dev) + " offers " + std::to_string(have) + " (" + hipGetErrorString(e) + ")");
+        return SGPR_E_HIP;
+    }
+    if (dev < 64) once->done |= bit;
+    return SGPR_OK;
+}
 
 int hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -449,7 +467,11 @@ static size_t embed_park_bytes(int G, int N) {
 // ... | split launch (sgpr_internal.hpp, EmbedArgs::sem_tab): one 64-bit flag (the flag array rounded up to 16 bytes: the
 // rows behind it are read and written as float4) + 16 rows of 32 floats per launch slot; a split launch has at most
 // num_cus / 2 graphs (launch_embed), so the region is sized for that many slots, not for G
-constexpr int kMaxSplitGraphs = 128;     // MI355X: 256 CUs / 2 (a handle-independent bound: workspace queries need no device)
+// The split launch serves at most min(num_cus / 2, kMaxSplitGraphs) graphs: launch_embed needs a CU per workgroup of
+// both halves, and the workspace region is sized for kMaxSplitGraphs slots whatever the device (workspace queries work
+// without a device: MI355X's 256 CUs / 2).  On a part with more CUs, launches of 129 .. num_cus / 2 graphs run unsplit
+// (same results; the latency form simply stops at 128 graphs).
+constexpr int kMaxSplitGraphs = 128;
 static int embed_sem_slots(const sgpr_handle*, int G) { return G < kMaxSplitGraphs ? G : kMaxSplitGraphs; }
 static size_t embed_sem_flag_bytes(int slots) { return ((size_t)slots * sizeof(unsigned long long) + 15) & ~(size_t)15; }
 static size_t embed_sem_bytes(const sgpr_handle* h, int G) {
@@ -694,7 +716,15 @@ int sgpr_pair_plan(const int32_t* h_idx1, const int32_t* h_idx2, int64_t P, int 
         set_error("sgpr_pair_plan: NULL argument, negative count or 2^31 pairs or more");
         return SGPR_E_INVALID;
     }
-    std::vector<int32_t> count((size_t)R + 1, 0);
+    // (host allocations proportional to R: a failure is an error code, never an exception across the C boundary)
+    std::vector<int32_t> count, cursor;
+    try {
+        count.assign((size_t)R + 1, 0);
+        cursor.assign((size_t)R + 1, 0);
+    } catch (const std::exception&) {
+        set_error("sgpr_pair_plan: out of host memory for " + std::to_string(R) + " row graphs");
+        return SGPR_E_INVALID;
+    }
     for (int64_t p = 0; p < P; ++p) {
         const int32_t a = h_idx1[p], b = h_idx2[p];
         if (a < 0 || a >= R || b < 0 || b >= M) {
@@ -724,7 +754,6 @@ int sgpr_pair_plan(const int32_t* h_idx1, const int32_t* h_idx2, int64_t P, int 
     int32_t* item_beg = item_row + ni;
     int32_t* cols = item_beg + ni + 1;
     int32_t* pos = cols + P;
-    std::vector<int32_t> cursor((size_t)R + 1, 0);
     int32_t at = 0, cr = 0, it = 0;
     for (int r = 0; r < R; ++r) {
         cursor[r] = at;

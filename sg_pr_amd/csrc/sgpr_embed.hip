@@ -75,6 +75,7 @@ constexpr int FMT_BF3 = 1;    // three bf16 planes, written once per layer by th
 constexpr int FMT_H2 = 2;     // two f16 planes (the default): half the matrix instructions and a third of the split work
 constexpr float kF16Safe = 60000.f;
 constexpr int kSmallParkBytes = 16 * 32 * 4 + 256;   // 16 parked super-node rows + the branch's scratch (cnt[16], rowlab[NP <= 64])
+constexpr int kHybridParkBytes = 16 * 32 * 4 + 64 + 256;   // the same for the large plans (rowlab[NP <= 256])
 constexpr int PE = 36;        // floats per row of E   (final node embedding, 32 ch + 4)
 constexpr int PP = 32;        // floats per row of the parked sem3 block (output of the first branch)
 constexpr int NT_MAX = 512;   // threads per workgroup: 256 or 512 (blockDim.x), up to 256 VGPRs per lane either way
@@ -108,6 +109,7 @@ __host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_pa
     p.P = 1;
     p.overlap = 1;
     p.park_in_lds = 1;
+    p.park_hybrid = 0;
     p.small_park = small_park ? 1 : 0;
     p.alias_da = 1;
     p.lean = rows;
@@ -146,7 +148,8 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
     p->offX = off;    off += p->NP * p->rowb;
     p->offRed = p->offX;
     p->small_park = small_park ? 1 : 0;
-    p->offPark = off; off += p->park_in_lds ? (small_park ? kSmallParkBytes : p->NP * PP * 4) : 0;
+    p->park_hybrid = p->park_in_lds ? 0 : 1;
+    p->offPark = off; off += p->park_in_lds ? (small_park ? kSmallParkBytes : p->NP * PP * 4) : kHybridParkBytes;
     p->offXX = off;   off += p->NP * 4;
     p->offIdx = off;  off += round_up(p->NP * p->kpitch * 2, 16);
     p->offA = off;
@@ -1926,6 +1929,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: wave-uniform task loops and branches
     int tid = tid0, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int NS = p.N;                                   // slots per graph in global memory
+    // the first branch's output: LDS, or (large plans) this graph's rows of the global workspace - unless the branch runs
+    // on the 16 super-node rows, which every plan holds in LDS (re-pointed below once that is known)
     float* park = p.park_in_lds ? reinterpret_cast<float*>(smem + p.offPark) : kp.a.park_ws + (size_t)g * p.NP * PP;
     // optional per-phase cycle accounting (thread 0 of every workgroup; phases end at barriers)
     unsigned long long t_prev = 0;
@@ -2105,8 +2110,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             return;
         }
         if (fast) {
-            // scratch that must survive the branch sits behind the 16 virtual rows of the parked block (LDS, or the
-            // global workspace of the large plans: same-workgroup visibility across the barriers either way)
+            if (!p.park_in_lds && p.park_hybrid) park = reinterpret_cast<float*>(smem + p.offPark);
+            // scratch that must survive the branch sits behind the 16 virtual rows of the parked block
             int* cnt = reinterpret_cast<int*>(park + 16 * PP);                     // [16] nodes per label, [12] = K
             signed char* rl = reinterpret_cast<signed char*>(cnt + 16);            // [NP]
             int* vmask = reinterpret_cast<int*>(nbr);                              // [16] neighbour label sets
@@ -2624,20 +2629,10 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
     }
 }
 
-template <typename K>
-static int set_lds_limit(K kernel, bool* done) {
-    if (!*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(embed kernel)");
-        *done = true;      // benign race: idempotent
-    }
-    return SGPR_OK;
-}
-
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
 static int launch_t(const KParams& kp, hipStream_t stream) {
-    static bool attr_set = false;
-    int rc = set_lds_limit(&embed_kernel<KP, DBG, LEAN, FMT, KC>, &attr_set);
+    static LdsLimitOnce once;
+    int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&embed_kernel<KP, DBG, LEAN, FMT, KC>), kLdsLimit, "embed_kernel");
     if (rc != SGPR_OK) return rc;
     const int grid = kp.a.G * ((LEAN != 0 && DBG == 0 && kp.a.sem_tab) ? 2 : 1);
     // (the epilogue's tail prep stages its operands in the same dynamic LDS: tiny plans are rounded up to it)
@@ -2650,8 +2645,8 @@ static int launch_t(const KParams& kp, hipStream_t stream) {
 
 template <int KP, int FMT>
 static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
-    static bool attr_set = false;
-    int rc = set_lds_limit(&embed_redo_kernel<KP, FMT>, &attr_set);
+    static LdsLimitOnce once;
+    int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&embed_redo_kernel<KP, FMT>), kLdsLimit, "embed_redo_kernel");
     if (rc != SGPR_OK) return rc;
     int lds = kp.p.lds_bytes > kp.p2.lds_bytes ? kp.p.lds_bytes : kp.p2.lds_bytes;
     if (kp.a.tail_Ab && lds < kPrepLdsBytes) lds = kPrepLdsBytes;

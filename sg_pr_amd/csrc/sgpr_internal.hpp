@@ -87,6 +87,8 @@ struct EmbedPlan {
     int pitchA;      // floats per row of the gather target A
     int overlap;     // 1: key matrix resident, selection (half the waves) overlaps the GEMMs (other half)
     int park_in_lds; // xyz3 parked in LDS (1) or in the global workspace (0)
+    int park_hybrid; // park_in_lds == 0 only: the 16 super-node rows of the first branch (+ its scratch) still sit in LDS
+                     // (offPark); only a graph that takes the generic semantic branch uses its rows of the global workspace
     int small_park;  // 1: the LDS park holds only the 16 super-node rows (lean production launches): a graph that needs the
                      // generic semantic branch is re-embedded by the second pass
     int alias_da;    // 1: the key matrix / chunk D shares the A region (a barrier separates selection and GEMMs)
@@ -177,6 +179,14 @@ int launch_cluster_scan(const float* pts, int stride, const uint32_t* label, int
 
 int launch_graph_edges(const float* pts, int stride, const int32_t* point_node, int P, int n, const double* centers,
                        double* min_dis, void* ws, hipStream_t stream);
+
+// Raising a kernel's dynamic-LDS limit (hipFuncSetAttribute) applies to the CURRENT device only: remembered per device
+// (one bit each; a process that drives several GPUs raises it once on each), with a message that says what did not fit -
+// a part with 64 KB of LDS per workgroup cannot run the kernels that stage a whole graph / histogram in 130 - 160 KB.
+struct LdsLimitOnce {
+    unsigned long long done = 0ull;      // benign race: setting the attribute twice is idempotent
+};
+int raise_lds_limit(LdsLimitOnce* once, const void* kernel, int bytes, const char* what);
 
 // makes `device` current for the lifetime of the object and restores the caller's device afterwards
 struct DeviceGuard {

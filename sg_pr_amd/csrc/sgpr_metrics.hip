@@ -1217,13 +1217,10 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
     a.gpt = d_rank ? groups_per_threshold : 0;
     a.slabs = static_cast<unsigned*>(d_workspace);
     a.slab_words = slab_words(T);
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_threshold_count_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   // (+ 16 B of static LDS)
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(pair_threshold_count_kernel)");
-        attr_set = true;
-    }
+    static LdsLimitOnce once;
+    if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&pair_threshold_count_kernel), 144 * 1024,   // (+ 16 B of static LDS)
+                                 "pair_threshold_count_kernel"))
+        return rc;
     const size_t lds = (size_t)a.Tp * sizeof(float) + (size_t)((T + 2) & ~1) * sizeof(unsigned) +
                        (d_rank ? (size_t)T * sizeof(unsigned long long) : 0);
     hipLaunchKernelGGL(pair_threshold_count_kernel, dim3(h->num_cus), dim3(PC_THREADS), lds, s, a);
@@ -1308,15 +1305,11 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     const size_t lds_plan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_SORT * sizeof(float) +
                             (size_t)(F1_NBP / 32 + 1) * sizeof(unsigned);
     static_assert(2 * F1_HASH + F1_SORT + 1 <= F1_NBP, "the hash table and the suffix sums reuse the positives' histogram");
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&f1_scan_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&f1_plan_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan);
-        if (e1 != hipSuccess || e2 != hipSuccess) return hip_fail(e1 != hipSuccess ? e1 : e2, "hipFuncSetAttribute(f1 kernels)");
-        attr_set = true;
-    }
+    static LdsLimitOnce once_scan, once_plan;
+    if (int rc = raise_lds_limit(&once_scan, reinterpret_cast<const void*>(&f1_scan_kernel), (int)lds_scan, "sgpr_f1_max (f1_scan_kernel)"))
+        return rc;
+    if (int rc = raise_lds_limit(&once_plan, reinterpret_cast<const void*>(&f1_plan_kernel), (int)lds_plan, "sgpr_f1_max (f1_plan_kernel)"))
+        return rc;
     hipError_t e = hipMemsetAsync(ws, 0, 256, s);                                      // counts, control block, sizes
     if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
     if ((int64_t)R * M == 0) {                       // an empty rectangle: F1-max 0 over 0 positive / 0 negative pairs, status 0

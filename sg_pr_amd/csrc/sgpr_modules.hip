@@ -71,13 +71,8 @@ int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStre
         set_error("sgpr_knn: C * N too large for one workgroup's LDS (" + std::to_string(lds) + " bytes)");
         return SGPR_E_NODES;
     }
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(knn_kernel)");
-        attr_set = true;
-    }
+    static LdsLimitOnce once;
+    if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&knn_kernel), 160 * 1024, "sgpr_knn")) return rc;
     hipLaunchKernelGGL(knn_kernel, dim3(B), dim3(KNN_THREADS), lds, stream, x, C, N, k,
                        reinterpret_cast<long long*>(idx));
     hipError_t e = hipGetLastError();

@@ -134,10 +134,17 @@ constexpr int AP_RW = 4;       // row graphs per wave: their A' operands (2 plan
 constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
 //        AP_SB = 64 (sgpr_prep.hpp): columns per super-block (4 MFMA column blocks)
 constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
-constexpr int AP_OCC = 4;      // resident workgroups per CU the kernel is compiled for (waves per SIMD)
+#ifndef SGPR_AP_OCC
+#define SGPR_AP_OCC 4
+#endif
+constexpr int AP_OCC = SGPR_AP_OCC;   // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 #ifndef SGPR_AP_NI
 #define SGPR_AP_NI 1
 #endif
+#ifndef SGPR_AP_CHAINS
+#define SGPR_AP_CHAINS 1        // 2: layer 1's correction products (lo.hi, hi.lo) in an accumulator chain of their own, met by the
+#endif                          // hi.hi chain in one vector add - a shorter dependent chain for four more vector instructions per
+                                // (row, block); A/B builds (tools/build_variant.sh): measured, see profiles/r05_tail_variants.txt
 #ifndef SGPR_AP_NT_STORE
 #define SGPR_AP_NT_STORE 0      // 1: the matrix leaves through non-temporal stores (A/B builds, tools/build_variant.sh)
 #endif
@@ -470,12 +477,24 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
                             asm volatile("" : "+v"(h[i]) : "v"(bh), "v"(bl));
                         }
                     } else {
+#if SGPR_AP_CHAINS == 2
+                        f32x4 hc[NI];
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(al[r0 + i], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(ah[r0 + i], bl, hc[i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = h[i] + hc[i];
+#else
 #pragma unroll
                         for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
 #pragma unroll
                         for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
 #pragma unroll
                         for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
+#endif
                     }
                     if (VAR & 8) __builtin_amdgcn_s_setprio(0);
 #pragma unroll

@@ -32,8 +32,10 @@ def score_pair_list(trainer, graph_pairs, group=None):
     "pair-list mode": the reference's loop eval_batch.py:30-36 walks the list in order, so rank r takes pairs
     [lo_r, hi_r) of it): every rank parses and embeds only the graphs its own pairs name, scores them, and the
     per-rank `float32[P_r]` / `float64[P_r]` vectors are all-gathered in rank order (two padded tensor collectives,
-    allpairs.all_gather_varlen) - every rank returns the full vectors, identical to the single-process ones because a
-    score depends on its two graphs only."""
+    allpairs.all_gather_varlen) - every rank returns the full vectors, identical to the single-process ones: a score
+    depends on its two graphs only, and the tail kernel is chosen by the length of the whole list, not of a shard (the
+    grouped kernel's one launch-wide decision - f16 planes or the exact fp32 path - differs between shards only when a
+    pooled vector leaves the f16 range, |pooled| > 6e4: never on real data, ~1e-7 apart when it does)."""
     from . import allpairs
     world, rank = allpairs._world_of(group)
     lo, hi = allpairs.shard_bounds(len(graph_pairs), world, rank)
@@ -65,7 +67,9 @@ def score_pair_list(trainer, graph_pairs, group=None):
         if paths:
             pooled = torch.cat([model.embed(centers[s:s + chunk], labels[s:s + chunk])[0]
                                 for s in range(0, len(paths), chunk)])
-            pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib)).reshape(-1)
+            # which tail kernel: decided on the WHOLE list's length, not on this rank's shard of it
+            grouped = len(graph_pairs) >= getattr(model, "GROUPED_MIN_PAIRS", 1 << 62)
+            pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib), grouped=grouped).reshape(-1)
         model.engine().check_status()      # bad labels / broken node_cap promises are errors, not silent NaNs
     except Exception as e:       # any rank-local failure must reach the agreement below, or the other ranks hang in it
         if world == 1:

@@ -126,13 +126,17 @@ class SG(torch.nn.Module):
 
     GROUPED_MIN_PAIRS = 2048     # below this the one-wave-per-pair kernel's single launch wins
 
-    def score_pooled(self, pooled_1, pooled_2, idx_1=None, idx_2=None):
+    def score_pooled(self, pooled_1, pooled_2, idx_1=None, idx_2=None, grouped=None):
         """NTN + head on pooled vectors (optionally gathered through index lists).  A list of GROUPED_MIN_PAIRS pairs
         or more over shared graphs - the reference's evaluation loop, eval_batch.py:30-36 - is grouped by row graph
         once on the host and scored by sgpr_score_pair_list (matrix cores, bilinear form hoisted per distinct row
-        graph); shorter lists and un-indexed sides take sgpr_score_pairs (one wave per pair, exact fp32)."""
+        graph); shorter lists and un-indexed sides take sgpr_score_pairs (one wave per pair, exact fp32).
+        grouped: True / False picks the kernel regardless of the length (a caller that holds one SHARD of a list decides
+        on the whole list's length, so that a pair's bits do not depend on how the list was split); None = by length."""
         eng = self.engine()
-        if idx_1 is not None and idx_2 is not None and len(idx_1) >= self.GROUPED_MIN_PAIRS:
+        if grouped is None:
+            grouped = idx_1 is not None and idx_2 is not None and len(idx_1) >= self.GROUPED_MIN_PAIRS
+        if grouped and idx_1 is not None and idx_2 is not None and len(idx_1) > 0:
             i1 = idx_1.cpu().numpy() if isinstance(idx_1, torch.Tensor) else np.asarray(idx_1)
             i2 = idx_2.cpu().numpy() if isinstance(idx_2, torch.Tensor) else np.asarray(idx_2)
             plan = eng.pair_plan(i1, i2, pooled_1.shape[0], pooled_2.shape[0])

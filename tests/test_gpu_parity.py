@@ -1044,9 +1044,11 @@ def test_device_roc_auc(eng):
     assert abs(f1 - metrics.f1_max(g8.numpy().ravel(), r.cpu().numpy().ravel())) < 1e-12 and passes == 1
 
 
+@pytest.mark.timeout(1200)
 def test_config5_full_size(eng, oracle, oracle_sd):
-    """BASELINE config 5 at FULL size: 1024 pairs = 2048 graphs, node_num 256, K 20 (the fp32-row LDS layout with the
-    chunked key matrix).  A 16-pair sample against the oracle plus size-independent properties over the whole batch."""
+    """BASELINE config 5 at FULL size: 1024 pairs = 2048 graphs, node_num 256, K 20 (the large LDS plan with the chunked
+    key matrix).  ALL 1024 pairs against the oracle ("within 1e-4 or a proven kNN tie") plus size-independent properties
+    over the whole batch."""
     from sg_pr_amd import synth
     centers, labels, _ = synth.config5_pairs(seed=0)
     assert centers.shape == (2048, 256, 3)
@@ -1055,14 +1057,42 @@ def test_config5_full_size(eng, oracle, oracle_sd):
     eng.check_status()
     scores = eng.score_pairs(pooled[0::2].contiguous(), pooled[1::2].contiguous())
     assert torch.isfinite(pooled).all() and torch.isfinite(scores).all()
-    sel = np.arange(0, 2048, 64)[:16]                                        # 16 pairs spread over the batch
-    gi = np.stack((2 * sel, 2 * sel + 1), axis=1).reshape(-1)
-    rp, ra, _ = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(centers[gi], labels[gi])), 20)
+    # ALL 1024 pairs against the oracle: every score within the 1e-4 bar, or one of the pair's graphs differs from the
+    # oracle through a PROVEN kNN tie (tests/tie_proof.py: fp32-level gap in float64 on the oracle's own layer input, the
+    # reference's own keys within 2 ulp)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tie_proof
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    rp_parts, ra_parts = [], []
+    for s0 in range(0, 2048, 128):
+        p_, a_, _ = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(centers[s0:s0 + 128], labels[s0:s0 + 128])), 20)
+        rp_parts.append(p_)
+        ra_parts.append(a_.reshape(a_.shape[0], -1))
+    rp, ra = torch.cat(rp_parts), torch.cat(ra_parts)
     rs = oracle.score_from_pooled(oracle_sd, rp[0::2], rp[1::2])
-    err = (scores.cpu()[sel] - rs).abs().max().item()
-    print("config 5 full size: max|dscore| on 16 sampled pairs =", err)
-    assert err <= SCORE_TOL
-    np.testing.assert_allclose(att.cpu().numpy()[gi], ra.numpy().reshape(len(gi), -1), rtol=0, atol=ATT_TOL)
+    d = (scores.cpu() - rs).abs().numpy()
+    off = np.flatnonzero(d > SCORE_TOL)
+    print("config 5 full size: max|dscore| over the 1024 pairs = %.3e; pairs beyond 1e-4: %d %s"
+          % (d.max(), off.size, off.tolist()))
+    assert off.size <= 10                                   # ties are rare events, not a regime
+    pooled_h = pooled.cpu().numpy()
+    dev = (pooled.cpu() - rp).abs().amax(1).numpy()
+    excused = np.zeros(2048, dtype=bool)
+    for pi in off:
+        reps = []
+        for g in (2 * pi, 2 * pi + 1):
+            if dev[g] > 1e-4:
+                rep = tie_proof.prove_graph(eng, oracle, oracle_sd, centers[g], labels[g], 20, pooled_h[g])
+                reps.append((int(g), rep["proven"], rep["reason"], [round(f["ratio_fp32"], 3) for f in rep["flips"]]))
+                excused[g] = rep["proven"]
+        print("  pair %d (|d score| %.2e): %s" % (pi, d[pi], reps))
+        assert reps and any(ok for _, ok, _, _ in reps), "pair %d differs by %.3g without a proven tie: %s" % (pi, d[pi], reps)
+    # attention weights of the graphs whose embedding agrees (a graph with a flipped neighbour legitimately differs)
+    agree = dev <= 1e-4
+    att_dev = np.abs(att.cpu().numpy() - ra.numpy()).max(1)
+    print("config 5 full size: graphs with |d pooled| <= 1e-4: %d of 2048; max |d att| among them %.2e" % (agree.sum(), att_dev[agree].max()))
+    assert agree.sum() >= 2000 and att_dev[agree].max() <= 10 * ATT_TOL
     # plain launch (no cap, storage order) and a two-shard launch: bit-identical pooled vectors
     p_plain, _, _ = eng.embed(centers, labels, 20)
     assert torch.equal(p_plain, pooled)
@@ -1164,11 +1194,13 @@ def test_full_sequence_parity_with_tie_proofs(eng, oracle, oracle_sd):
     assert r["flagged"].size <= 4541 // 100                                       # ties are rare events, not a regime
     # F1-max.  SURVEY 8d's |dF1| <= 1e-6 presumes score parity everywhere; it does not hold on the full matrix (observed
     # 3.6e-6): the proven-tie graphs move the 2 x 4541 scores of their rows and columns (by up to 5e-2), and scores that
-    # agree to 2.5e-5 can still trade places across the best threshold.  What holds, with a 10 x margin: 5e-5 on the
-    # full matrix - the curve itself is far from chance (F1-max 0.146 against a positive rate of 0.2 %).
+    # agree to 2.5e-5 can still trade places across the best threshold.  Gate: 1e-5 on the full matrix (3 x the
+    # observed) - the curve itself is far from chance (F1-max 0.146 against a positive rate of 0.2 %).
     assert r["f1_oracle"] > 0.1, "the sequence's PR curve is at chance: %r" % r["f1_oracle"]
-    assert abs(r["f1_hip"] - r["f1_oracle"]) <= 5e-5
-    assert abs(r["f1_hip_clean"] - r["f1_oracle_clean"]) <= 5e-5
+    assert abs(r["f1_hip"] - r["f1_oracle"]) <= 1e-5
+    assert abs(r["f1_hip_clean"] - r["f1_oracle_clean"]) <= 1e-5
+    # every accepted flip fits the fp32 term of the bound ALONE (the capped input-rounding term was never needed)
+    assert max(r.get("ratios_fp32") or [0.0]) <= 1.0, r.get("ratios_fp32")
     # the device F1-max (one engine call) on the HIP matrix = the sorted host computation on the same matrix
     pooled = r["pooled"]
     from sg_pr_amd import metrics
@@ -1495,7 +1527,8 @@ def test_grouped_pair_list_is_bitwise_the_dense_matrix(eng):
         eng.score_pair_list(pooled[:10].contiguous(), pooled, plan)
 
 
-def test_reference_pair_lists_full_size(eng, golden_dir, ckpt_path):
+@pytest.mark.timeout(900)
+def test_reference_pair_lists_full_size(eng, golden_dir, ckpt_path, oracle, oracle_sd):
     """The reference's own evaluation lists (data_process/pair_list/pair_list_3_20_{02,05,06,08}.npy, index pairs kept as
     tests/golden/pair_lists_3_20.npz) at full size over KITTI-like graphs: grouped scores == dense matrix entries bit
     for bit, and SG.score_pooled routes lists of this size through the grouped kernel."""
@@ -1519,6 +1552,40 @@ def test_reference_pair_lists_full_size(eng, golden_dir, ckpt_path):
         assert torch.equal(got, dense[torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()])
         via_model = model.score_pooled(pooled, pooled, torch.from_numpy(i1.astype(np.int32)), torch.from_numpy(i2.astype(np.int32)))
         assert torch.equal(via_model, got)
+        if name == "02":
+            # ... and the ORACLE on a sample of the list (not only HIP against HIP): the listed pairs of the first row
+            # graphs until 2000 pairs are reached, both graphs of every pair embedded by the oracle, the reference's
+            # per-pair tail on them (eval_batch.py:30-36 restated).  A graph whose embedding differs must be a proven
+            # kNN tie (tests/tie_proof.py); every score between the others is within the 1e-4 bar.
+            order = np.argsort(ij[:, 0], kind="stable")
+            take = order[:np.searchsorted(ij[order, 0], ij[order[2000], 0], side="right")]
+            assert take.size >= 2000
+            used = np.unique(ij[take])
+            remap = np.full(m, -1, dtype=np.int64)
+            remap[used] = np.arange(used.size)
+            torch.set_num_threads(min(64, os.cpu_count() or 8))
+            rp = torch.cat([oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(c[used[s0:s0 + 256]], l[used[s0:s0 + 256]])), 10)[0]
+                            for s0 in range(0, used.size, 256)])
+            rs = oracle.score_from_pooled(oracle_sd, rp[remap[ij[take, 0]]], rp[remap[ij[take, 1]]]).numpy()
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(perm.size)
+            hs = got.cpu().numpy()[inv[take]]                    # got is in the shuffled list's order
+            dev = (pooled.cpu()[torch.from_numpy(used)] - rp).abs().amax(1).numpy()
+            flagged = used[dev > 2e-4]
+            import sys
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import tie_proof
+            ph = pooled.cpu().numpy()
+            for g in flagged:
+                rep = tie_proof.prove_graph(eng, oracle, oracle_sd, c[g], l[g], 10, ph[g])
+                assert rep["proven"], (int(g), rep["reason"])
+            touched = np.isin(ij[take, 0], flagged) | np.isin(ij[take, 1], flagged)
+            dd = np.abs(hs - rs)
+            print("pair list 02: %d listed pairs over %d graphs against the oracle: max |d score| %.3e between graphs whose "
+                  "embeddings agree (%d pairs touch the %d proven-tie graphs, max |d| there %.3e)"
+                  % (take.size, used.size, dd[~touched].max(), int(touched.sum()), flagged.size,
+                     dd[touched].max() if touched.any() else 0.0))
+            assert dd[~touched].max() <= SCORE_TOL and flagged.size <= max(1, used.size // 100)
 
 
 def test_f1_max_bit_pattern_bins_at_their_edges(eng):

@@ -417,7 +417,7 @@ class _OracleModel:
         from sg_pr_amd import synth
         return self.oracle.embed(self.sd, torch.from_numpy(synth.dense_features(np.asarray(c), np.asarray(l))), 10)
 
-    def score_pooled(self, p1, p2, i1, i2):
+    def score_pooled(self, p1, p2, i1, i2, grouped=None):
         return self.oracle.score_from_pooled(self.sd, p1[i1.long()], p2[i2.long()])
 
     def engine(self):

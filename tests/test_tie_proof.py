@@ -67,6 +67,35 @@ def test_an_upstream_numerical_error_is_not_a_tie(oracle, oracle_sd):
     assert not rep["proven"] and "inputs differ" in rep["reason"]
 
 
+def test_input_gate_is_at_the_rounding_level(oracle, oracle_sd):
+    """The gate on the layer inputs is the GPU tests' FEAT_TOL (5e-6), not a loose 5e-5: an implementation whose layer
+    outputs are 2e-5 off (30 x today's kernels) cannot have its flips excused - and its own error cannot widen the bound
+    either (the perturbation term is capped at the fp32 term)."""
+    assert tie_proof.INPUT_TOL <= 5e-6
+    c, l, _, _ = synth.world_sequence(4, 100, seed=0)
+    f = torch.from_numpy(synth.dense_features(c[:1], l[:1]))
+    x, knn = tie_proof.oracle_trace(oracle, oracle_sd, f, 10)
+    xb = [v.copy() for v in x]
+    xb[1] = xb[1] + 2e-5 * np.sign(np.random.default_rng(0).standard_normal(xb[1].shape)).astype(np.float32)
+    rep = tie_proof.prove_ties(x, knn, xb, knn)
+    assert not rep["proven"] and "inputs differ" in rep["reason"]
+    # a flip between candidates 3 fp32 bounds apart, "explained" by a large input difference: the cap refuses it
+    li = 1
+    d2 = ((x[li][0][None, :].astype(np.float64) - x[li].astype(np.float64)) ** 2).sum(1)
+    order = np.argsort(d2, kind="stable")
+    nrm = (x[li].astype(np.float64) ** 2).sum(1)
+    kth = order[9]
+    far = [j for j in order[10:] if d2[j] - d2[kth] > 3 * tie_proof.TIE_C * 2.0 ** -24 * (nrm[0] + max(nrm[j], nrm[kth]))][0]
+    bad = [k.copy() for k in knn]
+    row0 = bad[li][0]
+    row0[np.flatnonzero(row0 == kth)[0]] = far
+    xh = [v.copy() for v in x]
+    xh[li] = xh[li].copy()
+    xh[li][far] += 4e-6                                           # inside the input gate, large enough for the old bound
+    rep = tie_proof.prove_ties(x, knn, xh, bad)
+    assert not rep["proven"] and "not a tie" in rep["reason"], rep
+
+
 def test_float64_oracle_flips_only_proven_ties(oracle, oracle_sd):
     """The same model evaluated in float64 is an implementation of the reference that is not its BLAS: wherever its
     embedding leaves the fp32 oracle's, the proof must find a near-tie (graph 595 of the world sequence is one)."""

@@ -13,21 +13,28 @@ checkable statement:
   2. in that layer every row whose neighbour set differs swaps candidates a (ours) and b (the oracle's) whose squared
      distances to the row, recomputed in float64 from the ORACLE's own fp32 layer input, are closer than
 
-         bound = c * 2^-24 * (|x_i|^2 + max(|x_a|^2, |x_b|^2))  +  perturbation,
+         bound = fp32 + min(perturbation, fp32),   fp32 = c * 2^-24 * (|x_i|^2 + max(|x_a|^2, |x_b|^2)),
 
-     the first term being the fp32 expansion's error scale (the three terms of pd are each rounded at the magnitude of
+     fp32 being the fp32 expansion's error scale (the three terms of pd are each rounded at the magnitude of
      |x|^2; c = TIE_C, far below the worst-case (C + 2) of a C-term dot product) and `perturbation` the exact first-order
      effect of the measured rounding-level difference between the two implementations' inputs to that layer
-     (2 |x_i - x_j| |dx_i - dx_j| + |dx_i - dx_j|^2 for j = a, b: Cauchy-Schwarz).
+     (2 |x_i - x_j| |dx_i - dx_j| + |dx_i - dx_j|^2 for j = a, b: Cauchy-Schwarz) - CAPPED at the fp32 term, so that the
+     implementation under test cannot buy itself a wider bound with its own numerical error, and
+  3. the REFERENCE's own arithmetic saw a tie, too: the oracle's fp32 ranking keys of a and b (dgcnn.py:15-17, its own
+     precision) differ by at most REF_GAP_ULPS units in the last place of |x_i|^2 + max(|x_a|^2, |x_b|^2); in the
+     coordinate layer, whose keys the kernel restates operation for operation, they must be EXACTLY equal (only
+     torch.topk's order among equal keys can then differ from the kernel's lowest-index rule).
 Layers after the first differing one are not examined: their inputs differ for a proven reason.
 
-A selection bug (a wrong neighbour that is NOT a near-tie) fails 2; a numerical bug upstream fails 1.
+A selection bug (a wrong neighbour that is NOT a near-tie) fails 2 and 3; a numerical bug upstream fails 1.
 """
 import numpy as np
 import torch
 
 TIE_C = 4.0            # multiples of 2^-24 (|x_i|^2 + |x_j|^2) a gap may have and still count as an fp32 tie
-INPUT_TOL = 5e-5       # max |difference| of a layer input between the two implementations before the first flip
+INPUT_TOL = 5e-6       # max |difference| of a layer input between the two implementations before the first flip (= the GPU
+                       # tests' FEAT_TOL on layer outputs; the kernels deliver <= 7.2e-7)
+REF_GAP_ULPS = 2.0     # units in the last place of |x_i|^2 + |x_j|^2 the reference's own fp32 keys of a flip may be apart
 LAYERS = ["xyz1", "xyz2", "xyz3", "sem1", "sem2", "sem3"]
 
 
@@ -67,7 +74,7 @@ def _multiset_diff(a, b):
     return out
 
 
-def prove_ties(x_o, knn_o, x_h, knn_h, tie_c=TIE_C, input_tol=INPUT_TOL):
+def prove_ties(x_o, knn_o, x_h, knn_h, tie_c=TIE_C, input_tol=INPUT_TOL, ref_gap_ulps=REF_GAP_ULPS):
     """x_o / x_h: the six layer inputs [N, C] of the oracle / of the implementation under test; knn_o / knn_h: their
     neighbour lists [N, k].  Returns a report dict: `proven` (bool), `flips` (one entry per differing row of the first
     differing layer of each branch: layer, row, ours, theirs, gap, bound, ratio), `reason` when not proven."""
@@ -105,16 +112,26 @@ def prove_ties(x_o, knn_o, x_h, knn_h, tie_c=TIE_C, input_tol=INPUT_TOL):
                         for j in (a, b):
                             dd = np.linalg.norm((xh[i] - xo[i]) - (xh[j] - xo[j]))
                             pert += 2.0 * np.sqrt(d2(j)) * dd + dd * dd
-                        bound = fp32 + pert
+                        bound = fp32 + min(pert, fp32)
                         pd = getattr(x_o, "pd", None)
                         ref_gap = float(abs(np.float64(pd[li][i, a]) - np.float64(pd[li][i, b]))) if pd is not None else None
+                        ulp = float(np.spacing(np.float32(nrm[i] + max(nrm[a], nrm[b]))))
                         rep["flips"].append({"layer": LAYERS[li], "row": int(i), "ours": a, "theirs": b, "gap": gap,
                                              "d2": d2(b), "fp32_bound": fp32, "perturbation": pert,
-                                             "ratio": gap / bound, "ref_gap": ref_gap})
+                                             "ratio": gap / bound, "ratio_fp32": gap / fp32, "ref_gap": ref_gap,
+                                             "ref_gap_ulps": None if ref_gap is None else ref_gap / ulp})
                         if not gap <= bound:
                             rep["proven"] = False
                             rep["reason"] += ("%s row %d: candidates %d / %d are %.3g apart in d^2 (bound %.3g): not a "
                                               "tie; " % (LAYERS[li], i, a, b, gap, bound))
+                        if ref_gap is not None:
+                            # the reference's own keys: a tie in ITS arithmetic (exactly equal in the coordinate layer)
+                            allowed = 0.0 if li == 0 else ref_gap_ulps * ulp
+                            if not ref_gap <= allowed:
+                                rep["proven"] = False
+                                rep["reason"] += ("%s row %d: the reference's fp32 keys of candidates %d / %d are %.3g apart "
+                                                  "(%.2f ulp; allowed %.3g): not a tie in its arithmetic; "
+                                                  % (LAYERS[li], i, a, b, ref_gap, ref_gap / ulp, allowed))
             break            # later layers of this branch differ for a proven (or disproven) reason
     return rep
 
@@ -153,6 +170,23 @@ def hip_trace(eng, centers, labels, k):
     return ins, [knn[i] for i in range(6)], pooled[0].cpu().numpy()
 
 
+def prove_graph(eng, oracle, sd, centers_g, labels_g, k, pooled_g=None):
+    """One graph whose embedding (or one of whose scores) differs from the oracle's: the report of prove_ties, with
+    `proven` additionally requiring that a flip was found and that the debug instance reproduces the production launch's
+    pooled vector (pooled_g, when given)."""
+    from sg_pr_amd import synth
+    x_h, knn_h, p_dbg = hip_trace(eng, centers_g, labels_g, k)
+    x_o, knn_o = oracle_trace(oracle, sd, torch.from_numpy(synth.dense_features(centers_g[None], labels_g[None])), k)
+    rep = prove_ties(x_o, knn_o, x_h, knn_h)
+    if pooled_g is not None and not np.array_equal(p_dbg, np.asarray(pooled_g)):
+        rep["proven"] = False
+        rep["reason"] += "the debug instance's pooled vector is not the production launch's; "
+    if not rep["flips"]:
+        rep["proven"] = False
+        rep["reason"] += "no neighbour set differs; "
+    return rep
+
+
 def census(eng, oracle, sd, centers, labels, poses, k=10, flag_tol=2e-4, score_tol=1e-4, log=print, oracle_rows=None):
     """Whole-sequence parity of the HIP path against the oracle with every deviation accounted for.  Returns a dict of
     the figures the test gates; `log` receives the human-readable lines (profiles/r04_seq_parity.txt).
@@ -187,15 +221,21 @@ def census(eng, oracle, sd, centers, labels, poses, k=10, flag_tol=2e-4, score_t
         (out["proven"] if rep["proven"] else out["unproven"]).append(int(g))
         for f in rep["flips"]:
             out["ratios"].append(f["ratio"])
-            log("  graph %d (|d pooled| %.2e) %s row %d: ours %d / oracle's %d, d^2 = %.6g, gap %.3g, bound %.3g "
-                "(fp32 %.3g + input rounding %.3g) -> %.2f of the bound; the oracle's own fp32 keys of the two: %s"
-                % (g, dev[g], f["layer"], f["row"], f["ours"], f["theirs"], f["d2"], f["gap"],
-                   f["fp32_bound"] + f["perturbation"], f["fp32_bound"], f["perturbation"], f["ratio"],
-                   "EQUAL (torch.topk's tie order decides)" if f["ref_gap"] == 0.0 else "%.3g apart" % f["ref_gap"]))
+            log("  graph %d (|d pooled| %.2e) %s row %d: ours %d / oracle's %d, d^2 = %.6g, gap %.3g = %.3f of the fp32 "
+                "bound %.3g alone (input rounding term %.3g, capped at the fp32 term: %.2f of the bound); the oracle's own "
+                "fp32 keys of the two: %s"
+                % (g, dev[g], f["layer"], f["row"], f["ours"], f["theirs"], f["d2"], f["gap"], f["ratio_fp32"],
+                   f["fp32_bound"], f["perturbation"], f["ratio"],
+                   "EQUAL (torch.topk's tie order decides)" if f["ref_gap"] == 0.0
+                   else "%.3g apart = %.2f ulp of |x_i|^2 + |x_j|^2" % (f["ref_gap"], f["ref_gap_ulps"])))
         if not rep["proven"]:
             log("  graph %d NOT PROVEN: %s" % (g, rep["reason"]))
-    log("proven ties: %d of %d flagged graphs; largest gap / bound %.3f"
-        % (len(out["proven"]), flagged.size, max(out["ratios"]) if out["ratios"] else 0.0))
+        out.setdefault("ratios_fp32", []).extend(f["ratio_fp32"] for f in rep["flips"])
+        out.setdefault("ref_gap_ulps", []).extend(f["ref_gap_ulps"] for f in rep["flips"] if f["ref_gap_ulps"] is not None)
+    log("proven ties: %d of %d flagged graphs; largest gap / bound %.3f, largest gap / fp32 term alone %.3f, the reference's "
+        "own keys at most %.2f ulp apart (input gate %.0e, reference-key gate %.1f ulp)"
+        % (len(out["proven"]), flagged.size, max(out["ratios"]) if out["ratios"] else 0.0,
+           max(out.get("ratios_fp32") or [0.0]), max(out.get("ref_gap_ulps") or [0.0]), INPUT_TOL, REF_GAP_ULPS))
     clean = np.setdiff1d(np.arange(G), flagged)
     out["clean_pooled_max"] = float(dev[clean].max()) if clean.size else 0.0
     # ---- score matrices
