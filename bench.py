@@ -109,6 +109,8 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=32,
                     help="launches per kernel of the untimed duration pass that follows the timed region (HIP events "
                          "around that many back-to-back embed calls, then tail calls; the timed region carries no events)")
+    ap.add_argument("--no-wide-range", action="store_true",
+                    help="skip the untimed pass at the reference's operand width (wide-range embed instance forced)")
     ap.add_argument("--no-fused-prep", action="store_true",
                     help="all-pairs workloads on one GPU: the separate preparation launch of sgpr_score_all_pairs instead "
                          "of the tail operands the embed launch leaves behind (sgpr_embed_ex; A/B of the two)")
@@ -474,6 +476,41 @@ def main():
         sharded = {"ms_per_step": ts / a.steps * 1e3, "value": units * a.steps / ts,
                    "note": "matrix left sharded by rows (no gather to rank 0)"}
 
+    # The same step at the reference's own operand width (extra information, after the timed region): debug bit 13 sends
+    # every graph through the wide-range embed instance (three bf16 planes = 24-bit operands, fp32's range) instead of the
+    # default two f16 planes (22 bits); the tail's operands stay two f16 planes (its exact-fp32 form is the one-wave-per-pair
+    # kernel, timed on a sample beside it).
+    wide = None
+    if world == 1 and not a.no_wide_range:
+        try:
+            eng.set_skip_mask(8192)
+            for _ in range(3):
+                step()
+            wsteps = max(5, min(20, a.steps))
+            tw = timed_steps(wsteps, step)
+            wide_embed_ms = kernel_ms(dur_calls["embed"], 8)
+            wide = {"ms_per_step": tw / wsteps * 1e3, "value_at_24bit_operands": units * wsteps / tw,
+                    "wide_range_launch_ms": wide_embed_ms, "steps": wsteps,
+                    "note": "embed on the wide-range instance (3 x bf16 planes = 24-bit matrix operands, forced through debug "
+                            "bit 13); tail unchanged (2 x f16 planes, fp32 accumulate)"}
+        except Exception as e:
+            wide = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            eng.set_skip_mask(0)
+        if allpairs_job and isinstance(wide, dict) and "error" not in wide:
+            try:
+                # the tail in exact fp32 (sgpr_score_pairs: one wave per pair, fp32 FMAs, no f16 planes) on a 2^20-pair sample
+                _pw = eng.embed(jobs[0]["d_centers"], jobs[0]["d_labels"], k)[0]
+                _gi = torch.randint(0, jobs[0]["m"], (2, 1 << 20), dtype=torch.int32, device=dev)
+                _so = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+                t_fp32 = kernel_ms(lambda: eng.score_pairs(_pw, _pw, _gi[0], _gi[1], out=_so), 4)
+                wide["tail_exact_fp32_pairs_per_s"] = (1 << 20) / (t_fp32 * 1e-3)
+                wide["value_at_fp32_everywhere"] = units / (wide_embed_ms * 1e-3 * launches_per_step + units / wide["tail_exact_fp32_pairs_per_s"])
+                wide["note"] += ("; value_at_fp32_everywhere = the wide-range embed + every pair through the exact-fp32 tail kernel "
+                                 "(extrapolated from a 2^20-pair sample)")
+            except Exception as e:
+                wide["tail_exact_fp32_error"] = "%s: %s" % (type(e).__name__, e)
+
     # what `value` excludes by contract: host <-> device transfers (SURVEY.md 8d counts them in its metric)
     end_to_end = None
     if allpairs_job and world == 1 and not a.no_end_to_end:
@@ -596,6 +633,9 @@ def main():
             "metric": "graph-pairs/sec", "value": value, "unit": "graph-pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if (allpairs_job or a.workload == "pairlist") else "weak",
+            "value_definition": "inputs and outputs resident in HBM (the bench contract); SURVEY.md 8d's transfer-inclusive "
+                                "figures are end_to_end.d2h (scores copied to the host) and end_to_end.device_f1 (F1-max on the "
+                                "device); a first call on fresh data also pays config.host_prep_ms_once (node_cap + launch order)",
             "vs_baseline": None, "dtype": "f32 (2xf16-plane operands on the matrix cores, fp32 accumulate; fp32 vector math)",
             "data": data_kind,
             "config": {"workload": wl_name, "graphs": int(sum(mm for _, mm in seqs)) if allpairs_job else int(m),
@@ -614,8 +654,12 @@ def main():
             "sharded_output": sharded,
             "end_to_end": end_to_end,
             "roofline": {"kernel": "sgpr::embed_kernel", "bound": "valu",
-                         "bound_note": "VALU issue + dependent latency (selection networks, gather-max, epilogues); the "
-                                       "matrix pipe is ~8 % busy and HBM ~0.5 % - priced against the fp32 vector peak",
+                         "bound_note": "frac = useful-work-equivalent throughput (algorithmic FLOPs of the factored formulation at "
+                                       "each graph's processed slots / launch time) against the fp32 VECTOR peak - not a pipe "
+                                       "utilisation; what binds the kernel is vector issue + dependent latency (selection "
+                                       "networks, gather-max, epilogues): roofline.issue.frac; the matrix pipe is ~10 % busy, "
+                                       "HBM ~0.8 % (roofline.hbm)",
+                         "wide_range": wide,
                          "achieved": ach_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP32_PEAK_TFLOPS, "traffic": traffic, "issue": issue, "launch_ms": embed_ms, "launches_timed": launches_timed,
                          "timing": "HIP events around %d back-to-back calls after the timed region (embed_kernel + its "

@@ -206,20 +206,25 @@ class AllPairsScorer:
         assert local.shape[0] == hi - lo
         if world == 1:
             return local
+        # ONE collective on equal-sized (padded) shards, straight into one tensor (all_gather_into_tensor: no list of
+        # per-rank buffers, no concatenation); when the ranks' shards are equal - M divisible by the world size - the
+        # gathered tensor IS pooled [M, F], otherwise the padding rows of the shorter shards are dropped by one index copy
         cap = shard_bounds(m, world, 0)[1]               # largest shard
-        buf = local.new_zeros((cap, local.shape[1]))
-        buf[: hi - lo] = local
+        if hi - lo == cap:
+            buf = local.contiguous()
+        else:
+            buf = local.new_zeros((cap, local.shape[1]))
+            buf[: hi - lo] = local
         staged = self._host_staged(buf)
         if staged:
             buf = buf.cpu()
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf, group=self.group)
-        parts = []
-        for r in range(world):
-            l, h = shard_bounds(m, world, r)
-            parts.append(gathered[r][: h - l])
-        out = torch.cat(parts, dim=0)
-        return out.to(local.device) if staged else out
+        gathered = buf.new_empty((world * cap, buf.shape[1]))
+        dist.all_gather_into_tensor(gathered, buf, group=self.group)
+        if world * cap != m:
+            keep = torch.cat([torch.arange(r * cap, r * cap + shard_bounds(m, world, r)[1] - shard_bounds(m, world, r)[0])
+                              for r in range(world)]).to(gathered.device)
+            gathered = gathered.index_select(0, keep)
+        return gathered.to(local.device) if staged else gathered
 
     def score_rows(self, pooled):
         """This rank's row block of the score matrix: [hi-lo, M]."""

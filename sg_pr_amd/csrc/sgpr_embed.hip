@@ -476,6 +476,12 @@ __device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f
 #ifndef SGPR_ASM_MINMAX
 #define SGPR_ASM_MINMAX 1
 #endif
+#ifndef SGPR_WPREFETCH
+#define SGPR_WPREFETCH 1      // lean 64-row production instance: a GEMM phase's first weight fragment requested before the selection
+#endif
+#ifndef SGPR_ATT_PREFETCH
+#define SGPR_ATT_PREFETCH 1   // attention: the column of att_w a lane needs two barriers later is requested ahead of the partial sums
+#endif
 #ifndef SGPR_SEM_STAGE
 #define SGPR_SEM_STAGE 1      // super-node branch, tabled layer 2: this graph's table rows staged in LDS / registers beside the keys
 #endif
@@ -1359,10 +1365,13 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
 // the weight fragment of the tile in registers and walks the row tiles, so the weights cross L2 -> CU once per
 // workgroup instead of once per row tile and the work divides evenly whatever nrt is.  a-tiles go straight to A;
 // the (at most two) b-tiles of a wave wait in registers until every wave has read its X operands, then replace X.
+// pre: the weight fragment of this wave's FIRST column tile (tile index `wave`: NW = 4, NCT = 4 or 8), requested by the
+// caller ahead of the phase (embed_graph asks for it before the selection, whose ~2 us hide the L2 round trip that
+// otherwise opens every GEMM phase); nullptr: loaded here
 template <int NKB, int COUT, int FMT, int NWC = 0>   // NWC: the number of waves when it is a compile-time constant (lean instances)
 __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
                                           const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int nrt,
-                                          int wave, int NW_, int ex = 0) {
+                                          int wave, int NW_, int ex = 0, const FragT<FMT>* pre = nullptr) {
     const int NW = NWC ? NWC : NW_;
     const bool constw = (ex & 512) != 0;       // ablation bit 9: constant weights instead of loads (a compile-time 0 in production)
     const int lane = phase_tid() & 63;
@@ -1378,7 +1387,10 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
     f32x4 k0[4], k1[4];
     // ---- a-tiles
     int ct = wave;
-    if (ct < NCA) load_wfrag<NKB>(Wb + (size_t)ct * wtile<NKB, FMT>(), w, constw);
+    if (pre) {                                       // (NW = 4: the wave's first tile is tile `wave`, a- or b-type)
+        w[0] = pre[0];
+        if (NKB != 1) w[1] = pre[1];
+    } else if (ct < NCA) load_wfrag<NKB>(Wb + (size_t)ct * wtile<NKB, FMT>(), w, constw);
     else if (ctb0 < NCT) load_wfrag<NKB>(Wb + (size_t)ctb0 * wtile<NKB, FMT>(), w, constw);
     for (; ct < NCA; ct += NW) {
         const int cn = ct + NW < NCA ? ct + NW : ctb0;          // next tile of this wave (a-type, else its first b-tile)
@@ -1426,14 +1438,15 @@ __device__ __forceinline__ void gemm_cols(unsigned char* __restrict__ X, float* 
 
 template <bool COLS, int FMT, int NWC = 0>
 __device__ __forceinline__ void gemm_layer(unsigned char* X, float* A, int pitchA, const unsigned short* Wb,
-                                           const float* tb, int Kp, int cout, int nrt, int gw, int GW, int ex = 0) {
+                                           const float* tb, int Kp, int cout, int nrt, int gw, int GW, int ex = 0,
+                                           const FragT<FMT>* pre = nullptr) {
     if (COLS) {   // capped plans: nrt <= 4, GW >= 2 (make_embed_plan); contains a barrier - every wave calls it
         if (Kp != 64)
-            gemm_cols<1, 64, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<1, 64, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex, pre);
         else if (cout == 64)
-            gemm_cols<4, 64, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<4, 64, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex, pre);
         else
-            gemm_cols<4, 32, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex);
+            gemm_cols<4, 32, FMT, NWC>(X, A, pitchA, Wb, tb, nrt, gw, GW, ex, pre);
         return;
     }
     if (Kp != 64)
@@ -1796,6 +1809,14 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
     }
 }
 
+// A graph's pooled vector leaves through agent-coherent stores (sc1: written through this XCD's L2): the workgroup that
+// completes a group of 16 launch slots reads the other fifteen from another XCD's side of the chip (tail_arrive) without
+// anyone flushing or invalidating an L2 - a release FENCE at agent scope walks the whole L2 (buffer_wbl2, ~1 us; measured:
+// one per workgroup took the KITTI-00 launch from 131 to 532 us).
+__device__ __forceinline__ void store_pooled(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ split launch (few graphs: the latency regime)
 // The two branches of dgcnn_conv_pass are independent until conv_end (sg_net.py:81-104).  When a launch has at most half
 // as many graphs as the GPU has CUs, every graph gets TWO workgroups, each on a CU of its own: workgroup s < G runs the
@@ -2054,7 +2075,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if (N > p.NC || N > kp.a.promise || rag_bad) {   // more slots to process than the caller's node_cap promised: fail loudly
         if (role == 1) return;                   // (reported by the graph's other workgroup)
         if (tid == 0) atomicOr(kp.a.status, rag_bad ? 8 : 2);
-        if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
+        if (tid < 32) store_pooled(kp.a.pooled + (size_t)g * 32 + tid, __int_as_float(0x7fc00000));
         if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
         return;
     }
@@ -2205,6 +2226,17 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         // ---- kNN keys (Gram on MFMA) -> selection, one chunk of rows at a time (a single chunk, upper-triangular
         //      tiles mirrored, when the whole key matrix is resident)
         constexpr bool kOwned = SGPR_OWNED_SELECT != 0 && LEAN != 0 && DBG == 0 && FMT == FMT_H2 && KC == 10;
+        // the 64-row production instance (128 registers per lane at four workgroups per CU, ~90 in use): the weights of
+        // this wave's first column tile of the layer's GEMMs are requested BEFORE the selection
+        constexpr bool kWPre = SGPR_WPREFETCH != 0 && kOwned && LEAN == 64 && SGPR_LEAN_WAVES == 4;
+        FragT<FMT> wpre[2];
+        if constexpr (kWPre) {
+            const unsigned short* wl = kp.w.wh[L] + (size_t)wave * (Kp == 64 ? wtile<4, FMT>() : wtile<1, FMT>());
+            if (Kp == 64)
+                load_wfrag<4>(wl, wpre);
+            else
+                load_wfrag<1>(wl, wpre);
+        }
         if constexpr (kOwned) {
             // lean production instances: keys in registers, selection right behind them, no barrier until the GEMMs' own
             // (A is written only by the GEMM phase and nothing reads it here; b replaces X behind gemm_cols' barrier, which
@@ -2267,7 +2299,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
-        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip);
+        if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip, kWPre ? wpre : nullptr);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
 
@@ -2381,7 +2413,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 if (tid == 0) request_redo(kp.a, launch_slot, 2);
             } else {
                 if (tid == 0) atomicOr(kp.a.status, 4);
-                if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
+                if (tid < 32) store_pooled(kp.a.pooled + (size_t)g * 32 + tid, __int_as_float(0x7fc00000));
             }
             return;
         }
@@ -2457,6 +2489,13 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     float* sig = xx;
     const int c = tid & 31;
     if (FMT == FMT_H2 && tid == 0) *ovflag = 0;
+    // column tid of the attention matrix (lanes 0..31): needed two barriers from here - requested now, so that its L2
+    // round trip runs under the partial sums instead of opening the tanh step
+    float attw[32];
+    if (SGPR_ATT_PREFETCH && tid < 32) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) attw[r] = kp.w.att_w[r * 32 + tid];
+    }
     for (int prt = tid >> 5; prt < NPART; prt += NT >> 5) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf(n >= nd ? wdup : 1.f, E[n * PE + c], s);
@@ -2471,7 +2510,12 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     __syncthreads();
     if (tid < 32) {
         float gc = 0.f;
-        for (int r = 0; r < 32; ++r) gc = fmaf(mean[r], kp.w.att_w[r * 32 + tid], gc);
+        if (SGPR_ATT_PREFETCH) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) gc = fmaf(mean[r], attw[r], gc);
+        } else {
+            for (int r = 0; r < 32; ++r) gc = fmaf(mean[r], kp.w.att_w[r * 32 + tid], gc);
+        }
         tg[tid] = tanhf(gc);
     }
     __syncthreads();
@@ -2496,7 +2540,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if (tid < 32) {
         float s = 0.f;
         for (int q = 0; q < NPART; ++q) s += red[q * 32 + tid];
-        kp.a.pooled[(size_t)g * 32 + tid] = s;
+        store_pooled(kp.a.pooled + (size_t)g * 32 + tid, s);
     }
     // a graph whose activations left the f16 range is embedded again by the wide-range instance (embed_redo_kernel)
     if (FMT == FMT_H2 && kp.a.redo && tid == 0) request_redo(kp.a, launch_slot, *ovflag ? 1 : 0);
@@ -2515,7 +2559,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
 // group prepares the 16 graphs with the code of ntn_prep_kernel (one fp32 MFMA GEMM per group: the 64 KB tensor crosses
 // L2 -> CU once per 16 graphs) - same instructions on the same operands, so the operands carry the bits the stand-alone
 // prep would produce.  The counter cell holds launch token << 32 | arrivals: whatever the workspace held before is another
-// launch's token (or garbage) and counts as zero.
+// launch's token (or garbage) and counts as zero.  No fences: pooled vectors cross between workgroups through agent-coherent
+// stores and loads (store_pooled / PREP_SLOTS' loads), the count through a relaxed agent-scope compare-and-swap issued after
+// the storing wave has waited for its stores.
 __device__ __forceinline__ void tail_prep_group(const KParams& kp, const int group, unsigned char* lds) {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half)
@@ -2526,9 +2572,11 @@ __device__ __forceinline__ void tail_prep_group(const KParams& kp, const int gro
 __device__ __forceinline__ void tail_arrive(const KParams& kp, const int slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* last = reinterpret_cast<int*>(smem);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this graph's pooled vector, before the count
-    __syncthreads();                                            // (also: embed_graph is done with LDS)
+    __syncthreads();                                            // embed_graph is done with LDS
     if (threadIdx.x == 0) {
+        // this graph's pooled vector (store_pooled, by lanes 0..31 of this very wave) has reached the coherent level
+        // before it is counted: the wave's outstanding stores are waited for, no cache is flushed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int group = slot >> 4;
         const unsigned want = (unsigned)min(16, kp.a.G - 16 * group);
         unsigned long long* cell = kp.a.tail_cnt + group;
@@ -2543,8 +2591,7 @@ __device__ __forceinline__ void tail_arrive(const KParams& kp, const int slot) {
     const bool mine = *last != 0;
     __syncthreads();                                            // (`last` sits in the staging area)
     if (!mine) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other 15 workgroups' pooled vectors
-    tail_prep_group(kp, slot >> 4, smem);
+    tail_prep_group(kp, slot >> 4, smem);                       // (reads the group's pooled vectors through agent-coherent loads)
 }
 
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
@@ -2616,9 +2663,8 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
         }
         if (kp.a.tail_Ab && again) {
             // the first pass prepared these groups from pooled vectors that have just been replaced: once more
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (this workgroup's own store_pooled, then its own coherent loads)
             __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll 1
             for (int q = 0; q < 4; ++q)
                 if ((again >> (16 * q)) & 0xffffull) {

@@ -57,6 +57,15 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     // two work units per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
     const int g0 = (block >> 1) * 16, half = block & 1;
     // where row slot s is read from / its operands are written to
+    // PREP_SLOTS reads pooled vectors other workgroups of the SAME launch have just stored (agent-coherent stores):
+    // agent-coherent loads, which never hit a stale line of this XCD's L2
+    auto ld = [](const float* p) {
+        return MODE == PREP_SLOTS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    };
+    auto ld4 = [&](const float* p) {
+        if (MODE != PREP_SLOTS) return *reinterpret_cast<const float4*>(p);
+        return make_float4(ld(p), ld(p + 1), ld(p + 2), ld(p + 3));
+    };
     auto src_of = [&](int s) { return (MODE != PREP_DENSE && row_ids) ? row_ids[s] : s; };
     auto dst_of = [&](int s) { return (MODE == PREP_SLOTS && row_ids) ? row_ids[s] : s; };
     float amax = 0.f, umax = 0.f, emax = 0.f, l1max = 0.f;       // l1max: max over (graph, t) of sum_j |A'[t][j]|
@@ -64,7 +73,7 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
         // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
         const int ga = min(g0 + l15, R - 1);
         const float* e = rows + (size_t)src_of(ga) * F + 4 * lq;
-        const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
+        const float4 ea0 = ld4(e), ea1 = ld4(e + 16);
         // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
         // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
         // (the embed epilogue takes them two tiles at a time: it shares its kernel with the embed phases, whose register
@@ -153,7 +162,7 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
         if (g < R) {
             const float* e1 = rows + (size_t)src_of(g) * F;
             float s = 0.f;
-            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
+            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], ld(e1 + lq * 8 + m), s);
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             s += w.ntn_bias[l15];
@@ -165,7 +174,7 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
         const bool has_col = MODE == PREP_SLOTS ? g < R : g < msb;
         if (has_col && lane < F) {                          // the column operand itself, two f16 planes
             const int c = MODE == PREP_SLOTS ? dst_of(g) : g;
-            const float x = (MODE == PREP_SLOTS || g < M) ? cols[(size_t)c * F + lane] : 0.f;
+            const float x = (MODE == PREP_SLOTS || g < M) ? ld(cols + (size_t)c * F + lane) : 0.f;
             emax = fmaxf(emax, fabsf(x));
             _Float16 h, l;
             prep_split2_f16(x, h, l);

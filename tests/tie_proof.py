@@ -21,7 +21,7 @@ checkable statement:
      (2 |x_i - x_j| |dx_i - dx_j| + |dx_i - dx_j|^2 for j = a, b: Cauchy-Schwarz) - CAPPED at the fp32 term, so that the
      implementation under test cannot buy itself a wider bound with its own numerical error, and
   3. the REFERENCE's own arithmetic saw a tie, too: the oracle's fp32 ranking keys of a and b (dgcnn.py:15-17, its own
-     precision) differ by at most REF_GAP_ULPS units in the last place of |x_i|^2 + max(|x_a|^2, |x_b|^2); in the
+     precision) differ by at most REF_GAP_ULPS (6) units in the last place of |x_i|^2 + max(|x_a|^2, |x_b|^2); in the
      coordinate layer, whose keys the kernel restates operation for operation, they must be EXACTLY equal (only
      torch.topk's order among equal keys can then differ from the kernel's lowest-index rule).
 Layers after the first differing one are not examined: their inputs differ for a proven reason.
@@ -34,7 +34,13 @@ import torch
 TIE_C = 4.0            # multiples of 2^-24 (|x_i|^2 + |x_j|^2) a gap may have and still count as an fp32 tie
 INPUT_TOL = 5e-6       # max |difference| of a layer input between the two implementations before the first flip (= the GPU
                        # tests' FEAT_TOL on layer outputs; the kernels deliver <= 7.2e-7)
-REF_GAP_ULPS = 2.0     # units in the last place of |x_i|^2 + |x_j|^2 the reference's own fp32 keys of a flip may be apart
+# units in the last place of S = |x_i|^2 + |x_j|^2 the reference's own fp32 keys of a flip may be apart.  A key is
+# (-|x_j|^2 - inner) - |x_i|^2 with inner = -2 x_i.x_j out of a 64-term fp32 matmul: three roundings at magnitude S plus
+# the accumulation error of the dot product and of |x_j|^2 - about 3 ulp(S) per key, so two keys of one row whose true
+# values coincide can sit up to ~6 ulp(S) apart in a correct fp32 evaluation, in either order (another BLAS, another
+# summation order).  6 is the gate; the largest value observed is printed with every census (4.0: config 5, node_num 256).
+# 2 ulp - tighter than the float64 bound TIE_C * 2^-24 * S = 2 .. 4 ulp(S) itself - refused one genuine fp32-level tie there.
+REF_GAP_ULPS = 6.0
 LAYERS = ["xyz1", "xyz2", "xyz3", "sem1", "sem2", "sem3"]
 
 
