@@ -1673,6 +1673,13 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
     // with the tables of sem_table_kernel (same instructions, run once at sgpr_create) layer 1 costs nothing per graph
     // and layer 2 is its selection and its gather.
     const bool tabled = FMT == FMT_H2 && w.sem_g != nullptr && !(skip & (65536 | 262144));
+    // lean instance: layer 3's matrix products run on waves 1 .. 3 (wave 0 takes the Gram tile); the weight fragment of a
+    // wave's first column tile is requested HERE, two phases ahead (its L2 round trip otherwise opens the GEMM phase)
+    constexpr bool kPre3 = SGPR_WPREFETCH != 0 && LEAN == 64 && FMT == FMT_H2 && !WAVE && SGPR_LEAN_WAVES == 4;
+    FragT<FMT> wpre3[2];
+    if constexpr (kPre3) {
+        if (wave >= 1 && !(skip & 16384)) load_wfrag<4>(w.wh[2] + (size_t)(wave - 1) * wtile<4, FMT>(), wpre3);
+    }
     // layer 1: the table, straight into X rows 0..15 (rows 13..15 zero)
     const float* wf0 = w.wf[0];                                         // [2 * 64][16] folded fp32 weights
     const float* tb0 = w.tb[0];
@@ -1721,7 +1728,8 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
                 gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, 0);
                 group_sync<WAVE>();                                           // = the barrier inside gemm_cols
             } else {
-                gemm_layer<true, FMT, SGPR_LEAN_WAVES - 1>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0);   // (lean: four waves)
+                gemm_layer<true, FMT, SGPR_LEAN_WAVES - 1>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0,
+                                                           (kPre3 && Lv == 2) ? wpre3 : nullptr);   // (lean: four waves)
             }
         } else {
             gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, wave);
@@ -2041,9 +2049,17 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     int N, nd;            // slots processed; slots before the trailing run of duplicates
     float wdup;           // weight of each kept duplicate in the attention pool
     bool one_rep;         // the last processed slot stands for >= k identical slots
+    // Everything the prologue decides - the trailing run, "does the super-node branch apply", the nodes per label - is a
+    // function of per-wave ballots: each wave publishes its ballots once, ONE barrier later every thread derives what it
+    // needs (three barriers from the input to the first layer instead of eight, no LDS atomics).
+    bool any_bad = false;     // a node without a label, a stray all-zero row among the nodes, no padding: the generic branch
+    int my_label_count = 0;   // lanes 0..11 of every wave: nodes that carry label `lane`
     {
         float* ref = red;                       // 16 floats: the last slot
         int* wmax = reinterpret_cast<int*>(red + 16);
+        unsigned long long* negm = reinterpret_cast<unsigned long long*>(red + 32);   // [8 waves] slots with a label < 0
+        unsigned long long* nm1 = negm + 8;                                           // [8] slots whose label is not -1
+        unsigned long long* labm = nm1 + 8;                                           // [8][12] slots per label
         if (tid == NS - 1) {
             ref[0] = fx;
             ref[1] = fy;
@@ -2056,12 +2072,33 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
 #pragma unroll
         for (int c = 0; c < kLabels; ++c) same = same && (sem[c] == ref[3 + c]);
         const unsigned long long differs = __ballot(tid < NS && !same);
-        if (lane == 0) wmax[wave] = differs ? wave * 64 + 63 - __clzll((long long)differs) : -1;
+        const unsigned long long neg = __ballot(tid < NS && mylab < 0), not_pad = __ballot(tid < NS && mylab != -1);
+        unsigned long long lab_mine = 0ull;                 // lane c < 12 keeps the ballot of label c
+#pragma unroll
+        for (int c = 0; c < kLabels; ++c) {
+            const unsigned long long mk = __ballot(tid < NS && mylab == c);
+            lab_mine = lane == c ? mk : lab_mine;
+        }
+        if (lane == 0) {
+            wmax[wave] = differs ? wave * 64 + 63 - __clzll((long long)differs) : -1;
+            negm[wave] = neg;
+            nm1[wave] = not_pad;
+        }
+        if (lane < kLabels) labm[wave * kLabels + lane] = lab_mine;
         __syncthreads();
         int last = -1;
 #pragma unroll
         for (int q = 0; q < NW; ++q) last = max(last, wmax[q]);
         nd = last + 1;
+        // (nd <= NS - 1: the last slot equals itself)  slots before the trailing run, per wave, as lane masks
+        any_bad = ((nm1[nd >> 6] >> (nd & 63)) & 1ull) != 0ull;       // the run's first slot is not padding
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int nb = min(max(nd - 64 * q, 0), 64);
+            const unsigned long long below = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+            any_bad = any_bad || (negm[q] & below) != 0ull;
+            if (lane < kLabels) my_label_count += __popcll(labm[q * kLabels + lane] & below);
+        }
         const int m = NS - nd;
         // m >= k copies: ONE representative slot is enough (a row can take at most k copies, and once a row
         // reaches the duplicate key every remaining neighbour slot is filled by copies: see select_phase);
@@ -2070,7 +2107,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         const int c = one_rep ? 1 : m;
         N = nd + c;
         wdup = (float)m / (float)c;
-        __syncthreads();                        // red / D region is reused below
+        // (the scratch above sits in the X region: the barrier before X is written again follows below)
     }
     if (N > p.NC || N > kp.a.promise || rag_bad) {   // more slots to process than the caller's node_cap promised: fail loudly
         if (role == 1) return;                   // (reported by the graph's other workgroup)
@@ -2113,16 +2150,6 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     const bool split = LEAN != 0 && DBG == 0 && role == 2;   // this graph's semantic branch runs in another workgroup
     {
         const int k0 = p.k;
-        const bool bad = (tid < nd && mylab < 0) || (tid == nd && mylab != -1);
-        // (__syncthreads_or would add static LDS on top of the 160 KB dynamic allocation)
-        int* flag = reinterpret_cast<int*>(red);
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        const unsigned long long bm = __ballot(bad);
-        if (lane == 0 && bm) atomicOr(flag, 1);
-        __syncthreads();
-        const bool any_bad = *flag != 0;
-        __syncthreads();                                    // red shares X, which is written next
         const bool fast = DBG != 2 && !(skip & 4096) && one_rep && !any_bad && NP >= 32;
         if (!fast && (p.small_park || role == 1)) {
             // this plan parks only the super-node rows: the graph takes the generic branch in the second pass
@@ -2130,23 +2157,20 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             if (tid == 0 && kp.a.redo && role != 1) request_redo(kp.a, launch_slot, 2);
             return;
         }
+        if (fast && !p.park_in_lds && p.park_hybrid) park = reinterpret_cast<float*>(smem + p.offPark);
+        // scratch that must survive the branch sits behind the 16 virtual rows of the parked block
+        int* cnt = reinterpret_cast<int*>(park + 16 * PP);                     // [16] nodes per label, [12] = K
+        signed char* rl = reinterpret_cast<signed char*>(cnt + 16);            // [NP]
+        int* vmask = reinterpret_cast<int*>(nbr);                              // [16] neighbour label sets
         if (fast) {
-            if (!p.park_in_lds && p.park_hybrid) park = reinterpret_cast<float*>(smem + p.offPark);
-            // scratch that must survive the branch sits behind the 16 virtual rows of the parked block
-            int* cnt = reinterpret_cast<int*>(park + 16 * PP);                     // [16] nodes per label, [12] = K
-            signed char* rl = reinterpret_cast<signed char*>(cnt + 16);            // [NP]
-            int* vmask = reinterpret_cast<int*>(nbr);                              // [16] neighbour label sets
             rowlab = rl;
             if (tid < NP) rl[tid] = (signed char)(tid < N ? (tid == nd ? kLabels : mylab) : kLabels + 1);
-            if (!split) {                                   // (split launch: the graph's other workgroup computes the branch)
-                if (tid < 16) cnt[tid] = tid == kLabels ? k0 : 0;
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < kLabels; ++c) {
-                    const unsigned long long mk = __ballot(tid < nd && mylab == c);
-                    if (lane == 0 && mk) atomicAdd(&cnt[c], __popcll(mk));
-                }
-                __syncthreads();
+            // (split launch: the graph's other workgroup computes the branch and needs no counts here)
+            if (!split && tid < 16) cnt[tid] = tid == kLabels ? k0 : (tid < kLabels ? my_label_count : 0);
+        }
+        __syncthreads();       // the prologue's scratch (in the X region) is dead; counts and row labels are visible
+        if (fast) {
+            if (!split) {
                 supernode_branch<FMT, LEAN, false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
 #if SGPR_EXP_DOUBLE & 8
                 __syncthreads();
@@ -2573,6 +2597,19 @@ __device__ __forceinline__ void tail_arrive(const KParams& kp, const int slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* last = reinterpret_cast<int*>(smem);
     __syncthreads();                                            // embed_graph is done with LDS
+#ifndef SGPR_EXP_ARRIVE
+#define SGPR_EXP_ARRIVE 0     // timing experiments only (results invalid): where the arrival's time goes - 1 nothing after the
+#endif                        // barrier, 2 wait for the stores + a plain flag store, 3 the counted arrival without the preparation
+#if SGPR_EXP_ARRIVE == 1
+    return;
+#elif SGPR_EXP_ARRIVE == 2
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned*>(kp.a.tail_cnt + (slot >> 4)) + (slot & 1), kp.a.sem_epoch, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+#endif
     if (threadIdx.x == 0) {
         // this graph's pooled vector (store_pooled, by lanes 0..31 of this very wave) has reached the coherent level
         // before it is counted: the wave's outstanding stores are waited for, no cache is flushed
@@ -2591,6 +2628,9 @@ __device__ __forceinline__ void tail_arrive(const KParams& kp, const int slot) {
     const bool mine = *last != 0;
     __syncthreads();                                            // (`last` sits in the staging area)
     if (!mine) return;
+#if SGPR_EXP_ARRIVE == 3
+    return;
+#endif
     tail_prep_group(kp, slot >> 4, smem);                       // (reads the group's pooled vectors through agent-coherent loads)
 }
 

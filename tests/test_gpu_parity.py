@@ -1089,9 +1089,11 @@ def test_config5_full_size(eng, oracle, oracle_sd):
         print("  pair %d (|d score| %.2e): %s" % (pi, d[pi], reps))
         assert reps and any(ok for _, ok, _, _ in reps), "pair %d differs by %.3g without a proven tie: %s" % (pi, d[pi], reps)
     # attention weights of the graphs whose embedding agrees (a graph with a flipped neighbour legitimately differs)
-    agree = dev <= 1e-4
+    # (|pooled| reaches ~25 at node_num 256: 3e-4 is this file's pooled gate for that shape)
+    agree = dev <= 3e-4
     att_dev = np.abs(att.cpu().numpy() - ra.numpy()).max(1)
-    print("config 5 full size: graphs with |d pooled| <= 1e-4: %d of 2048; max |d att| among them %.2e" % (agree.sum(), att_dev[agree].max()))
+    print("config 5 full size: graphs with |d pooled| <= 3e-4: %d of 2048 (<= 1e-4: %d); max |d att| among them %.2e"
+          % (agree.sum(), (dev <= 1e-4).sum(), att_dev[agree].max()))
     assert agree.sum() >= 2000 and att_dev[agree].max() <= 10 * ATT_TOL
     # plain launch (no cap, storage order) and a two-shard launch: bit-identical pooled vectors
     p_plain, _, _ = eng.embed(centers, labels, 20)
