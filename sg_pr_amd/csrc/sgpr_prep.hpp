@@ -1,7 +1,7 @@
-// Row / column operands of the all-pairs tail (sgpr_score.hip), shared by the stand-alone prep kernels and by the embed
-// kernels' epilogue (sgpr_embed.hip: the workgroup that completes a group of 16 launch slots prepares their operands, so a
-// dense matrix over the graphs of ONE embed call needs no prep launch).  Reference: TenorNetworkModule.forward,
-// layers_batch.py:77-81 - the bilinear form e1^T W and the block term's halves are hoisted per graph.
+// Row / column operands of the all-pairs tail (sgpr_score.hip): the stand-alone prep kernels' body, its A' tile code
+// (shared with score_all_pairs_self_kernel, which forms A' of the row graphs it works on by itself) and the f16 plane split
+// (shared with the embed kernels' epilogue, which leaves a graph's own column planes behind: sgpr_embed.hip).  Reference:
+// TenorNetworkModule.forward, layers_batch.py:77-81 - the bilinear form e1^T W and the block term's halves are hoisted per graph.
 #pragma once
 #include "sgpr_internal.hpp"
 
@@ -32,9 +32,96 @@ __device__ __forceinline__ float prep_wave_max(float v) {
 constexpr int PREP_DENSE = 0;     // rows [R][F] by index, operands written at the same index, columns in super-block order
 constexpr int PREP_LIST = 1;      // pair-list mode: the R row graphs are rows[row_ids[0 .. R)] (gathered, written compactly);
                                   // column operands per graph, Cb [M][2 planes][32] f16
-constexpr int PREP_SLOTS = 2;     // embed epilogue: the R launch slots hold graphs row_ids[slot] (NULL: slot) of ONE array
-                                  // rows == cols; every operand is written at its GRAPH index (dense layouts); block 0 also
-                                  // zero-fills the columns [M, round64(M))
+
+// A' = e^T W + Wb[:, F:] of the 16 row graphs g0 .. g0 + 15 (rows past R skipped), output tiles `half` (0 / 1: 16 of the
+// 32 tiles; tile = (t, j half), this wave takes four of them) -> two f16 planes in `stage` ([graph][plane][j >> 3][t & 7]
+// [j & 7]: the tail's A-operand units); amax / l1max: running max |A'| and max over (graph, t) of sum_j |A'[t][j]|.
+// QB tiles' weights are requested at a time (4: one L2 round trip per call).  256 threads.
+template <int MODE, int QB>
+__device__ __forceinline__ void prep_rows_tiles(const float* __restrict__ ntn_wt, const float* __restrict__ ntn_wb,
+                                                const float* __restrict__ rows, int R, const int g0,
+                                                const int half, const int32_t* __restrict__ row_ids,
+                                                unsigned short* __restrict__ stage, float& amax, float& l1max) {
+    constexpr int F = kF3, T = kT;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    auto ld = [](const float* p) { return *p; };
+    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p); };
+    auto src_of = [&](int s) { return (MODE != PREP_DENSE && row_ids) ? row_ids[s] : s; };
+    (void)ld;
+    // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
+    const int ga = min(g0 + l15, R - 1);
+    const float* e = rows + (size_t)src_of(ga) * F + 4 * lq;
+    const float4 ea0 = ld4(e), ea1 = ld4(e + 16);
+    // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
+    // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
+    float l1r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int qb = 0; qb < 4; qb += QB) {
+    float wv[QB][8], wbv[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int tile = half * 16 + wave * 4 + qb + q;
+        const int t = tile >> 1, j = (tile & 1) * 16 + l15;
+        const float* wp = ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            wv[q][s4] = wp[s4 * T * F];
+            wv[q][4 + s4] = wp[(16 + s4) * T * F];
+        }
+        wbv[q] = ntn_wb[t * 2 * F + F + j];
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int tile = half * 16 + wave * 4 + qb + q;
+        const int t = tile >> 1, j = (tile & 1) * 16 + l15;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wv[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wv[q][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wv[q][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wv[q][3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wv[q][4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wv[q][5], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wv[q][6], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wv[q][7], acc, 0, 0, 0);
+        // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
+        const float wbc = wbv[q];
+        // tiles q = 0, 1 (and 2, 3) are the two halves j < 16 / j >= 16 of the same t: a row of A' is the 16 lanes of
+        // a lane group in both of them
+        if ((q & 1) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) l1r[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g = g0 + 4 * lq + r;
+            if (g < R) {
+                const float a = acc[r] + wbc;
+                amax = fmaxf(amax, fabsf(a));
+                l1r[r] += fabsf(a);
+                _Float16 h, l;
+                prep_split2_f16(a, h, l);
+                // staged through LDS in the operand layout: the lanes hold one f16 each of a 16-byte operand unit
+                // (8 consecutive j of one (graph, plane, t)); 2-byte global stores cost the kernel a quarter of its time
+                unsigned short* dst = stage + (((4 * lq + r) * 2 * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
+                dst[0] = __builtin_bit_cast(unsigned short, h);
+                dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
+            }
+        }
+        if (q & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = l1r[r];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                l1max = fmaxf(l1max, v);
+            }
+        }
+    }
+    }
+}
 
 // 16 graphs per pair of work units (block >> 1 = the group, block & 1 = which half of the 32 output tiles and which 8 of
 // the 16 graphs' block terms / column operands).  Row graphs get A' (16 x 32 per graph) as ONE small GEMM,
@@ -57,95 +144,11 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     // two work units per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
     const int g0 = (block >> 1) * 16, half = block & 1;
     // where row slot s is read from / its operands are written to
-    // PREP_SLOTS reads pooled vectors other workgroups of the SAME launch have just stored (agent-coherent stores):
-    // agent-coherent loads, which never hit a stale line of this XCD's L2
-    auto ld = [](const float* p) {
-        return MODE == PREP_SLOTS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-    };
-    auto ld4 = [&](const float* p) {
-        if (MODE != PREP_SLOTS) return *reinterpret_cast<const float4*>(p);
-        return make_float4(ld(p), ld(p + 1), ld(p + 2), ld(p + 3));
-    };
+    auto ld = [](const float* p) { return *p; };
     auto src_of = [&](int s) { return (MODE != PREP_DENSE && row_ids) ? row_ids[s] : s; };
-    auto dst_of = [&](int s) { return (MODE == PREP_SLOTS && row_ids) ? row_ids[s] : s; };
+    auto dst_of = [&](int s) { return s; };
     float amax = 0.f, umax = 0.f, emax = 0.f, l1max = 0.f;       // l1max: max over (graph, t) of sum_j |A'[t][j]|
-    if (g0 < R && worker) {
-        // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
-        const int ga = min(g0 + l15, R - 1);
-        const float* e = rows + (size_t)src_of(ga) * F + 4 * lq;
-        const float4 ea0 = ld4(e), ea1 = ld4(e + 16);
-        // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
-        // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
-        // (the embed epilogue takes them two tiles at a time: it shares its kernel with the embed phases, whose register
-        // budget decides how many workgroups a CU holds, and the prep is off that kernel's critical path)
-        constexpr int QB = MODE == PREP_SLOTS ? 2 : 4;
-        float l1r[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int qb = 0; qb < 4; qb += QB) {
-        float wv[QB][8], wbv[QB];
-#pragma unroll
-        for (int q = 0; q < QB; ++q) {
-            const int tile = half * 16 + wave * 4 + qb + q;
-            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
-            const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                wv[q][s4] = wp[s4 * T * F];
-                wv[q][4 + s4] = wp[(16 + s4) * T * F];
-            }
-            wbv[q] = w.ntn_wb[t * 2 * F + F + j];
-        }
-#pragma unroll
-        for (int q = 0; q < QB; ++q) {
-            const int tile = half * 16 + wave * 4 + qb + q;
-            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wv[q][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wv[q][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wv[q][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wv[q][3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wv[q][4], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wv[q][5], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wv[q][6], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wv[q][7], acc, 0, 0, 0);
-            // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
-            const float wbc = wbv[q];
-            // tiles q = 0, 1 (and 2, 3) are the two halves j < 16 / j >= 16 of the same t: a row of A' is the 16 lanes of
-            // a lane group in both of them
-            if ((q & 1) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) l1r[r] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int g = g0 + 4 * lq + r;
-                if (g < R) {
-                    const float a = acc[r] + wbc;
-                    amax = fmaxf(amax, fabsf(a));
-                    l1r[r] += fabsf(a);
-                    _Float16 h, l;
-                    prep_split2_f16(a, h, l);
-                    // staged through LDS in the operand layout: the lanes hold one f16 each of a 16-byte operand unit
-                    // (8 consecutive j of one (graph, plane, t)); 2-byte global stores cost the kernel a quarter of its time
-                    unsigned short* dst = stage + (((4 * lq + r) * 2 * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
-                    dst[0] = __builtin_bit_cast(unsigned short, h);
-                    dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
-                }
-            }
-            if (q & 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = l1r[r];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
-                    l1max = fmaxf(l1max, v);
-                }
-            }
-        }
-        }
-    }
+    if (g0 < R && worker) prep_rows_tiles<MODE, 4>(w.ntn_wt, w.ntn_wb, rows, R, g0, half, row_ids, stage, amax, l1max);
     if (g0 < R) {
         __syncthreads();
         // 16 graphs x 2 planes x 4 (j >> 3) x 8 t of this half = 1024 units of 16 bytes, 8 consecutive t contiguous in memory
@@ -170,11 +173,10 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
             if (lq == 0) ur[(size_t)dst_of(g) * T + l15] = s;
         }
         const int msb = MODE == PREP_LIST ? M : (M + AP_SB - 1) / AP_SB * AP_SB;
-        // the column this pass handles: slot g's graph (PREP_SLOTS: always a real column), else column g (zeros past M)
-        const bool has_col = MODE == PREP_SLOTS ? g < R : g < msb;
+        const bool has_col = g < msb;                       // (columns past M: zeros)
         if (has_col && lane < F) {                          // the column operand itself, two f16 planes
-            const int c = MODE == PREP_SLOTS ? dst_of(g) : g;
-            const float x = (MODE == PREP_SLOTS || g < M) ? ld(cols + (size_t)c * F + lane) : 0.f;
+            const int c = g;
+            const float x = g < M ? ld(cols + (size_t)c * F + lane) : 0.f;
             emax = fmaxf(emax, fabsf(x));
             _Float16 h, l;
             prep_split2_f16(x, h, l);
@@ -188,16 +190,6 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
                 dst[0] = __builtin_bit_cast(unsigned short, h);
                 dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
             }
-        }
-    }
-    if (MODE == PREP_SLOTS && block == 0 && worker) {       // the zero columns [M, round64(M)) of the last super-block
-        const int msb = (M + AP_SB - 1) / AP_SB * AP_SB;
-        for (int e = threadIdx.x; e < (msb - M) * F; e += 256) {
-            const int c = M + e / F, j = e % F;
-            const int sb = c >> 6, cl = c & 63, c15 = cl >> 2, b = cl & 3;
-            unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
-            dst[0] = 0;
-            dst[4 * 64 * 8] = 0;
         }
     }
     // NaN inputs: fmaxf drops them, so fold an explicit "not finite" marker in (infinity fails every bound)

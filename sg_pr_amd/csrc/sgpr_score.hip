@@ -411,6 +411,127 @@ __device__ __forceinline__ int ap_mode(float am, float um, float em, float l1) {
 }
 
 // the work items [it0, it1) of one R x M rectangle
+// the super-blocks [sb0, sb1) of one work item for the wave's AP_RW row graphs (operands in registers): the hot loop
+template <int NI, int VAR, bool CL>
+__device__ __forceinline__ void ap_item_cols(const ApConsts& k, const f16x8 (&ah)[AP_RW], const f16x8 (&al)[AP_RW],
+                                             const f32x4 (&u4)[AP_RW], const int R, const int M,
+                                             const unsigned short* __restrict__ Cb, float* __restrict__ score,
+                                             const int64_t ld, const int rbase, const int sb0, const int sb1) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
+    const float4 b1v = k.b1v, side = k.side;
+    const float kL2E = 1.4426950408889634f;
+    const float nb2 = k.nb2;
+    // column operands of block (sb, b): e2_c[8g .. 8g+7], c = 64 sb + 4 l15 + b; 1 KB contiguous per wave and plane,
+    // straight from L2 / L1 (the four waves of a workgroup read the same blocks).  Staging them through LDS once per
+    // workgroup was measured and is no faster (112 vs 108 us): the kernel is bound by vector issue, not by operands.
+    const unsigned short* cp = Cb + (size_t)sb0 * (2 * 4 * 64 * 8) + (size_t)lane * 8;
+    f16x8 bh = *reinterpret_cast<const f16x8*>(cp);
+    f16x8 bl = *reinterpret_cast<const f16x8*>(cp + 4 * 64 * 8);
+    for (int sb = sb0; sb < sb1; ++sb) {
+        float zb[4][AP_RW];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            // next block: b + 1 of this super-block, or block 0 of the next one (the last one re-reads itself)
+            const int nb = b + 1 < 4 ? b + 1 : 0;
+            const int nsbk = b + 1 < 4 ? sb : min(sb + 1, sb1 - 1);
+            const unsigned short* np = Cb + ((size_t)nsbk * 2 * 4 + nb) * (64 * 8) + (size_t)lane * 8;
+            const f16x8 nbh = (VAR & 4) ? bh : *reinterpret_cast<const f16x8*>(np);
+            const f16x8 nbl = (VAR & 4) ? bl : *reinterpret_cast<const f16x8*>(np + 4 * 64 * 8);
+#pragma unroll
+            for (int r0 = 0; r0 < AP_RW; r0 += NI) {
+                f32x4 h[NI], q[NI];
+                f16x8 hb[NI];
+                if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+                if (VAR & 16) {                      // timing: no matrix instructions (opaque copies keep the vector work alive)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        h[i] = u4[r0 + i];
+                        asm volatile("" : "+v"(h[i]) : "v"(bh), "v"(bl));
+                    }
+                } else {
+#if SGPR_AP_CHAINS == 2
+                    f32x4 hc[NI];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(al[r0 + i], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(ah[r0 + i], bl, hc[i]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = h[i] + hc[i];
+#else
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
+#endif
+                }
+                if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4<CL>(h[i]);
+                if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+                if (VAR & 16) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        q[i] = f32x4{b1v.x, b1v.y, b1v.z, b1v.w};
+                        asm volatile("" : "+v"(q[i]) : "v"(hb[i]));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
+                }
+                if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    if (VAR & 32) {
+                        zb[b][r0 + i] = q[i][0];
+                        continue;
+                    }
+                    const float t0 = __builtin_amdgcn_fmed3f(q[i][0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[i][1], 0.f, side.y);
+                    const float t2 = __builtin_amdgcn_fmed3f(q[i][2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[i][3], 0.f, side.w);
+                    zb[b][r0 + i] = (t0 + t1) + (t2 + t3);           // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
+                }
+            }
+            bh = nbh;
+            bl = nbl;
+        }
+        // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
+        // full sum of row g (3 swaps + 3 adds per column block instead of 8 bpermutes), for its 4 columns
+        float sc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float p02 = swap32_add(zb[b][0], zb[b][2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
+            const float p13 = swap32_add(zb[b][1], zb[b][3]);    // likewise rows 1 / 3
+            const float zsel = swap16_add(p02, p13);             // even 16-lane rows: row 0 / 2, odd: row 1 / 3
+            // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
+            sc[b] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
+        }
+        const int r = rbase + g, c0 = sb * AP_SB + 4 * l15;
+        if ((VAR & 2) && sc[0] + sc[1] + sc[2] + sc[3] != 12345.678f) continue;
+        if (r < R) {
+            float* dst = score + (size_t)r * ld + c0;
+            if (c0 + 3 < M) {
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#if SGPR_AP_NT_STORE
+                __builtin_nontemporal_store(f32x4u{sc[0], sc[1], sc[2], sc[3]}, reinterpret_cast<f32x4u*>(dst));
+#else
+                *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
+#endif
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (c0 + b < M) dst[b] = sc[b];
+            }
+        }
+    }
+}
+
 template <int NI, int VAR, bool CL>
 __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k, const bool fast, int R, int M,
                                          const unsigned short* __restrict__ Ab, const unsigned short* __restrict__ Cb,
@@ -419,10 +540,6 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
                                          const int it0, const int it1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
-    const float4 b1v = k.b1v, side = k.side;
-    const float kL2E = 1.4426950408889634f;
-    const float nb2 = k.nb2;
     const int ncc = (M + AP_COLS - 1) / AP_COLS;
     f16x8 ah[AP_RW], al[AP_RW];
     f32x4 u4[AP_RW];
@@ -449,114 +566,99 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
             slow_tile(w, prow, pcol, rbase, min(R, rbase + AP_RW), sb0 * AP_SB, min(M, sb1 * AP_SB), score, ld);
             continue;
         }
-        // column operands of block (sb, b): e2_c[8g .. 8g+7], c = 64 sb + 4 l15 + b; 1 KB contiguous per wave and plane,
-        // straight from L2 / L1 (the four waves of a workgroup read the same blocks).  Staging them through LDS once per
-        // workgroup was measured and is no faster (112 vs 108 us): the kernel is bound by vector issue, not by operands.
-        const unsigned short* cp = Cb + (size_t)sb0 * (2 * 4 * 64 * 8) + (size_t)lane * 8;
-        f16x8 bh = *reinterpret_cast<const f16x8*>(cp);
-        f16x8 bl = *reinterpret_cast<const f16x8*>(cp + 4 * 64 * 8);
-        for (int sb = sb0; sb < sb1; ++sb) {
-            float zb[4][AP_RW];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                // next block: b + 1 of this super-block, or block 0 of the next one (the last one re-reads itself)
-                const int nb = b + 1 < 4 ? b + 1 : 0;
-                const int nsbk = b + 1 < 4 ? sb : min(sb + 1, sb1 - 1);
-                const unsigned short* np = Cb + ((size_t)nsbk * 2 * 4 + nb) * (64 * 8) + (size_t)lane * 8;
-                const f16x8 nbh = (VAR & 4) ? bh : *reinterpret_cast<const f16x8*>(np);
-                const f16x8 nbl = (VAR & 4) ? bl : *reinterpret_cast<const f16x8*>(np + 4 * 64 * 8);
-#pragma unroll
-                for (int r0 = 0; r0 < AP_RW; r0 += NI) {
-                    f32x4 h[NI], q[NI];
-                    f16x8 hb[NI];
-                    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
-                    if (VAR & 16) {                      // timing: no matrix instructions (opaque copies keep the vector work alive)
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) {
-                            h[i] = u4[r0 + i];
-                            asm volatile("" : "+v"(h[i]) : "v"(bh), "v"(bl));
-                        }
-                    } else {
-#if SGPR_AP_CHAINS == 2
-                        f32x4 hc[NI];
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(al[r0 + i], bh, f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, u4[r0 + i]);
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(ah[r0 + i], bl, hc[i]);
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) h[i] = h[i] + hc[i];
-#else
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
-#endif
-                    }
-                    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4<CL>(h[i]);
-                    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
-                    if (VAR & 16) {
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) {
-                            q[i] = f32x4{b1v.x, b1v.y, b1v.z, b1v.w};
-                            asm volatile("" : "+v"(q[i]) : "v"(hb[i]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
-                    }
-                    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        if (VAR & 32) {
-                            zb[b][r0 + i] = q[i][0];
-                            continue;
-                        }
-                        const float t0 = __builtin_amdgcn_fmed3f(q[i][0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[i][1], 0.f, side.y);
-                        const float t2 = __builtin_amdgcn_fmed3f(q[i][2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[i][3], 0.f, side.w);
-                        zb[b][r0 + i] = (t0 + t1) + (t2 + t3);           // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
-                    }
-                }
-                bh = nbh;
-                bl = nbl;
+        ap_item_cols<NI, VAR, CL>(k, ah, al, u4, R, M, Cb, score, ld, rbase, sb0, sb1);
+    }
+}
+
+// The same work items for the SQUARE matrix over the graphs of one embed call (sgpr_score_all_pairs_prepared): the embed
+// launch left u_r, the column planes and the range maxima behind (EmbedArgs::tail_*); A'_r = e^T W + Wb[:, F:] of the 16 row
+// graphs of a row group is formed HERE, by the workgroup that works on the group - the tile code of ntn_prep_kernel on the
+// same operands (same bits), 64 fp32 matrix instructions per wave, staged through LDS in the A-operand layout - instead of
+// by a preparation launch in front of this one.  A workgroup's items are contiguous: it meets one or two row groups.
+// The f16 range question is answered per row group (max |A'| and the row sums of |A'| of ITS rows; max |u|, max |e| of the
+// whole launch).
+// (a function of its own, NOT inlined: the tile code's registers - 32 weight operands in flight per lane - stay out of the
+// register allocation of the hot loops around it; it runs once or twice per workgroup)
+__device__ __attribute__((noinline)) float2 self_prep_group(const float* __restrict__ ntn_wt, const float* __restrict__ ntn_wb,
+                                                            const float* __restrict__ pooled, const int G, const int g0,
+                                                            unsigned short* __restrict__ stage) {
+    float amax = 0.f, l1max = 0.f;
+    prep_rows_tiles<PREP_DENSE, 4>(ntn_wt, ntn_wb, pooled, G, g0, 0, nullptr, stage, amax, l1max);
+    prep_rows_tiles<PREP_DENSE, 4>(ntn_wt, ntn_wb, pooled, G, g0, 1, nullptr, stage + kPrepStageBytes / 2, amax, l1max);
+    return make_float2(wave_max_f32(amax), wave_max_f32(l1max));
+}
+
+template <int NI>
+__device__ __forceinline__ void ap_items_self(const DevWeights& w, const ApConsts& k, const float um, const float em,
+                                              const int G, const unsigned short* __restrict__ Cb,
+                                              const float* __restrict__ ur, const float* __restrict__ pooled,
+                                              float* __restrict__ score, const int64_t ld, const int it0, const int it1,
+                                              unsigned char* __restrict__ lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    unsigned short* stage = reinterpret_cast<unsigned short*>(lds);                 // [half][kPrepStageBytes]
+    float* part = reinterpret_cast<float*>(lds + 2 * kPrepStageBytes);            // [4 waves][2]
+    const int ncc = (G + AP_COLS - 1) / AP_COLS;
+    const int nsb = (G + AP_SB - 1) / AP_SB;
+    f16x8 ah[AP_RW], al[AP_RW];
+    f32x4 u4[AP_RW];
+    int cur_rg = -1, rbase = 0, mode = 0;
+    for (int it = it0; it < it1; ++it) {
+        const int rg = it / ncc, cc = it - rg * ncc;
+        if (rg != cur_rg) {
+            if (cur_rg >= 0) __syncthreads();                 // every wave holds the previous group's operands in registers
+            cur_rg = rg;
+            rbase = rg * AP_ROWS + wave * AP_RW;
+            const float2 mx = self_prep_group(w.ntn_wt, w.ntn_wb, pooled, G, rg * AP_ROWS, stage);
+            if (lane == 0) {
+                part[2 * wave] = mx.x;
+                part[2 * wave + 1] = mx.y;
             }
-            // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
-            // full sum of row g (3 swaps + 3 adds per column block instead of 8 bpermutes), for its 4 columns
-            float sc[4];
+            __syncthreads();
+            const float am = fmaxf(fmaxf(part[0], part[2]), fmaxf(part[4], part[6]));
+            const float l1 = fmaxf(fmaxf(part[1], part[3]), fmaxf(part[5], part[7]));
+            mode = __builtin_amdgcn_readfirstlane(ap_mode(am, um, em, l1));
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float p02 = swap32_add(zb[b][0], zb[b][2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
-                const float p13 = swap32_add(zb[b][1], zb[b][3]);    // likewise rows 1 / 3
-                const float zsel = swap16_add(p02, p13);             // even 16-lane rows: row 0 / 2, odd: row 1 / 3
-                // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
-                sc[b] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
-            }
-            const int r = rbase + g, c0 = sb * AP_SB + 4 * l15;
-            if ((VAR & 2) && sc[0] + sc[1] + sc[2] + sc[3] != 12345.678f) continue;
-            if (r < R) {
-                float* dst = score + (size_t)r * ld + c0;
-                if (c0 + 3 < M) {
-                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-#if SGPR_AP_NT_STORE
-                    __builtin_nontemporal_store(f32x4u{sc[0], sc[1], sc[2], sc[3]}, reinterpret_cast<f32x4u*>(dst));
-#else
-                    *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
-#endif
-                } else {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (c0 + b < M) dst[b] = sc[b];
-                }
+            for (int rr = 0; rr < AP_RW; ++rr) {
+                // A'_r[t = l15][8g .. 8g+7]: unit ((row in group * 2 + plane) * 4 + g) * 8 + (t & 7) of half t >> 3
+                const int gi = wave * AP_RW + rr;
+                const unsigned short* sp = stage + (l15 >> 3) * (kPrepStageBytes / 2) + (((gi * 2) * 4 + g) * 8 + (l15 & 7)) * 8;
+                ah[rr] = *reinterpret_cast<const f16x8*>(sp);
+                al[rr] = *reinterpret_cast<const f16x8*>(sp + 4 * 8 * 8);
+                const int r = min(rbase + rr, G - 1);
+                const float4 u = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+                u4[rr] = f32x4{u.x, u.y, u.z, u.w};
             }
         }
+        const int sb0 = cc * (AP_COLS / AP_SB), sb1 = min(nsb, sb0 + AP_COLS / AP_SB);
+        if (rbase >= G) continue;                          // this wave's rows lie past the matrix edge
+        if (mode == 2)
+            ap_item_cols<NI, 0, true>(k, ah, al, u4, G, G, Cb, score, ld, rbase, sb0, sb1);
+        else if (mode == 1)
+            ap_item_cols<NI, 0, false>(k, ah, al, u4, G, G, Cb, score, ld, rbase, sb0, sb1);
+        else      // inputs outside the f16 range: exact fp32 per-pair arithmetic
+            slow_tile(w, pooled, pooled, rbase, min(G, rbase + AP_RW), sb0 * AP_SB, min(G, sb1 * AP_SB), score, ld);
     }
+}
+
+template <int OCC, int NI>
+__global__ __launch_bounds__(256, OCC) void score_all_pairs_self_kernel(const DevWeights w, int G,
+                                                                   const unsigned short* __restrict__ Cb,
+                                                                   const float* __restrict__ ur,
+                                                                   const float* __restrict__ rng, int nrng,
+                                                                   const float* __restrict__ pooled,
+                                                                   float* __restrict__ score, int64_t ld) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kPrepStageBytes + 64];
+    const int lane = threadIdx.x & 63;
+    float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;
+    ap_range(rng, nrng, am, um, em, l1);                  // (the launch-wide partials carry max |u| and max |e| only)
+    const ApConsts k = ap_consts(w, lane & 15, lane >> 4);
+    const int ncc = (G + AP_COLS - 1) / AP_COLS;
+    const int64_t items = (int64_t)ncc * ((G + AP_ROWS - 1) / AP_ROWS);
+    const unsigned nwg = gridDim.x;
+    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
+    ap_items_self<NI>(w, k, um, em, G, Cb, ur, pooled, score, ld, it0, it1, lds);
 }
 
 template <int OCC, int NI, int VAR>
@@ -642,19 +744,24 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// ---- operands left behind by an embed call (sgpr_embed.hip, tail_arrive): the workspace of launch_score_all_pairs for
-//      the square matrix over the call's G graphs, followed by the arrival counters (one 64-bit cell per 16 launch slots)
+// ---- operands left behind by an embed call (EmbedArgs::tail_*):  ur [G][16] f32 | gr [G][2] f32 | rng [64][4] f32 |
+//      Cb [ceil(G / 64)][2][4][64][8] f16
 size_t embed_tail_ws_bytes(int G) {
-    return align256(score_all_pairs_ws_bytes(G, G)) + (size_t)((G + 15) / 16) * sizeof(unsigned long long);
+    const size_t nsb = (size_t)(G + AP_SB - 1) / AP_SB;
+    return align256((size_t)G * T * sizeof(float)) + align256((size_t)G * 2 * sizeof(float)) +
+           align256((size_t)kTailRngBlocks * 4 * sizeof(float)) + nsb * 2 * 4 * 64 * 8 * sizeof(unsigned short);
 }
 
 void embed_tail_views(void* ws, int G, EmbedArgs* a) {
-    const int nrng = 2 * ap_prep_groups(G, G);
-    a->tail_ur = static_cast<float*>(ws);
-    a->tail_rng = a->tail_ur + (size_t)G * T;
-    a->tail_Ab = reinterpret_cast<unsigned short*>(a->tail_rng + (size_t)nrng * 4);
-    a->tail_Cb = a->tail_Ab + (size_t)G * 2 * 64 * 8;
-    a->tail_cnt = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + align256(score_all_pairs_ws_bytes(G, G)));
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    a->tail_ur = reinterpret_cast<float*>(p);
+    p += align256((size_t)G * T * sizeof(float));
+    a->tail_gr = reinterpret_cast<float*>(p);
+    p += align256((size_t)G * 2 * sizeof(float));
+    a->tail_rng = reinterpret_cast<float*>(p);
+    p += align256((size_t)kTailRngBlocks * 4 * sizeof(float));
+    a->tail_Cb = reinterpret_cast<unsigned short*>(p);
+    a->tail_total = G;
 }
 
 int launch_score_all_pairs_prepared(const sgpr_handle* h, const float* pooled, int G, float* score, int64_t ld,
@@ -662,14 +769,13 @@ int launch_score_all_pairs_prepared(const sgpr_handle* h, const float* pooled, i
     if (G == 0) return SGPR_OK;
     EmbedArgs v;
     embed_tail_views(tail_ws, G, &v);
-    const int nrng = 2 * ((G + 15) / 16);                 // the partials the embed launch wrote: two per group of 16 slots
     const int64_t items = (int64_t)((G + AP_COLS - 1) / AP_COLS) * ((G + AP_ROWS - 1) / AP_ROWS);
     const int64_t slots = (int64_t)h->num_cus * AP_OCC;
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    hipLaunchKernelGGL((score_all_pairs_kernel<AP_OCC, AP_NI, 0>), dim3(grid), dim3(256), 0, stream, h->w, G, G, v.tail_Ab, v.tail_Cb,
-                       v.tail_ur, v.tail_rng, nrng, pooled, pooled, score, ld);
+    hipLaunchKernelGGL((score_all_pairs_self_kernel<AP_OCC, AP_NI>), dim3(grid), dim3(256), 0, stream, h->w, G, v.tail_Cb, v.tail_ur,
+                       v.tail_rng, kTailRngBlocks, pooled, score, ld);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "score_all_pairs_kernel launch");
+    if (e != hipSuccess) return hip_fail(e, "score_all_pairs_self_kernel launch");
     return SGPR_OK;
 }
 
