@@ -111,9 +111,6 @@ def parse():
                          "around that many back-to-back embed calls, then tail calls; the timed region carries no events)")
     ap.add_argument("--no-wide-range", action="store_true",
                     help="skip the untimed pass at the reference's operand width (wide-range embed instance forced)")
-    ap.add_argument("--no-fused-prep", action="store_true",
-                    help="all-pairs workloads on one GPU: the separate preparation launch of sgpr_score_all_pairs instead "
-                         "of the tail operands the embed launch leaves behind (sgpr_embed_ex; A/B of the two)")
     ap.add_argument("--d2h-pieces", type=int, default=4,
                     help="end_to_end.d2h: row blocks whose device-to-host copy overlaps the scoring of the next one")
     return ap.parse_args()
@@ -241,15 +238,6 @@ def main():
             scorer = allpairs.AllPairsScorer(model=model)
             scorer.embed_fn = counted("embed", lambda c, l, cap=node_cap, o=order: eng.embed(c, l, k, node_cap=cap, order=o)[0])
             scorer.score_fn = counted("tail", model.score_all_pairs)
-            if world == 1 and not a.no_fused_prep:
-                # one process: the embed launch leaves the tail's operands behind (sgpr_embed_ex), the matrix is one launch
-                def _embed_tail(c, l, cap=node_cap, o=order):
-                    pooled, _, _, tail = eng.embed(c, l, k, node_cap=cap, order=o, tail=True)
-                    return pooled, tail
-                scorer.embed_tail_fn = counted("embed", _embed_tail)
-                scorer.score_prepared_fn = counted("tail", eng.score_all_pairs_prepared)
-            else:
-                scorer.embed_tail_fn = scorer.score_prepared_fn = None
             full_out = (torch.empty(m, m, dtype=torch.float32, device=dev)
                         if (world > 1 and rank == 0 and not a.no_gather) else None)
             jobs.append({"name": name, "m": m, "scorer": scorer, "out": full_out, "node_cap": node_cap,
@@ -284,10 +272,7 @@ def main():
         else:
             j0 = jobs[0]
             lo0, hi0 = allpairs.shard_bounds(j0["m"], world, rank)
-            if j0["scorer"].embed_tail_fn is not None:
-                dur_calls["embed"] = lambda: j0["scorer"].embed_tail_fn(j0["d_centers"], j0["d_labels"])
-            else:
-                dur_calls["embed"] = lambda: j0["scorer"].embed_fn(j0["d_centers"][lo0:hi0], j0["d_labels"][lo0:hi0])
+            dur_calls["embed"] = lambda: j0["scorer"].embed_fn(j0["d_centers"][lo0:hi0], j0["d_labels"][lo0:hi0])
         if seqset is not None and not a.per_sequence_tails and world == 1:
             _pl = [eng.embed(j["d_centers"], j["d_labels"], k)[0] for j in jobs]
             _outs = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
@@ -298,11 +283,7 @@ def main():
             _p0 = eng.embed(j0["d_centers"], j0["d_labels"], k)[0]
             _o0 = torch.empty(hi0 - lo0, j0["m"], dtype=torch.float32, device=dev)
             _r0 = _p0[lo0:hi0].contiguous()
-            if j0["scorer"].embed_tail_fn is not None:
-                _pt, _tail0 = j0["scorer"].embed_tail_fn(j0["d_centers"], j0["d_labels"])
-                dur_calls["tail"] = lambda: j0["scorer"].score_prepared_fn(_pt, _tail0, out=_o0)
-            else:
-                dur_calls["tail"] = lambda: j0["scorer"].score_fn(_r0, _p0, out=_o0)
+            dur_calls["tail"] = lambda: j0["scorer"].score_fn(_r0, _p0, out=_o0)
     elif a.workload == "pairlist":
         fx = np.load(os.path.join(REPO, "tests", "golden", "pair_lists_3_20.npz"))
         seqs, parts_c, parts_l, parts_i, parts_j, base = [], [], [], [], [], 0
@@ -532,10 +513,7 @@ def main():
             def e2e(consumer):
                 for j, (pc, pl, po), (order_r, cap_r), ho, do, pz in zip(jobs, pinned, rag_plan, host_out, dev_out, xz):
                     dc, dl, do_ = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True), po.to(dev, non_blocking=True)
-                    fused = consumer != "d2h" and not a.no_fused_prep
-                    emb_out = eng.embed_ragged(dc, dl, do_, n, k, node_cap=cap_r, order=order_r if a.embed_mode == "ordered" else None,
-                                               tail=fused)
-                    pooled = emb_out[0]
+                    pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=cap_r, order=order_r if a.embed_mode == "ordered" else None)[0]
                     if consumer == "d2h":
                         # the matrix leaves in row blocks: block i crosses PCIe on the copy stream while block i + 1 is scored
                         m = j["m"]
@@ -549,8 +527,7 @@ def main():
                                 ho[r0:r1].copy_(do[r0:r1], non_blocking=True)
                     else:
                         from sg_pr_amd import metrics
-                        mat = (eng.score_all_pairs_prepared(pooled, emb_out[3], out=do) if fused
-                               else model.score_all_pairs(pooled, pooled, out=do))
+                        mat = model.score_all_pairs(pooled, pooled, out=do)
                         metrics.f1_max_device(eng, mat, pose_xz=pz)
                 torch.cuda.synchronize()
 
@@ -698,10 +675,7 @@ def main():
             tb = sum(allpairs.shard_bounds(mm, world, 0)[1] * mm * 4 + (allpairs.shard_bounds(mm, world, 0)[1] + mm) * 128
                      for _, mm in seqs) / max(tail_calls_per_step, 1)
             gbs = tb / (tail_ms * 1e-3) / 1e9
-            fused_tail = bool(jobs[0]["scorer"].embed_tail_fn is not None and seqset is None)
-            res["roofline_tail"] = {"kernel": ("sgpr::score_all_pairs_kernel (operands prepared by the embed launch's epilogue)"
-                                               if fused_tail else "sgpr::ntn_prep_kernel + sgpr::score_all_pairs_kernel"),
-                                    "bound": "hbm",
+            res["roofline_tail"] = {"kernel": "sgpr::ntn_prep_kernel + sgpr::score_all_pairs_kernel", "bound": "hbm",
                                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                     "traffic": traffic_tail, "launch_ms": tail_ms, "rows_per_call": rows_per_call,
                                     "mean_cols": cols, "bytes_per_call_algorithmic": tb,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 7
+#define SGPR_ABI_VERSION 6
 
 enum {
     SGPR_OK = 0,
@@ -189,44 +189,6 @@ size_t sgpr_score_all_pairs_workspace_bytes(const sgpr_handle* h, int R, int M);
 int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols,
                          int M, float* d_score, int64_t ld, void* d_workspace, size_t workspace_bytes,
                          void* stream);
-
-/* Every form of sgpr_embed* through one descriptor (HOST struct, device pointers inside), plus the one thing none of
- * them has: `d_tail_workspace`.  The evaluation loop (eval_batch.py:26-36) scores every graph of a sequence against
- * every other, and the tail of SG.forward needs per graph only its pooled vector pushed through the Neural Tensor
- * Network's weights (layers_batch.py:77-81: e1^T W, the two halves of the block term) - work sgpr_score_all_pairs does
- * in a launch of its own before it can start.  With a tail workspace the embed launch leaves those operands behind: the
- * workgroup that completes a group of 16 graphs prepares them (same instructions, same operands, same bits as the
- * stand-alone preparation), and sgpr_score_all_pairs_prepared scores the G x G matrix over the graphs of that call with
- * ONE launch, bit-identical to sgpr_score_all_pairs(pooled, G, pooled, G).
- *   input: exactly one of  d_centers + d_labels (packed, sgpr_embed) | d_centers + d_ragged_labels + d_ragged_offsets
- *          (sgpr_embed_ragged) | d_dense (sgpr_embed_dense; no node_cap / order)
- *   d_order / n_order: as sgpr_embed_ordered (NULL: all G graphs in index order).  A tail workspace needs all G graphs
- *          embedded by the call (n_order == G, or no order).
- *   d_tail_workspace: NULL, or sgpr_embed_tail_workspace_bytes(h, G) bytes (any content: no initialisation needed) */
-typedef struct sgpr_embed_job {
-    const float* d_centers;
-    const int32_t* d_labels;
-    const int8_t* d_ragged_labels;
-    const int64_t* d_ragged_offsets;
-    const float* d_dense;
-    int G, N, k, node_cap;
-    const int32_t* d_order;
-    int n_order;
-    float* d_pooled;              /* [G][32] (required) */
-    float* d_att;                 /* [G][N] or NULL */
-    float* d_emb;                 /* [G][N][32] or NULL */
-    void* d_workspace;            /* sgpr_embed_workspace_bytes(h, G, N, k) */
-    size_t workspace_bytes;
-    void* d_tail_workspace;
-    size_t tail_workspace_bytes;
-} sgpr_embed_job;
-size_t sgpr_embed_tail_workspace_bytes(const sgpr_handle* h, int G);
-int sgpr_embed_ex(const sgpr_handle* h, const sgpr_embed_job* job, void* stream);
-/* score[r, c] = SG-tail(pooled[r], pooled[c]) for the G graphs of the sgpr_embed_ex call that filled d_tail_workspace
- * (same stream order: the embed call first).  d_pooled: that call's output (read only when an input leaves the f16 range:
- * the exact fp32 path). */
-int sgpr_score_all_pairs_prepared(const sgpr_handle* h, const float* d_pooled, int G, float* d_score, int64_t ld,
-                                  void* d_tail_workspace, size_t tail_workspace_bytes, void* stream);
 
 /* Several independent rectangles with ONE pair of launches - the matrices of the sequences of an evaluation job
  * (eval_batch.py:26-36 loops over `eva_batch.sequences`): the work items of all jobs form one list that the workgroups

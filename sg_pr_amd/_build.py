@@ -21,8 +21,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libsgpr_hip.so")
 SOURCES = ["sgpr_embed.hip", "sgpr_score.hip", "sgpr_metrics.hip", "sgpr_modules.hip", "sgpr_cluster.hip",
            "sgpr_api.hip"]
-HEADERS = [os.path.join(REPO, "include", "sgpr.h"), os.path.join(CSRC, "sgpr_internal.hpp"),
-           os.path.join(CSRC, "sgpr_prep.hpp")]
+HEADERS = [os.path.join(REPO, "include", "sgpr.h"), os.path.join(CSRC, "sgpr_internal.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 
 

@@ -153,20 +153,11 @@ class AllPairsScorer:
 
     def __init__(self, model=None, embed_fn=None, score_fn=None, group=None):
         self._engine = None
-        # one process, the whole matrix from one embed call: the embed launch leaves the tail's operands behind
-        # (sgpr_embed_ex + sgpr_score_all_pairs_prepared: no preparation launch; bit-identical to embed_fn + score_fn)
-        self.embed_tail_fn = None            # (centers, labels) -> (pooled, TailOperands)
-        self.score_prepared_fn = None        # (pooled, tail, out=None) -> [M, M]
         if model is not None:
             embed_fn = lambda c, l: model.embed(c, l)[0]   # noqa: E731
             score_fn = model.score_all_pairs
             self._engine = model.engine()
 
-            def embed_tail(c, l):
-                pooled, _, _, tail = model.embed(c, l, tail=True)
-                return pooled, tail
-            self.embed_tail_fn = embed_tail
-            self.score_prepared_fn = model.score_all_pairs_prepared
         if embed_fn is None or score_fn is None:
             raise ValueError("need a model or both embed_fn and score_fn")
         self.embed_fn = embed_fn
@@ -330,11 +321,8 @@ class AllPairsScorer:
         posts all its receives up front (one group per piece index, one receive per peer in it), straight into the
         rows of the matrix.  chunks = 1 is the plain form: score the block, then one gather (gather_matrix).
         local_pooled: see pooled_all."""
-        world, rank = self._world()
-        if world == 1 and local_pooled is None and self.embed_tail_fn is not None and self.score_prepared_fn is not None:
-            pooled, tail = self.embed_tail_fn(centers, labels)
-            return self.score_prepared_fn(pooled, tail, out=out)
         pooled = self.pooled_all(centers, labels, local=local_pooled)
+        world, rank = self._world()
         if not gather or world == 1 or chunks <= 1:
             block = self.score_rows(pooled)
             if not gather:

@@ -603,68 +603,6 @@ int sgpr_embed_ragged(const sgpr_handle* h, const float* d_centers, const int8_t
     return embed_common(h, a, N, k, node_cap, d_workspace, workspace_bytes, stream, G);
 }
 
-size_t sgpr_embed_tail_workspace_bytes(const sgpr_handle* h, int G) {
-    if (!h || G < 0) return 0;
-    return embed_tail_ws_bytes(G);
-}
-
-int sgpr_embed_ex(const sgpr_handle* h, const sgpr_embed_job* j, void* stream) {
-    if (!h || !j) {
-        set_error("sgpr_embed_ex: NULL argument");
-        return SGPR_E_INVALID;
-    }
-    const bool ragged = j->d_ragged_labels || j->d_ragged_offsets;
-    const int forms = (j->d_dense ? 1 : 0) + (ragged ? 1 : 0) + (j->d_labels ? 1 : 0);
-    if (forms != 1 || (ragged && !(j->d_ragged_labels && j->d_ragged_offsets)) || (!j->d_dense && !j->d_centers) ||
-        (j->d_dense && (j->d_order || j->node_cap))) {
-        set_error("sgpr_embed_ex: exactly one input form (packed, ragged or dense; dense takes no order / node_cap)");
-        return SGPR_E_INVALID;
-    }
-    if (j->G < 0 || j->n_order < 0 || j->n_order > j->G || (j->n_order > 0 && !j->d_order)) {
-        set_error("sgpr_embed_ex: order list of " + std::to_string(j->n_order) + " entries for " + std::to_string(j->G) + " graphs");
-        return SGPR_E_INVALID;
-    }
-    EmbedArgs a;
-    memset(&a, 0, sizeof(a));
-    a.centers = j->d_centers;
-    a.labels = j->d_labels;
-    a.rag_lab = reinterpret_cast<const signed char*>(j->d_ragged_labels);
-    a.rag_off = reinterpret_cast<const long long*>(j->d_ragged_offsets);
-    a.dense = j->d_dense;
-    a.ids = j->d_order;
-    a.G = j->d_order ? j->n_order : j->G;
-    a.pooled = j->d_pooled;
-    a.att = j->d_att;
-    a.emb = j->d_emb;
-    if (j->d_tail_workspace) {
-        if (a.G != j->G) {
-            set_error("sgpr_embed_ex: a tail workspace needs every graph embedded by the call (n_order == G)");
-            return SGPR_E_INVALID;
-        }
-        if (j->tail_workspace_bytes < embed_tail_ws_bytes(j->G)) {
-            set_error("sgpr_embed_ex: tail workspace of " + std::to_string(embed_tail_ws_bytes(j->G)) + " bytes required");
-            return SGPR_E_WORKSPACE;
-        }
-        if (j->G > 0) embed_tail_views(j->d_tail_workspace, j->G, &a);
-    }
-    return embed_common(h, a, j->N, j->k, j->node_cap, j->d_workspace, j->workspace_bytes, stream, j->G);
-}
-
-int sgpr_score_all_pairs_prepared(const sgpr_handle* h, const float* d_pooled, int G, float* d_score, int64_t ld,
-                                  void* d_tail_workspace, size_t tail_workspace_bytes, void* stream) {
-    if (!h || G < 0 || ld < G || (G > 0 && (!d_pooled || !d_score || !d_tail_workspace))) {
-        set_error("sgpr_score_all_pairs_prepared: NULL argument, negative count or ld < G");
-        return SGPR_E_INVALID;
-    }
-    if (G == 0) return SGPR_OK;
-    if (tail_workspace_bytes < embed_tail_ws_bytes(G)) {
-        set_error("sgpr_score_all_pairs_prepared: tail workspace of " + std::to_string(embed_tail_ws_bytes(G)) + " bytes required");
-        return SGPR_E_WORKSPACE;
-    }
-    DeviceGuard guard(h->device);
-    return launch_score_all_pairs_prepared(h, d_pooled, G, d_score, ld, d_tail_workspace, static_cast<hipStream_t>(stream));
-}
-
 int sgpr_embed_dense(const sgpr_handle* h, const float* d_features, int G, int N, int k, float* d_pooled,
                      float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes, void* stream) {
     EmbedArgs a;

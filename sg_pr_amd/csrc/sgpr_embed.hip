@@ -34,7 +34,6 @@
 #include <type_traits>
 
 #include "sgpr_internal.hpp"
-#include "sgpr_prep.hpp"
 #ifndef SGPR_EXP_BARRIERS
 #define SGPR_EXP_BARRIERS 1      // timing experiment only (tools/build_variant.sh): every workgroup barrier of this file N times -
 #endif                           // the launch's growth per extra copy is what its barriers cost (results stay valid)
@@ -1817,8 +1816,6 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
     }
 }
 
-__device__ __forceinline__ void store_pooled(float* p, float v) { *p = v; }
-
 // ------------------------------------------------------------------ split launch (few graphs: the latency regime)
 // The two branches of dgcnn_conv_pass are independent until conv_end (sg_net.py:81-104).  When a launch has at most half
 // as many graphs as the GPU has CUs, every graph gets TWO workgroups, each on a CU of its own: workgroup s < G runs the
@@ -2106,9 +2103,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if (N > p.NC || N > kp.a.promise || rag_bad) {   // more slots to process than the caller's node_cap promised: fail loudly
         if (role == 1) return;                   // (reported by the graph's other workgroup)
         if (tid == 0) atomicOr(kp.a.status, rag_bad ? 8 : 2);
-        if (tid < 32) store_pooled(kp.a.pooled + (size_t)g * 32 + tid, __int_as_float(0x7fc00000));
-        if (kp.a.tail_ur && tid == 0)                        // (its tail operands stay unwritten: never "in range")
-            *reinterpret_cast<float2*>(kp.a.tail_gr + 2 * (size_t)g) = make_float2(INFINITY, INFINITY);
+        if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
         if (FMT == FMT_H2 && kp.a.redo && tid == 0) kp.a.redo[launch_slot] = 0;
         return;
     }
@@ -2433,7 +2428,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                 if (tid == 0) request_redo(kp.a, launch_slot, 2);
             } else {
                 if (tid == 0) atomicOr(kp.a.status, 4);
-                if (tid < 32) store_pooled(kp.a.pooled + (size_t)g * 32 + tid, __int_as_float(0x7fc00000));
+                if (tid < 32) kp.a.pooled[(size_t)g * 32 + tid] = __int_as_float(0x7fc00000);
             }
             return;
         }
@@ -2516,13 +2511,6 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
 #pragma unroll
         for (int r = 0; r < 32; ++r) attw[r] = kp.w.att_w[r * 32 + tid];
     }
-    // ... and, when the launch leaves the tail's operands behind, wave 0's slice of the NTN block term (tail_local below)
-    float wbp[8], wbias = 0.f;
-    if (kp.a.tail_ur && wave == 0) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) wbp[m] = kp.w.ntn_wb[(lane & 15) * 2 * kF3 + (lane >> 4) * 8 + m];
-        wbias = kp.w.ntn_bias[lane & 15];
-    }
     for (int prt = tid >> 5; prt < NPART; prt += NT >> 5) {
         float s = 0.f;
         for (int n = prt; n < N; n += NPART) s = fmaf(n >= nd ? wdup : 1.f, E[n * PE + c], s);
@@ -2567,50 +2555,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     if (tid < 32) {
         float s = 0.f;
         for (int q = 0; q < NPART; ++q) s += red[q * 32 + tid];
-        store_pooled(kp.a.pooled + (size_t)g * 32 + tid, s);
-        if (kp.a.tail_ur) mean[tid] = s;                     // (the mean vector is dead: the pooled vector for tail_local)
-    }
-    if (kp.a.tail_ur) {
-        // ---- what the all-pairs tail needs of THIS graph beyond its pooled vector (EmbedArgs::tail_*), with the
-        //      instructions of ntn_prep_body on the same operands: u = Wb[:, :F] e + bias, the column planes, the maxima
-        __syncthreads();
-        if (wave == 0) {
-            const int t15 = lane & 15, tq = lane >> 4;
-            float su = 0.f;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) su = fmaf(wbp[m], mean[tq * 8 + m], su);
-            su += __shfl_xor(su, 16);
-            su += __shfl_xor(su, 32);
-            su += wbias;
-            if (tq == 0) kp.a.tail_ur[(size_t)g * kT + t15] = su;
-            float um = su == su ? fabsf(su) : INFINITY, em = 0.f;        // (NaN = a flagged error: never "in range")
-            if (lane < 32) {
-                const float x = mean[lane];
-                em = x == x ? fabsf(x) : INFINITY;
-                _Float16 h, l;
-                prep_split2_f16(x, h, l);
-                const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
-                unsigned short* dst = kp.a.tail_Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
-                dst[0] = __builtin_bit_cast(unsigned short, h);
-                dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
-            }
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                um = fmaxf(um, __shfl_xor(um, m));
-                em = fmaxf(em, __shfl_xor(em, m));
-            }
-            if (lane == 0) *reinterpret_cast<float2*>(kp.a.tail_gr + 2 * (size_t)g) = make_float2(um, em);
-            if (g == kp.a.tail_total - 1) {                  // the zero columns that fill the last super-block
-                const int msb = (kp.a.tail_total + AP_SB - 1) / AP_SB * AP_SB;
-                for (int e = lane; e < (msb - kp.a.tail_total) * kF3; e += 64) {
-                    const int c = kp.a.tail_total + e / kF3, j = e % kF3;
-                    const int sb = c >> 6, cl = c & 63, c15 = cl >> 2, b = cl & 3;
-                    unsigned short* dst = kp.a.tail_Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
-                    dst[0] = 0;
-                    dst[4 * 64 * 8] = 0;
-                }
-            }
-        }
+        kp.a.pooled[(size_t)g * 32 + tid] = s;
     }
     // a graph whose activations left the f16 range is embedded again by the wide-range instance (embed_redo_kernel)
     if (FMT == FMT_H2 && kp.a.redo && tid == 0) request_redo(kp.a, launch_slot, *ovflag ? 1 : 0);
@@ -2620,54 +2565,6 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
 #pragma unroll
         for (int q = 0; q < 8; ++q) atomicAdd(&prof_buf[q], pacc[q]);
     }
-}
-
-// ------------------------------------------------------------------ tail operands in the embed epilogue
-// (EmbedArgs::tail_*)  Measured and dropped on the way here (profiles/r05_fused_prep_arrival.txt): preparing the tail's
-// row operands inside the embed launch by "the workgroup that completes a group of 16 launch slots" - any arrival protocol
-// between the workgroups of a launch costs more than the preparation launch it replaces.
-// The per-graph maxima of a range of launch slots -> one partial (second pass, or tail_range_kernel)
-__device__ __forceinline__ void tail_range_block(const EmbedArgs& a, float* lds4) {
-    const int per = (a.G + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int b0 = (int)blockIdx.x * per, b1 = min(a.G, b0 + per);
-    float um = 0.f, em = 0.f;
-    for (int s = b0 + (int)threadIdx.x; s < b1; s += (int)blockDim.x) {
-        const int g = a.ids ? a.ids[s] : s;
-        const float2 v = *reinterpret_cast<const float2*>(a.tail_gr + 2 * (size_t)g);
-        // (a NaN pooled vector - a flagged error - must not pass as "in range": it counts as infinite)
-        um = fmaxf(um, v.x == v.x ? v.x : INFINITY);
-        em = fmaxf(em, v.y == v.y ? v.y : INFINITY);
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        um = fmaxf(um, __shfl_xor(um, m));
-        em = fmaxf(em, __shfl_xor(em, m));
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        lds4[2 * (threadIdx.x >> 6)] = um;
-        lds4[2 * (threadIdx.x >> 6) + 1] = em;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int q = 1; q < (int)(blockDim.x >> 6); ++q) {
-            um = fmaxf(um, lds4[2 * q]);
-            em = fmaxf(em, lds4[2 * q + 1]);
-        }
-        *reinterpret_cast<float4*>(a.tail_rng + 4 * (size_t)blockIdx.x) = make_float4(0.f, um, em, 0.f);
-    }
-}
-
-__global__ __launch_bounds__(256) void tail_range_kernel(const EmbedArgs a) {
-    __shared__ float lds4[16];
-    tail_range_block(a, lds4);
-}
-
-int launch_tail_range(const EmbedArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(tail_range_kernel, dim3(kTailRngBlocks), dim3(256), 0, stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "tail_range_kernel launch");
-    return SGPR_OK;
 }
 
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
@@ -2696,10 +2593,7 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
     // nothing requested by the first pass (every launch on real data): one load, done.  A PLAIN load: the word was
     // stored by the previous kernel of the stream (the kernel boundary makes it visible); an agent-coherent load would
     // cost this empty pass a trip past the L2 (the pass is pure latency: 4.6 us by rocprof with the coherent load)
-    if (kp.a.redo_count && *kp.a.redo_count != kp.a.sem_epoch) {
-        if (kp.a.tail_ur) tail_range_block(kp.a, reinterpret_cast<float*>(smem));   // (gridDim.x == kTailRngBlocks then)
-        return;
-    }
+    if (kp.a.redo_count && *kp.a.redo_count != kp.a.sem_epoch) return;
     // this workgroup's contiguous range of launch slots, 64 flags at a time: wave 0 reads them with one load and hands
     // the ballots to the other waves through the first bytes of LDS (one dependent load per slot made the empty pass
     // cost 23 us); the masks then live in registers, so embed_graph is free to overwrite LDS
@@ -2737,12 +2631,6 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
             __syncthreads();
         }
     }
-    // the per-graph maxima of this workgroup's slots (some just rewritten by it) -> its partial
-    if (kp.a.tail_ur) {
-        __threadfence();
-        __syncthreads();
-        tail_range_block(kp.a, reinterpret_cast<float*>(smem));
-    }
 }
 
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
@@ -2751,8 +2639,7 @@ static int launch_t(const KParams& kp, hipStream_t stream) {
     int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&embed_kernel<KP, DBG, LEAN, FMT, KC>), kLdsLimit, "embed_kernel");
     if (rc != SGPR_OK) return rc;
     const int grid = kp.a.G * ((LEAN != 0 && DBG == 0 && kp.a.sem_tab) ? 2 : 1);
-    const int lds = kp.p.lds_bytes;
-    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT, KC>), dim3(grid), dim3(kp.p.nt), lds, stream, kp);
+    hipLaunchKernelGGL((embed_kernel<KP, DBG, LEAN, FMT, KC>), dim3(grid), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_kernel launch");
     return SGPR_OK;
@@ -2818,9 +2705,7 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     else
         rc = mode == 2 ? launch_layout<32, 2>(plan, kp, stream)
                        : (mode == 1 ? launch_layout<32, 1>(plan, kp, stream) : launch_layout<32, 0>(plan, kp, stream));
-    if (rc != SGPR_OK) return rc;
-    if (plan.fmt != FMT_H2 || !a.redo || mode == 1)          // no second pass: the per-graph maxima are folded by a launch of their own
-        return a.tail_ur ? launch_tail_range(kp.a, stream) : rc;
+    if (rc != SGPR_OK || plan.fmt != FMT_H2 || !a.redo || mode == 1) return rc;
     // second pass over the graphs the f16 instance flagged, on the wide-range plan (no node_cap: any graph fits)
     KParams kr = kp;
     bool ok = make_embed_plan(plan.N, 0, plan.k, &kr.p, true) && make_embed_plan(plan.N, 0, plan.k, &kr.p2, false, false, kr.p.nt);
@@ -2833,7 +2718,7 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kr.a.dbg_knn = nullptr;
     kr.a.prof = nullptr;
     kr.a.skip = 0;
-    const int blocks = a.tail_ur ? kTailRngBlocks : (a.G < 64 ? a.G : 64);   // (with tail operands: one range partial per block)
+    const int blocks = a.G < 64 ? a.G : 64;
     if (plan.kp == 16)
         return kr.p.fmt == FMT_BF3 ? launch_redo_t<16, FMT_BF3>(kr, blocks, stream) : launch_redo_t<16, FMT_F32>(kr, blocks, stream);
     return kr.p.fmt == FMT_BF3 ? launch_redo_t<32, FMT_BF3>(kr, blocks, stream) : launch_redo_t<32, FMT_F32>(kr, blocks, stream);

@@ -132,17 +132,6 @@ struct EmbedArgs {
     unsigned sem_epoch;         // this launch's token: distinguishes its flags / redo_count from whatever the workspace held
     int32_t* status;
     unsigned long long* prof;   // optional [8] per-phase cycle counters (sgpr_debug_set_profile_buffer)
-    // tail operands (sgpr_embed_ex with a tail workspace): what the all-pairs tail needs of a graph beyond its pooled vector
-    // and that ONE graph determines - u_g = Wb[:, :F] e + bias (row side), the pooled vector as two f16 planes in the tail's
-    // column order (column side), max |u_g| / max |e| - is written by the graph's own workgroup, at the graph's index:
-    // nothing crosses between the workgroups of a launch.  The second pass (or tail_range_kernel) folds the per-graph
-    // maxima into tail_rng; the tail kernel itself forms A'_r = e^T W + Wb[:, F:] for the 16 row graphs it works on
-    // (score_all_pairs_self_kernel).  tail_ur == NULL: off
-    float* tail_ur;               // [G][16]
-    float* tail_gr;               // [G][2]   max |u_g|, max |e_g|
-    float* tail_rng;              // [kTailRngBlocks][4]  (0, max |u|, max |e|, 0) partials over the launch's graphs
-    unsigned short* tail_Cb;      // column planes, super-block order (sgpr_score.hip)
-    int tail_total;               // graphs of the matrix (columns >= tail_total up to the next multiple of 64 are zero-filled)
     int promise;                // the caller's node_cap (or N): checked even when the plan ignores it
     int skip;                   // debug/ablation only (sgpr_debug_set_profile_buffer's companion): phases to skip
 };
@@ -158,13 +147,6 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 size_t score_all_pairs_ws_bytes(int R, int M);
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
                            int64_t ld, void* ws, hipStream_t stream);
-// the tail workspace of an embed call and its views
-constexpr int kTailRngBlocks = 64;
-size_t embed_tail_ws_bytes(int G);
-int launch_tail_range(const EmbedArgs& a, hipStream_t stream);   // per-graph maxima -> tail_rng, when no second pass runs
-void embed_tail_views(void* ws, int G, EmbedArgs* a);
-int launch_score_all_pairs_prepared(const sgpr_handle* h, const float* pooled, int G, float* score, int64_t ld,
-                                    void* tail_ws, hipStream_t stream);
 size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs);
 int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs, void* ws, hipStream_t stream);
 size_t score_pair_list_ws_bytes(int NR, int M);

@@ -16,7 +16,6 @@
 #include <string.h>
 
 #include "sgpr_internal.hpp"
-#include "sgpr_prep.hpp"
 
 namespace sgpr {
 
@@ -132,7 +131,7 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
 // matrix core (tools/probes/f16_split_probe.hip), so small values only lose what fp32 would lose as well.
 constexpr int AP_RW = 4;       // row graphs per wave: their A' operands (2 planes) stay in registers
 constexpr int AP_ROWS = 16;    // row graphs per workgroup: 4 waves x AP_RW
-//        AP_SB = 64 (sgpr_prep.hpp): columns per super-block (4 MFMA column blocks)
+constexpr int AP_SB = 64;      // columns per super-block (4 MFMA column blocks)
 constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
 #ifndef SGPR_AP_OCC
 #define SGPR_AP_OCC 4
@@ -144,7 +143,7 @@ constexpr int AP_OCC = SGPR_AP_OCC;   // resident workgroups per CU the kernel i
 #ifndef SGPR_AP_CHAINS
 #define SGPR_AP_CHAINS 1        // 2: layer 1's correction products (lo.hi, hi.lo) in an accumulator chain of their own, met by the
 #endif                          // hi.hi chain in one vector add - a shorter dependent chain for four more vector instructions per
-                                // (row, block); A/B builds (tools/build_variant.sh): measured, see profiles/r05_tail_variants.txt
+                                // (row, block); A/B builds (tools/build_variant.sh): measured slower, profiles/r05_tail_variants.txt
 #ifndef SGPR_AP_NT_STORE
 #define SGPR_AP_NT_STORE 0      // 1: the matrix leaves through non-temporal stores (A/B builds, tools/build_variant.sh)
 #endif
@@ -180,13 +179,159 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return fmaxf(v, __shfl_xor(v, 32));
 }
 
-// (ntn_prep_body: sgpr_prep.hpp - shared with the embed kernels' epilogue)
+// 16 graphs per pair of workgroups.  Row graphs get A' (16 x 32 per graph) as ONE small GEMM per workgroup,
+// [16 graphs x 32] x [32 x 512] on the fp32 matrix cores - the 64 KB weight tensor crosses L2 -> CU once per 16 graphs
+// instead of once per graph - plus the column half of the block term, split into two f16 planes on the way out, and
+// u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
+// LIST (pair-list mode, score_pair_list_kernel): the R row graphs are rows[row_ids[0 .. R)] (the distinct row graphs of
+// the list, gathered) and the column operands are laid out per graph, Cb [M][2 planes][32] f16, instead of per super-block.
+template <bool LIST>
+__device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* __restrict__ rows, int R,
+                                              const float* __restrict__ cols, int M, unsigned short* __restrict__ Ab,
+                                              float* __restrict__ ur, float* __restrict__ rng,
+                                              unsigned short* __restrict__ Cb, const int block,
+                                              const int32_t* __restrict__ row_ids = nullptr) {
+    __shared__ float red[4][4];
+    __shared__ __attribute__((aligned(16))) unsigned short stage[16 * 2 * 4 * 8 * 8];   // [graph][plane][j >> 3][t & 7][j & 7]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
+    const int g0 = (block >> 1) * 16, half = block & 1;
+    float amax = 0.f, umax = 0.f, emax = 0.f, l1max = 0.f;       // l1max: max over (graph, t) of sum_j |A'[t][j]|
+    if (g0 < R) {
+        // A operand: E[g0 + l15][16 blk + 4 lq .. +3] (k order permuted: lane group q supplies k = 4q + s at step s)
+        const int ga = min(g0 + l15, R - 1);
+        const float* e = rows + (size_t)(LIST ? row_ids[ga] : ga) * F + 4 * lq;
+        const float4 ea0 = *reinterpret_cast<const float4*>(e), ea1 = *reinterpret_cast<const float4*>(e + 16);
+        // the wave's four output tiles: all 32 weight operands (and the four block-term values) are requested before the
+        // first matrix instruction - one L2 round trip for the workgroup's critical path instead of four
+        float wv[4][8], wbv[4], l1r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = half * 16 + wave * 4 + q;
+            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
+            const float* wp = w.ntn_wt + ((size_t)(4 * lq) * T + t) * F + j;            // Wt[i = 4 lq + s][t][j]
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                wv[q][s4] = wp[s4 * T * F];
+                wv[q][4 + s4] = wp[(16 + s4) * T * F];
+            }
+            wbv[q] = w.ntn_wb[t * 2 * F + F + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = half * 16 + wave * 4 + q;
+            const int t = tile >> 1, j = (tile & 1) * 16 + l15;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.x, wv[q][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.y, wv[q][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.z, wv[q][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea0.w, wv[q][3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.x, wv[q][4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.y, wv[q][5], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.z, wv[q][6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea1.w, wv[q][7], acc, 0, 0, 0);
+            // acc[r] = (e1^T W)_{g0 + 4 lq + r}[t][j]; the column half of the block term rides along: A' = A + Wb[t][F + j]
+            const float wbc = wbv[q];
+            // tiles q = 0, 1 (and 2, 3) are the two halves j < 16 / j >= 16 of the same t: a row of A' is the 16 lanes of
+            // a lane group in both of them
+            if ((q & 1) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) l1r[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = g0 + 4 * lq + r;
+                if (g < R) {
+                    const float a = acc[r] + wbc;
+                    amax = fmaxf(amax, fabsf(a));
+                    l1r[r] += fabsf(a);
+                    _Float16 h, l;
+                    split2_f16(a, h, l);
+                    // staged through LDS in the operand layout: the lanes hold one f16 each of a 16-byte operand unit
+                    // (8 consecutive j of one (graph, plane, t)); 2-byte global stores cost the kernel a quarter of its time
+                    unsigned short* dst = stage + (((4 * lq + r) * 2 * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
+                    dst[0] = __builtin_bit_cast(unsigned short, h);
+                    dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
+                }
+            }
+            if (q & 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = l1r[r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    l1max = fmaxf(l1max, v);
+                }
+            }
+        }
+    }
+    if (g0 < R) {
+        __syncthreads();
+        // 16 graphs x 2 planes x 4 (j >> 3) x 8 t of this half = 1024 units of 16 bytes, 8 consecutive t contiguous in memory
+        for (int u = threadIdx.x; u < 16 * 2 * 4 * 8; u += 256) {
+            const int tl = u & 7, jb = (u >> 3) & 3, pl = (u >> 5) & 1, gi = u >> 6;
+            if (g0 + gi < R)
+                *reinterpret_cast<uint4*>(Ab + (((size_t)(g0 + gi) * 2 + pl) * 64 + jb * 16 + half * 8 + tl) * 8) =
+                    *reinterpret_cast<const uint4*>(stage + (size_t)u * 8);
+        }
+    }
+    // block term of the row graphs and the column operands: one graph per wave pass
+    for (int gi = half * 8 + wave * 2; gi < half * 8 + wave * 2 + 2; ++gi) {
+        const int g = g0 + gi;
+        if (g < R) {
+            const float* e1 = rows + (size_t)(LIST ? row_ids[g] : g) * F;
+            float s = 0.f;
+            for (int m = 0; m < 8; ++m) s = fmaf(w.ntn_wb[l15 * 2 * F + lq * 8 + m], e1[lq * 8 + m], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            s += w.ntn_bias[l15];
+            umax = fmaxf(umax, fabsf(s));
+            if (lq == 0) ur[(size_t)g * T + l15] = s;
+        }
+        const int msb = LIST ? M : (M + AP_SB - 1) / AP_SB * AP_SB;
+        if (g < msb && lane < F) {                          // the column operand itself, two f16 planes (zeros past M)
+            const float x = g < M ? cols[(size_t)g * F + lane] : 0.f;
+            emax = fmaxf(emax, fabsf(x));
+            _Float16 h, l;
+            split2_f16(x, h, l);
+            if (LIST) {
+                unsigned short* dst = Cb + (size_t)g * (2 * F) + lane;
+                dst[0] = __builtin_bit_cast(unsigned short, h);
+                dst[F] = __builtin_bit_cast(unsigned short, l);
+            } else {
+                const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
+                unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
+                dst[0] = __builtin_bit_cast(unsigned short, h);
+                dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+            }
+        }
+    }
+    // NaN inputs: fmaxf drops them, so fold an explicit "not finite" marker in (infinity fails every bound)
+    amax = wave_max_f32(amax);
+    umax = wave_max_f32(umax);
+    emax = wave_max_f32(emax);
+    l1max = wave_max_f32(l1max);
+    if (lane == 0) {
+        red[wave][0] = amax;
+        red[wave][1] = umax;
+        red[wave][2] = emax;
+        red[wave][3] = l1max;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        rng[(size_t)block * 4 + q] = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
+    }
+}
+
 __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const float* __restrict__ rows, int R,
                                                        const float* __restrict__ cols, int M,
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                        float* __restrict__ rng, unsigned short* __restrict__ Cb) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kPrepLdsBytes];
-    ntn_prep_body<PREP_DENSE>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x, nullptr, lds);
+    ntn_prep_body<false>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
 }
 
 // several independent rectangles in one launch (sgpr_score_all_pairs_multi): job j owns the prep workgroups
@@ -214,8 +359,7 @@ __global__ __launch_bounds__(256) void ntn_prep_multi_kernel(const DevWeights w,
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
     const ApJob& q = jobs.job[j];
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kPrepLdsBytes];
-    ntn_prep_body<PREP_DENSE>(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j], nullptr, lds);
+    ntn_prep_body<false>(w, q.rows, q.R, q.cols, q.M, q.Ab, q.ur, q.rng, q.Cb, (int)blockIdx.x - jobs.block0[j]);
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
@@ -411,127 +555,6 @@ __device__ __forceinline__ int ap_mode(float am, float um, float em, float l1) {
 }
 
 // the work items [it0, it1) of one R x M rectangle
-// the super-blocks [sb0, sb1) of one work item for the wave's AP_RW row graphs (operands in registers): the hot loop
-template <int NI, int VAR, bool CL>
-__device__ __forceinline__ void ap_item_cols(const ApConsts& k, const f16x8 (&ah)[AP_RW], const f16x8 (&al)[AP_RW],
-                                             const f32x4 (&u4)[AP_RW], const int R, const int M,
-                                             const unsigned short* __restrict__ Cb, float* __restrict__ score,
-                                             const int64_t ld, const int rbase, const int sb0, const int sb1) {
-    const int lane = threadIdx.x & 63;
-    const int l15 = lane & 15, g = lane >> 4;
-    const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
-    const float4 b1v = k.b1v, side = k.side;
-    const float kL2E = 1.4426950408889634f;
-    const float nb2 = k.nb2;
-    // column operands of block (sb, b): e2_c[8g .. 8g+7], c = 64 sb + 4 l15 + b; 1 KB contiguous per wave and plane,
-    // straight from L2 / L1 (the four waves of a workgroup read the same blocks).  Staging them through LDS once per
-    // workgroup was measured and is no faster (112 vs 108 us): the kernel is bound by vector issue, not by operands.
-    const unsigned short* cp = Cb + (size_t)sb0 * (2 * 4 * 64 * 8) + (size_t)lane * 8;
-    f16x8 bh = *reinterpret_cast<const f16x8*>(cp);
-    f16x8 bl = *reinterpret_cast<const f16x8*>(cp + 4 * 64 * 8);
-    for (int sb = sb0; sb < sb1; ++sb) {
-        float zb[4][AP_RW];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            // next block: b + 1 of this super-block, or block 0 of the next one (the last one re-reads itself)
-            const int nb = b + 1 < 4 ? b + 1 : 0;
-            const int nsbk = b + 1 < 4 ? sb : min(sb + 1, sb1 - 1);
-            const unsigned short* np = Cb + ((size_t)nsbk * 2 * 4 + nb) * (64 * 8) + (size_t)lane * 8;
-            const f16x8 nbh = (VAR & 4) ? bh : *reinterpret_cast<const f16x8*>(np);
-            const f16x8 nbl = (VAR & 4) ? bl : *reinterpret_cast<const f16x8*>(np + 4 * 64 * 8);
-#pragma unroll
-            for (int r0 = 0; r0 < AP_RW; r0 += NI) {
-                f32x4 h[NI], q[NI];
-                f16x8 hb[NI];
-                if (VAR & 8) __builtin_amdgcn_s_setprio(1);
-                if (VAR & 16) {                      // timing: no matrix instructions (opaque copies keep the vector work alive)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        h[i] = u4[r0 + i];
-                        asm volatile("" : "+v"(h[i]) : "v"(bh), "v"(bl));
-                    }
-                } else {
-#if SGPR_AP_CHAINS == 2
-                    f32x4 hc[NI];
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(al[r0 + i], bh, f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, u4[r0 + i]);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(ah[r0 + i], bl, hc[i]);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = h[i] + hc[i];
-#else
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
-#endif
-                }
-                if (VAR & 8) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4<CL>(h[i]);
-                if (VAR & 8) __builtin_amdgcn_s_setprio(1);
-                if (VAR & 16) {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        q[i] = f32x4{b1v.x, b1v.y, b1v.z, b1v.w};
-                        asm volatile("" : "+v"(q[i]) : "v"(hb[i]));
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
-                }
-                if (VAR & 8) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    if (VAR & 32) {
-                        zb[b][r0 + i] = q[i][0];
-                        continue;
-                    }
-                    const float t0 = __builtin_amdgcn_fmed3f(q[i][0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[i][1], 0.f, side.y);
-                    const float t2 = __builtin_amdgcn_fmed3f(q[i][2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[i][3], 0.f, side.w);
-                    zb[b][r0 + i] = (t0 + t1) + (t2 + t3);           // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
-                }
-            }
-            bh = nbh;
-            bl = nbl;
-        }
-        // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
-        // full sum of row g (3 swaps + 3 adds per column block instead of 8 bpermutes), for its 4 columns
-        float sc[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const float p02 = swap32_add(zb[b][0], zb[b][2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
-            const float p13 = swap32_add(zb[b][1], zb[b][3]);    // likewise rows 1 / 3
-            const float zsel = swap16_add(p02, p13);             // even 16-lane rows: row 0 / 2, odd: row 1 / 3
-            // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
-            sc[b] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
-        }
-        const int r = rbase + g, c0 = sb * AP_SB + 4 * l15;
-        if ((VAR & 2) && sc[0] + sc[1] + sc[2] + sc[3] != 12345.678f) continue;
-        if (r < R) {
-            float* dst = score + (size_t)r * ld + c0;
-            if (c0 + 3 < M) {
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-#if SGPR_AP_NT_STORE
-                __builtin_nontemporal_store(f32x4u{sc[0], sc[1], sc[2], sc[3]}, reinterpret_cast<f32x4u*>(dst));
-#else
-                *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
-#endif
-            } else {
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (c0 + b < M) dst[b] = sc[b];
-            }
-        }
-    }
-}
-
 template <int NI, int VAR, bool CL>
 __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k, const bool fast, int R, int M,
                                          const unsigned short* __restrict__ Ab, const unsigned short* __restrict__ Cb,
@@ -540,6 +563,10 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
                                          const int it0, const int it1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
+    const f16x8 w1hi = k.w1hi, w1lo = k.w1lo;
+    const float4 b1v = k.b1v, side = k.side;
+    const float kL2E = 1.4426950408889634f;
+    const float nb2 = k.nb2;
     const int ncc = (M + AP_COLS - 1) / AP_COLS;
     f16x8 ah[AP_RW], al[AP_RW];
     f32x4 u4[AP_RW];
@@ -566,99 +593,114 @@ __device__ __forceinline__ void ap_items(const DevWeights& w, const ApConsts& k,
             slow_tile(w, prow, pcol, rbase, min(R, rbase + AP_RW), sb0 * AP_SB, min(M, sb1 * AP_SB), score, ld);
             continue;
         }
-        ap_item_cols<NI, VAR, CL>(k, ah, al, u4, R, M, Cb, score, ld, rbase, sb0, sb1);
-    }
-}
-
-// The same work items for the SQUARE matrix over the graphs of one embed call (sgpr_score_all_pairs_prepared): the embed
-// launch left u_r, the column planes and the range maxima behind (EmbedArgs::tail_*); A'_r = e^T W + Wb[:, F:] of the 16 row
-// graphs of a row group is formed HERE, by the workgroup that works on the group - the tile code of ntn_prep_kernel on the
-// same operands (same bits), 64 fp32 matrix instructions per wave, staged through LDS in the A-operand layout - instead of
-// by a preparation launch in front of this one.  A workgroup's items are contiguous: it meets one or two row groups.
-// The f16 range question is answered per row group (max |A'| and the row sums of |A'| of ITS rows; max |u|, max |e| of the
-// whole launch).
-// (a function of its own, NOT inlined: the tile code's registers - 32 weight operands in flight per lane - stay out of the
-// register allocation of the hot loops around it; it runs once or twice per workgroup)
-__device__ __attribute__((noinline)) float2 self_prep_group(const float* __restrict__ ntn_wt, const float* __restrict__ ntn_wb,
-                                                            const float* __restrict__ pooled, const int G, const int g0,
-                                                            unsigned short* __restrict__ stage) {
-    float amax = 0.f, l1max = 0.f;
-    prep_rows_tiles<PREP_DENSE, 4>(ntn_wt, ntn_wb, pooled, G, g0, 0, nullptr, stage, amax, l1max);
-    prep_rows_tiles<PREP_DENSE, 4>(ntn_wt, ntn_wb, pooled, G, g0, 1, nullptr, stage + kPrepStageBytes / 2, amax, l1max);
-    return make_float2(wave_max_f32(amax), wave_max_f32(l1max));
-}
-
-template <int NI>
-__device__ __forceinline__ void ap_items_self(const DevWeights& w, const ApConsts& k, const float um, const float em,
-                                              const int G, const unsigned short* __restrict__ Cb,
-                                              const float* __restrict__ ur, const float* __restrict__ pooled,
-                                              float* __restrict__ score, const int64_t ld, const int it0, const int it1,
-                                              unsigned char* __restrict__ lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    unsigned short* stage = reinterpret_cast<unsigned short*>(lds);                 // [half][kPrepStageBytes]
-    float* part = reinterpret_cast<float*>(lds + 2 * kPrepStageBytes);            // [4 waves][2]
-    const int ncc = (G + AP_COLS - 1) / AP_COLS;
-    const int nsb = (G + AP_SB - 1) / AP_SB;
-    f16x8 ah[AP_RW], al[AP_RW];
-    f32x4 u4[AP_RW];
-    int cur_rg = -1, rbase = 0, mode = 0;
-    for (int it = it0; it < it1; ++it) {
-        const int rg = it / ncc, cc = it - rg * ncc;
-        if (rg != cur_rg) {
-            if (cur_rg >= 0) __syncthreads();                 // every wave holds the previous group's operands in registers
-            cur_rg = rg;
-            rbase = rg * AP_ROWS + wave * AP_RW;
-            const float2 mx = self_prep_group(w.ntn_wt, w.ntn_wb, pooled, G, rg * AP_ROWS, stage);
-            if (lane == 0) {
-                part[2 * wave] = mx.x;
-                part[2 * wave + 1] = mx.y;
-            }
-            __syncthreads();
-            const float am = fmaxf(fmaxf(part[0], part[2]), fmaxf(part[4], part[6]));
-            const float l1 = fmaxf(fmaxf(part[1], part[3]), fmaxf(part[5], part[7]));
-            mode = __builtin_amdgcn_readfirstlane(ap_mode(am, um, em, l1));
+        // column operands of block (sb, b): e2_c[8g .. 8g+7], c = 64 sb + 4 l15 + b; 1 KB contiguous per wave and plane,
+        // straight from L2 / L1 (the four waves of a workgroup read the same blocks).  Staging them through LDS once per
+        // workgroup was measured and is no faster (112 vs 108 us): the kernel is bound by vector issue, not by operands.
+        const unsigned short* cp = Cb + (size_t)sb0 * (2 * 4 * 64 * 8) + (size_t)lane * 8;
+        f16x8 bh = *reinterpret_cast<const f16x8*>(cp);
+        f16x8 bl = *reinterpret_cast<const f16x8*>(cp + 4 * 64 * 8);
+        for (int sb = sb0; sb < sb1; ++sb) {
+            float zb[4][AP_RW];
 #pragma unroll
-            for (int rr = 0; rr < AP_RW; ++rr) {
-                // A'_r[t = l15][8g .. 8g+7]: unit ((row in group * 2 + plane) * 4 + g) * 8 + (t & 7) of half t >> 3
-                const int gi = wave * AP_RW + rr;
-                const unsigned short* sp = stage + (l15 >> 3) * (kPrepStageBytes / 2) + (((gi * 2) * 4 + g) * 8 + (l15 & 7)) * 8;
-                ah[rr] = *reinterpret_cast<const f16x8*>(sp);
-                al[rr] = *reinterpret_cast<const f16x8*>(sp + 4 * 8 * 8);
-                const int r = min(rbase + rr, G - 1);
-                const float4 u = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
-                u4[rr] = f32x4{u.x, u.y, u.z, u.w};
+            for (int b = 0; b < 4; ++b) {
+                // next block: b + 1 of this super-block, or block 0 of the next one (the last one re-reads itself)
+                const int nb = b + 1 < 4 ? b + 1 : 0;
+                const int nsbk = b + 1 < 4 ? sb : min(sb + 1, sb1 - 1);
+                const unsigned short* np = Cb + ((size_t)nsbk * 2 * 4 + nb) * (64 * 8) + (size_t)lane * 8;
+                const f16x8 nbh = (VAR & 4) ? bh : *reinterpret_cast<const f16x8*>(np);
+                const f16x8 nbl = (VAR & 4) ? bl : *reinterpret_cast<const f16x8*>(np + 4 * 64 * 8);
+#pragma unroll
+                for (int r0 = 0; r0 < AP_RW; r0 += NI) {
+                    f32x4 h[NI], q[NI];
+                    f16x8 hb[NI];
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+                    if (VAR & 16) {                      // timing: no matrix instructions (opaque copies keep the vector work alive)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            h[i] = u4[r0 + i];
+                            asm volatile("" : "+v"(h[i]) : "v"(bh), "v"(bl));
+                        }
+                    } else {
+#if SGPR_AP_CHAINS == 2
+                        f32x4 hc[NI];
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(al[r0 + i], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) hc[i] = mfma_f16(ah[r0 + i], bl, hc[i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = h[i] + hc[i];
+#else
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(al[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bl, h[i]);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) h[i] = mfma_f16(ah[r0 + i], bh, h[i]);
+#endif
+                    }
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) hb[i] = (VAR & 32) ? __builtin_bit_cast(f16x8, h[i]) : split_relu4<CL>(h[i]);
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+                    if (VAR & 16) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            q[i] = f32x4{b1v.x, b1v.y, b1v.z, b1v.w};
+                            asm volatile("" : "+v"(q[i]) : "v"(hb[i]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1lo, hb[i], f32x4{b1v.x, b1v.y, b1v.z, b1v.w});   // hi . W1lo
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) q[i] = mfma_f16(w1hi, hb[i], q[i]);                                 // (hi + lo) . W1hi
+                    }
+                    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        if (VAR & 32) {
+                            zb[b][r0 + i] = q[i][0];
+                            continue;
+                        }
+                        const float t0 = __builtin_amdgcn_fmed3f(q[i][0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[i][1], 0.f, side.y);
+                        const float t2 = __builtin_amdgcn_fmed3f(q[i][2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[i][3], 0.f, side.w);
+                        zb[b][r0 + i] = (t0 + t1) + (t2 + t3);           // partial over o = 4g..4g+3 of row r0+i, column 4 l15 + b
+                    }
+                }
+                bh = nbh;
+                bl = nbl;
+            }
+            // transpose-reduce over the four lane groups with the gfx950 lane-swap ops: lane group g ends up with the
+            // full sum of row g (3 swaps + 3 adds per column block instead of 8 bpermutes), for its 4 columns
+            float sc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float p02 = swap32_add(zb[b][0], zb[b][2]);    // lanes 0-31: row 0 over groups {g, g+2}; 32-63: row 2
+                const float p13 = swap32_add(zb[b][1], zb[b][3]);    // likewise rows 1 / 3
+                const float zsel = swap16_add(p02, p13);             // even 16-lane rows: row 0 / 2, odd: row 1 / 3
+                // sigmoid: v_exp_f32 / v_rcp_f32 (1 ulp each) - far inside the 1e-4 score tolerance
+                sc[b] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
+            }
+            const int r = rbase + g, c0 = sb * AP_SB + 4 * l15;
+            if ((VAR & 2) && sc[0] + sc[1] + sc[2] + sc[3] != 12345.678f) continue;
+            if (r < R) {
+                float* dst = score + (size_t)r * ld + c0;
+                if (c0 + 3 < M) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#if SGPR_AP_NT_STORE
+                    __builtin_nontemporal_store(f32x4u{sc[0], sc[1], sc[2], sc[3]}, reinterpret_cast<f32x4u*>(dst));
+#else
+                    *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
+#endif
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (c0 + b < M) dst[b] = sc[b];
+                }
             }
         }
-        const int sb0 = cc * (AP_COLS / AP_SB), sb1 = min(nsb, sb0 + AP_COLS / AP_SB);
-        if (rbase >= G) continue;                          // this wave's rows lie past the matrix edge
-        if (mode == 2)
-            ap_item_cols<NI, 0, true>(k, ah, al, u4, G, G, Cb, score, ld, rbase, sb0, sb1);
-        else if (mode == 1)
-            ap_item_cols<NI, 0, false>(k, ah, al, u4, G, G, Cb, score, ld, rbase, sb0, sb1);
-        else      // inputs outside the f16 range: exact fp32 per-pair arithmetic
-            slow_tile(w, pooled, pooled, rbase, min(G, rbase + AP_RW), sb0 * AP_SB, min(G, sb1 * AP_SB), score, ld);
     }
-}
-
-template <int OCC, int NI>
-__global__ __launch_bounds__(256, OCC) void score_all_pairs_self_kernel(const DevWeights w, int G,
-                                                                   const unsigned short* __restrict__ Cb,
-                                                                   const float* __restrict__ ur,
-                                                                   const float* __restrict__ rng, int nrng,
-                                                                   const float* __restrict__ pooled,
-                                                                   float* __restrict__ score, int64_t ld) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kPrepStageBytes + 64];
-    const int lane = threadIdx.x & 63;
-    float am = 0.f, um = 0.f, em = 0.f, l1 = 0.f;
-    ap_range(rng, nrng, am, um, em, l1);                  // (the launch-wide partials carry max |u| and max |e| only)
-    const ApConsts k = ap_consts(w, lane & 15, lane >> 4);
-    const int ncc = (G + AP_COLS - 1) / AP_COLS;
-    const int64_t items = (int64_t)ncc * ((G + AP_ROWS - 1) / AP_ROWS);
-    const unsigned nwg = gridDim.x;
-    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
-    ap_items_self<NI>(w, k, um, em, G, Cb, ur, pooled, score, ld, it0, it1, lds);
 }
 
 template <int OCC, int NI, int VAR>
@@ -744,41 +786,6 @@ int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// ---- operands left behind by an embed call (EmbedArgs::tail_*):  ur [G][16] f32 | gr [G][2] f32 | rng [64][4] f32 |
-//      Cb [ceil(G / 64)][2][4][64][8] f16
-size_t embed_tail_ws_bytes(int G) {
-    const size_t nsb = (size_t)(G + AP_SB - 1) / AP_SB;
-    return align256((size_t)G * T * sizeof(float)) + align256((size_t)G * 2 * sizeof(float)) +
-           align256((size_t)kTailRngBlocks * 4 * sizeof(float)) + nsb * 2 * 4 * 64 * 8 * sizeof(unsigned short);
-}
-
-void embed_tail_views(void* ws, int G, EmbedArgs* a) {
-    unsigned char* p = static_cast<unsigned char*>(ws);
-    a->tail_ur = reinterpret_cast<float*>(p);
-    p += align256((size_t)G * T * sizeof(float));
-    a->tail_gr = reinterpret_cast<float*>(p);
-    p += align256((size_t)G * 2 * sizeof(float));
-    a->tail_rng = reinterpret_cast<float*>(p);
-    p += align256((size_t)kTailRngBlocks * 4 * sizeof(float));
-    a->tail_Cb = reinterpret_cast<unsigned short*>(p);
-    a->tail_total = G;
-}
-
-int launch_score_all_pairs_prepared(const sgpr_handle* h, const float* pooled, int G, float* score, int64_t ld,
-                                    void* tail_ws, hipStream_t stream) {
-    if (G == 0) return SGPR_OK;
-    EmbedArgs v;
-    embed_tail_views(tail_ws, G, &v);
-    const int64_t items = (int64_t)((G + AP_COLS - 1) / AP_COLS) * ((G + AP_ROWS - 1) / AP_ROWS);
-    const int64_t slots = (int64_t)h->num_cus * AP_OCC;
-    const unsigned grid = (unsigned)(items < slots ? items : slots);
-    hipLaunchKernelGGL((score_all_pairs_self_kernel<AP_OCC, AP_NI>), dim3(grid), dim3(256), 0, stream, h->w, G, v.tail_Cb, v.tail_ur,
-                       v.tail_rng, kTailRngBlocks, pooled, score, ld);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "score_all_pairs_self_kernel launch");
-    return SGPR_OK;
-}
-
 size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs) {
     size_t total = 0;
     for (int j = 0; j < n; ++j) total += align256(score_all_pairs_ws_bytes(jobs[j].R, jobs[j].M));
@@ -855,8 +862,7 @@ __global__ __launch_bounds__(256) void ntn_prep_list_kernel(const DevWeights w, 
                                                             const float* __restrict__ cols, int M,
                                                             unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                             float* __restrict__ rng, unsigned short* __restrict__ Cg) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kPrepLdsBytes];
-    ntn_prep_body<PREP_LIST>(w, rows, NR, cols, M, Ab, ur, rng, Cg, (int)blockIdx.x, row_ids, lds);
+    ntn_prep_body<true>(w, rows, NR, cols, M, Ab, ur, rng, Cg, (int)blockIdx.x, row_ids);
 }
 
 struct PairPlan {                 // device views into the plan buffer (sgpr.h, sgpr_pair_plan)

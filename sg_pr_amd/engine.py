@@ -32,8 +32,7 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 # every symbol include/sgpr.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_capped", "sgpr_embed_ordered", "sgpr_embed_ragged",
-               "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_embed_tail_workspace_bytes", "sgpr_embed_ex",
-               "sgpr_score_all_pairs_prepared", "sgpr_score_pairs", "sgpr_pair_plan_ints", "sgpr_pair_plan",
+               "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_pair_plan_ints", "sgpr_pair_plan",
                "sgpr_score_pair_list_workspace_bytes", "sgpr_score_pair_list", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_score_all_pairs_multi_workspace_bytes", "sgpr_score_all_pairs_multi",
                "sgpr_forward_workspace_bytes", "sgpr_forward_dense", "sgpr_check_status",
@@ -59,26 +58,6 @@ class SgprPairsJob(ctypes.Structure):
     """struct sgpr_pairs_job of include/sgpr.h"""
     _fields_ = [("d_pooled_rows", ctypes.c_void_p), ("R", ctypes.c_int32), ("d_pooled_cols", ctypes.c_void_p),
                 ("M", ctypes.c_int32), ("d_score", ctypes.c_void_p), ("ld", ctypes.c_int64)]
-
-
-class SgprEmbedJob(ctypes.Structure):
-    """struct sgpr_embed_job of include/sgpr.h"""
-    _fields_ = [("d_centers", ctypes.c_void_p), ("d_labels", ctypes.c_void_p), ("d_ragged_labels", ctypes.c_void_p),
-                ("d_ragged_offsets", ctypes.c_void_p), ("d_dense", ctypes.c_void_p),
-                ("G", ctypes.c_int32), ("N", ctypes.c_int32), ("k", ctypes.c_int32), ("node_cap", ctypes.c_int32),
-                ("d_order", ctypes.c_void_p), ("n_order", ctypes.c_int32),
-                ("d_pooled", ctypes.c_void_p), ("d_att", ctypes.c_void_p), ("d_emb", ctypes.c_void_p),
-                ("d_workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
-                ("d_tail_workspace", ctypes.c_void_p), ("tail_workspace_bytes", ctypes.c_size_t)]
-
-
-class TailOperands:
-    """What an embed call with tail=True leaves behind for score_all_pairs_prepared: the row / column operands of the
-    all-pairs tail for the G graphs of that call (device workspace; valid until the tensor is released)."""
-
-    def __init__(self, ws, graphs):
-        self.ws = ws
-        self.graphs = int(graphs)
 
 
 class SgprDims(ctypes.Structure):
@@ -133,12 +112,6 @@ def load_library():
     lib.sgpr_embed_dense.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_debug.restype = i32
     lib.sgpr_embed_debug.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
-    lib.sgpr_embed_tail_workspace_bytes.restype = sz
-    lib.sgpr_embed_tail_workspace_bytes.argtypes = [vp, i32]
-    lib.sgpr_embed_ex.restype = i32
-    lib.sgpr_embed_ex.argtypes = [vp, ctypes.POINTER(SgprEmbedJob), vp]
-    lib.sgpr_score_all_pairs_prepared.restype = i32
-    lib.sgpr_score_all_pairs_prepared.argtypes = [vp, vp, i32, vp, i64, vp, sz, vp]
     lib.sgpr_score_pairs.restype = i32
     lib.sgpr_score_pairs.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sgpr_pair_plan_ints.restype = sz
@@ -359,22 +332,10 @@ class Engine:
         order = torch.argsort(eff, descending=True, stable=True).to(torch.int32).to(self.device)
         return order, int(eff.max().item())
 
-    def _embed_ex(self, job, g, tail):
-        """sgpr_embed_ex; tail=True adds the tail workspace and returns it as TailOperands."""
-        ops = None
-        if tail and g > 0:
-            tb = self.lib.sgpr_embed_tail_workspace_bytes(self._h, g)
-            ops = TailOperands(self._ws(tb), g)
-            job.d_tail_workspace, job.tail_workspace_bytes = ops.ws.data_ptr(), tb
-        self._check(self.lib.sgpr_embed_ex(self._h, ctypes.byref(job), self._stream()))
-        return ops
-
-    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None, tail=False):
+    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None):
         """centers [G,N,3] f32, labels [G,N] i32 (-1 = pad) -> pooled [G,32] (+ att [G,N], emb [G,N,32]).
         node_cap: optional promise on the processed slots per graph (node_cap_of); 0 = none.
-        order: optional i32 launch order (size_order) - graphs not listed keep uninitialised output rows.
-        tail=True: the launch also leaves the all-pairs tail's operands of its graphs behind (sgpr_embed_ex); a fourth
-        return value, TailOperands, goes to score_all_pairs_prepared (the order, if any, must list every graph)."""
+        order: optional i32 launch order (size_order) - graphs not listed keep uninitialised output rows."""
         centers = self._dev(centers, torch.float32, "centers")
         labels = self._dev(labels, torch.int32, "labels")
         g, n = labels.shape
@@ -392,18 +353,7 @@ class Engine:
             self._check(rc)
             return pooled, att, self._cut(emb), layers, knn
         if g == 0:
-            return (pooled, att, self._cut(emb), TailOperands(None, 0)) if tail else (pooled, att, self._cut(emb))
-        if tail:
-            if order is not None:
-                order = self._dev(order, torch.int32, "order")
-            job = SgprEmbedJob(d_centers=centers.data_ptr(), d_labels=labels.data_ptr(), G=g, N=n, k=k,
-                               node_cap=int(node_cap), d_order=order.data_ptr() if order is not None else None,
-                               n_order=order.numel() if order is not None else 0, d_pooled=pooled.data_ptr(),
-                               d_att=att.data_ptr() if att is not None else None,
-                               d_emb=emb.data_ptr() if emb is not None else None, d_workspace=ws.data_ptr(),
-                               workspace_bytes=ws_bytes)
-            ops = self._embed_ex(job, g, True)
-            return pooled, att, self._cut(emb), ops
+            return pooled, att, self._cut(emb)
         if order is not None:
             order = self._dev(order, torch.int32, "order")
             rc = self.lib.sgpr_embed_ordered(self._h, _ptr(centers), _ptr(labels), g, n, int(node_cap), k, _ptr(order),
@@ -447,10 +397,9 @@ class Engine:
         order = torch.argsort(eff, descending=True, stable=True).to(torch.int32).to(self.device)
         return order, int(eff.max().item())
 
-    def embed_ragged(self, centers, labels, offsets, node_num, k, want_att=False, want_emb=False, node_cap=0, order=None,
-                     tail=False):
+    def embed_ragged(self, centers, labels, offsets, node_num, k, want_att=False, want_emb=False, node_cap=0, order=None):
         """Ragged store (to_ragged) -> pooled [G,32] (+ att [G,node_num], emb [G,node_num,32]); bit-identical to `embed`
-        on the padded arrays.  node_cap / order: see ragged_order; tail: see embed."""
+        on the padded arrays.  node_cap / order: see ragged_order."""
         centers = self._dev(centers, torch.float32, "centers")
         labels = self._dev(labels, torch.int8, "labels")
         offsets = self._dev(offsets, torch.int64, "offsets")
@@ -460,21 +409,11 @@ class Engine:
         att = torch.empty(g, n, dtype=torch.float32, device=self.device) if want_att else None
         emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if want_emb else None
         if g == 0:
-            return (pooled, att, emb, TailOperands(None, 0)) if tail else (pooled, att, emb)
+            return pooled, att, emb
         ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
         ws = self._ws(ws_bytes)
         if order is not None:
             order = self._dev(order, torch.int32, "order")
-        if tail:
-            job = SgprEmbedJob(d_centers=centers.data_ptr(), d_ragged_labels=labels.data_ptr(),
-                               d_ragged_offsets=offsets.data_ptr(), G=g, N=n, k=k, node_cap=int(node_cap),
-                               d_order=order.data_ptr() if order is not None else None,
-                               n_order=order.numel() if order is not None else 0, d_pooled=pooled.data_ptr(),
-                               d_att=att.data_ptr() if att is not None else None,
-                               d_emb=emb.data_ptr() if emb is not None else None, d_workspace=ws.data_ptr(),
-                               workspace_bytes=ws_bytes)
-            ops = self._embed_ex(job, g, True)
-            return pooled, att, self._cut(emb), ops
         rc = self.lib.sgpr_embed_ragged(self._h, _ptr(centers), _ptr(labels), _ptr(offsets), g, n, int(node_cap), k,
                                         _ptr(order), order.numel() if order is not None else 0, _ptr(pooled), _ptr(att),
                                         _ptr(emb), _ptr(ws), ws_bytes, self._stream())
@@ -551,22 +490,6 @@ class Engine:
         ws = self._ws(ws_bytes)
         rc = self.lib.sgpr_score_all_pairs(self._h, _ptr(rows), r, _ptr(cols), m, _ptr(score), score.stride(0),
                                            _ptr(ws), ws_bytes, self._stream())
-        self._check(rc)
-        return score
-
-    def score_all_pairs_prepared(self, pooled, tail, out=None):
-        """The [G, G] score matrix over the graphs of the embed call that returned `tail` (embed(..., tail=True)): one
-        launch, no preparation pass; bit-identical to score_all_pairs(pooled, pooled)."""
-        pooled = self._dev(pooled, torch.float32, "pooled")
-        g = pooled.shape[0]
-        if g != tail.graphs:
-            raise ValueError("tail operands were prepared for %d graphs, got %d pooled vectors" % (tail.graphs, g))
-        score = out if out is not None else torch.empty(g, g, dtype=torch.float32, device=self.device)
-        assert score.shape == (g, g) and score.stride(1) == 1
-        if g == 0:
-            return score
-        rc = self.lib.sgpr_score_all_pairs_prepared(self._h, _ptr(pooled), g, _ptr(score), score.stride(0),
-                                                    _ptr(tail.ws), tail.ws.numel(), self._stream())
         self._check(rc)
         return score
 

@@ -98,10 +98,8 @@ class SG(torch.nn.Module):
         return score, att1.unsqueeze(-1), att2.unsqueeze(-1)
 
     # ------------------------------------------------------------------ packed fast paths (no one-hot tensors)
-    def embed(self, centers, labels, want_att=False, want_emb=False, node_cap=None, order=None, tail=False):
+    def embed(self, centers, labels, want_att=False, want_emb=False, node_cap=None, order=None):
         """Packed graphs (centers [G,N,3], labels [G,N], -1 = pad) -> pooled [G, filters_3] (+att, +emb).
-        tail=True: a fourth value, the all-pairs tail's operands of these graphs (engine.TailOperands), for
-        score_all_pairs_prepared - the matrix over the graphs of ONE embed call then costs one launch.
         node_cap: promise on the slots processed per graph; order: launch order, largest graphs first
         (engine.Engine.size_order gives both).  Host arrays get them computed automatically; device tensors run
         without unless given (computing them would synchronise).
@@ -117,12 +115,12 @@ class SG(torch.nn.Module):
             if node_cap is None and order is None and len(rag):
                 order, node_cap = eng.ragged_order(rag.offsets, rag.node_num, int(self.args.K))
             return eng.embed_ragged(rag.centers, rag.labels, rag.offsets - rag.offsets[0], rag.node_num, int(self.args.K),
-                                    want_att=want_att, want_emb=want_emb, node_cap=node_cap or 0, order=order, tail=tail)
+                                    want_att=want_att, want_emb=want_emb, node_cap=node_cap or 0, order=order)
         if node_cap is None and order is None:
             if not (isinstance(labels, torch.Tensor) and labels.is_cuda) and len(labels):
                 order, node_cap = eng.size_order(centers, labels, int(self.args.K))
         return eng.embed(centers, labels, int(self.args.K), want_att=want_att, want_emb=want_emb,
-                         node_cap=node_cap or 0, order=order, tail=tail)
+                         node_cap=node_cap or 0, order=order)
 
     GROUPED_MIN_PAIRS = 2048     # below this the one-wave-per-pair kernel's single launch wins
 
@@ -145,9 +143,6 @@ class SG(torch.nn.Module):
 
     def score_all_pairs(self, pooled_rows, pooled_cols, out=None):
         return self.engine().score_all_pairs(pooled_rows, pooled_cols, out=out)
-
-    def score_all_pairs_prepared(self, pooled, tail, out=None):
-        return self.engine().score_all_pairs_prepared(pooled, tail, out=out)
 
     def forward_packed(self, centers_1, labels_1, centers_2, labels_2, validate=True):
         """Faithful per-pair scoring of packed graphs: both sides embedded, then the tail.

@@ -1710,73 +1710,3 @@ def test_smaller_architectures_run_on_the_built_kernels(oracle):
     with pytest.raises(SgprError, match="SGPR_E_DIMS"):
         big.engine()
 
-
-def test_embed_tail_operands_are_bitwise_the_standalone_prep(eng, ckpt_path):
-    """sgpr_embed_ex with a tail workspace + sgpr_score_all_pairs_prepared == sgpr_embed* + sgpr_score_all_pairs, bit for
-    bit: the embed launch's epilogue prepares the tail's operands with the instructions of ntn_prep_kernel.  Covers
-    launches of one group and of many, ragged last groups, the split launch (<= 128 graphs), a launch order, the ragged
-    store, graphs the SECOND pass re-embeds (generic semantic branch, f16 overflow: their groups are prepared again),
-    the wide-range instance, node_num 256 (512-thread workgroups) and a tiny plan (LDS rounded up to the prep's)."""
-    from sg_pr_amd import allpairs, sg_net, synth
-    from sg_pr_amd.parser_sg import sgpr_args
-
-    def check(c, l, k, tag, **kw):
-        ref_p = eng.embed(c, l, k, **kw)[0]
-        ref = eng.score_all_pairs(ref_p, ref_p)
-        p, _, _, tail = eng.embed(c, l, k, tail=True, **kw)
-        got = eng.score_all_pairs_prepared(p, tail)
-        eng.check_status()
-        assert torch.equal(p, ref_p), tag
-        assert torch.equal(got, ref), tag
-        return ref
-
-    for g in (1, 15, 16, 17, 100, 129, 700):
-        c, l, _, _ = synth.kitti_like_sequence(g, 100, seed=40 + g)
-        check(c, l, 10, "plain G=%d" % g)
-        order, cap = eng.size_order(c, l, 10)
-        check(c, l, 10, "ordered G=%d" % g, node_cap=cap, order=order)
-    # the ragged store
-    c, l, _, _ = synth.kitti_like_sequence(333, 100, seed=5)
-    rc, rl, off = eng.to_ragged(c, l)
-    order, cap = eng.ragged_order(off, 100, 10)
-    ref_p = eng.embed(c, l, 10)[0]
-    ref = eng.score_all_pairs(ref_p, ref_p)
-    p, _, _, tail = eng.embed_ragged(rc, rl, off, 100, 10, node_cap=cap, order=order, tail=True)
-    assert torch.equal(p, ref_p) and torch.equal(eng.score_all_pairs_prepared(p, tail), ref)
-    # graphs that go through the second pass: small ones (generic semantic branch) and out-of-range ones (wide instance)
-    centers, labels, _ = synth.make_graphs(200, 100, 25, 60, 78, kitti_like=True)
-    small = np.arange(0, 200, 7)
-    centers[small, 6:] = 0.0
-    labels[small, 6:] = -1
-    centers[3::11] *= 2000.0
-    order, cap = eng.size_order(centers, labels, 10)
-    assert cap <= 64
-    check(centers, labels, 10, "second pass", node_cap=cap, order=order)
-    # the split launch (lean plan, at most 128 graphs): the xyz half of a graph counts it in
-    c2, l2, _ = synth.make_graphs(100, 64, 20, 54, 3)
-    check(c2, l2, 10, "split launch")
-    # the wide-range instance for every graph
-    eng.set_skip_mask(8192)
-    try:
-        check(c[:50], l[:50], 10, "wide-range instance")
-    finally:
-        eng.set_skip_mask(0)
-    # 512-thread workgroups (node_num 256) and a tiny plan
-    c5, l5, _ = synth.config5_pairs(seed=2)
-    check(c5[:70], l5[:70], 20, "node_num 256")
-    ct, lt, _ = synth.make_graphs(37, 12, 3, 9, 5, kitti_like=True)
-    check(ct, lt, 4, "node_num 12")
-    # AllPairsScorer.run takes the fused path in one process: same matrix as the two-call path
-    args = sgpr_args()
-    args.model = ckpt_path
-    model = sg_net.SGTrainer(args, False).model
-    scorer = allpairs.AllPairsScorer(model=model)
-    c, l, _, _ = synth.kitti_like_sequence(260, 100, seed=9)
-    fused = scorer.run(c, l)
-    scorer.embed_tail_fn = None
-    plain = scorer.run(c, l)
-    assert torch.equal(fused, plain)
-    # a tail workspace needs every graph embedded by the call
-    from sg_pr_amd.engine import SgprError
-    with pytest.raises(SgprError):
-        eng.embed(c, l, 10, order=torch.arange(10, dtype=torch.int32), tail=True)
