@@ -138,7 +138,7 @@ constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
 #endif
 constexpr int AP_OCC = SGPR_AP_OCC;   // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 #ifndef SGPR_AP_NI
-#define SGPR_AP_NI 1
+#define SGPR_AP_NI 2            // (same-box A/B, round 5: 97.7 -> 96.5 us per KITTI-00 matrix, twice; bit-identical - program order only)
 #endif
 #ifndef SGPR_AP_CHAINS
 #define SGPR_AP_CHAINS 1        // 2: layer 1's correction products (lo.hi, hi.lo) in an accumulator chain of their own, met by the
