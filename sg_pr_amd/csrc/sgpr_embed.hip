@@ -475,6 +475,9 @@ __device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f
 #ifndef SGPR_ASM_MINMAX
 #define SGPR_ASM_MINMAX 1
 #endif
+#ifndef SGPR_IN_PREFETCH
+#define SGPR_IN_PREFETCH 1024 // lean production launches: launch slots ahead whose input lines a workgroup pulls into its XCD's L2 (0: off)
+#endif
 #ifndef SGPR_WPREFETCH
 #define SGPR_WPREFETCH 1      // lean 64-row production instance: a GEMM phase's first weight fragment requested before the selection
 #endif
@@ -1929,7 +1932,8 @@ int launch_sem_tables(const DevWeights& w, float* d_table, float* d_vmax, hipStr
 // K-derived loop bounds and predicates of every phase fold away
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
 __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot,
-                                            const int role = 0) {   // role: 0 whole graph, 1 / 2 the halves of a split launch
+                                            const int role = 0,     // role: 0 whole graph, 1 / 2 the halves of a split launch
+                                            const int g_ahead = -1) {   // packed input: the graph whose lines are pulled into L2 (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // lean instance: the layout fields are the constants of lean_fixed_layout (the host built the plan from the same
     // function); N, NC, k stay run-time values
@@ -1974,6 +1978,20 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     }
 
     if (skip & 16) return;   // ablation: pure dispatch cost
+    // ---- L2 prefetch for the workgroup that will take this one's place: workgroups reach the XCDs round-robin by block
+    //      index, so launch slot s + kAhead (a multiple of 8, one round of resident workgroups later) runs on THIS XCD about
+    //      one workgroup lifetime from now; one load per 128-byte line of its graph, issued first and never waited for
+    //      until the end, turns that workgroup's opening HBM / MALL round trip into an L2 hit
+    float pf_val = 0.f;
+    if (SGPR_IN_PREFETCH && g_ahead >= 0 && kp.a.centers && kp.a.labels && !kp.a.rag_off) {
+        const int NSx = plan_in.N;
+        const int lc = (NSx * 12 + 127) / 128 + 1, ll = (NSx * 4 + 127) / 128 + 1;       // lines (+1: arbitrary alignment)
+        const int t = threadIdx.x;
+        if (t < lc)
+            pf_val = kp.a.centers[(size_t)g_ahead * NSx * 3 + min(t * 32, NSx * 3 - 1)];
+        else if (t < lc + ll)
+            pf_val = __int_as_float(kp.a.labels[(size_t)g_ahead * NSx + min((t - lc) * 32, NSx - 1)]);
+    }
     // ---- one slot per thread, fetched once for both branches: xyz + 12 semantic channels
     float fx = 0.f, fy = 0.f, fz = 0.f;
     int mylab = -2;                                       // packed input: this slot's label (-1 = pad)
@@ -2559,6 +2577,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     }
     // a graph whose activations left the f16 range is embedded again by the wide-range instance (embed_redo_kernel)
     if (FMT == FMT_H2 && kp.a.redo && tid == 0) request_redo(kp.a, launch_slot, *ovflag ? 1 : 0);
+    asm volatile("" ::"v"(pf_val));                          // (the prefetch loads above end here)
     SGPR_PROF(7)
 #undef SGPR_PROF
     if (prof && lane == 0) {
@@ -2580,7 +2599,13 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN 
             slot -= role == 2 ? kp.a.G : 0;                       // own producer still needs
         }
     }
-    embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role);
+    // (the prefetch partner: one round of resident workgroups ahead, same XCD; fetched beside this slot's own index)
+    int g_ahead = -1;
+    if constexpr (LEAN != 0 && DBG == 0 && SGPR_IN_PREFETCH != 0) {
+        const int s2 = slot + SGPR_IN_PREFETCH;
+        if (role == 0 && s2 < kp.a.G) g_ahead = kp.a.ids ? kp.a.ids[s2] : s2;
+    }
+    embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role, g_ahead);
 }
 
 // Second pass over the launch slots the f16 instance flagged (kp.a.redo):
