@@ -476,7 +476,8 @@ __device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f
 #define SGPR_ASM_MINMAX 1
 #endif
 #ifndef SGPR_IN_PREFETCH
-#define SGPR_IN_PREFETCH 1024 // lean production launches: launch slots ahead whose input lines a workgroup pulls into its XCD's L2 (0: off)
+#define SGPR_IN_PREFETCH 0    // launch slots ahead whose input lines a workgroup pulls into its XCD's L2 (A/B builds; measured: 1024 / 512
+                              // slots ahead 128.4 -> 130.0 / 130.2 us per KITTI-00 launch - the opening round trip is not what a workgroup waits for)
 #endif
 #ifndef SGPR_WPREFETCH
 #define SGPR_WPREFETCH 1      // lean 64-row production instance: a GEMM phase's first weight fragment requested before the selection
