@@ -30,6 +30,10 @@ data_process/pair_list/pair_list_3_20_*.npy - 184 133 listed pairs over 12 584 g
 shuffled order like the reference's files; graphs = synthetic KITTI-like sequences of those lengths.  One step = every
 graph embedded once + the listed pairs scored by sgpr_score_pair_list (grouped by row graph, matrix cores).
 
+`value` keeps inputs and outputs resident in HBM (`value_definition` says so in the line); `roofline.wide_range` repeats
+the step after the timed region with the embed's wide-range instance forced (three bf16 planes = the reference's 24-bit
+operand width instead of the default two f16 planes) and prices the all-fp32 variant from a sample of the exact tail.
+
 Other workloads (parity-test shapes, not the headline): `pairs128` (config 2: 128 pairs, N=64, k=10, faithful
 per-pair forward) and `stress` (config 5: 1024 pairs, N=256, k=20).
 """

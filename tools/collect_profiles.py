@@ -64,6 +64,22 @@ if not pmc_only:
     kernel_stats("kt_pairs128", tag + "_pairs128_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairs128 --no-cpu-baseline --steps 50")
     kernel_stats("kt_consumers", tag + "_consumers_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_f1.py 3")
     kernel_stats("kt_pairlist", tag + "_pairlist_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --workload pairlist --no-cpu-baseline --steps 50")
+    kernel_stats("kt_wide", tag + "_wide_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_embed.py kitti00 5 8192   "
+                 "(debug bit 13: every graph on the wide-range instance - three bf16 planes, 24-bit operands)")
+    for nm, out in (("seq_parity_world.txt", "_seq_parity_world.txt"), ("seq_parity_both.txt", "_seq_parity.txt"),
+                    ("tailmix_probe.txt", "_tailmix_probe.txt")):
+        f = os.path.join(src, nm)
+        if os.path.exists(f):
+            open(os.path.join(dst, tag + out), "w").write(open(f).read())
+    try:
+        line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
+        wide = json.loads(line)["roofline"].get("wide_range")
+        if wide:
+            json.dump({"source": "python bench.py (the default line's roofline.wide_range)", "wide_range": wide,
+                       "default_ms_per_step": json.loads(line)["ms_per_step"], "default_value": json.loads(line)["value"]},
+                      open(os.path.join(dst, tag + "_wide_bench.json"), "w"), indent=1)
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
     for kind in ("kitti", "world"):
         f = os.path.join(src, "f1_phases_%s.log" % kind)
         if os.path.exists(f):

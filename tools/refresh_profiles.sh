@@ -38,6 +38,13 @@ r = json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1])
 assert r["roofline"]["traffic"] is not None and r["roofline"].get("issue"), r["roofline"]
 print("bench line carries traffic", r["roofline"]["traffic"], "and issue", r["roofline"]["issue"]["frac"])
 PY
+# the embed launch at the reference's operand width (wide-range instance forced, debug bit 13): kernel stats beside the
+# bench line's roofline.wide_range
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_wide -- python $R/tools/run_embed.py kitti00 5 8192 > $O/kt_wide.log 2>&1 </dev/null
+# whole-sequence parity census with tie proofs (the gated form is the GPU test of the same name)
+( cd $R && SGPR_SEQ_PARITY_OUT=$O/seq_parity_world.txt timeout 900 python -m pytest tests -m gpu -q -x -k "full_sequence_parity" > $O/seq_parity_pytest.log 2>&1 )
+timeout 900 python $R/tools/seq_parity.py 4541 $O/seq_parity_both.txt > $O/seq_parity.log 2>&1 </dev/null
+timeout 60 $R/tools/probes/tailmix_probe > $O/tailmix_probe.txt 2>&1
 timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
 timeout 200 python $R/tools/f1_phases.py kitti > $O/f1_phases_kitti.log 2>&1 </dev/null
 timeout 200 python $R/tools/f1_phases.py world > $O/f1_phases_world.log 2>&1 </dev/null
