@@ -316,11 +316,8 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
 
 // out[i] = sum over the slabs: 32 counters per workgroup, 32 threads per counter (each sums every 32nd slab: one round
 // of independent loads), 128-B coalesced reads
-// out_hi != nullptr: the counters 0..T are PACKED words (sgpr_f1_max, pass A: negatives in the low `hi_shift` bits, positives
-// above them, per workgroup) - the two fields are summed separately (the sum of the packed words would carry from one into the other)
 __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int slab_words, int T,
-                                                        unsigned long long* __restrict__ out, const int* __restrict__ dT = nullptr,
-                                                        unsigned long long* __restrict__ out_hi = nullptr, int hi_shift = 0) {
+                                                        unsigned long long* __restrict__ out, const int* __restrict__ dT = nullptr) {
     __shared__ unsigned long long part[32][33];
     if (dT) {
         T = *dT;
@@ -328,16 +325,8 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
     }
     const int b = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + b;                  // counters 0..T, then T+1 = bad, T+2 = rank sum
-    unsigned long long s = 0ull, sh = 0ull;
-    if (i <= T && out_hi) {
-        const unsigned lo_mask = (1u << hi_shift) - 1u;
-#pragma unroll 8
-        for (int q = grp; q < n_slabs; q += 32) {
-            const unsigned wv = slabs[(size_t)q * slab_words + i];
-            s += wv & lo_mask;
-            sh += wv >> hi_shift;
-        }
-    } else if (i <= T) {
+    unsigned long long s = 0ull;
+    if (i <= T) {
 #pragma unroll 8
         for (int q = grp; q < n_slabs; q += 32) s += slabs[(size_t)q * slab_words + i];
     } else if (i <= T + 2) {
@@ -350,16 +339,6 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 #pragma unroll
         for (int q = 1; q < 32; ++q) s += part[q][b];
         out[i] = s;
-    }
-    if (out_hi) {                                         // (kernel-uniform)
-        __syncthreads();
-        part[grp][b] = sh;
-        __syncthreads();
-        if (grp == 0 && i <= T) {
-#pragma unroll
-            for (int q = 1; q < 32; ++q) sh += part[q][b];
-            out_hi[i] = sh;
-        }
     }
 }
 
@@ -394,7 +373,6 @@ constexpr int F1_PICK = 4095;                                    // values pass 
 constexpr int F1_SORT = 4096;
 constexpr int F1_PBUF = 8192;                                    // staged positives per workgroup between two flushes
 constexpr int F1_THREADS = 1024;
-constexpr int F1_PSH = 20;                                       // pass A's packed histogram word: negatives below bit 20, positives above
 
 // monotone: s1 < s2 => key(s1) <= key(s2), for every s >= 0 (not NaN).  1 - s is exact for s in [1/2, 1] (Sterbenz).
 __device__ __forceinline__ int f1_key(float s) {
@@ -583,11 +561,7 @@ constexpr int F1_WBUF = F1_PBUF / (F1_THREADS / 64);          // 512 staged posi
 __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, unsigned* __restrict__ slabs, int slab_words,
                                                              float* __restrict__ pos, long long cap,
                                                              unsigned long long* __restrict__ count,
-                                                             unsigned char* __restrict__ cls_out, const int packed) {
-    // packed (the launch guarantees fewer than 2^20 pairs per workgroup): a positive ALSO counts into its bin, above bit
-    // F1_PSH of the same histogram word - the plan kernel then gets the positives by bin from the slabs' sums instead of
-    // a pass of its single workgroup over the list (14 us of its 70); more than 4095 positives of one workgroup in one bin
-    // overflow the field, which the plan kernel sees (the sums do not add up to the list's length) and reports as status 1
+                                                             unsigned char* __restrict__ cls_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
     unsigned* hist = reinterpret_cast<unsigned*>(f1_smem);                  // [F1_NBP]
     float* buf = reinterpret_cast<float*>(hist + F1_NBP) + (threadIdx.x >> 6) * F1_WBUF;   // this wave's staging area
@@ -639,10 +613,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
                 }
                 const unsigned long long m = __ballot(p);
                 if (m) {
-                    if (p) {
-                        buf[nst + __popcll(m & ((1ull << lane) - 1ull))] = x;
-                        if (packed) atomicAdd(&hist[f1_key(x)], 1u << F1_PSH);
-                    }
+                    if (p) buf[nst + __popcll(m & ((1ull << lane) - 1ull))] = x;
                     nst += __popcll(m);
                 }
             }
@@ -745,9 +716,7 @@ __device__ __forceinline__ unsigned f1_hash(unsigned bits) { return (bits * 2654
 //      Out: ctrl, mark bits [F1_NBP / 32 + 1], thr [T2], info [T2], dT2; tpge / fpge [F1_NB + 1] = pairs in bins >= b.
 //      A single workgroup lives on latency: the bins' sums are scanned in registers (thread t owns 24 consecutive bins),
 //      every pass over the positives keeps eight independent loads in flight.
-__global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long long* __restrict__ negb,
-                                                             const unsigned long long* __restrict__ posb_g,   // positives by bin out of pass A's packed histogram, or nullptr
-                                                             const float* __restrict__ pos,
+__global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long long* __restrict__ negb, const float* __restrict__ pos,
                                                              const unsigned long long* __restrict__ count, long long cap,
                                                              unsigned long long* __restrict__ tpge, unsigned long long* __restrict__ fpge,
                                                              unsigned* __restrict__ mark_out, float* __restrict__ thr,
@@ -779,14 +748,13 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     }
     constexpr int PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;             // 24 bins per thread
     static_assert(PER % 2 == 0, "bins per thread");
-    if (!posb_g)
-        for (int i = tid; i < F1_NBP; i += F1_THREADS) posb[i] = 0u;
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) posb[i] = 0u;
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
     if (tid == 0) ndist = nv = 0u;
     __syncthreads();
     // (keeping a thread's ~47 positives in registers for the second look at them was measured: the unrolled body spills,
     // 14 -> 63 us; both passes read the list from L2 with sixteen / eight independent loads in flight)
-    for (long long i0 = 0; !posb_g && i0 < na; i0 += 16 * F1_THREADS) {
+    for (long long i0 = 0; i0 < na; i0 += 16 * F1_THREADS) {
         float x[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -815,7 +783,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int b = tid * PER + q;
-        ps[q] = b < F1_NB ? (posb_g ? (unsigned)posb_g[b] : posb[b]) : 0u;
+        ps[q] = b < F1_NB ? posb[b] : 0u;
         sn += ng[q];
         sp += ps[q];
         any = any || ps[q] != 0u || ng[q] != 0ull;
@@ -827,10 +795,6 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         tot[1] = an + sn;
     }
     __syncthreads();
-    if (posb_g && tot[0] != (unsigned long long)na) {                       // a packed field overflowed: the caller falls back
-        if (tid == 0) ctrl->status = 1;
-        return;
-    }
     const double P = (double)tot[0];
     // F1 = 2 TP / (TP + FP + P) is monotone in g = TP / (TP + FP + P).  Which edge is best and which bins can beat it is
     // decided on g in fp32 (one division per occupied bin; f1_of's three float64 divisions per bin and test were 40 us of
@@ -1272,7 +1236,7 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
 //      (two arrays) | candidate-bin marks | thresholds, their info, negatives by bucket of pass B | positives | counter slabs
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct F1Layout {
-    size_t off_negb, off_posb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
+    size_t off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
     long long cap;
     int slabs_a, slabs_b, words_a, words_b;
 };
@@ -1287,7 +1251,6 @@ static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     L.words_b = slab_words(F1_SORT);
     size_t off = 256;                                                       // header
     L.off_negb = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
-    L.off_posb = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_tpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_fpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_mark = off;  off += a256((F1_NBP / 32 + 1) * sizeof(unsigned));
@@ -1355,17 +1318,9 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
         return SGPR_OK;
     }
     const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
-    // packed histogram words in pass A when no workgroup can see 2^20 pairs (its waves take ceil(tasks / waves) strip tasks
-    // of F1_ROWS x 256 pairs each)
-    const long long ntasks = (long long)((M + 255) >> 8) * ((R + F1_ROWS - 1) / F1_ROWS), nwaves = (long long)L.slabs_a * (F1_THREADS / 64);
-    const long long per_wg = (F1_THREADS / 64) * ((ntasks + nwaves - 1) / nwaves) * F1_ROWS * 256;
-    const int packed = per_wg < (1LL << F1_PSH) ? 1 : 0;
-    unsigned long long* posb = reinterpret_cast<unsigned long long*>(ws + L.off_posb);
-    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count, cls, packed);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb,
-                       static_cast<const int*>(nullptr), packed ? posb : static_cast<unsigned long long*>(nullptr), F1_PSH);
-    hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb,
-                       packed ? posb : static_cast<unsigned long long*>(nullptr), pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
+    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count, cls);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb);
+    hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
                        ctrl, reinterpret_cast<unsigned long long*>(ws + 128));
     hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b, cls);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_SORT + 3 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_b, L.words_b, 0, neg2, dT2);
