@@ -34,22 +34,31 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 6
+#define SGPR_ABI_VERSION 7
 
 enum {
     SGPR_OK = 0,
     SGPR_E_INVALID = -1,   /* NULL pointer / negative count                                   */
-    SGPR_E_DIMS = -2,      /* architecture larger than the kernels are built for (see sgpr_dims) */
-    SGPR_E_NODES = -3,     /* node_num outside [k, SGPR_MAX_NODES], or a graph exceeded node_cap      */
-    SGPR_E_K = -4,         /* K outside [1, SGPR_MAX_K] or K > node_num                        */
+    SGPR_E_DIMS = -2,      /* architecture beyond the any-shape limits, or an entry point the tuned kernels alone serve */
+    SGPR_E_NODES = -3,     /* node_num outside [k, SGPR_ANY_MAX_NODES], or a graph exceeded node_cap  */
+    SGPR_E_K = -4,         /* K outside [1, SGPR_ANY_MAX_K] or K > node_num                    */
     SGPR_E_LABEL = -5,     /* a label outside [-1, num_labels) was seen (sgpr_check_status)    */
     SGPR_E_HIP = -6,       /* HIP runtime error (message has hipGetErrorString)                */
     SGPR_E_WORKSPACE = -7, /* workspace missing or too small                                   */
     SGPR_E_BLOB = -8       /* weights blob has the wrong number of floats                      */
 };
 
-#define SGPR_MAX_NODES 256 /* one workgroup stages a whole graph in LDS */
+/* the tuned kernels (matrix cores, one workgroup stages a whole graph in LDS): every shipped checkpoint and config */
+#define SGPR_MAX_NODES 256
 #define SGPR_MAX_K 32
+/* the any-shape kernels (plain fp32, activations in a global scratch area): what the reference can be configured to
+ * beyond that (parser_sg.py:12-22 takes any filters_* / tensor_neurons / bottle_neck_neurons / node_num / K) */
+#define SGPR_ANY_MAX_LABELS 64
+#define SGPR_ANY_MAX_FILTERS 256  /* filters_1, filters_2 */
+#define SGPR_ANY_MAX_FILTERS_3 128
+#define SGPR_ANY_MAX_NEURONS 64   /* tensor_neurons, bottle_neck_neurons */
+#define SGPR_ANY_MAX_NODES 1024
+#define SGPR_ANY_MAX_K 64
 
 typedef struct sgpr_handle sgpr_handle;
 
@@ -60,8 +69,17 @@ typedef struct sgpr_handle sgpr_handle;
  * no larger in any of the six: sgpr_create embeds its tensors into the built
  * shapes with zero weights for the channels it does not have, which is exact
  * (device buffers keep the built widths: pooled [G, 32], emb [G, N, 32], the
- * missing channels are 0; dense features are [G, 3 + num_labels, N]).  A
- * larger architecture -> SGPR_E_DIMS. */
+ * missing channels are 0; dense features are [G, 3 + num_labels, N]).
+ * A LARGER architecture (any of the six, up to the SGPR_ANY_MAX_* limits) gets
+ * an "any-shape" handle: the same entry points on plain-fp32 kernels
+ * (sgpr_generic.hip) - correct against the same oracle, not tuned - with device
+ * buffers of the model's own width (pooled [G, filters_3], emb [G, N, filters_3]:
+ * sgpr_pooled_width).  Not served on such a handle: sgpr_score_pair_list (use
+ * sgpr_score_pairs) and sgpr_embed_debug's dumps -> SGPR_E_DIMS.  Beyond the
+ * SGPR_ANY_MAX_* limits -> SGPR_E_DIMS at sgpr_create.
+ * node_num in (SGPR_MAX_NODES, SGPR_ANY_MAX_NODES] or K in (SGPR_MAX_K,
+ * SGPR_ANY_MAX_K] run on the any-shape embed kernel on every handle (the pooled
+ * width stays the handle's). */
 typedef struct sgpr_dims {
     int32_t num_labels;
     int32_t filters_1;
@@ -90,6 +108,11 @@ size_t sgpr_weights_count(const sgpr_dims* dims);
  * kernels and uploads them to `device`.  `weights` is HOST memory. */
 int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, int device, sgpr_handle** out);
 void sgpr_destroy(sgpr_handle* h);
+
+/* Floats per row of the handle's pooled / emb buffers: 32 (the built width) for every architecture the tuned kernels
+ * serve, filters_3 on an any-shape handle.  sgpr_is_any_shape: 1 for a handle of a larger architecture. */
+int sgpr_pooled_width(const sgpr_handle* h);
+int sgpr_is_any_shape(const sgpr_handle* h);
 
 /* Bytes of device workspace sgpr_embed* needs for (G graphs, N slots): one flag byte per launch slot (written by the
  * f16-plane kernel instance, read by its wide-range / generic-branch second pass in the same call) plus, for N > 128,
@@ -281,7 +304,7 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
 int sgpr_topk_rows(const sgpr_handle* h, const float* d_score, int R, int M, int64_t ld, int row0, int window, int k,
                    float* d_values, int32_t* d_indices, void* stream);
 
-/* LDS bytes / threads per workgroup the embed kernel uses for (N, k); 0 if unsupported. */
+/* LDS bytes per workgroup the embed kernel uses for (N, k) on this handle; 0 if unsupported. */
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 
 /* ---- stand-alone forms of the reference's building blocks (SURVEY.md 8b "signatures to keep") -------------------
@@ -291,8 +314,8 @@ size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k);
  *
  * sgpr_knn replaces dgcnn.knn (dgcnn.py:14-20): d_x [B,C,N] f32 -> d_idx [B,N,k] int64 (torch.topk's index type), the
  * k nearest candidates of every node under pd[i][j] = -|x_j|^2 + 2 x_i.x_j - |x_i|^2, best first; equal distances keep
- * the lower candidate index first (torch.topk's tie order is implementation-defined).  N <= SGPR_MAX_NODES, k <= N,
- * k <= SGPR_MAX_K. */
+ * the lower candidate index first (torch.topk's tie order is implementation-defined).  N <= SGPR_ANY_MAX_NODES, k <= N,
+ * k <= SGPR_ANY_MAX_K (beyond SGPR_MAX_NODES / SGPR_MAX_K: one wave per row instead of the LDS-resident kernel). */
 int sgpr_knn(const float* d_x, int B, int C, int N, int k, int64_t* d_idx, void* stream);
 
 /* Replaces dgcnn.get_graph_feature (dgcnn.py:23-49) for given neighbour lists d_idx [B,N,k] (int64, from sgpr_knn or
@@ -305,10 +328,19 @@ int sgpr_graph_feature(const float* d_x, const int64_t* d_idx, int B, int C, int
 int sgpr_attention_pool(const float* d_weight, const float* d_emb, int B, int N, float* d_rep, float* d_att,
                         void* stream);
 
+/* The same module at any width F <= SGPR_ANY_MAX_FILTERS_3 (d_weight [F,F], d_emb [B,N,F], d_rep [B,F]); plain fp32. */
+int sgpr_attention_pool_any(const float* d_weight, const float* d_emb, int B, int N, int F, float* d_rep, float* d_att,
+                            void* stream);
+
 /* Replaces TenorNetworkModule.forward (layers_batch.py:70-83): d_weight [F3,F3,T], d_weight_block [T,2*F3],
  * d_bias [T], d_e1 / d_e2 [B,F3] -> d_out [B,T] = relu(e1^T W e2 + Wb [e1;e2] + bias).  F3 = 32, T = 16. */
 int sgpr_ntn(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,
              const float* d_e2, int64_t B, float* d_out, void* stream);
+
+/* The same module at any width F <= SGPR_ANY_MAX_FILTERS_3, T <= SGPR_ANY_MAX_NEURONS tensor neurons (d_weight [F,F,T],
+ * d_weight_block [T,2F], d_bias [T], d_e1 / d_e2 [B,F] -> d_out [B,T]); plain fp32. */
+int sgpr_ntn_any(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,
+                 const float* d_e2, int64_t B, int F, int T, float* d_out, void* stream);
 
 /* ---- upstream of the path: labelled LiDAR scan -> semantic-graph nodes -------------------------
  * Replaces, for one scan, gen_labels + the node half of gen_graphs (data_process/gen_label_graph.py:196-365):

@@ -93,13 +93,14 @@ class RaggedGraphs:
             raise ValueError("RaggedGraphs: offsets [G+1] must span the %d stored nodes" % int(labels.shape[0]))
 
     @classmethod
-    def from_padded(cls, centers, labels, device=None):
-        """(centers [G,N,3], labels [G,N], -1 = trailing pad) -> RaggedGraphs (tensors moved to `device` when given)."""
+    def from_padded(cls, centers, labels, device=None, num_labels=None):
+        """(centers [G,N,3], labels [G,N], -1 = trailing pad) -> RaggedGraphs (tensors moved to `device` when given).
+        num_labels: the model's label count when it is not the shipped 12 (labels outside [0, num_labels) are refused)."""
         from .engine import Engine
         import numpy as np
         c = centers.cpu().numpy() if isinstance(centers, torch.Tensor) else np.asarray(centers)
         l = labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
-        rc, rl, off = Engine.to_ragged(c, l)
+        rc, rl, off = Engine.to_ragged(c, l) if num_labels is None else Engine.to_ragged(c, l, num_labels)
         tc, tl = torch.from_numpy(rc), torch.from_numpy(rl)
         if device is not None:
             tc, tl = tc.to(device), tl.to(device)

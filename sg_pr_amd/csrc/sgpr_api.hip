@@ -52,6 +52,14 @@ static bool dims_full(const sgpr_dims* d) {
            d->tensor_neurons == kT && d->bottle_neck_neurons == kB;
 }
 
+// what the any-shape kernels (sgpr_generic.hip) serve
+static bool dims_generic(const sgpr_dims* d) {
+    return d && d->num_labels >= 1 && d->num_labels <= SGPR_GENERIC_MAX_LABELS && d->filters_1 >= 1 &&
+           d->filters_1 <= SGPR_GENERIC_MAX_FILTERS && d->filters_2 >= 1 && d->filters_2 <= SGPR_GENERIC_MAX_FILTERS &&
+           d->filters_3 >= 1 && d->filters_3 <= SGPR_GENERIC_MAX_F3 && d->tensor_neurons >= 1 &&
+           d->tensor_neurons <= SGPR_GENERIC_MAX_T && d->bottle_neck_neurons >= 1 && d->bottle_neck_neurons <= SGPR_GENERIC_MAX_T;
+}
+
 struct BlockShape {
     int cout, cin2;
 };
@@ -174,14 +182,95 @@ static void split3_host(float w, unsigned short (&pl)[3]) {
     pl[2] = bf16_rne_host(r);
 }
 
+// The any-shape model of a blob (GenericModel): BatchNorm folded in double precision at the model's own dimensions,
+// uploaded as one allocation.  Blob order: s_conv1, f_conv1, s_conv2, f_conv2, s_conv3, f_conv3, conv_end, tail tensors.
+static int build_generic_model(const float* weights, const sgpr_dims* d, sgpr_handle* h) {
+    BlockShape bs[7];
+    block_shapes(d, bs);
+    std::vector<float> host;
+    size_t off_wa[6], off_wb[6], off_tb[6], off_wend = 0, off_tend = 0;
+    const float* src = weights;
+    GenericModel& m = h->gm;
+    memset(&m, 0, sizeof(m));
+    m.L = d->num_labels; m.f1 = d->filters_1; m.f2 = d->filters_2; m.f3 = d->filters_3;
+    m.T = d->tensor_neurons; m.B = d->bottle_neck_neurons;
+    m.cmax = std::max(std::max(3, m.L), std::max(m.f1, std::max(m.f2, m.f3)));
+    for (int b = 0; b < 7; ++b) {
+        const int cout = bs[b].cout, cin2 = bs[b].cin2, cin = cin2 / 2;
+        const float* W = src;
+        const float* gamma = W + (size_t)cout * cin2;
+        const float* beta = gamma + cout;
+        const float* mean = beta + cout;
+        const float* var = mean + cout;
+        src = var + cout;
+        if (b < 6) {
+            // blob order alternates the branches (s1, f1, s2, f2, s3, f3); the model keeps xyz layers 0..2, semantic 3..5
+            const int l6 = (b & 1) * 3 + (b >> 1);
+            m.cin[l6] = cin;
+            m.cout[l6] = cout;
+            off_wa[l6] = host.size();
+            host.resize(host.size() + (size_t)cout * cin);
+            off_wb[l6] = host.size();
+            host.resize(host.size() + (size_t)cout * cin);
+            off_tb[l6] = host.size();
+            host.resize(host.size() + cout);
+            for (int c = 0; c < cout; ++c) {
+                const double s = (double)gamma[c] / std::sqrt((double)var[c] + 1e-5);
+                for (int i = 0; i < cin; ++i) {
+                    const double w1 = W[(size_t)c * cin2 + i], w2 = W[(size_t)c * cin2 + cin + i];
+                    host[off_wa[l6] + (size_t)c * cin + i] = (float)(s * w1);            // acts on x_j
+                    host[off_wb[l6] + (size_t)c * cin + i] = (float)(s * (w2 - w1));     // acts on x_i
+                }
+                host[off_tb[l6] + c] = (float)((double)beta[c] - (double)mean[c] * s);
+            }
+        } else {
+            off_wend = host.size();
+            host.resize(host.size() + (size_t)cout * cin2);
+            off_tend = host.size();
+            host.resize(host.size() + cout);
+            for (int c = 0; c < cout; ++c) {
+                const double s = (double)gamma[c] / std::sqrt((double)var[c] + 1e-5);
+                for (int i = 0; i < cin2; ++i) host[off_wend + (size_t)c * cin2 + i] = (float)(s * W[(size_t)c * cin2 + i]);
+                host[off_tend + c] = (float)((double)beta[c] - (double)mean[c] * s);
+            }
+        }
+    }
+    const size_t f = m.f3, t = m.T, bn = m.B;
+    const size_t off_tail = host.size();
+    const size_t n_tail = f * f + f * f * t + t * 2 * f + t + bn * t + bn + bn + 1;
+    host.insert(host.end(), src, src + n_tail);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_gblob), host.size() * sizeof(float));
+    if (e != hipSuccess) return hip_fail(e, "sgpr_create: any-shape model");
+    e = hipMemcpy(h->d_gblob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "sgpr_create: any-shape model upload");
+    const float* dv = h->d_gblob;
+    for (int l = 0; l < 6; ++l) {
+        m.wa[l] = dv + off_wa[l];
+        m.wb[l] = dv + off_wb[l];
+        m.tb[l] = dv + off_tb[l];
+    }
+    m.w_end = dv + off_wend;
+    m.t_end = dv + off_tend;
+    const float* q = dv + off_tail;
+    m.att_w = q;    q += f * f;
+    m.ntn_w = q;    q += f * f * t;
+    m.ntn_wb = q;   q += t * 2 * f;
+    m.ntn_bias = q; q += t;
+    m.fc1_w = q;    q += bn * t;
+    m.fc1_b = q;    q += bn;
+    m.fc2_w = q;    q += bn;
+    m.fc2_b = q;
+    return SGPR_OK;
+}
+
 int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, int device, sgpr_handle** out) {
     if (!weights || !dims || !out) {
         set_error("sgpr_create: NULL argument");
         return SGPR_E_INVALID;
     }
-    if (!dims_supported(dims)) {
-        set_error("sgpr_create: the kernels are built for {labels 12, filters 64/64/32, tensor 16, bottleneck 16} and serve "
-                  "every architecture that is no larger in any of the six; this one is larger");
+    if (!dims_supported(dims) && !dims_generic(dims)) {
+        set_error("sgpr_create: architecture outside what the any-shape kernels serve (labels <= 64, filters <= 256, "
+                  "filters_3 <= 128, tensor / bottleneck neurons <= 64)");
         return SGPR_E_DIMS;
     }
     if (n_floats != weights_count(dims)) {
@@ -189,6 +278,31 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
                   std::to_string(weights_count(dims)));
         return SGPR_E_BLOB;
     }
+    if (!dims_supported(dims)) {
+        // larger than the shape the tuned kernels are built for {labels 12, filters 64/64/32, tensor 16, bottleneck 16}:
+        // the handle runs every call on the any-shape kernels (sgpr_generic.hip)
+        DeviceGuard guard(device);
+        sgpr_handle* h = new sgpr_handle();
+        memset(static_cast<void*>(h), 0, sizeof(*h));
+        h->device = device;
+        h->dims = *dims;
+        h->generic_only = 1;
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_status), sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemset(h->d_status, 0, sizeof(int32_t));
+        int rc = e == hipSuccess ? build_generic_model(weights, dims, h) : hip_fail(e, "sgpr_create");
+        if (rc != SGPR_OK) {
+            if (h->d_status) (void)hipFree(h->d_status);
+            if (h->d_gblob) (void)hipFree(h->d_gblob);
+            delete h;
+            return rc;
+        }
+        h->num_cus = prop.multiProcessorCount;
+        *out = h;
+        return SGPR_OK;
+    }
+    const float* user_weights = weights;
     const sgpr_dims user_dims = *dims;
     const sgpr_dims full_dims = {kLabels, kF1, kF2, kF3, kT, kB};
     std::vector<float> padded;
@@ -407,6 +521,18 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
             h->w.sem_b2 = h->w.sem_a2 + 2 * 16 * 64;
         }
     }
+    // the any-shape model of the same checkpoint: serves node_num / K beyond the tuned kernels' limits
+    h->generic_only = 0;
+    h->d_gblob = nullptr;
+    {
+        const int rc = build_generic_model(user_weights, &user_dims, h);
+        if (rc != SGPR_OK) {
+            (void)hipFree(h->d_blob);
+            (void)hipFree(h->d_status);
+            delete h;
+            return rc;
+        }
+    }
     *out = h;
     return SGPR_OK;
 }
@@ -414,6 +540,7 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
 void sgpr_destroy(sgpr_handle* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
+    if (h->d_gblob) (void)hipFree(h->d_gblob);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_status) (void)hipFree(h->d_status);
     delete h;
@@ -482,16 +609,62 @@ static size_t embed_ws_bytes(const sgpr_handle* h, int G, int N) {
     return embed_flag_bytes(G) + embed_park_bytes(G, N) + embed_sem_bytes(h, G);
 }
 
+// which launches run on the any-shape kernels (sgpr_generic.hip): every launch of a handle whose architecture is larger
+// than the built shape, and launches beyond the tuned kernels' node_num / K limits on any handle
+static bool needs_generic(const sgpr_handle* h, int N, int k) {
+    return h->generic_only || N > SGPR_MAX_NODES || k > SGPR_MAX_K;
+}
+static bool generic_nk_ok(int N, int k) {
+    return N >= 1 && N <= SGPR_GENERIC_MAX_NODES && k >= 1 && k <= SGPR_GENERIC_MAX_K && k <= N;
+}
+static int pooled_width(const sgpr_handle* h) { return h->generic_only ? h->gm.f3 : kF3; }
+
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
     EmbedPlan p;
-    if (!h || G < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
+    if (!h || G < 0) return 0;
+    if (needs_generic(h, N, k)) return generic_nk_ok(N, k) ? generic_embed_ws_bytes(h, G, N, k) + 256 : 0;
+    if (!make_embed_plan(N, 0, k, &p)) return 0;
     return embed_ws_bytes(h, G, N);
 }
 
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
     EmbedPlan p;
-    if (!h || !make_embed_plan(N, 0, k, &p)) return 0;
+    if (!h) return 0;
+    if (needs_generic(h, N, k)) return generic_nk_ok(N, k) ? 2 * SGPR_GENERIC_MAX_F3 * sizeof(float) : 0;
+    if (!make_embed_plan(N, 0, k, &p)) return 0;
     return (size_t)p.lds_bytes;
+}
+
+int sgpr_pooled_width(const sgpr_handle* h) { return h ? pooled_width(h) : 0; }
+int sgpr_is_any_shape(const sgpr_handle* h) { return (h && h->generic_only) ? 1 : 0; }
+
+// an embed launch on the any-shape kernels
+static int embed_generic(const sgpr_handle* h, EmbedArgs a, int N, int k, void* ws, size_t ws_bytes, void* stream) {
+    if ((a.dbg_layers || a.dbg_knn) && h->generic_only) {
+        set_error("sgpr_embed_debug: the layer dump's rows are 64 floats - not served for an architecture beyond the built shape");
+        return SGPR_E_DIMS;
+    }
+    if (a.G < 0) {
+        set_error("negative graph count");
+        return SGPR_E_INVALID;
+    }
+    if (N < 1 || N > SGPR_GENERIC_MAX_NODES) {
+        set_error("node_num " + std::to_string(N) + " outside [1, " + std::to_string(SGPR_GENERIC_MAX_NODES) + "]");
+        return SGPR_E_NODES;
+    }
+    if (k < 1 || k > SGPR_GENERIC_MAX_K || k > N) {
+        set_error("K " + std::to_string(k) + " outside [1, min(node_num, " + std::to_string(SGPR_GENERIC_MAX_K) + ")]");
+        return SGPR_E_K;
+    }
+    const size_t need = generic_embed_ws_bytes(h, a.G, N, k);
+    if (!ws || ws_bytes < need) {
+        set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required (sgpr_embed_workspace_bytes)");
+        return SGPR_E_WORKSPACE;
+    }
+    a.status = h->d_status;
+    a.num_labels = h->dims.num_labels;
+    DeviceGuard guard(h->device);
+    return launch_embed_generic(h, a, N, k, ws, static_cast<hipStream_t>(stream));
 }
 
 static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int node_cap, void* ws, size_t ws_bytes,
@@ -501,6 +674,7 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
         set_error("sgpr_embed: NULL argument");
         return SGPR_E_INVALID;
     }
+    if (needs_generic(h, N, k)) return embed_generic(h, a, N, k, ws, ws_bytes, stream);
     // with at most one graph per CU there is nothing to overlap: keep the 512-thread workgroups (lower latency)
     a.promise = (node_cap > 0 && node_cap < N) ? node_cap : N;   // still enforced (a broken promise stays loud)
     if (a.G <= h->num_cus) node_cap = 0;
@@ -638,6 +812,8 @@ int sgpr_score_pairs(const sgpr_handle* h, const float* d_pooled1, const int32_t
         return SGPR_E_INVALID;
     }
     DeviceGuard guard(h->device);
+    if (h->generic_only)
+        return launch_score_generic(h, d_pooled1, d_idx1, d_pooled2, d_idx2, P, 0, d_score, 0, static_cast<hipStream_t>(stream));
     return launch_score_pairs(h, d_pooled1, d_idx1, d_pooled2, d_idx2, P, d_score, static_cast<hipStream_t>(stream));
 }
 
@@ -727,6 +903,11 @@ int sgpr_score_pair_list(const sgpr_handle* h, const float* d_pooled_rows, int R
         return SGPR_E_INVALID;
     }
     if (P == 0) return SGPR_OK;
+    if (h->generic_only) {
+        set_error("sgpr_score_pair_list: the grouped pair-list kernel is built for tensor networks up to 32 x 32 x 16; a larger "
+                  "architecture scores its lists through sgpr_score_pairs");
+        return SGPR_E_DIMS;
+    }
     const size_t need = score_pair_list_ws_bytes(n_rows, M);
     if (!d_workspace || workspace_bytes < need) {
         set_error("sgpr_score_pair_list: workspace of " + std::to_string(need) + " bytes required");
@@ -750,6 +931,11 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
         return SGPR_E_INVALID;
     }
     if (R == 0 || M == 0) return SGPR_OK;
+    if (h->generic_only) {                                   // (no workspace: one wave per pair of the rectangle)
+        DeviceGuard guard(h->device);
+        return launch_score_generic(h, d_pooled_rows, nullptr, d_pooled_cols, nullptr, (int64_t)R * M, M, d_score, ld,
+                                    static_cast<hipStream_t>(stream));
+    }
     const size_t need = score_all_pairs_ws_bytes(R, M);
     if (need > 0 && (!d_workspace || workspace_bytes < need)) {
         set_error("sgpr_score_all_pairs: workspace of " + std::to_string(need) + " bytes required");
@@ -785,6 +971,15 @@ int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pair
                                size_t workspace_bytes, void* stream) {
     int rc = check_jobs(h, n_jobs, jobs);
     if (rc != SGPR_OK) return rc;
+    if (h->generic_only) {
+        DeviceGuard guard(h->device);
+        for (int j = 0; j < n_jobs && rc == SGPR_OK; ++j)
+            if (jobs[j].R > 0 && jobs[j].M > 0)
+                rc = launch_score_generic(h, jobs[j].d_pooled_rows, nullptr, jobs[j].d_pooled_cols, nullptr,
+                                          (int64_t)jobs[j].R * jobs[j].M, jobs[j].M, jobs[j].d_score, jobs[j].ld,
+                                          static_cast<hipStream_t>(stream));
+        return rc;
+    }
     const size_t need = score_all_pairs_multi_ws_bytes(n_jobs, jobs);
     if (need > 0 && (!d_workspace || workspace_bytes < need)) {
         set_error("sgpr_score_all_pairs_multi: workspace of " + std::to_string(need) + " bytes required");
@@ -797,8 +992,62 @@ int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pair
 // workspace of sgpr_forward_dense: pooled [2B][32] | embed workspace for 2B graphs
 size_t sgpr_forward_workspace_bytes(const sgpr_handle* h, int B, int N, int k) {
     EmbedPlan p;
-    if (!h || B < 0 || !make_embed_plan(N, 0, k, &p)) return 0;
+    if (!h || B < 0) return 0;
+    if (needs_generic(h, N, k)) {
+        if (!generic_nk_ok(N, k)) return 0;
+        const size_t pooled = ((size_t)2 * B * pooled_width(h) * sizeof(float) + 255) / 256 * 256;
+        return pooled + generic_embed_ws_bytes(h, 2 * B, N, k) + 256;
+    }
+    if (!make_embed_plan(N, 0, k, &p)) return 0;
     return (size_t)2 * B * kF3 * sizeof(float) + embed_ws_bytes(h, 2 * B, N);
+}
+
+// sgpr_forward_dense on the any-shape kernels: the two sides embed as one launch of 2B graphs (one launch per side when
+// the attention buffers are separate), then one wave per pair
+static int forward_dense_generic(const sgpr_handle* h, const float* f1, const float* f2, int B, int N, int k,
+                                 float* d_score, float* d_att1, float* d_att2, void* d_workspace,
+                                 size_t workspace_bytes, void* stream) {
+    const size_t need = sgpr_forward_workspace_bytes(h, B, N, k);
+    if (need == 0) {
+        set_error("sgpr_forward_dense: node_num " + std::to_string(N) + " / K " + std::to_string(k) + " outside the any-shape "
+                  "limits (node_num <= " + std::to_string(SGPR_GENERIC_MAX_NODES) + ", K <= min(node_num, " +
+                  std::to_string(SGPR_GENERIC_MAX_K) + "))");
+        return (N < 1 || N > SGPR_GENERIC_MAX_NODES) ? SGPR_E_NODES : SGPR_E_K;
+    }
+    if (!d_workspace || workspace_bytes < need) {
+        set_error("sgpr_forward_dense: workspace of " + std::to_string(need) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    const int pw = pooled_width(h);
+    float* pooled = static_cast<float*>(d_workspace);
+    const size_t pooled_bytes = ((size_t)2 * B * pw * sizeof(float) + 255) / 256 * 256;
+    void* ws = static_cast<char*>(d_workspace) + pooled_bytes;
+    const size_t ws_bytes = workspace_bytes - pooled_bytes;
+    EmbedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dense = f1;
+    a.dense2 = f2;
+    a.g_split = B;
+    a.G = 2 * B;
+    a.pooled = pooled;
+    int rc;
+    if ((d_att1 && d_att2 && d_att2 == d_att1 + (size_t)B * N) || (!d_att1 && !d_att2)) {
+        a.att = d_att1;
+        rc = embed_generic(h, a, N, k, ws, ws_bytes, stream);
+    } else {
+        EmbedArgs a1 = a, a2 = a;
+        a1.dense2 = nullptr; a1.G = B; a1.att = d_att1;
+        a2.dense = f2; a2.dense2 = nullptr; a2.G = B; a2.att = d_att2;
+        a2.pooled = pooled + (size_t)B * pw;
+        rc = embed_generic(h, a1, N, k, ws, ws_bytes, stream);
+        if (rc == SGPR_OK) rc = embed_generic(h, a2, N, k, ws, ws_bytes, stream);
+    }
+    if (rc != SGPR_OK) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->generic_only)
+        return launch_score_generic(h, pooled, nullptr, pooled + (size_t)B * pw, nullptr, B, 0, d_score, 0, s);
+    return launch_score_pairs(h, pooled, nullptr, pooled + (size_t)B * kF3, nullptr, B, d_score, s);
 }
 
 int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const float* d_features_2, int B, int N,
@@ -808,6 +1057,9 @@ int sgpr_forward_dense(const sgpr_handle* h, const float* d_features_1, const fl
         set_error("sgpr_forward_dense: NULL argument or negative batch");
         return SGPR_E_INVALID;
     }
+    if (needs_generic(h, N, k))
+        return forward_dense_generic(h, d_features_1, d_features_2, B, N, k, d_score, d_att1, d_att2, d_workspace,
+                                     workspace_bytes, stream);
     EmbedPlan plan;
     int rc = check_nk(2 * B, N, k, 0, &plan, wide_range(h), !h->dbg_prof && !(h->dbg_skip & ~kProductionSkipBits));
     if (rc != SGPR_OK) return rc;
@@ -859,14 +1111,16 @@ int sgpr_knn(const float* d_x, int B, int C, int N, int k, int64_t* d_idx, void*
         set_error("sgpr_knn: NULL argument, negative batch or no channels");
         return SGPR_E_INVALID;
     }
-    if (N < 1 || N > SGPR_MAX_NODES) {
-        set_error("sgpr_knn: N " + std::to_string(N) + " outside [1, " + std::to_string(SGPR_MAX_NODES) + "]");
+    if (N < 1 || N > SGPR_ANY_MAX_NODES) {
+        set_error("sgpr_knn: N " + std::to_string(N) + " outside [1, " + std::to_string(SGPR_ANY_MAX_NODES) + "]");
         return SGPR_E_NODES;
     }
-    if (k < 1 || k > SGPR_MAX_K || k > N) {
-        set_error("sgpr_knn: K " + std::to_string(k) + " outside [1, min(N, " + std::to_string(SGPR_MAX_K) + ")]");
+    if (k < 1 || k > SGPR_ANY_MAX_K || k > N) {
+        set_error("sgpr_knn: K " + std::to_string(k) + " outside [1, min(N, " + std::to_string(SGPR_ANY_MAX_K) + ")]");
         return SGPR_E_K;
     }
+    if (N > SGPR_MAX_NODES || k > SGPR_MAX_K)                    // beyond the LDS-resident kernel: one wave per row
+        return launch_knn_any(d_x, B, C, N, k, d_idx, static_cast<hipStream_t>(stream));
     return launch_knn(d_x, B, C, N, k, d_idx, static_cast<hipStream_t>(stream));
 }
 
@@ -889,6 +1143,34 @@ int sgpr_attention_pool(const float* d_weight, const float* d_emb, int B, int N,
         return SGPR_E_NODES;
     }
     return launch_attention_pool(d_weight, d_emb, B, N, d_rep, d_att, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_attention_pool_any(const float* d_weight, const float* d_emb, int B, int N, int F, float* d_rep, float* d_att,
+                            void* stream) {
+    if (!d_weight || !d_emb || !d_rep || B < 0 || N < 1) {
+        set_error("sgpr_attention_pool_any: NULL argument, negative batch or no nodes");
+        return SGPR_E_INVALID;
+    }
+    if (F < 1 || F > SGPR_ANY_MAX_FILTERS_3) {
+        set_error("sgpr_attention_pool_any: width " + std::to_string(F) + " outside [1, " +
+                  std::to_string(SGPR_ANY_MAX_FILTERS_3) + "]");
+        return SGPR_E_DIMS;
+    }
+    return launch_attention_any(d_weight, d_emb, B, N, F, d_rep, d_att, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_ntn_any(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,
+                 const float* d_e2, int64_t B, int F, int T, float* d_out, void* stream) {
+    if (!d_weight || !d_weight_block || !d_bias || !d_e1 || !d_e2 || !d_out || B < 0) {
+        set_error("sgpr_ntn_any: NULL argument or negative batch");
+        return SGPR_E_INVALID;
+    }
+    if (F < 1 || F > SGPR_ANY_MAX_FILTERS_3 || T < 1 || T > SGPR_ANY_MAX_NEURONS) {
+        set_error("sgpr_ntn_any: width " + std::to_string(F) + " / " + std::to_string(T) + " neurons outside [1, " +
+                  std::to_string(SGPR_ANY_MAX_FILTERS_3) + "] / [1, " + std::to_string(SGPR_ANY_MAX_NEURONS) + "]");
+        return SGPR_E_DIMS;
+    }
+    return launch_ntn_any(d_weight, d_weight_block, d_bias, d_e1, d_e2, B, F, T, d_out, static_cast<hipStream_t>(stream));
 }
 
 int sgpr_ntn(const float* d_weight, const float* d_weight_block, const float* d_bias, const float* d_e1,

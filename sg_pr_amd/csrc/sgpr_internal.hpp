@@ -55,6 +55,32 @@ struct DevWeights {
 };
 constexpr int kSemTableFloats = 4 * 256 + 32 + 2 * 2 * 16 * 64;
 
+// Any-shape model (sgpr_generic.hip): the folded fp32 weights at the model's own dimensions, for what the tuned kernels
+// are not built for - architectures beyond the built shape, node_num > SGPR_MAX_NODES, K > SGPR_MAX_K.
+#define SGPR_GENERIC_MAX_LABELS SGPR_ANY_MAX_LABELS
+#define SGPR_GENERIC_MAX_FILTERS SGPR_ANY_MAX_FILTERS
+#define SGPR_GENERIC_MAX_F3 SGPR_ANY_MAX_FILTERS_3
+#define SGPR_GENERIC_MAX_T SGPR_ANY_MAX_NEURONS          // tensor neurons and bottleneck neurons
+#define SGPR_GENERIC_MAX_NODES SGPR_ANY_MAX_NODES
+#define SGPR_GENERIC_MAX_K SGPR_ANY_MAX_K
+struct GenericModel {
+    int L, f1, f2, f3, T, B, cmax;      // cmax: widest activation row (max of 3, L, f1, f2, f3)
+    int cin[6], cout[6];                // EdgeConv blocks: xyz branch (s_conv1..3), then the semantic branch (f_conv1..3)
+    const float* wa[6];                 // [cout][cin]  s * W[:, :cin]            (acts on x_j)
+    const float* wb[6];                 // [cout][cin]  s * (W[:, cin:] - W[:, :cin])   (acts on x_i)
+    const float* tb[6];                 // [cout]       beta - mean * s,  s = gamma / sqrt(var + 1e-5)
+    const float* w_end;                 // [f3][2 f3]   conv_end, BatchNorm folded
+    const float* t_end;                 // [f3]
+    const float* att_w;                 // [f3][f3]
+    const float* ntn_w;                 // [f3][f3][T]
+    const float* ntn_wb;                // [T][2 f3]
+    const float* ntn_bias;              // [T]
+    const float* fc1_w;                 // [B][T]
+    const float* fc1_b;                 // [B]
+    const float* fc2_w;                 // [B]
+    const float* fc2_b;                 // [1]
+};
+
 }  // namespace sgpr
 
 struct sgpr_handle {
@@ -69,6 +95,9 @@ struct sgpr_handle {
     int dbg_skip;
     unsigned long long* dbg_prof;
     int f16_weights;     // every folded weight fits the f16 range (else the wide-range layouts are used throughout)
+    int generic_only;    // the architecture is larger than the built shape: every call runs on the any-shape kernels
+    float* d_gblob;      // owns the any-shape model's weights
+    sgpr::GenericModel gm;
 };
 
 namespace sgpr {
@@ -152,6 +181,16 @@ int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_j
 size_t score_pair_list_ws_bytes(int NR, int M);
 int launch_score_pair_list(const sgpr_handle* h, const float* rows, const float* cols, int M, const int32_t* plan,
                            int NR, int NI, int64_t P, float* score, void* ws, hipStream_t stream);
+int generic_embed_slots(const sgpr_handle* h, int G);
+size_t generic_embed_ws_bytes(const sgpr_handle* h, int G, int N, int k);
+int launch_embed_generic(const sgpr_handle* h, const EmbedArgs& a, int N, int k, void* ws, hipStream_t stream);
+// list form (M == 0: pair p = (i1 ? i1[p] : p, i2 ? i2[p] : p) -> score[p]) or dense rectangle (M > 0: P = R * M pairs -> score[r * ld + c])
+int launch_knn_any(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);
+int launch_attention_any(const float* w, const float* emb, int B, int N, int F, float* rep, float* att, hipStream_t stream);
+int launch_ntn_any(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t P, int F,
+                   int T, float* out, hipStream_t stream);
+int launch_score_generic(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,
+                         int64_t P, int M, float* score, int64_t ld, hipStream_t stream);
 int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,
                float* out, hipStream_t stream);
 int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);

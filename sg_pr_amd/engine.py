@@ -30,7 +30,8 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
                -6: "SGPR_E_HIP", -7: "SGPR_E_WORKSPACE", -8: "SGPR_E_BLOB"}
 
 # every symbol include/sgpr.h declares (tests check the library exports all of them)
-ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_workspace_bytes", "sgpr_embed",
+ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_pooled_width", "sgpr_is_any_shape",
+               "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_capped", "sgpr_embed_ordered", "sgpr_embed_ragged",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_pair_plan_ints", "sgpr_pair_plan",
                "sgpr_score_pair_list_workspace_bytes", "sgpr_score_pair_list", "sgpr_score_all_pairs_workspace_bytes",
@@ -39,6 +40,7 @@ ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_embed_
                "sgpr_pair_positives", "sgpr_pair_threshold_counts_workspace_bytes", "sgpr_pair_threshold_counts",
                "sgpr_f1_max_workspace_bytes", "sgpr_f1_max", "sgpr_topk_rows",
                "sgpr_embed_lds_bytes", "sgpr_knn", "sgpr_graph_feature", "sgpr_attention_pool", "sgpr_ntn",
+               "sgpr_attention_pool_any", "sgpr_ntn_any",
                "sgpr_cluster_workspace_bytes", "sgpr_cluster_scan", "sgpr_graph_edges",
                "sgpr_debug_set_profile_buffer", "sgpr_debug_set_skip_mask", "sgpr_debug_uses_f16_planes", "sgpr_last_error",
                "sgpr_abi_version"]
@@ -98,6 +100,10 @@ def load_library():
     lib.sgpr_create.argtypes = [vp, sz, ctypes.POINTER(SgprDims), i32, ctypes.POINTER(vp)]
     lib.sgpr_destroy.restype = None
     lib.sgpr_destroy.argtypes = [vp]
+    lib.sgpr_pooled_width.restype = i32
+    lib.sgpr_pooled_width.argtypes = [vp]
+    lib.sgpr_is_any_shape.restype = i32
+    lib.sgpr_is_any_shape.argtypes = [vp]
     lib.sgpr_embed_workspace_bytes.restype = sz
     lib.sgpr_embed_workspace_bytes.argtypes = [vp, i32, i32, i32]
     lib.sgpr_embed.restype = i32
@@ -161,6 +167,10 @@ def load_library():
     lib.sgpr_attention_pool.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.sgpr_ntn.restype = i32
     lib.sgpr_ntn.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
+    lib.sgpr_attention_pool_any.restype = i32
+    lib.sgpr_attention_pool_any.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.sgpr_ntn_any.restype = i32
+    lib.sgpr_ntn_any.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     lib.sgpr_cluster_workspace_bytes.restype = sz
     lib.sgpr_cluster_workspace_bytes.argtypes = [i32]
     lib.sgpr_cluster_scan.restype = i32
@@ -212,10 +222,13 @@ class Engine:
                                "there is no CPU fallback")
         self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
         self.dims = dims if dims is not None else default_dims()
-        # The kernels run on the built shapes (32 pooled features, 12 label channels ...); a smaller architecture is served
-        # by zero-padding its tensors at sgpr_create.  Device buffers keep the built widths (pooled [G, 32]: the channels
-        # the checkpoint does not have are exactly 0); node embeddings are cut to filters_3 where they leave the engine.
+        # The tuned kernels run on the built shapes (32 pooled features, 12 label channels ...); a smaller architecture is
+        # served by zero-padding its tensors at sgpr_create.  Device buffers keep the built widths (pooled [G, 32]: the
+        # channels the checkpoint does not have are exactly 0); node embeddings are cut to filters_3 where they leave the
+        # engine.  A larger architecture gets an any-shape handle (plain-fp32 kernels, buffers of the model's own width).
         self.f3 = int(self.dims.filters_3)
+        self.pw = F3                                                     # floats per pooled / emb row (set below)
+        self.any_shape = False
         if isinstance(state_dict, (np.ndarray, torch.Tensor)):          # already the flat fp32 blob (sg_pr_amd.ops)
             blob = np.ascontiguousarray(torch.as_tensor(state_dict).detach().cpu().numpy(), dtype=np.float32).ravel()
         else:
@@ -227,6 +240,8 @@ class Engine:
         self._check(rc)
         assert want == blob.size
         self._h = h
+        self.pw = int(self.lib.sgpr_pooled_width(h))
+        self.any_shape = bool(self.lib.sgpr_is_any_shape(h))
 
     def close(self):
         if self._h is not None:
@@ -255,8 +270,8 @@ class Engine:
         return t
 
     def _cut(self, emb):
-        """node embeddings [.., 32] -> [.., filters_3] (a view; identity for the shipped architecture)"""
-        return emb if emb is None or self.f3 == F3 else emb[..., :self.f3]
+        """node embeddings [.., pooled width] -> [.., filters_3] (a view; identity for the shipped architecture)"""
+        return emb if emb is None or self.f3 == self.pw else emb[..., :self.f3]
 
     def _ws(self, nbytes):
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
@@ -340,9 +355,9 @@ class Engine:
         labels = self._dev(labels, torch.int32, "labels")
         g, n = labels.shape
         assert centers.shape == (g, n, 3), "centers must be [G, N, 3]"
-        pooled = torch.empty(g, F3, dtype=torch.float32, device=self.device)
+        pooled = torch.empty(g, self.pw, dtype=torch.float32, device=self.device)
         att = torch.empty(g, n, dtype=torch.float32, device=self.device) if (want_att or debug) else None
-        emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if (want_emb or debug) else None
+        emb = torch.empty(g, n, self.pw, dtype=torch.float32, device=self.device) if (want_emb or debug) else None
         ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
         ws = self._ws(ws_bytes)
         if debug:
@@ -405,9 +420,9 @@ class Engine:
         offsets = self._dev(offsets, torch.int64, "offsets")
         g, n = offsets.numel() - 1, int(node_num)
         assert centers.dim() == 2 and centers.shape[1] == 3 and labels.shape[0] == centers.shape[0], "centers [S,3], labels [S]"
-        pooled = torch.empty(g, F3, dtype=torch.float32, device=self.device)
+        pooled = torch.empty(g, self.pw, dtype=torch.float32, device=self.device)
         att = torch.empty(g, n, dtype=torch.float32, device=self.device) if want_att else None
-        emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if want_emb else None
+        emb = torch.empty(g, n, self.pw, dtype=torch.float32, device=self.device) if want_emb else None
         if g == 0:
             return pooled, att, emb
         ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
@@ -426,9 +441,9 @@ class Engine:
         g, ch, n = features.shape
         if ch != 3 + self.dims.num_labels:
             raise ValueError("features must be [G, %d, N], got %s" % (3 + self.dims.num_labels, tuple(features.shape)))
-        pooled = torch.empty(g, F3, dtype=torch.float32, device=self.device)
+        pooled = torch.empty(g, self.pw, dtype=torch.float32, device=self.device)
         att = torch.empty(g, n, dtype=torch.float32, device=self.device) if want_att else None
-        emb = torch.empty(g, n, F3, dtype=torch.float32, device=self.device) if want_emb else None
+        emb = torch.empty(g, n, self.pw, dtype=torch.float32, device=self.device) if want_emb else None
         ws_bytes = self.lib.sgpr_embed_workspace_bytes(self._h, g, n, k)
         ws = self._ws(ws_bytes)
         rc = self.lib.sgpr_embed_dense(self._h, _ptr(features), g, n, k, _ptr(pooled), _ptr(att), _ptr(emb), _ptr(ws),
@@ -712,8 +727,14 @@ def attention_pool(weight, emb):
     emb = _gpu_f32(emb, "embedding")
     weight = _gpu_f32(weight, "weight_matrix").to(emb.device)
     b, n, f = emb.shape
-    if f > F3 or tuple(weight.shape) != (f, f):
-        raise ValueError("attention_pool is built for filters_3 <= %d" % F3)
+    if tuple(weight.shape) != (f, f):
+        raise ValueError("attention_pool: weight_matrix must be [%d, %d]" % (f, f))
+    if f > F3:          # wider than the built module: the any-width kernel (plain fp32)
+        rep = torch.empty(b, f, dtype=torch.float32, device=emb.device)
+        att = torch.empty(b, n, dtype=torch.float32, device=emb.device)
+        with torch.cuda.device(emb.device):
+            _raise_if(lib, lib.sgpr_attention_pool_any(_ptr(weight), _ptr(emb), b, n, f, _ptr(rep), _ptr(att), _stream_of(emb)))
+        return rep, att
     if f < F3:          # a smaller width is the built one with zero channels (exactly: zeros add nothing to any sum)
         emb = torch.nn.functional.pad(emb, (0, F3 - f))
         weight = torch.nn.functional.pad(weight, (0, F3 - f, 0, F3 - f))
@@ -734,9 +755,15 @@ def ntn(weight, weight_block, bias, e1, e2):
     bs = _gpu_f32(bias, "bias").to(e1.device).view(-1)
     b = e1.shape[0]
     f, t = (int(w.shape[0]), int(w.shape[2])) if w.dim() == 3 else (-1, -1)
-    if (f < 1 or f > F3 or t < 1 or t > 16 or e1.shape != (b, f) or e2.shape != (b, f) or tuple(w.shape) != (f, f, t) or
+    if (f < 1 or t < 1 or e1.shape != (b, f) or e2.shape != (b, f) or tuple(w.shape) != (f, f, t) or
             tuple(wb.shape) != (t, 2 * f) or bs.numel() != t):
-        raise ValueError("ntn is built for filters_3 <= 32, tensor_neurons <= 16")
+        raise ValueError("ntn: weight_matrix [F,F,T], weight_matrix_block [T,2F], bias [T], embeddings [B,F]")
+    if f > F3 or t > 16:   # wider than the built module: the any-width kernel (plain fp32)
+        out = torch.empty(b, t, dtype=torch.float32, device=e1.device)
+        with torch.cuda.device(e1.device):
+            _raise_if(lib, lib.sgpr_ntn_any(_ptr(w.contiguous()), _ptr(wb.contiguous()), _ptr(bs.contiguous()), _ptr(e1),
+                                            _ptr(e2), b, f, t, _ptr(out), _stream_of(e1)))
+        return out
     if f < F3 or t < 16:   # a smaller module is the built one with zero weights for what it does not have
         pad = torch.nn.functional.pad
         e1, e2 = pad(e1, (0, F3 - f)).contiguous(), pad(e2, (0, F3 - f)).contiguous()

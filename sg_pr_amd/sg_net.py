@@ -134,6 +134,8 @@ class SG(torch.nn.Module):
         eng = self.engine()
         if grouped is None:
             grouped = idx_1 is not None and idx_2 is not None and len(idx_1) >= self.GROUPED_MIN_PAIRS
+        if self.engine().any_shape:          # (an architecture beyond the built shape: the grouped kernel is not built for it)
+            grouped = False
         if grouped and idx_1 is not None and idx_2 is not None and len(idx_1) > 0:
             i1 = idx_1.cpu().numpy() if isinstance(idx_1, torch.Tensor) else np.asarray(idx_1)
             i2 = idx_2.cpu().numpy() if isinstance(idx_2, torch.Tensor) else np.asarray(idx_2)

@@ -208,11 +208,14 @@ def test_reference_api_drop_in(golden_dir, ckpt_path):
 
 def test_error_codes(eng):
     from sg_pr_amd.engine import SgprError
-    c = torch.zeros(1, 300, 3)
-    l = torch.zeros(1, 300, dtype=torch.int32)
+    c = torch.zeros(1, 1025, 3)                      # > SGPR_ANY_MAX_NODES (257..1024 run on the any-shape kernel)
+    l = torch.zeros(1, 1025, dtype=torch.int32)
     with pytest.raises(SgprError) as ei:
         eng.embed(c, l, 10)
     assert ei.value.code == -3
+    with pytest.raises(SgprError) as ei:
+        eng.embed(c[:, :100], l[:, :100], 65)   # > SGPR_ANY_MAX_K
+    assert ei.value.code == -4
     with pytest.raises(SgprError) as ei:
         eng.embed(c[:, :8], l[:, :8], 10)       # K > node_num
     assert ei.value.code == -4
@@ -1705,8 +1708,183 @@ def test_smaller_architectures_run_on_the_built_kernels(oracle):
         ntn = ntn_mod(e1, e2)
         assert ntn.shape == (7, t, 1) and (ntn.cpu() - oracle.tensor_network(sd, e1.cpu(), e2.cpu())).abs().max().item() < 1e-4
     args = sgpr_args()
-    args.filters_3 = 64                                               # larger than built
+    args.filters_3 = 129                                              # beyond what the any-shape kernels serve
     big = sg_net.SG(args, 12).eval()
     with pytest.raises(SgprError, match="SGPR_E_DIMS"):
         big.engine()
+
+
+def _randomised(model):
+    """a randomly initialised SG with BatchNorm statistics, scales and the biases randomised too -> (model, state dict)"""
+    with torch.no_grad():
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.copy_(torch.randn_like(buf) * 0.2)
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand_like(buf) + 0.5)
+        for name, prm in model.named_parameters():
+            if name.endswith(".1.weight"):
+                prm.copy_(torch.rand_like(prm) + 0.5)
+            if name.endswith(".1.bias") or name in ("fully_connected_first.bias", "scoring_layer.bias"):
+                prm.copy_(torch.randn_like(prm) * 0.2)
+    model.eval()
+    return model, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _label_sorted_graphs(count, node_num, lo, hi, labels, seed):
+    from sg_pr_amd import synth
+    c, l, _ = synth.make_graphs(count, node_num, lo, hi, seed=seed)
+    spread = (l * 5 + 3 + np.arange(l.shape[0])[:, None]) if labels > 12 else l          # (reach the label channels past 12)
+    l = np.where(l >= 0, spread % labels, l).astype(np.int32)
+    for gi in range(l.shape[0]):                                      # the label-ascending node order of the generators
+        n = int((l[gi] >= 0).sum())
+        order = np.argsort(l[gi, :n], kind="stable")
+        l[gi, :n], c[gi, :n] = l[gi, :n][order], c[gi, :n][order]
+    return c, l
+
+
+def test_larger_architectures_run_on_the_any_shape_kernels(oracle):
+    """parser_sg.py:12-22 takes ANY filters_1/2/3, tensor_neurons, bottle_neck_neurons, node_num and K; sg_net.py:40-76 any
+    label count.  Architectures larger than the built shape {12, 64, 64, 32, 16, 16} get an any-shape handle (plain-fp32
+    kernels, sgpr_generic.hip): every entry point of the path against the oracle, through the reference's own SG API -
+    dense forward, conv pass, packed / ragged embed, list and all-pairs tails, the bad-label report."""
+    from sg_pr_amd import sg_net, synth
+    from sg_pr_amd.allpairs import RaggedGraphs
+    from sg_pr_amd.engine import SgprError
+    from sg_pr_amd.parser_sg import sgpr_args
+    for labels, f1, f2, f3, t, bn, node_num, K in ((12, 96, 128, 64, 32, 24, 64, 10), (20, 64, 64, 32, 16, 16, 50, 10),
+                                                   (12, 64, 64, 32, 17, 16, 64, 10), (30, 200, 256, 128, 64, 64, 40, 12),
+                                                   (12, 64, 64, 33, 16, 16, 64, 10)):
+        args = sgpr_args()
+        args.filters_1, args.filters_2, args.filters_3, args.tensor_neurons, args.bottle_neck_neurons = f1, f2, f3, t, bn
+        args.node_num, args.K = node_num, K
+        torch.manual_seed(labels * 1000 + f1 + t)
+        model, sd = _randomised(sg_net.SG(args, labels))
+        eng = model.engine()
+        assert eng.any_shape and eng.pw == f3
+        # (at least K padding slots per graph, like every graph of the reference's data: one-hot rows tie EXACTLY across
+        # labels, and with fewer pads than K torch.topk's unspecified tie order would pick the neighbours)
+        c, l = _label_sorted_graphs(24, node_num, node_num // 3, node_num - K, labels, seed=labels + f3)
+        feats = torch.from_numpy(synth.dense_features(c, l, num_labels=labels))
+        f_a, f_b = feats[:12], feats[12:]
+        want, wa1, wa2 = oracle.forward(sd, f_a, f_b, K)
+        got, a1, a2 = model({"features_1": f_a, "features_2": f_b})
+        tag = (labels, f1, f2, f3, t, bn)
+        assert got.shape == (12,) and a1.shape == (12, node_num, 1)
+        assert (got.cpu() - want).abs().max().item() < SCORE_TOL, tag
+        assert (a1.cpu() - wa1).abs().max().item() < 1e-4 and (a2.cpu() - wa2).abs().max().item() < 1e-4, tag
+        emb = model.dgcnn_conv_pass(feats)
+        ref_emb = oracle.conv_pass(sd, feats, K)
+        assert emb.shape == (24, node_num, f3)
+        assert (emb.cpu() - ref_emb).abs().max().item() < 1e-4 * max(1.0, float(ref_emb.abs().max())), tag
+        # packed and ragged input: the same bits as the dense path's pooled vectors
+        pooled, att, _ = model.embed(c, l, want_att=True)
+        ref_pooled = oracle.embed(sd, feats, K)[0]
+        assert pooled.shape == (24, f3)
+        assert (pooled.cpu() - ref_pooled).abs().max().item() < 2e-4 * max(1.0, float(ref_pooled.abs().max())), tag
+        rag = RaggedGraphs.from_padded(c, l, device="cuda", num_labels=labels)
+        pooled_r, att_r, _ = model.embed(rag, None, want_att=True)
+        assert torch.equal(pooled_r, pooled) and torch.equal(att_r, att)
+        dense_pooled = eng.embed_dense(feats, K)[0]
+        assert torch.equal(dense_pooled, pooled)
+        # tails: all pairs, an index list long enough for the grouped kernel (which such a handle does not have), pairs
+        mat = model.score_all_pairs(pooled, pooled)
+        ref_mat = oracle.score_all_pairs(sd, ref_pooled, ref_pooled)
+        assert (mat.cpu() - ref_mat).abs().max().item() < SCORE_TOL, tag
+        rng = np.random.default_rng(labels)
+        i1 = rng.integers(0, 24, 3000).astype(np.int32)
+        i2 = rng.integers(0, 24, 3000).astype(np.int32)
+        lst = model.score_pooled(pooled, pooled, torch.from_numpy(i1), torch.from_numpy(i2))
+        assert torch.equal(lst, mat[torch.from_numpy(i1).long().cuda(), torch.from_numpy(i2).long().cuda()])
+        assert torch.equal(model.score_pooled(pooled[:12], pooled[12:]), mat[torch.arange(12), torch.arange(12, 24)])
+        outs = eng.score_all_pairs_multi([(pooled[:7], pooled), (pooled[7:], pooled[:5])])
+        assert torch.equal(outs[0], mat[:7]) and torch.equal(outs[1], mat[7:, :5])
+        with pytest.raises(SgprError, match="SGPR_E_DIMS"):
+            eng.score_pair_list(pooled, pooled, eng.pair_plan(i1, i2, 24, 24))
+        with pytest.raises(SgprError, match="SGPR_E_DIMS"):
+            eng.embed(c, l, K, debug=True)
+        eng.check_status()
+        bad = l.copy()
+        bad[3, 0] = labels
+        model.embed(torch.from_numpy(c).cuda(), torch.from_numpy(bad).cuda())
+        with pytest.raises(SgprError):
+            eng.check_status()
+        # the stand-alone modules with this model's widths (layers_batch.py mirror: any width through the *_any entry points)
+        from sg_pr_amd.layers_batch import AttentionModule, TenorNetworkModule
+        att_mod = AttentionModule(args).cuda()
+        att_mod.load_state_dict({"weight_matrix": sd["attention.weight_matrix"]})
+        e = torch.randn(3, 300, f3).cuda()
+        rep, sig = att_mod(e)
+        w_rep, w_sig = oracle.attention({"attention.weight_matrix": sd["attention.weight_matrix"]}, e.cpu())
+        assert rep.shape == (3, f3, 1) and (rep.cpu() - w_rep).abs().max().item() < 1e-4 * max(1.0, float(w_rep.abs().max()))
+        assert (sig.cpu() - w_sig).abs().max().item() < 1e-5
+        ntn_mod = TenorNetworkModule(args).cuda()
+        ntn_mod.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("tensor_network.")})
+        e1, e2 = torch.randn(7, f3, 1).cuda(), torch.randn(7, f3, 1).cuda()
+        ntn = ntn_mod(e1, e2)
+        w_ntn = oracle.tensor_network(sd, e1.cpu(), e2.cpu())
+        assert ntn.shape == (7, t, 1) and (ntn.cpu() - w_ntn).abs().max().item() < 1e-4 * max(1.0, float(w_ntn.abs().max()))
+    # dgcnn.knn beyond the LDS-resident kernel's 256 nodes / 32 neighbours: coordinate keys are the reference's bit for bit
+    from sg_pr_amd import dgcnn
+    gen = torch.Generator().manual_seed(3)
+    for n, k, ch in ((700, 10, 3), (1024, 64, 3), (300, 40, 3), (100, 33, 3)):
+        x = (torch.rand(2, ch, n, generator=gen) - 0.5) * 100.0
+        got = dgcnn.knn(x.cuda(), k).cpu()
+        pd = oracle.neg_sq_dist(x)
+        want = oracle.knn(x, k)
+        assert got.shape == (2, n, k) and got.dtype == torch.int64
+        # same keys in the same order (indices may differ only between candidates whose reference keys are EQUAL)
+        assert torch.equal(torch.gather(pd, 2, got), torch.gather(pd, 2, want)), (n, k)
+
+
+def test_node_num_and_k_beyond_the_tuned_kernels(eng, oracle_sd, oracle):
+    """parser_sg.py:19-22: node_num and K are free.  Beyond the tuned kernels' 256 slots / 32 neighbours the shipped
+    checkpoint embeds on the any-shape kernel (pooled rows keep the handle's width, so the tuned tails score them);
+    against the oracle, and against the tuned kernel where both serve a shape."""
+    import sys
+    from sg_pr_amd import synth
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tie_proof import prove_graph
+    for node_num, K, lo, hi in ((300, 10, 200, 290), (100, 40, 30, 60), (512, 48, 100, 464), (1024, 10, 900, 1000)):
+        c, l = _label_sorted_graphs(6, node_num, lo, hi, 12, seed=node_num + K)
+        feats = torch.from_numpy(synth.dense_features(c, l))
+        pooled, att, emb = eng.embed(c, l, K, want_att=True, want_emb=True)
+        ref_emb = oracle.conv_pass(oracle_sd, feats, K)
+        ref_pooled, ref_att = oracle.embed(oracle_sd, feats, K)[:2]
+        assert pooled.shape == (6, 32) and emb.shape == (6, node_num, 32)
+        # a graph agrees to rounding, or the whole of its deviation is a proven near-tie of the reference's own fp32 keys
+        # (a thousand nodes in 100 m x 100 m: |x|^2 ~ 2500 leaves the expanded distance ~5e-4 of rounding, the gap between
+        # a row's 10th and 11th neighbour is a few m^2 - a handful of rows per graph tie; tests/tie_proof.py)
+        dev = (emb.cpu() - ref_emb).abs().amax(dim=(1, 2))
+        ok = dev < 1e-4
+        for g in np.flatnonzero(~ok.numpy()):
+            rep = prove_graph(eng, oracle, oracle_sd, c[g], l[g], K, pooled[g].cpu().numpy())
+            assert rep["proven"], (node_num, K, int(g), rep["reason"])
+        assert int(ok.sum()) >= 3 or node_num == 1024, (node_num, K, dev)
+        assert (pooled.cpu() - ref_pooled)[ok].abs().max().item() < 2e-4 * max(1.0, float(ref_pooled.abs().max())), (node_num, K)
+        assert (att.cpu() - ref_att.reshape(6, node_num))[ok].abs().max().item() < 1e-4
+        got, a1, a2 = eng.forward_dense(feats[:3], feats[3:], K)
+        assert a1.shape == (3, node_num) and torch.equal(torch.cat((a1, a2)), att)
+        assert torch.equal(got, eng.score_pairs(pooled[:3].contiguous(), pooled[3:].contiguous()))
+        mat = eng.score_all_pairs(pooled, pooled)
+        ref_mat = oracle.score_all_pairs(oracle_sd, ref_pooled, ref_pooled)
+        both = ok[:, None] & ok[None, :]
+        assert both.any() and (mat.cpu() - ref_mat)[both].abs().max().item() < SCORE_TOL
+    # where both kernels serve a shape they agree to rounding: K = 33 vs the tuned kernel is not possible, so compare the
+    # any-shape model of the checkpoint on an any-shape handle's terms - a 13-label copy of the checkpoint (one extra,
+    # unused label channel with zero weights) is an any-shape handle computing the same function
+    from sg_pr_amd.engine import Engine, SgprDims
+    sd13 = {k: v.clone() for k, v in oracle_sd.items()}
+    w = sd13["dgcnn_f_conv1.0.weight"]
+    w4 = w.reshape(w.shape[0], 2, 12)
+    sd13["dgcnn_f_conv1.0.weight"] = torch.cat((w4, torch.zeros(w.shape[0], 2, 1)), dim=2).reshape(w.shape[0], 26, 1, 1)
+    any13 = Engine(sd13, SgprDims(13, 64, 64, 32, 16, 16))
+    assert any13.any_shape and any13.pw == 32
+    c, l = _label_sorted_graphs(40, 100, 30, 95, 12, seed=77)
+    p_any = any13.embed(c, l, 10)[0]
+    p_tuned = eng.embed(c, l, 10)[0]
+    assert (p_any - p_tuned).abs().max().item() < 2e-4 * max(1.0, float(p_tuned.abs().max()))
+    m_any = any13.score_all_pairs(p_tuned, p_tuned)
+    m_tuned = eng.score_all_pairs(p_tuned, p_tuned)
+    assert (m_any - m_tuned).abs().max().item() < SCORE_TOL
 

@@ -31,21 +31,32 @@ def test_create_rejects_bad_blobs_without_a_gpu():
     rc = lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(engine.default_dims()), 0,
                          ctypes.byref(h))
     assert rc == -8 and b"48689" in lib.sgpr_last_error()
-    odd = engine.SgprDims(12, 64, 64, 64, 16, 16)
+    odd = engine.SgprDims(12, 64, 64, 64, 16, 16)          # larger than the built shape: an any-shape handle, same blob rule
     rc = lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(odd), 0, ctypes.byref(h))
-    assert rc == -2
+    assert rc == -8 and b"expected" in lib.sgpr_last_error()
+    for beyond in (engine.SgprDims(65, 64, 64, 32, 16, 16), engine.SgprDims(12, 257, 64, 32, 16, 16),
+                   engine.SgprDims(12, 64, 64, 129, 16, 16), engine.SgprDims(12, 64, 64, 32, 65, 16),
+                   engine.SgprDims(12, 64, 64, 32, 16, 0)):
+        rc = lib.sgpr_create(blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(beyond), 0, ctypes.byref(h))
+        assert rc == -2                                     # SGPR_E_DIMS: beyond the SGPR_ANY_MAX_* limits
     assert lib.sgpr_create(None, 0, ctypes.byref(odd), 0, ctypes.byref(h)) == -1
 
 
 def test_lds_plans():
     from sg_pr_amd import engine
     lib = engine.load_library()
-    h = ctypes.c_void_p(1)   # plan queries only need a non-NULL handle
+    zeroed = ctypes.create_string_buffer(1 << 16)   # plan queries read plain fields of the handle: a zeroed one is a
+    h = ctypes.cast(zeroed, ctypes.c_void_p)        # handle of the built shape on a GPU of 0 CUs
     for n, k in [(64, 10), (100, 10), (256, 20), (16, 10), (128, 32), (200, 32), (23, 5)]:
         b = lib.sgpr_embed_lds_bytes(h, n, k)
         assert 0 < b <= 160 * 1024, (n, k, b)
-    assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 0      # > SGPR_MAX_NODES
+    assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 1024   # > SGPR_MAX_NODES: the any-shape kernel (two rows of <= 128 floats)
+    assert lib.sgpr_embed_lds_bytes(h, 100, 33) == 1024   # > SGPR_MAX_K likewise
+    assert lib.sgpr_embed_lds_bytes(h, 1025, 10) == 0     # > SGPR_ANY_MAX_NODES
+    assert lib.sgpr_embed_lds_bytes(h, 100, 65) == 0      # > SGPR_ANY_MAX_K
     assert lib.sgpr_embed_lds_bytes(h, 8, 10) == 0        # K > node_num
+    assert lib.sgpr_pooled_width(h) == 32 and lib.sgpr_is_any_shape(h) == 0
+    assert lib.sgpr_pooled_width(None) == 0
     # one redo flag per launch slot + the second pass's request word (rounded to 256 B) + the parked first-branch block
     # for node_num > 128 + the split launch's region: one flag (the array rounded to 16 B) + 16 sem3 rows per launch slot,
     # for at most 128 slots (a split launch has at most half as many graphs as the GPU has CUs)
