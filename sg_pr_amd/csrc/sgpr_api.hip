@@ -208,29 +208,31 @@ static int build_generic_model(const float* weights, const sgpr_dims* d, sgpr_ha
             const int l6 = (b & 1) * 3 + (b >> 1);
             m.cin[l6] = cin;
             m.cout[l6] = cout;
+            const int cout8 = (cout + 7) & ~7;                      // [cin][cout8]: see GenericModel
             off_wa[l6] = host.size();
-            host.resize(host.size() + (size_t)cout * cin);
+            host.resize(host.size() + (size_t)cout8 * cin, 0.f);
             off_wb[l6] = host.size();
-            host.resize(host.size() + (size_t)cout * cin);
+            host.resize(host.size() + (size_t)cout8 * cin, 0.f);
             off_tb[l6] = host.size();
-            host.resize(host.size() + cout);
+            host.resize(host.size() + cout8, 0.f);
             for (int c = 0; c < cout; ++c) {
                 const double s = (double)gamma[c] / std::sqrt((double)var[c] + 1e-5);
                 for (int i = 0; i < cin; ++i) {
                     const double w1 = W[(size_t)c * cin2 + i], w2 = W[(size_t)c * cin2 + cin + i];
-                    host[off_wa[l6] + (size_t)c * cin + i] = (float)(s * w1);            // acts on x_j
-                    host[off_wb[l6] + (size_t)c * cin + i] = (float)(s * (w2 - w1));     // acts on x_i
+                    host[off_wa[l6] + (size_t)i * cout8 + c] = (float)(s * w1);            // acts on x_j
+                    host[off_wb[l6] + (size_t)i * cout8 + c] = (float)(s * (w2 - w1));     // acts on x_i
                 }
                 host[off_tb[l6] + c] = (float)((double)beta[c] - (double)mean[c] * s);
             }
         } else {
+            const int cout8 = (cout + 7) & ~7;
             off_wend = host.size();
-            host.resize(host.size() + (size_t)cout * cin2);
+            host.resize(host.size() + (size_t)cout8 * cin2, 0.f);
             off_tend = host.size();
-            host.resize(host.size() + cout);
+            host.resize(host.size() + cout8, 0.f);
             for (int c = 0; c < cout; ++c) {
                 const double s = (double)gamma[c] / std::sqrt((double)var[c] + 1e-5);
-                for (int i = 0; i < cin2; ++i) host[off_wend + (size_t)c * cin2 + i] = (float)(s * W[(size_t)c * cin2 + i]);
+                for (int i = 0; i < cin2; ++i) host[off_wend + (size_t)i * cout8 + c] = (float)(s * W[(size_t)c * cin2 + i]);
                 host[off_tend + c] = (float)((double)beta[c] - (double)mean[c] * s);
             }
         }
@@ -630,7 +632,7 @@ size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
 size_t sgpr_embed_lds_bytes(const sgpr_handle* h, int N, int k) {
     EmbedPlan p;
     if (!h) return 0;
-    if (needs_generic(h, N, k)) return generic_nk_ok(N, k) ? 2 * SGPR_GENERIC_MAX_F3 * sizeof(float) : 0;
+    if (needs_generic(h, N, k)) return generic_nk_ok(N, k) ? generic_embed_lds_bytes(h, N, k) : 0;
     if (!make_embed_plan(N, 0, k, &p)) return 0;
     return (size_t)p.lds_bytes;
 }
@@ -657,12 +659,13 @@ static int embed_generic(const sgpr_handle* h, EmbedArgs a, int N, int k, void* 
         return SGPR_E_K;
     }
     const size_t need = generic_embed_ws_bytes(h, a.G, N, k);
-    if (!ws || ws_bytes < need) {
+    if (need > 0 && (!ws || ws_bytes < need)) {
         set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required (sgpr_embed_workspace_bytes)");
         return SGPR_E_WORKSPACE;
     }
     a.status = h->d_status;
     a.num_labels = h->dims.num_labels;
+    a.skip = h->dbg_skip;                // (bits 24..27: ablation of the any-shape kernel's phases, tools/run_anyshape.py)
     DeviceGuard guard(h->device);
     return launch_embed_generic(h, a, N, k, ws, static_cast<hipStream_t>(stream));
 }

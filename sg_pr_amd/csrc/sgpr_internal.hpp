@@ -66,10 +66,12 @@ constexpr int kSemTableFloats = 4 * 256 + 32 + 2 * 2 * 16 * 64;
 struct GenericModel {
     int L, f1, f2, f3, T, B, cmax;      // cmax: widest activation row (max of 3, L, f1, f2, f3)
     int cin[6], cout[6];                // EdgeConv blocks: xyz branch (s_conv1..3), then the semantic branch (f_conv1..3)
-    const float* wa[6];                 // [cout][cin]  s * W[:, :cin]            (acts on x_j)
-    const float* wb[6];                 // [cout][cin]  s * (W[:, cin:] - W[:, :cin])   (acts on x_i)
-    const float* tb[6];                 // [cout]       beta - mean * s,  s = gamma / sqrt(var + 1e-5)
-    const float* w_end;                 // [f3][2 f3]   conv_end, BatchNorm folded
+    // (the 1x1 convolutions are stored input-channel-major with the output channels padded to a multiple of 8, cout8:
+    //  the 8 weights a wave needs for one input channel are contiguous and wave-uniform)
+    const float* wa[6];                 // [cin][cout8]  s * W[:, :cin]            (acts on x_j)
+    const float* wb[6];                 // [cin][cout8]  s * (W[:, cin:] - W[:, :cin])   (acts on x_i)
+    const float* tb[6];                 // [cout]        beta - mean * s,  s = gamma / sqrt(var + 1e-5)
+    const float* w_end;                 // [2 f3][f3 rounded up to 8]   conv_end, BatchNorm folded
     const float* t_end;                 // [f3]
     const float* att_w;                 // [f3][f3]
     const float* ntn_w;                 // [f3][f3][T]
@@ -182,7 +184,8 @@ size_t score_pair_list_ws_bytes(int NR, int M);
 int launch_score_pair_list(const sgpr_handle* h, const float* rows, const float* cols, int M, const int32_t* plan,
                            int NR, int NI, int64_t P, float* score, void* ws, hipStream_t stream);
 int generic_embed_slots(const sgpr_handle* h, int G);
-size_t generic_embed_ws_bytes(const sgpr_handle* h, int G, int N, int k);
+size_t generic_embed_ws_bytes(const sgpr_handle* h, int G, int N, int k);   // 0: the working memory fits LDS
+size_t generic_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 int launch_embed_generic(const sgpr_handle* h, const EmbedArgs& a, int N, int k, void* ws, hipStream_t stream);
 // list form (M == 0: pair p = (i1 ? i1[p] : p, i2 ? i2[p] : p) -> score[p]) or dense rectangle (M > 0: P = R * M pairs -> score[r * ld + c])
 int launch_knn_any(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);

@@ -1795,8 +1795,11 @@ def test_larger_architectures_run_on_the_any_shape_kernels(oracle):
         i1 = rng.integers(0, 24, 3000).astype(np.int32)
         i2 = rng.integers(0, 24, 3000).astype(np.int32)
         lst = model.score_pooled(pooled, pooled, torch.from_numpy(i1), torch.from_numpy(i2))
-        assert torch.equal(lst, mat[torch.from_numpy(i1).long().cuda(), torch.from_numpy(i2).long().cuda()])
-        assert torch.equal(model.score_pooled(pooled[:12], pooled[12:]), mat[torch.arange(12), torch.arange(12, 24)])
+        # (the list kernel sums a pair's bilinear form in another order than the rectangle's row-hoisted form: fp32 rounding)
+        assert (lst - mat[torch.from_numpy(i1).long().cuda(), torch.from_numpy(i2).long().cuda()]).abs().max().item() < 5e-5
+        assert (lst.cpu() - ref_mat[torch.from_numpy(i1).long(), torch.from_numpy(i2).long()]).abs().max().item() < SCORE_TOL
+        pairs = model.score_pooled(pooled[:12], pooled[12:])
+        assert (pairs - mat[torch.arange(12), torch.arange(12, 24)]).abs().max().item() < 5e-5
         outs = eng.score_all_pairs_multi([(pooled[:7], pooled), (pooled[7:], pooled[:5])])
         assert torch.equal(outs[0], mat[:7]) and torch.equal(outs[1], mat[7:, :5])
         with pytest.raises(SgprError, match="SGPR_E_DIMS"):
@@ -1856,7 +1859,7 @@ def test_node_num_and_k_beyond_the_tuned_kernels(eng, oracle_sd, oracle):
         # (a thousand nodes in 100 m x 100 m: |x|^2 ~ 2500 leaves the expanded distance ~5e-4 of rounding, the gap between
         # a row's 10th and 11th neighbour is a few m^2 - a handful of rows per graph tie; tests/tie_proof.py)
         dev = (emb.cpu() - ref_emb).abs().amax(dim=(1, 2))
-        ok = dev < 1e-4
+        ok = dev < 2e-5             # (rounding level; a flip with a smaller effect than 1e-4 per node still moves a sum over 1024)
         for g in np.flatnonzero(~ok.numpy()):
             rep = prove_graph(eng, oracle, oracle_sd, c[g], l[g], K, pooled[g].cpu().numpy())
             assert rep["proven"], (node_num, K, int(g), rep["reason"])
@@ -1869,7 +1872,14 @@ def test_node_num_and_k_beyond_the_tuned_kernels(eng, oracle_sd, oracle):
         mat = eng.score_all_pairs(pooled, pooled)
         ref_mat = oracle.score_all_pairs(oracle_sd, ref_pooled, ref_pooled)
         both = ok[:, None] & ok[None, :]
-        assert both.any() and (mat.cpu() - ref_mat)[both].abs().max().item() < SCORE_TOL
+        # the tail on the same pooled vectors, then end to end.  (Hundreds of nodes pool into vectors of magnitude ~1e3 and
+        # tensor-network pre-activations of ~1e5: the fp32 rounding of the pooled sums alone - the oracle's own summation
+        # order is as arbitrary as ours - moves a score by more than 1e-4 there; the end-to-end gate is 1e-4 up to 300 slots,
+        # beyond that the pooled vectors are held to 2e-4 relative above and the tail to 1e-4 on equal inputs)
+        ours = pooled.cpu()
+        assert (mat.cpu() - oracle.score_all_pairs(oracle_sd, ours, ours)).abs().max().item() < SCORE_TOL, (node_num, K)
+        e2e = (mat.cpu() - ref_mat)[both].abs().max().item()
+        assert both.any() and e2e < (SCORE_TOL if node_num <= 300 else 1e-3), (node_num, K, e2e)
     # where both kernels serve a shape they agree to rounding: K = 33 vs the tuned kernel is not possible, so compare the
     # any-shape model of the checkpoint on an any-shape handle's terms - a 13-label copy of the checkpoint (one extra,
     # unused label channel with zero weights) is an any-shape handle computing the same function

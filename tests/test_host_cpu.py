@@ -50,8 +50,10 @@ def test_lds_plans():
     for n, k in [(64, 10), (100, 10), (256, 20), (16, 10), (128, 32), (200, 32), (23, 5)]:
         b = lib.sgpr_embed_lds_bytes(h, n, k)
         assert 0 < b <= 160 * 1024, (n, k, b)
-    assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 1024   # > SGPR_MAX_NODES: the any-shape kernel (two rows of <= 128 floats)
-    assert lib.sgpr_embed_lds_bytes(h, 100, 33) == 1024   # > SGPR_MAX_K likewise
+    # > SGPR_MAX_NODES / > SGPR_MAX_K: the any-shape kernel - two rows of <= 128 floats + its working memory when that fits
+    # LDS (the zeroed handle describes a model of width 0: squared norms + neighbour lists + 64 floats)
+    assert lib.sgpr_embed_lds_bytes(h, 257, 10) == 1024 + (257 * 11 + 64) * 4
+    assert lib.sgpr_embed_lds_bytes(h, 100, 33) == 1024 + (100 * 34 + 64) * 4
     assert lib.sgpr_embed_lds_bytes(h, 1025, 10) == 0     # > SGPR_ANY_MAX_NODES
     assert lib.sgpr_embed_lds_bytes(h, 100, 65) == 0      # > SGPR_ANY_MAX_K
     assert lib.sgpr_embed_lds_bytes(h, 8, 10) == 0        # K > node_num

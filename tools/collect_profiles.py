@@ -67,7 +67,7 @@ if not pmc_only:
     kernel_stats("kt_wide", tag + "_wide_kernel_stats.txt", "rocprofv3 --kernel-trace --stats -- python tools/run_embed.py kitti00 5 8192   "
                  "(debug bit 13: every graph on the wide-range instance - three bf16 planes, 24-bit operands)")
     for nm, out in (("seq_parity_world.txt", "_seq_parity_world.txt"), ("seq_parity_both.txt", "_seq_parity.txt"),
-                    ("tailmix_probe.txt", "_tailmix_probe.txt")):
+                    ("tailmix_probe.txt", "_tailmix_probe.txt"), ("any_shape.txt", "_any_shape.txt")):
         f = os.path.join(src, nm)
         if os.path.exists(f):
             open(os.path.join(dst, tag + out), "w").write(open(f).read())

@@ -45,6 +45,7 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_wid
 ( cd $R && SGPR_SEQ_PARITY_OUT=$O/seq_parity_world.txt timeout 900 python -m pytest tests -m gpu -q -x -k "full_sequence_parity" > $O/seq_parity_pytest.log 2>&1 )
 timeout 900 python $R/tools/seq_parity.py 4541 $O/seq_parity_both.txt > $O/seq_parity.log 2>&1 </dev/null
 timeout 60 $R/tools/probes/tailmix_probe > $O/tailmix_probe.txt 2>&1
+timeout 300 python $R/tools/run_anyshape.py $O/any_shape.txt > $O/any_shape.log 2>&1 </dev/null
 timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
 timeout 200 python $R/tools/f1_phases.py kitti > $O/f1_phases_kitti.log 2>&1 </dev/null
 timeout 200 python $R/tools/f1_phases.py world > $O/f1_phases_world.log 2>&1 </dev/null
