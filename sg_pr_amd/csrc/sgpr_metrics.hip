@@ -561,7 +561,7 @@ constexpr int F1_WBUF = F1_PBUF / (F1_THREADS / 64);          // 512 staged posi
 __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, unsigned* __restrict__ slabs, int slab_words,
                                                              float* __restrict__ pos, long long cap,
                                                              unsigned long long* __restrict__ count,
-                                                             unsigned char* __restrict__ cls_out) {
+                                                             unsigned char* __restrict__ cls_out, unsigned* __restrict__ posb_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
     unsigned* hist = reinterpret_cast<unsigned*>(f1_smem);                  // [F1_NBP]
     float* buf = reinterpret_cast<float*>(hist + F1_NBP) + (threadIdx.x >> 6) * F1_WBUF;   // this wave's staging area
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
         for (int i = lane; i < nst; i += 64) {
             const long long idx = (long long)g + i;
             if (idx < cap) pos[idx] = buf[i];
+            atomicAdd(&posb_g[f1_key(buf[i])], 1u);       // positives by bin (rare: ~1 pair in 400), for the plan kernel
         }
         nst = 0;
     };
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
                                                              unsigned long long* __restrict__ tpge, unsigned long long* __restrict__ fpge,
                                                              unsigned* __restrict__ mark_out, float* __restrict__ thr,
                                                              F1Thr* __restrict__ info, int* __restrict__ dT2, F1Ctrl* __restrict__ ctrl,
-                                                             unsigned long long* __restrict__ stamps) {
+                                                             unsigned long long* __restrict__ stamps, const unsigned* __restrict__ posb_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
 #define F1_STAMP(i) if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64();
     F1_STAMP(0)
@@ -748,24 +749,18 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     }
     constexpr int PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;             // 24 bins per thread
     static_assert(PER % 2 == 0, "bins per thread");
-    for (int i = tid; i < F1_NBP; i += F1_THREADS) posb[i] = 0u;
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
     if (tid == 0) ndist = nv = 0u;
-    __syncthreads();
-    // (keeping a thread's ~47 positives in registers for the second look at them was measured: the unrolled body spills,
-    // 14 -> 63 us; both passes read the list from L2 with sixteen / eight independent loads in flight)
-    for (long long i0 = 0; i0 < na; i0 += 16 * F1_THREADS) {
-        float x[16];
+    // positives by bin: counted by pass A where it found them (one global atomic per positive pair; round 4 spent 14 us
+    // of this single workgroup on a pass over the list with LDS atomics) - this thread's 24 bins: six 16-byte loads
+    unsigned ps[PER];
+    static_assert(PER % 4 == 0, "bins per thread");
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const long long i = i0 + u * F1_THREADS + tid;
-            x[u] = i < na ? pos[i] : -1.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (x[u] >= 0.f) atomicAdd(&posb[f1_key(x[u])], 1u);
+    for (int q = 0; q < PER; q += 4) {
+        const uint4 x = *reinterpret_cast<const uint4*>(posb_g + tid * PER + q);   // (the array holds F1_THREADS * PER words)
+        ps[q] = x.x; ps[q + 1] = x.y; ps[q + 2] = x.z; ps[q + 3] = x.w;
     }
-    // this thread's negatives: 12 independent 16-byte loads (requested only now: 48 registers the list passes need)
+    // this thread's negatives: 12 independent 16-byte loads
     unsigned long long ng[PER];
 #pragma unroll
     for (int q = 0; q < PER; q += 2) {
@@ -777,13 +772,12 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     }
     __syncthreads();
     F1_STAMP(1)
-    unsigned ps[PER];
     unsigned long long sn = 0ull, sp = 0ull;
     bool any = false;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int b = tid * PER + q;
-        ps[q] = b < F1_NB ? posb[b] : 0u;
+        if (b >= F1_NB) ps[q] = 0u;
         sn += ng[q];
         sp += ps[q];
         any = any || ps[q] != 0u || ng[q] != 0ull;
@@ -1236,7 +1230,7 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
 //      (two arrays) | candidate-bin marks | thresholds, their info, negatives by bucket of pass B | positives | counter slabs
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct F1Layout {
-    size_t off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
+    size_t off_posb, off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
     long long cap;
     int slabs_a, slabs_b, words_a, words_b;
 };
@@ -1250,6 +1244,7 @@ static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     L.words_a = F1_NBP + 4;
     L.words_b = slab_words(F1_SORT);
     size_t off = 256;                                                       // header
+    L.off_posb = off;  off += a256((size_t)F1_THREADS * ((F1_NBP + F1_THREADS - 1) / F1_THREADS) * sizeof(unsigned));   // (zeroed with the header)
     L.off_negb = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_tpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_fpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
@@ -1290,6 +1285,7 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     unsigned long long* count = reinterpret_cast<unsigned long long*>(ws);            // [2]
     F1Ctrl* ctrl = reinterpret_cast<F1Ctrl*>(ws + 64);
     int* dT2 = reinterpret_cast<int*>(ws + 192);
+    unsigned* posb = reinterpret_cast<unsigned*>(ws + L.off_posb);
     unsigned long long* negb = reinterpret_cast<unsigned long long*>(ws + L.off_negb);
     unsigned long long* tpge = reinterpret_cast<unsigned long long*>(ws + L.off_tpge);
     unsigned long long* fpge = reinterpret_cast<unsigned long long*>(ws + L.off_fpge);
@@ -1310,7 +1306,7 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
         return rc;
     if (int rc = raise_lds_limit(&once_plan, reinterpret_cast<const void*>(&f1_plan_kernel), (int)lds_plan, "sgpr_f1_max (f1_plan_kernel)"))
         return rc;
-    hipError_t e = hipMemsetAsync(ws, 0, 256, s);                                      // counts, control block, sizes
+    hipError_t e = hipMemsetAsync(ws, 0, L.off_negb, s);                               // counts, control block, sizes, positives by bin
     if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
     if ((int64_t)R * M == 0) {                       // an empty rectangle: F1-max 0 over 0 positive / 0 negative pairs, status 0
         e = hipMemsetAsync(d_result, 0, 8 * sizeof(double), s);
@@ -1318,10 +1314,10 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
         return SGPR_OK;
     }
     const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
-    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count, cls);
+    hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count, cls, posb);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb);
     hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
-                       ctrl, reinterpret_cast<unsigned long long*>(ws + 128));
+                       ctrl, reinterpret_cast<unsigned long long*>(ws + 128), posb);
     hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b, cls);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_SORT + 3 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_b, L.words_b, 0, neg2, dT2);
     hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(F1_THREADS), 0, s, neg2, info, ctrl, d_result);
