@@ -134,7 +134,7 @@ __device__ __forceinline__ void knn_select_row(const float* __restrict__ X, cons
 // One EdgeConv block on X [cin][N] -> Y [cout][N]:  kNN in X's own space (dgcnn.knn), then
 //   Y[co][i] = lrelu(max_{j in knn(i)} a[co][j] + b[co][i]),  a = Wa X,  b = Wb X + t   (BatchNorm folded: sgpr_create)
 // (b waits in Y until the gather replaces it)
-__device__ void generic_edgeconv(const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ A,
+__device__ __forceinline__ void generic_edgeconv(const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ A,
                                  float* __restrict__ xx, int* __restrict__ idx, const int N, const int k, const int cin,
                                  const int cout, const float* __restrict__ wa, const float* __restrict__ wb,
                                  const float* __restrict__ tb, float* __restrict__ dbg_y, int32_t* __restrict__ dbg_idx,
@@ -205,6 +205,10 @@ __device__ void generic_edgeconv(const float* __restrict__ X, float* __restrict_
     __syncthreads();
 }
 
+// IN_LDS: the working memory is the dynamic LDS block (every pointer into it derives from the LDS symbol, so the compiler
+// addresses it with ds_ instructions; one instance that picks LDS or global at run time addresses both through flat_
+// instructions and ran 2 x slower)
+template <bool IN_LDS>
 __global__ __launch_bounds__(EMB_THREADS) void generic_embed_kernel(const GenericModel m, const EmbedArgs a, const int N,
                                                                     const int k, float* __restrict__ scratch,
                                                                     const size_t per_wg, const int pw) {
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(EMB_THREADS) void generic_embed_kernel(const Generi
     __shared__ float ctx[SGPR_GENERIC_MAX_F3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* base = scratch ? scratch + (size_t)blockIdx.x * per_wg : emb_smem;
+    float* base = IN_LDS ? emb_smem : scratch + (size_t)blockIdx.x * per_wg;
     float* X0 = base;                                             // every activation block is [channels][N]
     float* X1 = X0 + (size_t)N * m.cmax;
     float* A = X1 + (size_t)N * m.cmax;
@@ -350,12 +354,16 @@ int launch_embed_generic(const sgpr_handle* h, const EmbedArgs& a, int N, int k,
     const int pw = h->generic_only ? h->gm.f3 : kF3;
     const bool in_lds = generic_in_lds(h->gm, N, k);
     static LdsLimitOnce once;
-    if (in_lds)
-        if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&generic_embed_kernel), (int)kGenericLdsBytes,
+    if (in_lds) {
+        if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&generic_embed_kernel<true>), (int)kGenericLdsBytes,
                                      "generic_embed_kernel"))
             return rc;
-    hipLaunchKernelGGL(generic_embed_kernel, dim3(slots), dim3(EMB_THREADS), in_lds ? per_wg * sizeof(float) : 0, stream, h->gm,
-                       a, N, k, in_lds ? nullptr : static_cast<float*>(ws), per_wg, pw);
+        hipLaunchKernelGGL(generic_embed_kernel<true>, dim3(slots), dim3(EMB_THREADS), per_wg * sizeof(float), stream, h->gm, a, N,
+                           k, nullptr, per_wg, pw);
+    } else {
+        hipLaunchKernelGGL(generic_embed_kernel<false>, dim3(slots), dim3(EMB_THREADS), 0, stream, h->gm, a, N, k,
+                           static_cast<float*>(ws), per_wg, pw);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "generic_embed_kernel launch");
     return SGPR_OK;
