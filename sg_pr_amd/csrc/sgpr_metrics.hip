@@ -316,8 +316,11 @@ __global__ __launch_bounds__(PC_THREADS) void pair_threshold_count_kernel(const 
 
 // out[i] = sum over the slabs: 32 counters per workgroup, 32 threads per counter (each sums every 32nd slab: one round
 // of independent loads), 128-B coalesced reads
+// out_t (optional): the sums once more in the order the F1 plan kernel reads them - counter i = t * per + q of thread t
+// at [q * 1024 + t] (one coalesced load per q instead of 192-byte strides between the lanes)
 __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restrict__ slabs, int n_slabs, int slab_words, int T,
-                                                        unsigned long long* __restrict__ out, const int* __restrict__ dT = nullptr) {
+                                                        unsigned long long* __restrict__ out, const int* __restrict__ dT = nullptr,
+                                                        unsigned long long* __restrict__ out_t = nullptr, int per = 1) {
     __shared__ unsigned long long part[32][33];
     if (dT) {
         T = *dT;
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 #pragma unroll
         for (int q = 1; q < 32; ++q) s += part[q][b];
         out[i] = s;
+        if (out_t && i <= T) out_t[(size_t)(i % per) * 1024 + i / per] = s;
     }
 }
 
@@ -373,6 +377,9 @@ constexpr int F1_PICK = 4095;                                    // values pass 
 constexpr int F1_SORT = 4096;
 constexpr int F1_PBUF = 8192;                                    // staged positives per workgroup between two flushes
 constexpr int F1_THREADS = 1024;
+constexpr int F1_PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;   // 24 consecutive bins per thread of the plan kernel
+// where the plan kernel's thread bin / F1_PER finds the count of `bin` in the transposed per-bin arrays
+__device__ __forceinline__ int f1_tslot(int bin) { return (bin % F1_PER) * F1_THREADS + bin / F1_PER; }
 
 // monotone: s1 < s2 => key(s1) <= key(s2), for every s >= 0 (not NaN).  1 - s is exact for s in [1/2, 1] (Sterbenz).
 __device__ __forceinline__ int f1_key(float s) {
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
         for (int i = lane; i < nst; i += 64) {
             const long long idx = (long long)g + i;
             if (idx < cap) pos[idx] = buf[i];
-            atomicAdd(&posb_g[f1_key(buf[i])], 1u);       // positives by bin (rare: ~1 pair in 400), for the plan kernel
+            atomicAdd(&posb_g[f1_tslot(f1_key(buf[i]))], 1u);   // positives by bin (rare: ~1 pair in 400), for the plan kernel
         }
         nst = 0;
     };
@@ -722,7 +729,8 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
                                                              unsigned long long* __restrict__ tpge, unsigned long long* __restrict__ fpge,
                                                              unsigned* __restrict__ mark_out, float* __restrict__ thr,
                                                              F1Thr* __restrict__ info, int* __restrict__ dT2, F1Ctrl* __restrict__ ctrl,
-                                                             unsigned long long* __restrict__ stamps, const unsigned* __restrict__ posb_g) {
+                                                             unsigned long long* __restrict__ stamps, const unsigned* __restrict__ posb_g,
+                                                             const unsigned long long* __restrict__ negb_t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
 #define F1_STAMP(i) if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64();
     F1_STAMP(0)
@@ -747,28 +755,22 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         if (tid == 0) ctrl->status = 2;
         return;
     }
-    constexpr int PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;             // 24 bins per thread
+    constexpr int PER = F1_PER;                                             // 24 bins per thread
     static_assert(PER % 2 == 0, "bins per thread");
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
     if (tid == 0) ndist = nv = 0u;
     // positives by bin: counted by pass A where it found them (one global atomic per positive pair; round 4 spent 14 us
-    // of this single workgroup on a pass over the list with LDS atomics) - this thread's 24 bins: six 16-byte loads
+    // of this single workgroup on a pass over the list with LDS atomics); negatives by bin: slab_sum_kernel's sums.  Both
+    // arrive transposed ([q][thread]): 48 coalesced loads per thread (in the bins' own order - 96 / 192 bytes between
+    // neighbouring lanes - the same loads took 8 us)
     unsigned ps[PER];
-    static_assert(PER % 4 == 0, "bins per thread");
-#pragma unroll
-    for (int q = 0; q < PER; q += 4) {
-        const uint4 x = *reinterpret_cast<const uint4*>(posb_g + tid * PER + q);   // (the array holds F1_THREADS * PER words)
-        ps[q] = x.x; ps[q + 1] = x.y; ps[q + 2] = x.z; ps[q + 3] = x.w;
-    }
-    // this thread's negatives: 12 independent 16-byte loads
     unsigned long long ng[PER];
 #pragma unroll
-    for (int q = 0; q < PER; q += 2) {
+    for (int q = 0; q < PER; ++q) {
         const int b = tid * PER + q;
-        ulonglong2 x = make_ulonglong2(0ull, 0ull);
-        if (b + 1 < F1_NBP) x = *reinterpret_cast<const ulonglong2*>(negb + b);
-        ng[q] = b < F1_NB ? x.x : 0ull;
-        ng[q + 1] = b + 1 < F1_NB ? x.y : 0ull;
+        ps[q] = posb_g[q * F1_THREADS + tid];
+        const unsigned long long x = negb_t[q * F1_THREADS + tid];
+        ng[q] = b < F1_NB ? x : 0ull;
     }
     __syncthreads();
     F1_STAMP(1)
@@ -892,9 +894,47 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     while (np2 < (int)n2) np2 <<= 1;
     for (int i = tid; i < np2; i += F1_THREADS) v[i] = INFINITY;
     __syncthreads();
-    for (int i = tid; i < F1_HASH; i += F1_THREADS)
-        if (hkey[i] != 0xffffffffu) v[atomicAdd(&nv, 1u)] = __uint_as_float(hkey[i]);
-    lds_bitonic_sort(v, np2);
+    {
+        // compaction of the table's occupied slots: one LDS atomic per WAVE (a returning atomic on one address per value
+        // serialises the whole workgroup behind the LDS atomic unit: ~400 of them were a third of this phase)
+        constexpr int SLOTS = F1_HASH / F1_THREADS;                            // 8 slots per thread
+        const int lane = tid & 63;
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        unsigned keys[SLOTS];
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            keys[q] = hkey[q * F1_THREADS + tid];
+            total += __popcll(__ballot(keys[q] != 0xffffffffu));
+        }
+        unsigned base = 0u;
+        if (lane == 0 && total) base = atomicAdd(&nv, (unsigned)total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const bool have = keys[q] != 0xffffffffu;
+            const unsigned long long m = __ballot(have);
+            if (have) v[base + __popcll(m & lt_mask)] = __uint_as_float(keys[q]);
+            base += __popcll(m);
+        }
+    }
+    if (np2 <= F1_THREADS) {
+        // up to 1024 values (the usual case: a few hundred): every value is distinct, so its rank - the number of smaller
+        // ones, counted against the whole array with broadcast 16-byte LDS reads - is its place.  Two barriers instead of
+        // the bitonic network's 45 dependent steps (12.5 -> ~4 us of this phase).
+        __syncthreads();
+        const float mine = tid < (int)n2 ? v[tid] : INFINITY;
+        int rank = 0;
+        for (int j = 0; j < (int)n2; j += 4) {                    // (v is padded with +inf up to np2 >= n2 rounded up to 4)
+            const float4 w = *reinterpret_cast<const float4*>(v + j);
+            rank += (w.x < mine ? 1 : 0) + (w.y < mine ? 1 : 0) + (w.z < mine ? 1 : 0) + (w.w < mine ? 1 : 0);
+        }
+        __syncthreads();
+        if (tid < (int)n2) v[rank] = mine;
+        __syncthreads();
+    } else {
+        lds_bitonic_sort(v, np2);
+    }
     F1_STAMP(4)
     // ---- pairs of the sorted entries >= i (suffix sums of the multiplicities)
     constexpr int PT = F1_SORT / F1_THREADS;                               // 4 consecutive entries per thread
@@ -919,12 +959,14 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     for (int q = 0; q < PT; ++q) ssum[tid * PT + q] = mult[q] + (unsigned)above;
     if (tid == 0) ssum[F1_SORT] = 0u;
     __syncthreads();
+    // (entry i = tid, tid + 1024, ...: the few hundred entries of a typical matrix spread over as many threads, so that
+    // the two global reads per entry - written by this workgroup a few microseconds ago - are ONE round trip, requested
+    // before the bisection, not four in a row inside the first hundred threads: 8.0 -> 4.5 us of this phase)
 #pragma unroll 1
-    for (int q = 0; q < PT; ++q) {
-        const int i = tid * PT + q;
-        if (i >= (int)n2) continue;
+    for (int i = tid; i < (int)n2; i += F1_THREADS) {
         const float s = v[i];
         const int b = f1_key(s);
+        const unsigned long long tp_bin = tpge[b + 1], fp_bin = fpge[b + 1];
         // the end of this bin's segment of the sorted list: first entry of a later bin (bisection on the monotone key)
         int lo = i + 1, hi = (int)n2;
         while (lo < hi) {
@@ -933,8 +975,8 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         }
         thr[i] = s;
         F1Thr e;
-        e.tp = tpge[b + 1] + (unsigned long long)(ssum[i] - ssum[lo]);
-        e.fp_above = fpge[b + 1];
+        e.tp = tp_bin + (unsigned long long)(ssum[i] - ssum[lo]);
+        e.fp_above = fp_bin;
         e.seg_end = lo;
         e.pad = 0;
         info[i] = e;
@@ -1230,7 +1272,7 @@ int sgpr_pair_threshold_counts(const sgpr_handle* h, const float* d_score, int R
 //      (two arrays) | candidate-bin marks | thresholds, their info, negatives by bucket of pass B | positives | counter slabs
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct F1Layout {
-    size_t off_posb, off_negb, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
+    size_t off_posb, off_negb, off_negbt, off_tpge, off_fpge, off_mark, off_thr, off_info, off_neg2, off_pos, off_slabs, off_cls, total;
     long long cap;
     int slabs_a, slabs_b, words_a, words_b;
 };
@@ -1246,6 +1288,7 @@ static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     size_t off = 256;                                                       // header
     L.off_posb = off;  off += a256((size_t)F1_THREADS * ((F1_NBP + F1_THREADS - 1) / F1_THREADS) * sizeof(unsigned));   // (zeroed with the header)
     L.off_negb = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
+    L.off_negbt = off; off += a256((size_t)F1_THREADS * F1_PER * sizeof(unsigned long long));     // the same sums, transposed
     L.off_tpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_fpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_mark = off;  off += a256((F1_NBP / 32 + 1) * sizeof(unsigned));
@@ -1287,6 +1330,7 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     int* dT2 = reinterpret_cast<int*>(ws + 192);
     unsigned* posb = reinterpret_cast<unsigned*>(ws + L.off_posb);
     unsigned long long* negb = reinterpret_cast<unsigned long long*>(ws + L.off_negb);
+    unsigned long long* negb_t = reinterpret_cast<unsigned long long*>(ws + L.off_negbt);
     unsigned long long* tpge = reinterpret_cast<unsigned long long*>(ws + L.off_tpge);
     unsigned long long* fpge = reinterpret_cast<unsigned long long*>(ws + L.off_fpge);
     unsigned* mark = reinterpret_cast<unsigned*>(ws + L.off_mark);
@@ -1315,9 +1359,9 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     }
     const PairScan sc = make_scan(d_score, R, M, ld, row0, d_pose_xz, d_pos, d_neg, d_gt, ldg);
     hipLaunchKernelGGL(f1_scan_kernel, dim3(L.slabs_a), dim3(F1_THREADS), lds_scan, s, sc, slabs, L.words_a, pos, L.cap, count, cls, posb);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb, nullptr, negb_t, F1_PER);
     hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
-                       ctrl, reinterpret_cast<unsigned long long*>(ws + 128), posb);
+                       ctrl, reinterpret_cast<unsigned long long*>(ws + 128), posb, negb_t);
     hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b, cls);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_SORT + 3 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_b, L.words_b, 0, neg2, dT2);
     hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(F1_THREADS), 0, s, neg2, info, ctrl, d_result);
