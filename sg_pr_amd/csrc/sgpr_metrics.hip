@@ -802,13 +802,18 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         return a > 0.f ? a * __builtin_amdgcn_rcpf(a + (float)fp + Pf) : 0.f;     // (1 ulp: the margin below is 1e-5)
     };
     float gbest = 0.f;
+    float* gkeep = reinterpret_cast<float*>(posb);       // [PER][F1_THREADS] edge values of the first sweep (this thread's own)
     {
         unsigned long long rn = an, rp = ap;
 #pragma unroll
         for (int q = PER - 1; q >= 0; --q) {
             rn += ng[q];
             rp += ps[q];
-            if (ps[q] != 0u || ng[q] != 0ull) gbest = fmaxf(gbest, g32(rp, rn));   // (an empty bin repeats the edge above it)
+            if (ps[q] != 0u || ng[q] != 0ull) {           // (an empty bin repeats the edge above it)
+                const float gq = g32(rp, rn);
+                gkeep[q * F1_THREADS + tid] = gq;         // (kept for the second sweep: the positives' histogram area is idle)
+                gbest = fmaxf(gbest, gq);
+            }
         }
     }
     gbest = (float)block_max((double)gbest, shd);
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
             rn += ng[q];
             rp += ps[q];
             if (ps[q] != 0u || ng[q] != 0ull) {
-                const float gq = g32(rp, rn);
+                const float gq = gkeep[q * F1_THREADS + tid];
                 if (gq > 0.f && gq >= gcut) best = fmax(best, f1_of((double)rp, (double)rn, P));
             }
         }
