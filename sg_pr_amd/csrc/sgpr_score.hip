@@ -136,6 +136,9 @@ constexpr int AP_COLS = 256;   // column graphs per work item (4 super-blocks)
 #ifndef SGPR_AP_OCC
 #define SGPR_AP_OCC 4
 #endif
+// the multi-rectangle kernel carries the job table on top: at four workgroups per CU (128 VGPRs) it spills 360 bytes per
+// lane, at three (166 VGPRs) nothing - config 4's tail 368.5 -> 358.9 us on one box (profiles/r05_tail_variants.txt)
+constexpr int AP_MULTI_OCC = 3;
 constexpr int AP_OCC = SGPR_AP_OCC;   // resident workgroups per CU the kernel is compiled for (waves per SIMD)
 #ifndef SGPR_AP_NI
 #define SGPR_AP_NI 2            // (same-box A/B, round 5: 97.7 -> 96.5 us per KITTI-00 matrix, twice; bit-identical - program order only)
@@ -831,11 +834,11 @@ int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_j
     hipLaunchKernelGGL(ntn_prep_multi_kernel, dim3(blocks), dim3(256), 0, stream, h->w, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_multi_kernel launch");
-    const int64_t slots = (int64_t)h->num_cus * AP_OCC;
+    const int64_t slots = (int64_t)h->num_cus * AP_MULTI_OCC;
     const unsigned grid = (unsigned)(items < slots ? items : slots);
     // (one row graph at a time here: interleaving two costs this instance - two instantiations of the loop in one job
     //  loop - 380 -> ~900 bytes of scratch per lane: 334 -> 420 us on the five KITTI matrices, same-box A/B, round 5)
-    hipLaunchKernelGGL((score_all_pairs_multi_kernel<AP_OCC, 1>), dim3(grid), dim3(256), 0, stream, h->w, a);
+    hipLaunchKernelGGL((score_all_pairs_multi_kernel<AP_MULTI_OCC, 1>), dim3(grid), dim3(256), 0, stream, h->w, a);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_multi_kernel launch");
     return SGPR_OK;
