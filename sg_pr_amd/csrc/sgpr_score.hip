@@ -836,8 +836,9 @@ int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_j
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_multi_kernel launch");
     const int64_t slots = (int64_t)h->num_cus * AP_MULTI_OCC;
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    // (one row graph at a time here: interleaving two costs this instance - two instantiations of the loop in one job
-    //  loop - 380 -> ~900 bytes of scratch per lane: 334 -> 420 us on the five KITTI matrices, same-box A/B, round 5)
+    // (one row graph at a time here: at four workgroups per CU interleaving two cost this instance - two instantiations
+    //  of the loop in one job loop - 380 -> ~900 bytes of scratch per lane, 334 -> 420 us on the five KITTI matrices; at
+    //  three per CU nothing spills either way and the two are on par, 358.9 / 360.8 us: same-box A/Bs, round 5)
     hipLaunchKernelGGL((score_all_pairs_multi_kernel<AP_MULTI_OCC, 1>), dim3(grid), dim3(256), 0, stream, h->w, a);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "score_all_pairs_multi_kernel launch");
