@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 5, pass j: the multi-rectangle tail (config 4) at other occupancies / with two row graphs interleaved - same box
+# round 5, pass j: the multi-rectangle tail (config 4) at other occupancies / with two row graphs interleaved - same box.
+# The variants are builds (tools/build_variant.sh m_ni<N>_occ<O> --src <copy>) of a copy of the tree in which the two
+# constants of launch_score_all_pairs_multi - AP_MULTI_OCC and the kernel's NI template argument - were edited by hand.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5j; rm -rf $O; mkdir -p $O
 cd $R
