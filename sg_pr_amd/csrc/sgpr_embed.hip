@@ -94,6 +94,9 @@ __device__ __forceinline__ int phase_tid() {
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+#ifndef SGPR_BIG_OWNED
+#define SGPR_BIG_OWNED 1      // production plans beyond 64 rows on the owned-rows instance (0: A/B builds on the chunked plans)
+#endif
 
 // The LDS layout of every lean plan (node_cap <= 64, f16 planes) is ONE fixed layout - 64 rows, 16 neighbour slots per
 // row - so that the lean kernel instance sees its offsets and pitches as compile-time constants (no scalar registers
@@ -112,6 +115,7 @@ __host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_pa
     p.small_park = small_park ? 1 : 0;
     p.alias_da = 1;
     p.lean = rows;
+    p.big = 0;
     p.xplanes = 1;
     p.fmt = FMT_H2;
     p.rowb = PXH;
@@ -178,6 +182,7 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
     p->RC = rc;
     // lean plans (NP <= 64, plane layouts): one wave per 16-row tile, 12..16 waves per CU on the <= 128-VGPR kernel instance
     p->lean = 0;
+    p->big = 0;
     if (planes && p->overlap && p->NP <= 64 && min_nt == 0) {
         int nt3 = 64 * (p->NP / 16);
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
@@ -192,6 +197,45 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
     return true;
 }
 
+// Production plans beyond 64 processed slots, K = 10 or 20 (embed_big_kernel): one wave per 16-row tile (up to 16 waves),
+// at most 128 registers per lane - sixteen waves per CU where the chunked plans run eight.  No key matrix: a wave takes
+// the Gram tiles of its rows against every candidate tile from the accumulators (select_owned_big), so LDS holds X, the
+// neighbour lists, the gather target and the 16 super-node rows of the semantic branch (a graph that needs the generic
+// branch goes to the second pass, as on the lean plans).
+static bool plan_big(int N, int NC, int k, EmbedPlan* p) {
+    if ((k != 10 && k != 20) || NC <= 64) return false;
+    EmbedPlan full;
+    if (!plan_layout(N, NC, k, FMT_H2, &full)) return false;
+    *p = full;
+    p->NP = round_up(NC, 16);
+    p->pitchD = 20;                       // (only the 16 x 16 key tile of the super-node branch)
+    p->park_in_lds = 0;
+    p->park_hybrid = 1;
+    p->small_park = 1;
+    p->alias_da = 1;
+    p->lean = 0;
+    p->big = full.overlap ? 2 : 1;
+    p->overlap = 0;
+    p->xplanes = 1;
+    p->fmt = FMT_H2;
+    p->rowb = PXH;
+    int off = 0;
+    p->offX = off;    off += p->NP * PXH;
+    p->offRed = p->offX;
+    p->offPark = off; off += kHybridParkBytes;
+    p->offXX = off;   off += p->NP * 4;
+    p->offIdx = off;  off += round_up(p->NP * p->kpitch * 2, 16);
+    p->offA = off;
+    p->offD = off;
+    p->pitchA = off + p->NP * 68 * 4 <= kLdsLimit ? 68 : 64;
+    p->lds_bytes = off + p->NP * p->pitchA * 4;
+    if (p->lds_bytes > kLdsLimit) return false;
+    p->nt = 64 * (p->NP / 16);
+    if (p->nt < round_up(N, 64)) p->nt = round_up(N, 64);       // one thread per input slot
+    p->RC = p->NP;
+    return p->nt <= 1024;
+}
+
 bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p, bool wide_range, bool small_park, int min_nt) {
     if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > SGPR_MAX_K || k > N) return false;
     const int NC = (node_cap <= 0 || node_cap > N) ? N : node_cap;
@@ -201,6 +245,9 @@ bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p, bool wide_range, 
     // production launches of lean plans park only the 16 super-node rows of the first branch (four workgroups per CU
     // instead of three); a graph that needs the generic branch is handed to the second pass (embed_redo_kernel)
     if (small_park && plan_layout(N, NC, k, FMT_H2, p, true, 0)) return true;
+#if SGPR_BIG_OWNED
+    if (small_park && plan_big(N, NC, k, p)) return true;
+#endif
     return plan_layout(N, NC, k, FMT_H2, p, false, min_nt);
 }
 
@@ -1171,6 +1218,222 @@ __device__ __forceinline__ void select_owned(const EmbedPlan& p, const int n, co
     }
 }
 
+// ------------------------------------------------------------------ owned rows beyond 64 slots (embed_big_kernel)
+// L, O ascending with +inf from entry K on -> L = the K smallest of the union, ascending (the butterfly step of
+// select_phase as a function: min(L[s], O[KP-1-s]) is a bitonic sequence holding the KP smallest)
+template <int KP, int K>
+__device__ __forceinline__ void merge_keep(float (&L)[KP], const float (&O)[KP]) {
+    float o[KP];
+#pragma unroll
+    for (int s = 0; s < KP; ++s) o[s] = (KP - 1 - s < K) ? O[KP - 1 - s] : INFINITY;
+#pragma unroll
+    for (int s = 0; s < KP; ++s) L[s] = s < K ? ((KP - 1 - s < K) ? kmin(L[s], o[s]) : L[s]) : o[s];
+    bitonic_merge<KP>(L);
+#pragma unroll
+    for (int s = K; s < KP; ++s) L[s] = INFINITY;
+}
+
+// candidate index of bit u of a 64-bit owned mask (16 tiles x 4 elements)
+__device__ __forceinline__ void emit_owned64(unsigned long long take, int lq, int pitchA, unsigned short* __restrict__ out, int& pos) {
+    while (take) {
+        const int u = __ffsll((long long)take) - 1;
+        take &= take - 1ull;
+        out[pos++] = (unsigned short)(owned_cand(u, lq) * pitchA);
+    }
+}
+
+// Wave w owns the 16 rows of row tile w; up to 16 candidate tiles = 64 candidates per lane, which do not fit the 128
+// registers of a sixteen-wave workgroup beside the sorting networks.  So the candidates STREAM: four tiles at a time the
+// lane's 16 keys are sorted and merged into its running list of the K smallest (pass 1; the butterfly over the row's four
+// lanes then yields the K-th smallest key of the row, as in select_owned), and the Gram tiles are computed AGAIN to mark
+// the candidates at or below that key (pass 2: the matrix cores are ~10 % busy, the same instructions on the same operands
+// give the same bits).  Keys: `sym` != 0 - the resident plans' operation order (select_owned), else the chunked plans'
+// (gram_tile: rows as the A operand for every tile) - whatever the full plan of the same launch produces, so that a
+// capped and an uncapped launch rank near-ties alike.
+template <int FMT, int K, int KP>
+__device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n, const int nrt, const bool one_rep,
+                                                 const unsigned char* __restrict__ X, const float* __restrict__ xx,
+                                                 unsigned short* __restrict__ nbr, const int wave, const bool coord,
+                                                 const bool sym) {
+    constexpr int XR = xrow<FMT>();
+    if (wave >= nrt) return;                         // no rows of the graph in this wave's tile
+    const int lane = phase_tid() & 63, l15 = lane & 15, lq = lane >> 4;
+    const int i = 16 * wave + l15;
+    const bool active = i < n;
+    const int jr = n - 1, tr = jr >> 4, rr = jr & 3, lqr = (jr >> 2) & 3;
+    FragT<FMT> b[2];
+    float4 ci = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (coord)
+        ci = *reinterpret_cast<const float4*>(X + i * XR + (XR - 16));
+    else
+        xload<4, FMT>(X + i * XR, lq, b);
+    // the keys of candidate tile tj (< nrt) for this lane: candidates 16 tj + 4 lq + r
+    auto keys4 = [&](const int tj, float (&key)[4]) {
+        if (coord) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 cj = *reinterpret_cast<const float4*>(X + (16 * tj + 4 * lq + r) * XR + (XR - 16));
+                const float dot = fmaf(ci.z, cj.z, fmaf(ci.y, cj.y, __fmul_rn(ci.x, cj.x)));
+                const float t = fmaf(2.f, dot, -cj.w);
+                key[r] = __fsub_rn(ci.w, t);         // (+inf for an empty slot: its |x|^2 is)
+            }
+        } else {
+            FragT<FMT> a[2];
+            xload<4, FMT>(X + (16 * tj + l15) * XR, lq, a);
+            const f32x4 g = (sym && tj < wave) ? tile16<4, FMT>(a, b) : tile16_swapped<FMT>(a, b);
+            const int jb = 16 * tj + 4 * lq;
+            const float4 xj = *reinterpret_cast<const float4*>(xx + jb);
+            key[0] = fmaf(-2.f, g[0], jb + 0 < n ? xj.x : INFINITY);
+            key[1] = fmaf(-2.f, g[1], jb + 1 < n ? xj.y : INFINITY);
+            key[2] = fmaf(-2.f, g[2], jb + 2 < n ? xj.z : INFINITY);
+            key[3] = fmaf(-2.f, g[3], jb + 3 < n ? xj.w : INFINITY);
+        }
+    };
+    // ---- pass 1: this lane's K smallest keys
+    float L[KP], krep_part = 0.f;
+#pragma unroll
+    for (int s = 0; s < KP; ++s) L[s] = INFINITY;
+#pragma unroll 1
+    for (int g0 = 0; g0 < nrt; g0 += 4) {            // wave-uniform
+        float d[16];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            if (g0 + tq < nrt) {
+                keys4(g0 + tq, key);
+                if (g0 + tq == tr) krep_part = rr == 0 ? key[0] : (rr == 1 ? key[1] : (rr == 2 ? key[2] : key[3]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[4 * tq + r] = key[r];
+        }
+        float S[KP];
+        list_from_32<KP, K, 0, 16>(d, 4 * min(4, nrt - g0), S);
+        merge_keep<KP, K>(L, S);
+    }
+    // ---- the butterfly over the row's four lanes (16 and 32 lanes away); the last round only needs the K-th key
+    {
+        float O[KP];
+#pragma unroll
+        for (int s = 0; s < KP; ++s) O[s] = s < K ? __shfl_xor(L[s], 16) : INFINITY;
+        merge_keep<KP, K>(L, O);
+    }
+    float tau;                                       // the K-th smallest key of the row
+    {
+        float mn[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) mn[s] = kmin(L[s], __shfl_xor(L[K - 1 - s], 32));
+        float m3[(K + 2) / 3];
+#pragma unroll
+        for (int s = 0; s < (K + 2) / 3; ++s)
+            m3[s] = max3(mn[3 * s], mn[3 * s + 1 < K ? 3 * s + 1 : 3 * s], mn[3 * s + 2 < K ? 3 * s + 2 : 3 * s]);
+        tau = m3[0];
+#pragma unroll
+        for (int s = 1; s + 1 < (K + 2) / 3; s += 2) tau = max3(tau, m3[s], m3[s + 1]);
+        if (((K + 2) / 3) % 2 == 0) tau = kmax(tau, m3[(K + 2) / 3 - 1]);
+    }
+    unsigned short* out = nbr + i * p.kpitch;
+    bool dup_cut = false;
+    if (one_rep) {
+        const float krep = __shfl(krep_part, l15 + 16 * lqr);
+        if (krep < tau) {
+            tau = krep;
+            dup_cut = true;
+        }
+        if (active) {
+            const unsigned short rep = (unsigned short)(jr * p.pitchA);
+            for (int q = lq; q < K; q += 4) out[q] = rep;
+        }
+    }
+    // ---- pass 2: the candidates at or below tau (bit 4 tj + r of the lane's mask)
+    unsigned long long gt = 0ull;
+#pragma unroll 2
+    for (int tj = 0; tj < nrt; ++tj) {
+        float key[4];
+        keys4(tj, key);
+        unsigned nib = 0u;
+#pragma unroll
+        for (int r = 3; r >= 0; --r) nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(tau - key[r]), 31);
+        gt |= (unsigned long long)nib << (4 * tj);
+    }
+    const unsigned long long valid = nrt >= 16 ? ~0ull : ((1ull << (4 * nrt)) - 1ull);
+    const unsigned long long le = ~gt & valid;
+    const int n_le = __popcll(le);
+    int incl = n_le;                                 // inclusive prefix over the row's lanes (lq order)
+    {
+        const int t1 = __shfl_up(incl, 16);
+        incl += lq >= 1 ? t1 : 0;
+        const int t2 = __shfl_up(incl, 32);
+        incl += lq >= 2 ? t2 : 0;
+    }
+    const int total_le = __shfl(incl, 48 + l15);
+    if (__ballot(active && !(dup_cut || total_le == K)) == 0ull) {
+        if (active) {
+            int pos = incl - n_le;
+            emit_owned64(le, lq, p.pitchA, out, pos);
+        }
+        return;
+    }
+    // ---- ties across the cut (identical nodes, kept padding copies): a third pass marks the candidates below tau; then
+    //      everything below, and the first T candidates AT tau in candidate-index order = (tile, lane group, element)
+    unsigned long long ltm = 0ull;
+#pragma unroll 1
+    for (int tj = 0; tj < nrt; ++tj) {
+        float key[4];
+        keys4(tj, key);
+        unsigned nib = 0u;
+#pragma unroll
+        for (int r = 3; r >= 0; --r) nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(key[r] - tau), 31);
+        ltm |= (unsigned long long)nib << (4 * tj);
+    }
+    ltm &= valid;
+    unsigned long long eq = ~(ltm | gt) & valid;     // (inf - inf is a positive NaN: an empty slot at an infinite tau is "equal")
+    if (dup_cut) {                                   // everything at or below the representative's key, no tie limit
+        ltm |= eq;
+        eq = 0ull;
+    }
+    const int n_less = __popcll(ltm);
+    int less_incl = n_less;
+    {
+        const int t1 = __shfl_up(less_incl, 16);
+        less_incl += lq >= 1 ? t1 : 0;
+        const int t2 = __shfl_up(less_incl, 32);
+        less_incl += lq >= 2 ? t2 : 0;
+    }
+    const int total_less = __shfl(less_incl, 48 + l15);
+    const int T = dup_cut ? 0 : K - total_less;      // ties to accept
+    if (active) {
+        int pos = less_incl - n_less;
+        emit_owned64(ltm, lq, p.pitchA, out, pos);
+    }
+    int before = 0;                                  // ties in the tiles before the current one
+#pragma unroll 1
+    for (int tj = 0; tj < nrt; ++tj) {               // (every lane runs the exchanges; only active rows emit)
+        const unsigned bits0 = (unsigned)(eq >> (4 * tj)) & 0xfu;
+        const int own = __popc(bits0);
+        int tin = own;
+        {
+            const int t1 = __shfl_up(tin, 16);
+            tin += lq >= 1 ? t1 : 0;
+            const int t2 = __shfl_up(tin, 32);
+            tin += lq >= 2 ? t2 : 0;
+        }
+        const int all = __shfl(tin, 48 + l15);
+        const int start = before + tin - own;
+        const int take_n = max(0, min(own, T - start));
+        unsigned bits = bits0, keep = 0u;
+        for (int c = 0; c < take_n; ++c) {
+            const unsigned low = bits & (0u - bits);
+            keep |= low;
+            bits ^= low;
+        }
+        if (active) {
+            int tpos = total_less + min(start, T);
+            emit_owned64((unsigned long long)keep << (4 * tj), lq, p.pitchA, out, tpos);
+        }
+        before += all;
+    }
+}
+
 // ------------------------------------------------------------------ selection by value bisection (wave per row)
 // wave64 min / max of a u32 (result uniform)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
@@ -1360,6 +1623,36 @@ __device__ __forceinline__ void gemm_rows(unsigned char* __restrict__ X, float* 
     for (int cb = 0; cb < NCA; ++cb) {
         *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * lq) * 4) = make_float4(b0[cb][0], b0[cb][1], b0[cb][2], b0[cb][3]);
         if (two) *reinterpret_cast<float4*>(x1 + (cb * 16 + 4 * lq) * 4) = make_float4(b1[cb][0], b1[cb][1], b1[cb][2], b1[cb][3]);
+    }
+}
+
+// ------------------------------------------------------------------ per-node GEMMs of a wave's OWN row tile (embed_big_kernel)
+// gemm_rows for one row tile: a = x.W1' -> A (LDS, the gather target); b = x.(W2-W1)' + t stays in registers (bout) -
+// the caller stores it over the wave's rows of X once every wave has read them as candidates / operands (a barrier).
+template <int NKB, int COUT, int FMT>
+__device__ __forceinline__ void gemm_own(const unsigned char* __restrict__ X, float* __restrict__ A, int pitchA,
+                                         const unsigned short* __restrict__ Wb, const float* __restrict__ tb, int rt,
+                                         f32x4 (&bout)[4]) {
+    const int lane = phase_tid() & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int NCA = COUT / 16, NCT = 2 * NCA;
+    const unsigned char* x0 = X + (rt * 16 + l15) * xrow<FMT>();
+    FragT<FMT> w[2], wn[2], xf[2];
+    load_wfrag<NKB>(Wb, w);
+    xload<NKB, FMT>(x0, lq, xf);
+    float* a0 = A + (rt * 16 + l15) * pitchA + 4 * lq;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (ct + 1 < NCT) load_wfrag<NKB>(Wb + (size_t)(ct + 1) * wtile<NKB, FMT>(), wn);
+        const f32x4 r0 = tile16<NKB>(w, xf);        // r0[c] = out[channel ct*16 + 4lq + c][node rt*16 + l15]
+        if (ct < NCA) {
+            *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        } else {
+            const float4 t4 = *reinterpret_cast<const float4*>(tb + (ct - NCA) * 16 + 4 * lq);
+            const f32x4 t = {t4.x, t4.y, t4.z, t4.w};
+            bout[ct < NCA ? 0 : ct - NCA] = r0 + t;
+        }
+        if (ct + 1 < NCT) copy_frag<NKB>(w, wn);
     }
 }
 
@@ -1731,8 +2024,8 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
                 gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, 0);
                 group_sync<WAVE>();                                           // = the barrier inside gemm_cols
             } else {
-                gemm_layer<true, FMT, SGPR_LEAN_WAVES - 1>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0,
-                                                           (kPre3 && Lv == 2) ? wpre3 : nullptr);   // (lean: four waves)
+                gemm_layer<true, FMT, (LEAN > 0 ? SGPR_LEAN_WAVES - 1 : 0)>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave - 1, NW - 1, 0,
+                                                           (kPre3 && Lv == 2) ? wpre3 : nullptr);   // (lean: four waves; LEAN < 0: the big instance's)
             }
         } else {
             gram_tiles_sym<4, FMT, false>(X, xx, Dv, pitchD, kLabels + 1, 1, wave);
@@ -1931,7 +2224,8 @@ int launch_sem_tables(const DevWeights& w, float* d_table, float* d_vmax, hipStr
 // LEAN (64 / 48): the instance of the fixed lean layouts - kLeanNT = 256 threads, four / five workgroups per CU (91 / 79 VGPRs)
 // KC: K as a compile-time constant (10, the reference's, in the lean production instances; 0 = read from the plan): the
 // K-derived loop bounds and predicates of every phase fold away
-template <int KP, int DBG, int LEAN, int FMT, int KC = 0>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
+// BIG: the owned-rows instance for plans beyond 64 rows (embed_big_kernel; production only: DBG = 0, LEAN = 0, FMT_H2, KC = 10 / 20)
+template <int KP, int DBG, int LEAN, int FMT, int KC = 0, bool BIG = false>   // DBG: 0 production, 1 phase timers + ablation mask, 2 + layer / kNN dumps
 __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& plan_in, const int g, const int launch_slot,
                                             const int role = 0,     // role: 0 whole graph, 1 / 2 the halves of a split launch
                                             const int g_ahead = -1) {   // packed input: the graph whose lines are pulled into L2 (see below)
@@ -2089,21 +2383,23 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             const unsigned long long mk = __ballot(tid < NS && mylab == c);
             lab_mine = lane == c ? mk : lab_mine;
         }
-        if (lane == 0) {
+        // (slots sit in the first NS / 64 <= 8 waves; the big instance runs up to 16)
+        const int NWI = NW < 8 ? NW : 8;
+        if (lane == 0 && wave < NWI) {
             wmax[wave] = differs ? wave * 64 + 63 - __clzll((long long)differs) : -1;
             negm[wave] = neg;
             nm1[wave] = not_pad;
         }
-        if (lane < kLabels) labm[wave * kLabels + lane] = lab_mine;
+        if (lane < kLabels && wave < NWI) labm[wave * kLabels + lane] = lab_mine;
         __syncthreads();
         int last = -1;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) last = max(last, wmax[q]);
+        for (int q = 0; q < NWI; ++q) last = max(last, wmax[q]);
         nd = last + 1;
         // (nd <= NS - 1: the last slot equals itself)  slots before the trailing run, per wave, as lane masks
         any_bad = ((nm1[nd >> 6] >> (nd & 63)) & 1ull) != 0ull;       // the run's first slot is not padding
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
+        for (int q = 0; q < NWI; ++q) {
             const int nb = min(max(nd - 64 * q, 0), 64);
             const unsigned long long below = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
             any_bad = any_bad || (negm[q] & below) != 0ull;
@@ -2134,7 +2430,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     // (P is a power of two: shifts, not integer divisions - the scalar division sequences of this handful of lines were
     // several hundred instructions per wave and graph)
     int lp = 31 - __clz(p.P);
-    if (LEAN != 0) {
+    if (LEAN != 0 || BIG) {
         lp = 2;        // lean instances: always four lanes per row (<= 64 rows x 4 = the workgroup), <= 16 candidates per lane
     } else {
         const int rows = p.overlap ? NP : p.RC;
@@ -2181,7 +2477,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         __syncthreads();       // the prologue's scratch (in the X region) is dead; counts and row labels are visible
         if (fast) {
             if (!split) {
-                supernode_branch<FMT, LEAN, false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
+                supernode_branch<FMT, (BIG ? -1 : LEAN), false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
 #if SGPR_EXP_DOUBLE & 8
                 __syncthreads();
                 supernode_branch<FMT, LEAN, false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
@@ -2271,13 +2567,37 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             else
                 load_wfrag<1>(wl, wpre);
         }
+        if constexpr (BIG) {
+            // ---- owned rows beyond 64 slots (only the xyz layers 3..5 get here: the semantic branch ran on the super-nodes):
+            //      selection from the accumulators, then the wave's own row tile of the per-node GEMMs; b waits in registers
+            //      until every wave has read X (as candidates and as operands)
+            f32x4 bown[4];
+            const bool mine = wave < nrt;
+            select_owned_big<FMT, KC, KP>(p, N, nrt, one_rep, X, xx, nbr, wave, L == 3, p.big == 2);
+            if (mine) {
+                if (Kp != 64)
+                    gemm_own<1, 64, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
+                else if (cout == 64)
+                    gemm_own<4, 64, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
+                else
+                    gemm_own<4, 32, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
+            }
+            __syncthreads();                          // A is complete; X has been read by everyone
+            if (mine) {
+                unsigned char* x0 = X + (wave * 16 + l15) * XROW;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    if (cb < (cout >> 4))
+                        *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * lq) * 4) = make_float4(bown[cb][0], bown[cb][1], bown[cb][2], bown[cb][3]);
+            }
+        }
         if constexpr (kOwned) {
             // lean production instances: keys in registers, selection right behind them, no barrier until the GEMMs' own
             // (A is written only by the GEMM phase and nothing reads it here; b replaces X behind gemm_cols' barrier, which
             // every wave reaches after its selection)
             select_owned<FMT>(p, N, nrt, one_rep, X, xx, nbr, wave, L == 3);
         }
-        for (int rc0 = 0; !kOwned && rc0 < NP; rc0 += p.RC) {
+        for (int rc0 = 0; !kOwned && !BIG && rc0 < NP; rc0 += p.RC) {
             const int rows_chunk = min(p.RC, NP - rc0);
             if (skip & 4) {
             } else if (L == 3) {
@@ -2333,9 +2653,11 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             SGPR_PROF(1)
         }
         // per-node GEMMs (MFMA); A overwrites the key matrix
+        if constexpr (!BIG) {
         if (!(skip & 2)) gemm_layer<(LEAN != 0), FMT, (LEAN != 0 ? SGPR_LEAN_WAVES : 0)>(X, A, p.pitchA, (FMT == FMT_H2 ? kp.w.wh[L] : kp.w.wb[L]), kp.w.tb[L], Kp, cout, nrt, wave, NW, skip, kWPre ? wpre : nullptr);
         __syncthreads();  // neighbour lists, A and b (in X) are complete
         SGPR_PROF(3)
+        }
 
         // ---- gather-max over the k neighbours: cout/4 lanes per row, 4 channels (16 B) per lane
         {
@@ -2350,9 +2672,8 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             // [N, NP) are skipped (their rows are zero-filled below: the matrix phases still read them as operands)
             // (a wave's last group may have no partner: that iteration runs the one-row form instead of computing - and
             // discarding - a second copy of the same row)
-            auto rows = [&](auto two_tag, const int ia) {
+            auto rows = [&](auto two_tag, const int ia, const int ib) {
                 constexpr bool TWO = decltype(two_tag)::value;
-                const int ib = ia + rstep;
                 const int ra = min(ia, N - 1), rb = TWO ? min(ib, N - 1) : ra;   // padded rows: compute a real row
                 float4 ma, mb;
                 if constexpr (TWO) {
@@ -2401,14 +2722,34 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     }
                 }
             };
+            if constexpr (BIG) {
+                // the wave's own 16 rows (its neighbour lists and its b rows are its own LDS traffic: program order), two
+                // groups of rpw rows at a time; all-padding groups of the graph's last tile get zero planes
+                if (wave < nrt) {
+                    constexpr int QW = 256 / 16;
+                    for (int r0 = 0; r0 < 16; r0 += 2 * rpw) {
+                        const int ga = 16 * wave + r0;      // (wave-uniform)
+                        if (ga < N) {
+                            if (ga + rpw < N)
+                                rows(std::true_type{}, ga + sub, ga + rpw + sub);
+                            else
+                                rows(std::false_type{}, ga + sub, ga + sub);
+                        }
+                        const int z0 = ga >= N ? ga : (ga + rpw >= N ? ga + rpw : ga + 2 * rpw), z1 = ga + 2 * rpw;
+                        for (int e = lane; e < (z1 - z0) * QW; e += 64)
+                            *reinterpret_cast<uint4*>(X + (z0 + e / QW) * XROW + (e % QW) * 16) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+            } else {
             for (int ia = wave * rpw + sub; ia - sub < ((skip & 8) ? 0 : N); ia += 2 * rstep) {
                 if (ia + rstep - sub < N)                  // wave-uniform
-                    rows(std::true_type{}, ia);
+                    rows(std::true_type{}, ia, ia + rstep);
                 else
-                    rows(std::false_type{}, ia);
+                    rows(std::false_type{}, ia, ia);
+            }
             }
             // rows of the skipped all-padding groups: zero planes (finite operands for the next layer's matrix phases)
-            if (L != 2 && !(skip & 8)) {
+            if (!BIG && L != 2 && !(skip & 8)) {
                 constexpr int QW = (FMT == FMT_BF3 ? 384 : 256) / 16;        // 16-byte pieces per row
                 const int nq = (N + rpw - 1) & ~(rpw - 1);
                 for (int e = tid; e < (NP - nq) * QW; e += NT)
@@ -2609,6 +2950,13 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN 
     embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role, g_ahead);
 }
 
+// Owned rows beyond 64 slots: up to sixteen waves (one per 16-row tile) under a 128-register budget
+template <int KP, int KC>
+__global__ __launch_bounds__(1024) void embed_big_kernel(const KParams kp) {
+    const int slot = (int)blockIdx.x;
+    embed_graph<KP, 0, 0, FMT_H2, KC, true>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, 0, -1);
+}
+
 // Second pass over the launch slots the f16 instance flagged (kp.a.redo):
 //   1  a coordinate or an activation reached the f16 range -> bf16 planes / fp32 rows (plan kp.p: fp32's range)
 //   2  the graph needs the generic semantic branch, which the lean plan's 16-row park cannot hold -> the full f16 plan kp.p2
@@ -2671,6 +3019,17 @@ static int launch_t(const KParams& kp, hipStream_t stream) {
     return SGPR_OK;
 }
 
+template <int KP, int KC>
+static int launch_big_t(const KParams& kp, hipStream_t stream) {
+    static LdsLimitOnce once;
+    int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&embed_big_kernel<KP, KC>), kLdsLimit, "embed_big_kernel");
+    if (rc != SGPR_OK) return rc;
+    hipLaunchKernelGGL((embed_big_kernel<KP, KC>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "embed_big_kernel launch");
+    return SGPR_OK;
+}
+
 template <int KP, int FMT>
 static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
     static LdsLimitOnce once;
@@ -2686,6 +3045,8 @@ static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
 template <int KP, int DBG>
 static int launch_layout(const EmbedPlan& plan, const KParams& kp, hipStream_t stream) {
     if (plan.fmt == FMT_H2) {
+        if (DBG == 0 && plan.big)                                  // owned rows beyond 64 slots (K = 10 / 20 only: plan_big)
+            return KP == 16 ? launch_big_t<16, 10>(kp, stream) : launch_big_t<32, 20>(kp, stream);
         if (KP == 16 && DBG == 0 && plan.lean && plan.k == 10)     // the reference's K: compile-time constant
             return plan.lean == 48 ? launch_t<16, 0, 48, FMT_H2, 10>(kp, stream) : launch_t<16, 0, 64, FMT_H2, 10>(kp, stream);
         if (KP == 32 && DBG == 0 && !plan.lean && plan.k == 20)    // the stress configuration's K: compile-time constant, too

@@ -124,6 +124,8 @@ struct EmbedPlan {
                      // generic semantic branch is re-embedded by the second pass
     int alias_da;    // 1: the key matrix / chunk D shares the A region (a barrier separates selection and GEMMs)
     int lean;        // 1: NP <= 64 - one wave per 16-row tile, weight-stationary GEMMs, <= 168-VGPR kernel instance
+    int big;         // owned-rows instance for plans beyond 64 rows (sgpr_embed.hip, embed_big_kernel): 0 no; 1 keys in the
+                     // chunked plans' operation order, 2 in the resident plans' (what the full plan of the same launch uses)
     int xplanes;     // 1: X rows are bf16 / f16 planes; 0: fp32 rows (272 B) split when loaded
     int fmt;         // X layout: 2 = two f16 planes (272 B rows, the default), 1 = three bf16 planes (400 B), 0 = fp32 rows
     int rowb;        // bytes per X row
