@@ -518,7 +518,7 @@ __device__ __forceinline__ float max3(float a, float b, float c);   // (v_max3_f
 #ifndef SGPR_EXP_DOUBLE
 #define SGPR_EXP_DOUBLE 0     // timing experiments only (tools/build_variant.sh): run an idempotent phase TWICE - the launch's time
 #endif                        // difference is what the phase costs, with valid results (1 counting selection, 2 selection, 4 Gram
-                              // tiles, 8 super-node branch, 16 coordinate-layer keys)
+                              // tiles, 8 super-node branch, 16 coordinate-layer keys; big instance: 32 selection, 64 per-node GEMMs)
 #ifndef SGPR_ASM_MINMAX
 #define SGPR_ASM_MINMAX 1
 #endif
@@ -1244,31 +1244,24 @@ __device__ __forceinline__ void emit_owned64(unsigned long long take, int lq, in
 
 // Wave w owns the 16 rows of row tile w; up to 16 candidate tiles = 64 candidates per lane, which do not fit the 128
 // registers of a sixteen-wave workgroup beside the sorting networks.  So the candidates STREAM: four tiles at a time the
-// lane's 16 keys are sorted and merged into its running list of the K smallest (pass 1; the butterfly over the row's four
+// lane's 16 keys are sorted and merged into its running list of smallest keys (pass 1; the butterfly over the row's four
 // lanes then yields the K-th smallest key of the row, as in select_owned), and the Gram tiles are computed AGAIN to mark
 // the candidates at or below that key (pass 2: the matrix cores are ~10 % busy, the same instructions on the same operands
 // give the same bits).  Keys: `sym` != 0 - the resident plans' operation order (select_owned), else the chunked plans'
 // (gram_tile: rows as the A operand for every tile) - whatever the full plan of the same launch produces, so that a
 // capped and an uncapped launch rank near-ties alike.
-template <int FMT, int K, int KP>
-__device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n, const int nrt, const bool one_rep,
-                                                 const unsigned char* __restrict__ X, const float* __restrict__ xx,
-                                                 unsigned short* __restrict__ nbr, const int wave, const bool coord,
-                                                 const bool sym) {
-    constexpr int XR = xrow<FMT>();
-    if (wave >= nrt) return;                         // no rows of the graph in this wave's tile
-    const int lane = phase_tid() & 63, l15 = lane & 15, lq = lane >> 4;
-    const int i = 16 * wave + l15;
-    const bool active = i < n;
-    const int jr = n - 1, tr = jr >> 4, rr = jr & 3, lqr = (jr >> 2) & 3;
+// The keys of candidate tile tj for this lane (candidates 16 tj + 4 lq + r).  xx[j] is +inf for every slot the graph does
+// not have (embed_graph's gather epilogue writes it so), the coordinate layer's |x|^2 likewise: no index test per key
+template <int FMT>
+struct OwnedKeys {
+    const unsigned char* X;
+    const float* xx;
     FragT<FMT> b[2];
-    float4 ci = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (coord)
-        ci = *reinterpret_cast<const float4*>(X + i * XR + (XR - 16));
-    else
-        xload<4, FMT>(X + i * XR, lq, b);
-    // the keys of candidate tile tj (< nrt) for this lane: candidates 16 tj + 4 lq + r
-    auto keys4 = [&](const int tj, float (&key)[4]) {
+    float4 ci;
+    int wave, l15, lq;
+    bool coord, sym;
+    __device__ __forceinline__ void operator()(const int tj, float (&key)[4]) const {
+        constexpr int XR = xrow<FMT>();
         if (coord) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1281,18 +1274,27 @@ __device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n
             FragT<FMT> a[2];
             xload<4, FMT>(X + (16 * tj + l15) * XR, lq, a);
             const f32x4 g = (sym && tj < wave) ? tile16<4, FMT>(a, b) : tile16_swapped<FMT>(a, b);
-            const int jb = 16 * tj + 4 * lq;
-            const float4 xj = *reinterpret_cast<const float4*>(xx + jb);
-            key[0] = fmaf(-2.f, g[0], jb + 0 < n ? xj.x : INFINITY);
-            key[1] = fmaf(-2.f, g[1], jb + 1 < n ? xj.y : INFINITY);
-            key[2] = fmaf(-2.f, g[2], jb + 2 < n ? xj.z : INFINITY);
-            key[3] = fmaf(-2.f, g[3], jb + 3 < n ? xj.w : INFINITY);
+            const float4 xj = *reinterpret_cast<const float4*>(xx + 16 * tj + 4 * lq);
+            key[0] = fmaf(-2.f, g[0], xj.x);
+            key[1] = fmaf(-2.f, g[1], xj.y);
+            key[2] = fmaf(-2.f, g[2], xj.z);
+            key[3] = fmaf(-2.f, g[3], xj.w);
         }
-    };
-    // ---- pass 1: this lane's K smallest keys
-    float L[KP], krep_part = 0.f;
+    }
+};
+
+// Pass 1 and the butterflies: the K-th smallest key of the lane's row.  KL = entries a lane keeps of its OWN quarter of
+// the candidates.  KL == K is exact by construction.  KL < K (2 KL >= K) is exact unless some lane holds more than KL of
+// the row's K smallest - then its list was cut short, which shows as last_kept (the lane's KL-th smallest) <= the result:
+// the caller repeats the pass with KL = K (a quarter of the candidates holding 13 of the 20 nearest: ~2e-4 per lane).
+// krep_part: the key of candidate n - 1 (tile tr, element rr), picked up while its tile goes by.
+template <int FMT, int K, int KP, int KL, int KPL>
+__device__ __forceinline__ float owned_kth(const OwnedKeys<FMT>& keys, const int nrt, const int tr, const int rr,
+                                           float& krep_part, float& last_kept) {
+    static_assert(2 * KL >= K && KL <= K && KPL <= KP, "owned_kth: list sizes");
+    float L[KPL];
 #pragma unroll
-    for (int s = 0; s < KP; ++s) L[s] = INFINITY;
+    for (int s = 0; s < KPL; ++s) L[s] = INFINITY;
 #pragma unroll 1
     for (int g0 = 0; g0 < nrt; g0 += 4) {            // wave-uniform
         float d[16];
@@ -1300,36 +1302,86 @@ __device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n
         for (int tq = 0; tq < 4; ++tq) {
             float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
             if (g0 + tq < nrt) {
-                keys4(g0 + tq, key);
+                keys(g0 + tq, key);
                 if (g0 + tq == tr) krep_part = rr == 0 ? key[0] : (rr == 1 ? key[1] : (rr == 2 ? key[2] : key[3]));
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) d[4 * tq + r] = key[r];
         }
-        float S[KP];
-        list_from_32<KP, K, 0, 16>(d, 4 * min(4, nrt - g0), S);
-        merge_keep<KP, K>(L, S);
+        float S[KPL];
+        list_from_32<KPL, KL, 0, 16>(d, 4 * min(4, nrt - g0), S);
+        merge_keep<KPL, KL>(L, S);
     }
+    last_kept = L[KL - 1];
     // ---- the butterfly over the row's four lanes (16 and 32 lanes away); the last round only needs the K-th key
-    {
+    float V[KP];
+    if constexpr (KL == K) {
+#pragma unroll
+        for (int s = 0; s < KP; ++s) V[s] = L[s < KPL ? s : 0];
         float O[KP];
 #pragma unroll
-        for (int s = 0; s < KP; ++s) O[s] = s < K ? __shfl_xor(L[s], 16) : INFINITY;
-        merge_keep<KP, K>(L, O);
+        for (int s = 0; s < KP; ++s) O[s] = s < K ? __shfl_xor(V[s], 16) : INFINITY;
+        merge_keep<KP, K>(V, O);
+    } else {
+        // two lists of KL: own ascending, then +inf, then the partner's descending - a bitonic sequence of KP
+#pragma unroll
+        for (int s = 0; s < KP; ++s) V[s] = INFINITY;
+#pragma unroll
+        for (int s = 0; s < KL; ++s) {
+            V[s] = L[s];
+            V[KP - 1 - s] = __shfl_xor(L[s], 16);
+        }
+        bitonic_merge<KP>(V);
     }
-    float tau;                                       // the K-th smallest key of the row
-    {
-        float mn[K];
+    float mn[K];
 #pragma unroll
-        for (int s = 0; s < K; ++s) mn[s] = kmin(L[s], __shfl_xor(L[K - 1 - s], 32));
-        float m3[(K + 2) / 3];
+    for (int s = 0; s < K; ++s) mn[s] = kmin(V[s], __shfl_xor(V[K - 1 - s], 32));
+    constexpr int G3 = (K + 2) / 3;
+    float m3[G3];
 #pragma unroll
-        for (int s = 0; s < (K + 2) / 3; ++s)
-            m3[s] = max3(mn[3 * s], mn[3 * s + 1 < K ? 3 * s + 1 : 3 * s], mn[3 * s + 2 < K ? 3 * s + 2 : 3 * s]);
-        tau = m3[0];
+    for (int s = 0; s < G3; ++s)
+        m3[s] = max3(mn[3 * s], mn[3 * s + 1 < K ? 3 * s + 1 : 3 * s], mn[3 * s + 2 < K ? 3 * s + 2 : 3 * s]);
+    float tau = m3[0];
 #pragma unroll
-        for (int s = 1; s + 1 < (K + 2) / 3; s += 2) tau = max3(tau, m3[s], m3[s + 1]);
-        if (((K + 2) / 3) % 2 == 0) tau = kmax(tau, m3[(K + 2) / 3 - 1]);
+    for (int s = 1; s + 1 < G3; s += 2) tau = max3(tau, m3[s], m3[s + 1]);
+    if (G3 % 2 == 0) tau = kmax(tau, m3[G3 - 1]);
+    return tau;
+}
+
+#ifndef SGPR_BIG_KL20
+#define SGPR_BIG_KL20 12      // K = 20: entries a lane keeps of its own candidates in the first attempt (20: always exact, no retry)
+#endif
+template <int FMT, int K, int KP>
+__device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n, const int nrt, const bool one_rep,
+                                                 const unsigned char* __restrict__ X, const float* __restrict__ xx,
+                                                 unsigned short* __restrict__ nbr, const int wave, const bool coord,
+                                                 const bool sym) {
+    constexpr int XR = xrow<FMT>();
+    if (wave >= nrt) return;                         // no rows of the graph in this wave's tile
+    const int lane = phase_tid() & 63, l15 = lane & 15, lq = lane >> 4;
+    const int i = 16 * wave + l15;
+    const bool active = i < n;
+    const int jr = n - 1, tr = jr >> 4, rr = jr & 3, lqr = (jr >> 2) & 3;
+    OwnedKeys<FMT> keys;
+    keys.X = X;
+    keys.xx = xx;
+    keys.wave = wave;
+    keys.l15 = l15;
+    keys.lq = lq;
+    keys.coord = coord;
+    keys.sym = sym;
+    keys.ci = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (coord)
+        keys.ci = *reinterpret_cast<const float4*>(X + i * XR + (XR - 16));
+    else
+        xload<4, FMT>(X + i * XR, lq, keys.b);
+    // ---- pass 1: the K-th smallest key of the row
+    constexpr int KL = (K == 20 && SGPR_BIG_KL20 < 20) ? SGPR_BIG_KL20 : K, KPL = KL <= 16 ? 16 : 32;
+    float krep_part = 0.f, last_kept = 0.f;
+    float tau = owned_kth<FMT, K, KP, KL, KPL>(keys, nrt, tr, rr, krep_part, last_kept);
+    if constexpr (KL < K) {
+        if (__ballot(active && !(last_kept > tau)) != 0ull)      // some lane's list may have been cut short: the exact pass
+            tau = owned_kth<FMT, K, KP, K, KP>(keys, nrt, tr, rr, krep_part, last_kept);
     }
     unsigned short* out = nbr + i * p.kpitch;
     bool dup_cut = false;
@@ -1349,7 +1401,7 @@ __device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n
 #pragma unroll 2
     for (int tj = 0; tj < nrt; ++tj) {
         float key[4];
-        keys4(tj, key);
+        keys(tj, key);
         unsigned nib = 0u;
 #pragma unroll
         for (int r = 3; r >= 0; --r) nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(tau - key[r]), 31);
@@ -1379,7 +1431,7 @@ __device__ __forceinline__ void select_owned_big(const EmbedPlan& p, const int n
 #pragma unroll 1
     for (int tj = 0; tj < nrt; ++tj) {
         float key[4];
-        keys4(tj, key);
+        keys(tj, key);
         unsigned nib = 0u;
 #pragma unroll
         for (int r = 3; r >= 0; --r) nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(key[r] - tau), 31);
@@ -2574,6 +2626,20 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             f32x4 bown[4];
             const bool mine = wave < nrt;
             select_owned_big<FMT, KC, KP>(p, N, nrt, one_rep, X, xx, nbr, wave, L == 3, p.big == 2);
+#if SGPR_EXP_DOUBLE & 32
+            select_owned_big<FMT, KC, KP>(p, N, nrt, one_rep, X, xx, nbr, wave, L == 3, p.big == 2);
+#endif
+#if SGPR_EXP_DOUBLE & 64
+            if (mine) {
+                if (Kp != 64)
+                    gemm_own<1, 64, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
+                else if (cout == 64)
+                    gemm_own<4, 64, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
+                else
+                    gemm_own<4, 32, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
+                asm volatile("" : "+v"(bown[0]), "+v"(bown[1]), "+v"(bown[2]), "+v"(bown[3]));
+            }
+#endif
             if (mine) {
                 if (Kp != 64)
                     gemm_own<1, 64, FMT>(X, A, p.pitchA, kp.w.wh[L], kp.w.tb[L], wave, bown);
@@ -2717,8 +2783,9 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                     sa += lane_xor(sa, 8);
                     if (TWO) sb += lane_xor(sb, 8);
                     if ((lane & 15) == 0) {
-                        xx[ia] = sa;
-                        if (TWO) xx[ib] = sb;
+                        // (big instance: +inf for the slots the graph does not have - OwnedKeys ranks them last without an index test)
+                        xx[ia] = (!BIG || ia < N) ? sa : INFINITY;
+                        if (TWO) xx[ib] = (!BIG || ib < N) ? sb : INFINITY;
                     }
                 }
             };
@@ -2736,8 +2803,10 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
                                 rows(std::false_type{}, ga + sub, ga + sub);
                         }
                         const int z0 = ga >= N ? ga : (ga + rpw >= N ? ga + rpw : ga + 2 * rpw), z1 = ga + 2 * rpw;
-                        for (int e = lane; e < (z1 - z0) * QW; e += 64)
+                        for (int e = lane; e < (z1 - z0) * QW; e += 64) {
                             *reinterpret_cast<uint4*>(X + (z0 + e / QW) * XROW + (e % QW) * 16) = make_uint4(0u, 0u, 0u, 0u);
+                            if (e % QW == 0) xx[z0 + e / QW] = INFINITY;
+                        }
                     }
                 }
             } else {
