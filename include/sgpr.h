@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 7
+#define SGPR_ABI_VERSION 8
 
 enum {
     SGPR_OK = 0,
@@ -129,6 +129,10 @@ size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k);
 int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int k,
                float* d_pooled, float* d_att, float* d_emb, void* d_workspace, size_t workspace_bytes,
                void* stream);
+/* Without a node_cap promise (this call; node_cap 0 below) a launch of more graphs than the device has CUs still runs on
+ * the 64-row layout (K <= 16): a graph that needs more processed slots is embedded in the same call by the kernel
+ * instance sized for N (same bits; no error) - data whose graphs mostly exceed 64 processed slots is served faster
+ * with its node_cap (sgpr_size_order), which sizes one launch for all of them. */
 
 /* sgpr_embed with a promise about the input: no graph of the batch needs more than `node_cap` PROCESSED slots
  * (= slots before the trailing run of m identical padding slots, + 1 when m >= k, + m otherwise; 0 = no promise).
@@ -147,6 +151,17 @@ int sgpr_embed_capped(const sgpr_handle* h, const float* d_centers, const int32_
 int sgpr_embed_ordered(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, int G, int N, int node_cap,
                        int k, const int32_t* d_order, int n_order, float* d_pooled, float* d_att, float* d_emb,
                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The data-set properties sgpr_embed_capped / _ordered / _ragged take, computed on the device (two small launches, no
+ * host pass): d_order [G] i32 = graph indices by PROCESSED slots, largest first, stable; d_info [2] i32 = { node_cap =
+ * the largest processed-slot count of the batch, graphs beyond 64 processed slots }.  Padded arrays (d_centers, d_labels;
+ * d_offsets NULL) or a ragged store (d_offsets [G+1] i64; d_centers / d_labels unused, may be NULL).  The caller reads
+ * d_info[0] back once per data set (4 bytes) and passes it as node_cap.  The reference has no counterpart: it pads
+ * every graph to node_num (sg_net.py:258-272) and pays for node_num slots.  Workspace: sgpr_size_order_workspace_bytes(G). */
+size_t sgpr_size_order_workspace_bytes(int G);
+int sgpr_size_order(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, const int64_t* d_offsets, int G,
+                    int N, int k, int32_t* d_order, int32_t* d_info, void* d_workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* sgpr_embed_ordered over a RAGGED graph store: only the real nodes of a graph are in memory -
  *   d_centers [S,3] f32, d_labels [S] i8 (0 .. num_labels-1), d_offsets [G+1] i64: graph g owns nodes

@@ -556,6 +556,9 @@ void sgpr_destroy(sgpr_handle* h) {
 // debug-mask bits that keep the production kernel instance: 8192 forces the wide-range instance, 1 << 20 makes the split
 // launch's odd producers withhold their flag (test hook for the late-producer hand-over to the second pass)
 static constexpr int kProductionSkipBits = 8192 | (1 << 20);
+#ifndef SGPR_AUTO_LEAN
+#define SGPR_AUTO_LEAN 1      // 0 (A/B builds): a launch without a node_cap promise is sized for node_num
+#endif
 static bool wide_range(const sgpr_handle* h) { return !h->f16_weights || (h->dbg_skip & 8192); }
 
 static int check_nk(int G, int N, int k, int node_cap, EmbedPlan* plan, bool wide, bool small_park = false) {
@@ -680,10 +683,23 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     if (needs_generic(h, N, k)) return embed_generic(h, a, N, k, ws, ws_bytes, stream);
     // with at most one graph per CU there is nothing to overlap: keep the 512-thread workgroups (lower latency)
     a.promise = (node_cap > 0 && node_cap < N) ? node_cap : N;   // still enforced (a broken promise stays loud)
+    const bool promised = node_cap > 0 && node_cap < N;
     if (a.G <= h->num_cus) node_cap = 0;
     EmbedPlan plan;
     // production launches (no dumps, timers or ablation) of lean plans park only the super-node rows
     const bool production = !a.dbg_layers && !a.dbg_knn && !h->dbg_prof && !(h->dbg_skip & ~kProductionSkipBits);
+    // No promise, more graphs than CUs (the throughput regime): the launch still runs on the lean 64-row plan - four
+    // workgroups per CU, what KITTI-like data fits into - and a graph with more processed slots is handed to the
+    // owned-rows instance sized for node_num in the same call (launch_embed), instead of every graph paying for the
+    // largest one could be.  (The reference has no such prerequisite either: sg_net.py:503-525.)
+    bool auto_lean = false;
+    if (!promised && production && !wide_range(h) && a.G > h->num_cus && N > 64 && SGPR_AUTO_LEAN) {
+        EmbedPlan lean;
+        if (make_embed_plan(N, 64, k, &lean, false, true) && lean.lean) {
+            node_cap = 64;
+            auto_lean = true;
+        }
+    }
     int rc = check_nk(a.G, N, k, node_cap, &plan, wide_range(h), production);
     if (rc != SGPR_OK) return rc;
     // graphs are addressed by their own index: an ordered launch needs rows for all of them
@@ -695,6 +711,8 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     }
     a.redo = static_cast<unsigned char*>(ws);
     a.redo_count = embed_redo_count(a.redo, gtot);
+    a.over_count = a.redo_count + 1;                 // (the second word of the 8 bytes behind the flags)
+    a.auto_over = auto_lean ? 1 : 0;
     a.park_ws = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot));
     unsigned char* sem = static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot) + embed_park_bytes(gtot, N);
     a.sem_flag = reinterpret_cast<unsigned long long*>(sem);               // indexed by launch slot (< a.G <= num_cus / 2)
@@ -757,6 +775,29 @@ int sgpr_embed_ordered(const sgpr_handle* h, const float* d_centers, const int32
     a.att = d_att;
     a.emb = d_emb;
     return embed_common(h, a, N, k, node_cap, d_workspace, workspace_bytes, stream, G);
+}
+
+size_t sgpr_size_order_workspace_bytes(int G) { return G < 0 ? 0 : size_order_ws_bytes(G); }
+
+int sgpr_size_order(const sgpr_handle* h, const float* d_centers, const int32_t* d_labels, const int64_t* d_offsets, int G,
+                    int N, int k, int32_t* d_order, int32_t* d_info, void* d_workspace, size_t workspace_bytes,
+                    void* stream) {
+    if (!h || G < 0 || !d_info || (G > 0 && (!d_order || (!d_offsets && (!d_centers || !d_labels))))) {
+        set_error("sgpr_size_order: NULL argument or negative count");
+        return SGPR_E_INVALID;
+    }
+    if (N < 1 || N > SGPR_MAX_NODES || k < 1 || k > N) {
+        set_error("sgpr_size_order: node_num " + std::to_string(N) + " / K " + std::to_string(k) +
+                  " outside the tuned kernels' range (the any-shape kernels take no node_cap)");
+        return SGPR_E_NODES;
+    }
+    if (!d_workspace || workspace_bytes < size_order_ws_bytes(G)) {
+        set_error("sgpr_size_order: workspace of " + std::to_string(size_order_ws_bytes(G)) + " bytes required");
+        return SGPR_E_WORKSPACE;
+    }
+    DeviceGuard guard(h->device);
+    return launch_size_order(d_centers, d_labels, reinterpret_cast<const long long*>(d_offsets), G, N, k, h->dims.num_labels,
+                             d_order, d_info, d_workspace, static_cast<hipStream_t>(stream));
 }
 
 int sgpr_embed_ragged(const sgpr_handle* h, const float* d_centers, const int8_t* d_labels, const int64_t* d_offsets,

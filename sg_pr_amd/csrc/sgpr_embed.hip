@@ -94,6 +94,11 @@ __device__ __forceinline__ int phase_tid() {
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+#ifndef SGPR_OVER_IN_REDO
+#define SGPR_OVER_IN_REDO 0   // "auto" launches, node_num <= 128, K = 10: 1 = the second pass serves the oversize graphs instead of a launch
+#endif                        // of their own.  Measured (tools/run_auto.py, same box): KITTI-00 shape, no oversize graph: 147.7 us per
+                              // call against 149 + 5 (the empty launch) - nothing; 693 / 2180 oversize graphs of 4541: 501 / 791 us
+                              // against 307 / 443 (one workgroup per CU at the second pass's LDS size instead of two): off
 #ifndef SGPR_BIG_OWNED
 #define SGPR_BIG_OWNED 1      // production plans beyond 64 rows on the owned-rows instance (0: A/B builds on the chunked plans)
 #endif
@@ -255,7 +260,9 @@ struct KParams {
     DevWeights w;
     EmbedPlan p;
     EmbedPlan p2;     // embed_redo_kernel only: the full f16 plan beside the wide-range plan in p
+    EmbedPlan p3;     // embed_redo_kernel only: the owned-rows plan for node_num slots (big != 0: the kernel serves flag 3 itself)
     EmbedArgs a;
+    int num_cus;      // (host side: grid of the persistent launches)
 };
 
 // ------------------------------------------------------------------ MFMA helpers
@@ -2467,6 +2474,23 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         wdup = (float)m / (float)c;
         // (the scratch above sits in the X region: the barrier before X is written again follows below)
     }
+    if (N > p.NC && N <= kp.a.promise && !rag_bad && (kp.a.auto_over == 1 || kp.a.auto_over == 3) && kp.a.redo) {
+        // no promise was made and this launch's plan is the lean one: the graph goes to the owned-rows instance for
+        // node_num slots - inside the second pass (auto_over 3: flag 3 + the second pass's word) or in a launch of its own
+        // (1: flag 3 + over_count) - or, where that instance does not exist for this K, to the second pass's full plan
+        if (role == 1) return;
+        if (tid == 0) {
+            if (kp.a.auto_over == 3) {
+                request_redo(kp.a, launch_slot, 3);
+            } else if (kp.a.over_count) {
+                kp.a.redo[launch_slot] = 3;
+                __hip_atomic_store(kp.a.over_count, kp.a.sem_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                request_redo(kp.a, launch_slot, 2);
+            }
+        }
+        return;
+    }
     if (N > p.NC || N > kp.a.promise || rag_bad) {   // more slots to process than the caller's node_cap promised: fail loudly
         if (role == 1) return;                   // (reported by the graph's other workgroup)
         if (tid == 0) atomicOr(kp.a.status, rag_bad ? 8 : 2);
@@ -3022,6 +3046,18 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN 
 // Owned rows beyond 64 slots: up to sixteen waves (one per 16-row tile) under a 128-register budget
 template <int KP, int KC>
 __global__ __launch_bounds__(1024) void embed_big_kernel(const KParams kp) {
+    if (kp.a.auto_over == 2) {
+        // the launch behind an "auto" lean launch: the slots that launch flagged 3 (more processed slots than the lean
+        // plan holds), workgroup b those congruent to b.  Nothing flagged (KITTI-like data): one load, done - a PLAIN
+        // load, the word was stored by the previous kernel of the stream (see embed_redo_kernel)
+        if (*kp.a.over_count != kp.a.sem_epoch) return;
+        for (int slot = (int)blockIdx.x; slot < kp.a.G; slot += (int)gridDim.x) {      // (workgroup-uniform)
+            if (kp.a.redo[slot] != 3) continue;
+            embed_graph<KP, 0, 0, FMT_H2, KC, true>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, 0, -1);
+            __syncthreads();                             // LDS is reused by the next graph
+        }
+        return;
+    }
     const int slot = (int)blockIdx.x;
     embed_graph<KP, 0, 0, FMT_H2, KC, true>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, 0, -1);
 }
@@ -3046,16 +3082,39 @@ __global__ __launch_bounds__(NT_MAX, 1) void embed_redo_kernel(const KParams kp)
         if (threadIdx.x < 64) {
             const int slot = base + (int)threadIdx.x;
             const int f = slot < b1 ? kp.a.redo[slot] : 0;
-            const unsigned long long m1 = __ballot(f == 1), m2 = __ballot(f == 2);
+            // (3 without kp.p3.big belongs to embed_big_kernel's own launch, which ran ahead of this one)
+            const unsigned long long m1 = __ballot(f == 1), m2 = __ballot(f == 2), m3 = __ballot(f == 3);
             if (threadIdx.x == 0) {
                 reinterpret_cast<unsigned long long*>(smem)[0] = m1;
                 reinterpret_cast<unsigned long long*>(smem)[1] = m2;
+                reinterpret_cast<unsigned long long*>(smem)[2] = m3;
             }
         }
         __syncthreads();
         unsigned long long wide = reinterpret_cast<const unsigned long long*>(smem)[0];
         unsigned long long full = reinterpret_cast<const unsigned long long*>(smem)[1];
+        unsigned long long over = reinterpret_cast<const unsigned long long*>(smem)[2];
         __syncthreads();
+        // an "auto" lean launch's oversize graphs (more processed slots than its 64 rows): the owned-rows code for node_num
+        // slots (K = 10, node_num <= 128: it fits this kernel's 512 threads); it resets the flag and may raise 2 (the graph
+        // needs the generic semantic branch) or 1 (f16 range)
+#if SGPR_OVER_IN_REDO
+        if constexpr (KP == 16) {
+            while (over && kp.p3.big) {                      // workgroup-uniform
+                const int bit = __ffsll((long long)over) - 1;
+                const int slot = base + bit;
+                over &= over - 1;
+                embed_graph<KP, 0, 0, FMT_H2, 10, true>(kp, kp.p3, kp.a.ids ? kp.a.ids[slot] : slot, slot);
+                __threadfence();
+                __syncthreads();
+                const int f = __hip_atomic_load(&kp.a.redo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f == 2) full |= 1ull << bit;
+                if (f == 1) wide |= 1ull << bit;
+            }
+        }
+#else
+        (void)over;
+#endif
         // the graphs that need the generic semantic branch first: the full f16 plan resets the slot's flag and raises it
         // again (1) when an activation or a coordinate leaves the f16 range - such a slot joins the wide-range list
         while (full) {                                       // workgroup-uniform
@@ -3093,7 +3152,12 @@ static int launch_big_t(const KParams& kp, hipStream_t stream) {
     static LdsLimitOnce once;
     int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&embed_big_kernel<KP, KC>), kLdsLimit, "embed_big_kernel");
     if (rc != SGPR_OK) return rc;
-    hipLaunchKernelGGL((embed_big_kernel<KP, KC>), dim3(kp.a.G), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
+    int grid = kp.a.G;
+    if (kp.a.auto_over == 2) {                        // persistent: as many workgroups as the device holds at once
+        const int per_cu = kp.p.lds_bytes <= kLdsLimit / 2 && kp.p.nt <= 512 ? 2 : 1;
+        if (grid > per_cu * kp.num_cus) grid = per_cu * kp.num_cus;
+    }
+    hipLaunchKernelGGL((embed_big_kernel<KP, KC>), dim3(grid), dim3(kp.p.nt), kp.p.lds_bytes, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_big_kernel launch");
     return SGPR_OK;
@@ -3104,7 +3168,8 @@ static int launch_redo_t(const KParams& kp, int blocks, hipStream_t stream) {
     static LdsLimitOnce once;
     int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&embed_redo_kernel<KP, FMT>), kLdsLimit, "embed_redo_kernel");
     if (rc != SGPR_OK) return rc;
-    const int lds = kp.p.lds_bytes > kp.p2.lds_bytes ? kp.p.lds_bytes : kp.p2.lds_bytes;
+    int lds = kp.p.lds_bytes > kp.p2.lds_bytes ? kp.p.lds_bytes : kp.p2.lds_bytes;
+    if (kp.p3.big && kp.p3.lds_bytes > lds) lds = kp.p3.lds_bytes;
     hipLaunchKernelGGL((embed_redo_kernel<KP, FMT>), dim3(blocks), dim3(kp.p.nt), lds, stream, kp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "embed_redo_kernel launch");
@@ -3136,7 +3201,25 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kp.p = plan;
     kp.p2 = plan;
     kp.a = a;
+    kp.num_cus = h->num_cus;
     if (kp.a.promise <= 0 || kp.a.promise > plan.N) kp.a.promise = plan.N;   // no promise made
+    // "auto" launch (embed_common): a lean plan although nothing was promised - oversize graphs are handed on
+    EmbedPlan over_plan;
+    bool over_launch = false, over_in_redo = false;
+    if (kp.a.auto_over == 1) {
+        if (!(plan.fmt == FMT_H2 && plan.lean && a.redo && a.over_count)) {
+            kp.a.auto_over = 0;
+        } else {
+            over_launch = make_embed_plan(plan.N, 0, plan.k, &over_plan, false, true) && over_plan.big;
+            if (!over_launch) {
+                kp.a.over_count = nullptr;                        // (no owned-rows instance for this K: the second pass's full plan)
+            } else if (over_plan.nt <= 512 && plan.k == 10 && SGPR_OVER_IN_REDO) {
+                kp.a.auto_over = 3;                               // node_num <= 128: the second pass runs the owned-rows code itself
+                over_launch = false;
+                over_in_redo = true;
+            }
+        }
+    }
     // split launch: lean production plans on packed input when every workgroup of both halves gets a CU of its own
     // (measured: two workgroups sharing a CU cost each other more than the split saves - 64 graphs 38.0 -> 31.7 us per
     // call, 128 graphs 38.1 -> 34.6, 256 graphs 37.9 -> 44.2); the caller reserved sem_tab / sem_flag in the workspace
@@ -3161,11 +3244,25 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     else
         rc = mode == 2 ? launch_layout<32, 2>(plan, kp, stream)
                        : (mode == 1 ? launch_layout<32, 1>(plan, kp, stream) : launch_layout<32, 0>(plan, kp, stream));
+    if (rc == SGPR_OK && over_launch && mode == 0) {
+        // the graphs the lean launch could not hold, on the owned-rows instance sized for node_num (persistent workgroups)
+        KParams ko = kp;
+        ko.p = over_plan;
+        ko.p2 = over_plan;
+        ko.a.auto_over = 2;
+        ko.a.sem_tab = nullptr;
+        ko.a.sem_flag = nullptr;
+        rc = over_plan.kp == 16 ? launch_big_t<16, 10>(ko, stream) : launch_big_t<32, 20>(ko, stream);
+    }
     if (rc != SGPR_OK || plan.fmt != FMT_H2 || !a.redo || mode == 1) return rc;
     // second pass over the graphs the f16 instance flagged, on the wide-range plan (no node_cap: any graph fits)
     KParams kr = kp;
-    bool ok = make_embed_plan(plan.N, 0, plan.k, &kr.p, true) && make_embed_plan(plan.N, 0, plan.k, &kr.p2, false, false, kr.p.nt);
+    const int nt_floor = over_in_redo ? (over_plan.nt > 256 ? 512 : 256) : 0;
+    bool ok = make_embed_plan(plan.N, 0, plan.k, &kr.p, true, false, nt_floor) && make_embed_plan(plan.N, 0, plan.k, &kr.p2, false, false, kr.p.nt);
     if (ok && kr.p2.nt != kr.p.nt) ok = make_embed_plan(plan.N, 0, plan.k, &kr.p, true, false, kr.p2.nt);   // one block size for both
+    kr.p3 = plan;
+    kr.p3.big = 0;
+    if (over_in_redo) kr.p3 = over_plan;
     if (!ok || kr.p.nt != kr.p2.nt) {
         set_error("no second-pass LDS plan for node_num " + std::to_string(plan.N));
         return SGPR_E_NODES;
@@ -3174,7 +3271,9 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kr.a.dbg_knn = nullptr;
     kr.a.prof = nullptr;
     kr.a.skip = 0;
-    const int blocks = a.G < 64 ? a.G : 64;
+    // (an "auto" launch may hand this pass many graphs: a workgroup per CU)
+    const int nblk = over_in_redo ? h->num_cus : 64;
+    const int blocks = a.G < nblk ? a.G : nblk;
     if (plan.kp == 16)
         return kr.p.fmt == FMT_BF3 ? launch_redo_t<16, FMT_BF3>(kr, blocks, stream) : launch_redo_t<16, FMT_F32>(kr, blocks, stream);
     return kr.p.fmt == FMT_BF3 ? launch_redo_t<32, FMT_BF3>(kr, blocks, stream) : launch_redo_t<32, FMT_F32>(kr, blocks, stream);

@@ -155,6 +155,12 @@ struct EmbedArgs {
     float* park_ws;         // [G][NP][32] when !park_in_lds
     unsigned char* redo;    // [launch slots] written by the f16 instance: 1 = the graph left the f16 range -> embed_redo_kernel
     unsigned* redo_count;   // one word: receives sem_epoch when any slot asks for the second pass (else untouched)
+    // no promise from the caller and a plan for fewer slots than node_num (launch_embed, "auto" launches): a graph that
+    // needs more processed slots than the plan holds is handed on instead of being an error - redo[slot] = 3 and the
+    // launch's token in over_count (the owned-rows instance for node_num slots takes those graphs in a launch of its own),
+    // or a plain second-pass request when over_count is NULL
+    unsigned* over_count;
+    int auto_over;          // 1: the hand-over above applies; 2 (embed_big_kernel only): persistent launch over the slots flagged 3
     // split launch (sgpr_embed.hip): workgroup s < G (a PRODUCER: the semantic half of launch slot s) publishes the 16
     // sem3 rows of the slot in sem_tab[s][16][32] and sem_flag[s] = token(s); workgroup G + s (the CONSUMER: the xyz half)
     // picks them up before conv_end.  Producers own the lower block indices and are therefore dispatched first - the
@@ -201,6 +207,10 @@ int launch_ntn(const float* w, const float* wb, const float* bias, const float* 
 int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);
 int launch_graph_feature(const float* x, const int64_t* idx, int B, int C, int N, int k, float* out, hipStream_t stream);
 int launch_attention_pool(const float* w, const float* emb, int B, int N, float* rep, float* att, hipStream_t stream);
+
+size_t size_order_ws_bytes(int G);
+int launch_size_order(const float* centers, const int32_t* labels, const long long* rag_off, int G, int N, int k,
+                      int num_labels, int32_t* order, int32_t* info, void* ws, hipStream_t stream);
 
 size_t cluster_ws_bytes(int P);
 int launch_cluster_scan(const float* pts, int stride, const uint32_t* label, int P, int max_nodes, double* centers,

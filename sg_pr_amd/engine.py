@@ -14,6 +14,7 @@ from . import _build
 
 NUM_LABELS = 12
 F3 = 32
+MAX_NODES = 256     # SGPR_MAX_NODES of include/sgpr.h: node_num of the tuned kernels (beyond: the any-shape kernels)
 
 # order of the fp32 tensors in the weights blob (include/sgpr.h, sgpr_weights_count)
 _CONV_BLOCKS = ["dgcnn_s_conv1", "dgcnn_f_conv1", "dgcnn_s_conv2", "dgcnn_f_conv2",
@@ -33,6 +34,7 @@ ERROR_NAMES = {-1: "SGPR_E_INVALID", -2: "SGPR_E_DIMS", -3: "SGPR_E_NODES", -4: 
 ABI_SYMBOLS = ["sgpr_weights_count", "sgpr_create", "sgpr_destroy", "sgpr_pooled_width", "sgpr_is_any_shape",
                "sgpr_embed_workspace_bytes", "sgpr_embed",
                "sgpr_embed_capped", "sgpr_embed_ordered", "sgpr_embed_ragged",
+               "sgpr_size_order_workspace_bytes", "sgpr_size_order",
                "sgpr_embed_dense", "sgpr_embed_debug", "sgpr_score_pairs", "sgpr_pair_plan_ints", "sgpr_pair_plan",
                "sgpr_score_pair_list_workspace_bytes", "sgpr_score_pair_list", "sgpr_score_all_pairs_workspace_bytes",
                "sgpr_score_all_pairs", "sgpr_score_all_pairs_multi_workspace_bytes", "sgpr_score_all_pairs_multi",
@@ -114,6 +116,10 @@ def load_library():
     lib.sgpr_embed_ordered.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_ragged.restype = i32
     lib.sgpr_embed_ragged.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+    lib.sgpr_size_order_workspace_bytes.restype = sz
+    lib.sgpr_size_order_workspace_bytes.argtypes = [i32]
+    lib.sgpr_size_order.restype = i32
+    lib.sgpr_size_order.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.sgpr_embed_dense.restype = i32
     lib.sgpr_embed_dense.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sgpr_embed_debug.restype = i32
@@ -338,14 +344,42 @@ class Engine:
         return int(eff.max().item()) if eff.numel() else 0
 
     def size_order(self, centers, labels, k):
-        """Launch order for sgpr_embed_ordered: graph indices sorted by processed slots, largest first, plus the
-        node_cap they justify -> (order i32 device tensor [G], node_cap).  A property of the packed data - build it
-        once per dataset (it synchronises for device inputs)."""
+        """Launch order for sgpr_embed_ordered: graph indices sorted by processed slots, largest first (stable), plus
+        the node_cap they justify -> (order i32 device tensor [G], node_cap).  A property of the packed data - build
+        it once per dataset.  Computed on the device (sgpr_size_order: two small launches and a 4-byte read-back, which
+        synchronises); host arrays are uploaded first.  Beyond the tuned kernels' node_num / on an any-shape handle
+        (where no launch takes a node_cap) the torch form below answers."""
+        labels_t = torch.as_tensor(labels)
+        g, n = labels_t.shape
+        if g == 0:
+            return torch.empty(0, dtype=torch.int32, device=self.device), 0
+        if n > MAX_NODES or self.any_shape:
+            return self.size_order_torch(centers, labels, k)
+        order, info = self.size_order_device(self._dev(centers, torch.float32, "centers"),
+                                             self._dev(labels_t, torch.int32, "labels"), None, n, k)
+        return order, int(info[0].item())
+
+    def size_order_torch(self, centers, labels, k):
+        """size_order by torch ops (the checker of the device kernel; any node_num)."""
         eff = self.processed_slots(centers, labels, k)
         if eff.numel() == 0:
             return torch.empty(0, dtype=torch.int32, device=self.device), 0
         order = torch.argsort(eff, descending=True, stable=True).to(torch.int32).to(self.device)
         return order, int(eff.max().item())
+
+    def size_order_device(self, centers, labels, offsets, node_num, k):
+        """sgpr_size_order without the read-back: (order i32 [G], info i32 [2] = node_cap, graphs beyond 64 slots), both
+        on the device, asynchronous.  Padded arrays (offsets None) or a ragged store's offsets (centers / labels None)."""
+        g = (offsets.numel() - 1) if offsets is not None else labels.shape[0]
+        order = torch.empty(g, dtype=torch.int32, device=self.device)
+        info = torch.zeros(2, dtype=torch.int32, device=self.device)
+        ws_bytes = self.lib.sgpr_size_order_workspace_bytes(g)
+        ws = self._ws(ws_bytes)
+        rc = self.lib.sgpr_size_order(self._h, _ptr(centers if offsets is None else None),
+                                      _ptr(labels if offsets is None else None), _ptr(offsets), g, int(node_num), int(k),
+                                      _ptr(order), _ptr(info), _ptr(ws), ws_bytes, self._stream())
+        self._check(rc)
+        return order, info
 
     def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None):
         """centers [G,N,3] f32, labels [G,N] i32 (-1 = pad) -> pooled [G,32] (+ att [G,N], emb [G,N,32]).
@@ -403,6 +437,9 @@ class Engine:
     def ragged_order(self, offsets, node_num, k):
         """size_order for a ragged store: (largest-first launch order i32 device tensor, node_cap).  A graph of c nodes
         in node_num slots has m = node_num - c padding slots, of which one is processed when m >= k (else all m)."""
+        if node_num <= MAX_NODES and not self.any_shape and len(offsets) > 1:
+            order, info = self.size_order_device(None, None, self._dev(offsets, torch.int64, "offsets"), node_num, k)
+            return order, int(info[0].item())
         off = torch.as_tensor(offsets).to(torch.int64).cpu()
         cnt = off[1:] - off[:-1]
         m = node_num - cnt

@@ -334,6 +334,67 @@ def test_ordered_embed_is_bitwise_equal_and_loud(eng):
     assert ei.value.code == -3
 
 
+def test_plain_embed_hands_oversize_graphs_on(eng):
+    """sgpr_embed without a node_cap promise (the reference has no such prerequisite, sg_net.py:503-525) runs the 64-row
+    layout when there are more graphs than CUs; a graph with more processed slots is embedded in the same call by the
+    instance sized for node_num - inside the second pass (node_num <= 128) or in a launch of its own (node_num 256) -
+    with the bits of the capped launch, and is no error.  An explicit promise that is broken stays loud."""
+    from sg_pr_amd import synth
+    from sg_pr_amd.engine import SgprError
+    for num, n, lo, hi, kitti in ((1500, 100, 25, 70, True), (700, 100, 40, 85, False), (900, 128, 30, 110, False),
+                                  (600, 256, 20, 120, False), (400, 100, 3, 60, False)):
+        centers, labels, _ = synth.make_graphs(num, n, lo, hi, 900 + n + hi, kitti_like=kitti)
+        eff = eng.processed_slots(centers, labels, 10)
+        cap = int(eff.max())
+        plain, att0, emb0 = eng.embed(centers, labels, 10, want_att=True, want_emb=True)
+        eng.check_status()                                            # nothing to report
+        capped, att1, emb1 = eng.embed(centers, labels, 10, want_att=True, want_emb=True, node_cap=cap)
+        eng.check_status()
+        assert torch.equal(plain, capped) and torch.equal(att0, att1) and torch.equal(emb0, emb1), (num, n, cap)
+        assert not torch.isnan(plain).any()
+        if hi > 64:
+            assert int((eff > 64).sum()) > 0                          # the hand-over ran
+    # ragged store and explicit launch order, still without a promise
+    centers, labels, _ = synth.make_graphs(1200, 100, 30, 80, 77)
+    rc, rl, ro = eng.to_ragged(centers, labels)
+    order, cap = eng.size_order(centers, labels, 10)
+    ref = eng.embed(centers, labels, 10, node_cap=cap)[0]
+    assert torch.equal(eng.embed_ragged(rc, rl, ro, 100, 10)[0], ref)
+    assert torch.equal(eng.embed(centers, labels, 10, order=order)[0], ref)
+    eng.check_status()
+    # a promise is a promise
+    bad = eng.embed(centers, labels, 10, node_cap=64)[0]
+    assert torch.isnan(bad).any()
+    with pytest.raises(SgprError) as ei:
+        eng.check_status()
+    assert ei.value.code == -3
+
+
+def test_size_order_on_the_device(eng):
+    """sgpr_size_order (processed slots -> node_cap + stable largest-first order, two launches on the device) against
+    the torch form of the same rule, padded arrays and ragged stores; labels outside the checkpoint's classes count as
+    padding there as they do in the embed kernel (which reports them)."""
+    from sg_pr_amd import synth
+    for num, n, lo, hi, k in ((4541, 100, 25, 60, 10), (700, 64, 17, 64, 10), (1000, 256, 100, 236, 20), (3, 100, 1, 5, 10),
+                              (70000, 24, 1, 24, 4), (513, 100, 0, 100, 10)):
+        centers, labels, _ = synth.make_graphs(num, n, max(lo, 1), hi, 5 + num)
+        if lo == 0:
+            labels[::7] = -1                                          # empty graphs
+            centers[::7] = 0.0
+        want_order, want_cap = eng.size_order_torch(centers, labels, k)
+        order, cap = eng.size_order(centers, labels, k)
+        assert cap == want_cap and torch.equal(order, want_order), (num, n)
+        info = eng.size_order_device(torch.from_numpy(centers).cuda(), torch.from_numpy(labels).cuda(), None, n, k)[1]
+        assert info.tolist() == [want_cap, int((eng.processed_slots(centers, labels, k) > 64).sum())]
+        rc, rl, ro = eng.to_ragged(centers, labels)
+        r_order, r_cap = eng.ragged_order(ro, n, k)
+        off = torch.as_tensor(ro)
+        cnt = off[1:] - off[:-1]
+        m = n - cnt
+        eff = cnt + torch.where((m >= k) & (m > 1), torch.ones_like(m), m)
+        assert r_cap == int(eff.max()) and torch.equal(r_order.cpu(), torch.argsort(eff, descending=True, stable=True).to(torch.int32))
+
+
 def test_device_f1_max_and_counts(eng):
     """the score matrix stays on the GPU.  sgpr_pair_positives / sgpr_pair_threshold_counts == their numpy
     restatements (poses and explicit labels, sharded rows, ranking of the negatives), and F1-max / ROC area equal the
