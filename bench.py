@@ -52,7 +52,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak (= fp32 matrix peak)
-SHADER_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: peak engine clock
+SHADER_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: peak engine clock (used only when the --pmc passes carry no measured one)
 KITTI_FRAMES = {"00": 4541, "02": 4661, "05": 2761, "06": 1101, "08": 4071}
 
 
@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--graphs", type=int, default=4541, help="M for the kitti00 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-pairs", type=int, default=0,
+                    help="size of the CPU baseline's sample in pairs (0: bounded by --cpu-seconds; SURVEY.md 8d's calibration "
+                         "sample is 100000 - minutes of CPU time, profiles/rNN_cpu_baseline_100k.json)")
     ap.add_argument("--embed-mode", default="ordered", choices=["ordered", "capped"],
                     help="launch the graphs largest-first (default) or in storage order")
     ap.add_argument("--no-gather", action="store_true", help="leave the score matrix sharded (skip the gather)")
@@ -207,7 +210,8 @@ def main():
     n_eff_all = []                  # processed slots of those graphs (algorithmic FLOPs)
     host_inputs = []                # (centers, labels) numpy, for the transfer-inclusive runs and the CPU baseline
     host_pairs, plan, plan_ms = None, None, None
-    host_prep_ms = 0.0              # one-off host cost of node_cap / launch order (and the pair plan): data-set properties
+    prep_ms = 0.0                   # one-off cost of node_cap / launch order on the DEVICE (sgpr_size_order on the resident
+                                    # arrays + a 4-byte read-back): data-set properties
 
     def counted(kind, fn):
         def wrapped(*x, **kw):
@@ -234,18 +238,22 @@ def main():
                 centers, labels, _, poses = synth.kitti_like_sequence(num_graphs=m, node_num=n, seed=si)
             host_inputs.append((centers, labels, poses))
             lo, hi = allpairs.shard_bounds(m, world, rank)
-            t_h = time.perf_counter()
-            node_cap = eng.node_cap_of(centers, labels, k)   # dataset property (the graph store knows its node counts)
-            order = eng.size_order(centers[lo:hi], labels[lo:hi], k)[0] if a.embed_mode == "ordered" else None
+            d_c, d_l = torch.from_numpy(centers).to(dev), torch.from_numpy(labels).to(dev)
+            eng.size_order(d_c[lo:hi], d_l[lo:hi], k)        # (first use: module load)
             torch.cuda.synchronize()
-            host_prep_ms += (time.perf_counter() - t_h) * 1e3
+            t_h = time.perf_counter()
+            order, node_cap = eng.size_order(d_c[lo:hi], d_l[lo:hi], k)   # on the device, from the resident arrays
+            torch.cuda.synchronize()
+            prep_ms += (time.perf_counter() - t_h) * 1e3
+            if a.embed_mode != "ordered":
+                order = None
             scorer = allpairs.AllPairsScorer(model=model)
             scorer.embed_fn = counted("embed", lambda c, l, cap=node_cap, o=order: eng.embed(c, l, k, node_cap=cap, order=o)[0])
             scorer.score_fn = counted("tail", model.score_all_pairs)
             full_out = (torch.empty(m, m, dtype=torch.float32, device=dev)
                         if (world > 1 and rank == 0 and not a.no_gather) else None)
             jobs.append({"name": name, "m": m, "scorer": scorer, "out": full_out, "node_cap": node_cap,
-                         "d_centers": torch.from_numpy(centers).to(dev), "d_labels": torch.from_numpy(labels).to(dev)})
+                         "d_centers": d_c, "d_labels": d_l})
             units += m * m
             graphs_per_step += hi - lo
             n_eff_all.append(synth.effective_nodes(centers[lo:hi], labels[lo:hi], k))
@@ -256,10 +264,13 @@ def main():
             seqset = allpairs.SequenceSet(jobs[0]["scorer"], [(j["d_centers"], j["d_labels"]) for j in jobs],
                                           batch_tails=not a.per_sequence_tails)
             eng.score_all_pairs_multi = counted("tail", eng.score_all_pairs_multi)   # (the batched tails' launches)
-            t_h = time.perf_counter()
-            set_order = (eng.size_order(seqset.centers, seqset.labels, k)[0] if a.embed_mode == "ordered" else None)
             torch.cuda.synchronize()
-            host_prep_ms += (time.perf_counter() - t_h) * 1e3
+            t_h = time.perf_counter()
+            set_order, node_cap_report = eng.size_order(seqset.centers, seqset.labels, k)
+            torch.cuda.synchronize()
+            prep_ms = (time.perf_counter() - t_h) * 1e3          # (the set's order replaces the per-sequence ones)
+            if a.embed_mode != "ordered":
+                set_order = None
             set_embed = counted("embed", lambda c, l: eng.embed(c, l, k, node_cap=node_cap_report, order=set_order)[0])
 
         def step(gather=not a.no_gather):
@@ -277,6 +288,11 @@ def main():
             j0 = jobs[0]
             lo0, hi0 = allpairs.shard_bounds(j0["m"], world, rank)
             dur_calls["embed"] = lambda: j0["scorer"].embed_fn(j0["d_centers"][lo0:hi0], j0["d_labels"][lo0:hi0])
+            _c0, _l0 = j0["d_centers"][lo0:hi0].contiguous(), j0["d_labels"][lo0:hi0].contiguous()
+            _ord0 = eng.size_order_device(_c0, _l0, None, n, k)[0]
+            dur_calls["embed_plain"] = lambda: eng.embed(_c0, _l0, k)[0]
+            dur_calls["embed_order_only"] = lambda: eng.embed(_c0, _l0, k, order=_ord0)[0]
+            dur_calls["size_order"] = lambda: eng.size_order_device(_c0, _l0, None, n, k)[0]
         if seqset is not None and not a.per_sequence_tails and world == 1:
             _pl = [eng.embed(j["d_centers"], j["d_labels"], k)[0] for j in jobs]
             _outs = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
@@ -305,31 +321,39 @@ def main():
         li, lj = np.concatenate(parts_i), np.concatenate(parts_j)
         perm = np.random.default_rng(2024).permutation(li.size)       # the reference's files are in shuffled order
         li, lj = li[perm].astype(np.int32), lj[perm].astype(np.int32)
-        lo, hi = allpairs.shard_bounds(li.size, world, rank)          # pair-list mode shards the LIST
+        # pair-list mode (sg_pr_amd/eval_batch.py:score_pair_list): the GRAPHS are sharded - rank r embeds graphs
+        # [glo_r, ghi_r) of the table, one all_gather_into_tensor of pooled (M x 128 bytes) - then the list: rank r scores
+        # pairs [lo_r, hi_r) against the full table (a contiguous split of the shuffled LIST alone would make every rank
+        # embed ~85 % of all graphs)
+        m = centers.shape[0]
+        lo, hi = allpairs.shard_bounds(li.size, world, rank)
+        glo, ghi = allpairs.shard_bounds(m, world, rank)
         li, lj = li[lo:hi], lj[lo:hi]
         host_inputs.append((centers, labels, None))
         host_pairs = (li, lj)
-        m = centers.shape[0]
         units = int(sum(fx["seq_" + nm].shape[0] for nm, _ in seqs))
-        used = np.unique(np.concatenate((li, lj)))                    # a rank embeds only the graphs its pairs name
-        remap = np.full(m, -1, dtype=np.int32)
-        remap[used] = np.arange(used.size, dtype=np.int32)
+        used = np.arange(glo, ghi)                                    # the graphs THIS rank embeds
+        remap = np.arange(m, dtype=np.int32)                          # (pooled holds the whole table after the all-gather)
         d_centers, d_labels = torch.from_numpy(centers[used]).to(dev), torch.from_numpy(labels[used]).to(dev)
-        t_h = time.perf_counter()
-        node_cap_report = eng.node_cap_of(centers[used], labels[used], k)
-        order = eng.size_order(centers[used], labels[used], k)[0] if a.embed_mode == "ordered" else None
+        eng.size_order(d_centers, d_labels, k)
         torch.cuda.synchronize()
-        host_prep_ms += (time.perf_counter() - t_h) * 1e3
         t_h = time.perf_counter()
-        plan = eng.pair_plan(remap[li], remap[lj], used.size, used.size)
+        order, node_cap_report = eng.size_order(d_centers, d_labels, k)
+        torch.cuda.synchronize()
+        prep_ms += (time.perf_counter() - t_h) * 1e3
+        if a.embed_mode != "ordered":
+            order = None
+        t_h = time.perf_counter()
+        plan = eng.pair_plan(remap[li], remap[lj], m, m)
         plan_ms = (time.perf_counter() - t_h) * 1e3
         graphs_per_step = int(used.size)
         n_eff_all.append(synth.effective_nodes(centers[used], labels[used], k))
-        embed_t = counted("embed", lambda: eng.embed(d_centers, d_labels, k, node_cap=node_cap_report, order=order)[0])
+        embed_local = counted("embed", lambda: eng.embed(d_centers, d_labels, k, node_cap=node_cap_report, order=order)[0])
+        embed_t = (lambda: allpairs.all_gather_rows(embed_local(), m)) if world > 1 else embed_local
         _pooled0 = embed_t()
         _score0 = torch.empty(plan.P, dtype=torch.float32, device=dev)
         tail_t = counted("tail", lambda pooled: eng.score_pair_list(pooled, pooled, plan, out=_score0))
-        dur_calls["embed"] = embed_t
+        dur_calls["embed"] = embed_local
         dur_calls["tail"] = lambda: tail_t(_pooled0)
         _d_i, _d_j = torch.from_numpy(remap[li]).to(dev), torch.from_numpy(remap[lj]).to(dev)
         dur_calls["tail_one_wave_per_pair"] = lambda: eng.score_pairs(_pooled0, _pooled0, _d_i, _d_j, out=_score0)
@@ -361,11 +385,14 @@ def main():
         d_centers, d_labels = torch.from_numpy(centers).to(dev), torch.from_numpy(labels).to(dev)
         cc = torch.cat((d_centers[0::2], d_centers[1::2])).contiguous()
         ll = torch.cat((d_labels[0::2], d_labels[1::2])).contiguous()
-        t_h = time.perf_counter()
-        node_cap_report = eng.node_cap_of(centers, labels, k)
-        order = eng.size_order(cc, ll, k)[0] if a.embed_mode == "ordered" else None
+        eng.size_order(cc, ll, k)
         torch.cuda.synchronize()
-        host_prep_ms += (time.perf_counter() - t_h) * 1e3
+        t_h = time.perf_counter()
+        order, node_cap_report = eng.size_order(cc, ll, k)
+        torch.cuda.synchronize()
+        prep_ms += (time.perf_counter() - t_h) * 1e3
+        if a.embed_mode != "ordered":
+            order = None
         graphs_per_step = m
         n_eff_all.append(synth.effective_nodes(centers, labels, k))
         embed_t = counted("embed", lambda: eng.embed(cc, ll, k, node_cap=node_cap_report, order=order)[0])
@@ -435,6 +462,14 @@ def main():
 
     launches_timed = max(16, a.kernel_reps)
     embed_ms = kernel_ms(dur_calls["embed"], launches_timed)
+    # the same graphs through the calls that need no data-set property: no node_cap promise (the 64-row layout + hand-over of
+    # larger graphs), with and without the device-made launch order
+    embed_forms = None
+    if world == 1 and "embed_plain" in dur_calls:
+        embed_forms = {"ordered_with_node_cap": embed_ms,
+                       "plain_no_promise": kernel_ms(dur_calls["embed_plain"], launches_timed),
+                       "ordered_no_promise": kernel_ms(dur_calls["embed_order_only"], launches_timed),
+                       "size_order_launches": kernel_ms(dur_calls["size_order"], launches_timed)}
     tail_ms = kernel_ms(dur_calls["tail"], launches_timed) if "tail" in dur_calls else None
     one_wave_ms = kernel_ms(dur_calls["tail_one_wave_per_pair"], 16) if "tail_one_wave_per_pair" in dur_calls else None
     step_ms = dt / a.steps * 1e3
@@ -500,11 +535,12 @@ def main():
     end_to_end = None
     if allpairs_job and world == 1 and not a.no_end_to_end:
         try:
-            # the graphs cross PCIe as the ragged store (sgpr_embed_ragged: 13 bytes per real node, no padding slots); the
-            # launch order and node_cap are properties of the data set, computed once and kept on the device
+            # the graphs cross PCIe as the ragged store (sgpr_embed_ragged: 13 bytes per real node, no padding slots); what a
+            # FRESH data set pays is inside the step: the launch order is computed on the device from the offsets that just
+            # arrived (sgpr_size_order, no read-back) and the launch makes no node_cap promise (the 64-row layout + the
+            # hand-over of larger graphs)
             ragged = [eng.to_ragged(c, l) for c, l, _ in host_inputs]
             pinned = [tuple(torch.from_numpy(x).pin_memory() for x in r) for r in ragged]
-            rag_plan = [eng.ragged_order(r[2], n, k) for r in ragged]
             h2d_bytes = sum(x.nbytes for r in ragged for x in r)
             host_out = [torch.empty(j["m"], j["m"], dtype=torch.float32).pin_memory() for j in jobs]
             xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
@@ -515,9 +551,10 @@ def main():
             dev_out = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
 
             def e2e(consumer):
-                for j, (pc, pl, po), (order_r, cap_r), ho, do, pz in zip(jobs, pinned, rag_plan, host_out, dev_out, xz):
+                for j, (pc, pl, po), ho, do, pz in zip(jobs, pinned, host_out, dev_out, xz):
                     dc, dl, do_ = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True), po.to(dev, non_blocking=True)
-                    pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=cap_r, order=order_r if a.embed_mode == "ordered" else None)[0]
+                    order_r = eng.size_order_device(None, None, do_, n, k)[0] if a.embed_mode == "ordered" else None
+                    pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=0, order=order_r)[0]
                     if consumer == "d2h":
                         # the matrix leaves in row blocks: block i crosses PCIe on the copy stream while block i + 1 is scored
                         m = j["m"]
@@ -543,7 +580,8 @@ def main():
                     e2e(consumer)
                 te = (time.perf_counter() - t0) / reps
                 end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
-            end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB) + the step + either "
+            end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB) + the launch order on "
+                                  "the device from the offsets that arrived + the step without a node_cap promise + either "
                                   "the D2H copy of the score matrices into pinned memory (%.1f MB, in %d row blocks whose copies "
                                   "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "
                                   "engine call with 64 bytes crossing PCIe (`device_f1`); %d repetitions"
@@ -580,16 +618,25 @@ def main():
                         # = 4 x SQ_ACTIVE_INST_VALU (the counter ticks once per 4 cycles an instruction occupies the
                         # pipe, matrix instructions included) against the SIMD-cycles of the launch (4 SIMDs per CU at
                         # the shader clock); the kernel's launch time tracks its instruction count
-                        simd_cycles = embed_ms * 1e-3 * SHADER_CLOCK_HZ * 4 * eng_cus
+                        # the shader clock is the one MEASURED under this kernel (tools/collect_profiles.py: SQ_BUSY_CYCLES over
+                        # the 32 shader engines / the kernel's duration in the same counter pass - a lower bound of the
+                        # clock, so an upper bound of the fraction; GRBM_GUI_ACTIVE gives the other side)
+                        clk_lo, clk_hi = pc.get("clock_ghz_from_sq_busy"), pc.get("clock_ghz_from_grbm")
+                        clock_hz = clk_lo * 1e9 if clk_lo else SHADER_CLOCK_HZ
+                        simd_cycles = embed_ms * 1e-3 * clock_hz * 4 * eng_cus
                         busy = 4.0 * pc.get("SQ_ACTIVE_INST_VALU", 0)
                         issue = {"bound": "valu_issue", "achieved": busy, "peak": simd_cycles, "unit": "SIMD-cycles",
                                  "frac": busy / simd_cycles,
+                                 "shader_clock_ghz": {"used": clock_hz / 1e9, "from_sq_busy_cycles": clk_lo, "from_grbm_gui_active": clk_hi,
+                                                      "measured": bool(clk_lo)},
+                                 "frac_at_grbm_clock": (busy / (embed_ms * 1e-3 * clk_hi * 1e9 * 4 * eng_cus)) if clk_hi else None,
                                  "instructions_per_launch": {k_: pc.get(k_) for k_ in (
                                      "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM")},
                                  "mfma_busy_cycles": pc.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                                  "wave_cycles": pc.get("SQ_WAVE_CYCLES"), "wait_cycles": pc.get("SQ_WAIT_ANY"),
                                  "note": "counters from the committed rocprofv3 --pmc passes of these sources; "
-                                         "launch time from this run; shader clock %.1f GHz assumed" % (SHADER_CLOCK_HZ / 1e9)}
+                                         "launch time from this run; shader clock %.2f GHz %s" % (
+                                             clock_hz / 1e9, "measured in the counter pass" if clk_lo else "assumed")}
                 pt = pmc.get("sgpr::score_all_pairs_kernel")
                 if pt and a.graphs == 4541:
                     traffic_tail = (2 * pt["FETCH_SIZE_KiB"] + pt["WRITE_SIZE_KiB"]) * 1024.0
@@ -599,7 +646,7 @@ def main():
                         # at throughput); the HBM figure above is what SURVEY 8d prices it against.  The
                         # event-timed call holds the prep kernel as well: the SIMD-cycles are an upper bound, the
                         # fraction a lower one (the kernel alone: profiles/rNN_kernel_stats.txt)
-                        simd_cycles_t = tail_ms * 1e-3 * SHADER_CLOCK_HZ * 4 * eng_cus
+                        simd_cycles_t = tail_ms * 1e-3 * (pmc.get("embed_kernel_counters", {}).get("clock_ghz_from_sq_busy") or SHADER_CLOCK_HZ / 1e9) * 1e9 * 4 * eng_cus
                         busy_t = 4.0 * tc["SQ_ACTIVE_INST_VALU"]
                         issue_tail = {"bound": "valu_issue", "achieved": busy_t, "peak": simd_cycles_t, "unit": "SIMD-cycles",
                                       "frac": busy_t / simd_cycles_t,
@@ -616,25 +663,27 @@ def main():
             "higher_is_better": True, "scaling": "strong" if (allpairs_job or a.workload == "pairlist") else "weak",
             "value_definition": "inputs and outputs resident in HBM (the bench contract); SURVEY.md 8d's transfer-inclusive "
                                 "figures are end_to_end.d2h (scores copied to the host) and end_to_end.device_f1 (F1-max on the "
-                                "device); a first call on fresh data also pays config.host_prep_ms_once (node_cap + launch order)",
+                                "device; they include the launch order computed on the device per step and make no node_cap promise)",
             "vs_baseline": None, "dtype": "f32 (2xf16-plane operands on the matrix cores, fp32 accumulate; fp32 vector math)",
             "data": data_kind,
             "config": {"workload": wl_name, "graphs": int(sum(mm for _, mm in seqs)) if allpairs_job else int(m),
                        "node_num": n, "K": k, "pairs_per_step": int(units), "node_cap": int(node_cap_report),
                        "embed_launch_order": "largest graph first" if a.embed_mode == "ordered" else "as stored",
-                       "parallelism": ("list-sharded x%d" if a.workload == "pairlist" else "row-sharded x%d") % world, "backend": backend if world > 1 else None,
+                       "parallelism": ("graphs + list sharded x%d" if a.workload == "pairlist" else "row-sharded x%d") % world, "backend": backend if world > 1 else None,
                        "gather_to_rank0": (not a.no_gather) if allpairs_job else None,
                        "gather_chunks": a.chunks if (allpairs_job and world > 1) else None,
                        "checkpoint": "tests/golden/model.pth",
-                       "host_prep_ms_once": host_prep_ms,
-                       "host_prep_note": "node_cap + largest-first launch order, computed once per data set outside "
-                                         "the timed step (and outside end_to_end)"},
+                       "device_prep_ms_once": prep_ms,
+                       "device_prep_note": "node_cap + largest-first launch order of the resident arrays: sgpr_size_order on the "
+                                           "device + a 4-byte read-back (wall time incl. the synchronisation), once per data set, "
+                                           "outside the timed step; end_to_end recomputes the order per step and promises no node_cap",
+                       "embed_calls_ms": embed_forms},
             "kernel_durations": {"embed_call_ms": embed_ms, "tail_call_ms": tail_ms, "sum_per_step_ms": kernels_ms,
                                  "ms_per_step": step_ms, "consistent": durations_consistent,
                                  "launches_timed": launches_timed},
             "sharded_output": sharded,
             "end_to_end": end_to_end,
-            "roofline": {"kernel": "sgpr::embed_kernel", "bound": "valu",
+            "roofline": {"kernel": "sgpr::embed_big_kernel" if a.workload == "stress" else "sgpr::embed_kernel", "bound": "valu",
                          "bound_note": "frac = useful-work-equivalent throughput (algorithmic FLOPs of the factored formulation at "
                                        "each graph's processed slots / launch time) against the fp32 VECTOR peak - not a pipe "
                                        "utilisation; what binds the kernel is vector issue + dependent latency (selection "
@@ -648,6 +697,11 @@ def main():
                          "graphs_per_launch": g / launches_per_step, "launches_per_step": launches_per_step,
                          "flops_per_launch_algorithmic": flops, "mean_nodes_processed": float(np.mean(n_eff)),
                          "dense_equivalent_tflops": flops_dense / (embed_ms * 1e-3) / 1e12,
+                         "frac_8d_dense": flops_dense / (embed_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         "frac_8d_dense_note": "SURVEY.md 8d's algorithmic FLOPs (factored formulation at ALL node_num slots) / launch "
+                                               "time / fp32 peak: above 1 because the kernel - exactly - does not do that work "
+                                               "(trailing duplicate slots collapse to one, the semantic branch runs on 13 label "
+                                               "super-nodes); not a utilisation, see issue.frac",
                          "flops_per_graph_dense": embed_flops_per_graph(n, k),
                          "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_graph": embed_bytes_per_graph(n)}},
@@ -687,7 +741,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.model, host_inputs[0][0], host_inputs[0][1], n, k, a.cpu_seconds,
-                                                   allpairs_job, pairs=host_pairs if a.workload == "pairlist" else None)
+                                                   allpairs_job, pairs=host_pairs if a.workload == "pairlist" else None,
+                                                   sample_pairs=a.cpu_pairs)
             except Exception as e:      # the GPU measurement above stands whatever happens to the host-side comparison leg
                 res["cpu_baseline"] = {"value": None, "unit": "graph-pairs/s", "cores": 0, "kind": "port", "sample": "failed",
                                        "error": "%s: %s" % (type(e).__name__, e)}
@@ -708,7 +763,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job, pairs=None):
+def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job, pairs=None, sample_pairs=0):
     """The oracle (faithful torch-CPU restatement of the reference forward: both graphs of
     every pair embedded, materialised edge tensors) timed on the host cores over a bounded
     sample of pairs drawn from the same workload."""
@@ -747,6 +802,8 @@ def cpu_baseline(ckpt, centers, labels, n, k, target_s, allpairs_job, pairs=None
     one, cores = best
     torch.set_num_threads(cores)
     reps = int(max(1, min(64, round(target_s / max(one, 1e-3)))))
+    if sample_pairs > 0:                      # an explicit sample size (100 000 pairs) instead of the time bound
+        reps = (int(sample_pairs) + bsz - 1) // bsz
     t0 = time.perf_counter()
     for _ in range(reps):
         f1, f2 = batch()

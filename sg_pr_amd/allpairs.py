@@ -64,6 +64,34 @@ def all_gather_varlen(t, group=None):
     return (out.to(dev) if staged else out), lens
 
 
+def all_gather_rows(local, total, group=None):
+    """The rows [lo_r, hi_r) = shard_bounds(total, world, r) of a 2-D tensor, one shard per rank -> all `total` rows on every
+    rank: ONE collective on equal-sized (padded) shards, straight into one tensor (all_gather_into_tensor: no list of
+    per-rank buffers, no concatenation); when the shards are equal - total divisible by the world size - the gathered
+    tensor IS the result, otherwise the padding rows of the shorter shards are dropped by one index copy."""
+    world, rank = _world_of(group)
+    lo, hi = shard_bounds(total, world, rank)
+    assert local.shape[0] == hi - lo
+    if world == 1:
+        return local
+    cap = shard_bounds(total, world, 0)[1]               # largest shard
+    if hi - lo == cap:
+        buf = local.contiguous()
+    else:
+        buf = local.new_zeros((cap,) + tuple(local.shape[1:]))
+        buf[: hi - lo] = local
+    staged = _host_staged(buf, group)
+    if staged:
+        buf = buf.cpu()
+    gathered = buf.new_empty((world * cap,) + tuple(buf.shape[1:]))
+    dist.all_gather_into_tensor(gathered, buf, group=group)
+    if world * cap != total:
+        keep = torch.cat([torch.arange(r * cap, r * cap + shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0])
+                          for r in range(world)]).to(gathered.device)
+        gathered = gathered.index_select(0, keep)
+    return gathered.to(local.device) if staged else gathered
+
+
 def agree_on_error(err, like=None, group=None):
     """Rank-local failures ahead of a collective would leave the other ranks blocked in it: every rank contributes
     its exception (or None) to one MAX all_reduce of a flag and ALL ranks raise when any of them failed."""
@@ -195,28 +223,7 @@ class AllPairsScorer:
         lo, hi = shard_bounds(m, world, rank)
         if local is None:
             local = self.embed_fn(*_graph_slice(centers, labels, lo, hi))
-        assert local.shape[0] == hi - lo
-        if world == 1:
-            return local
-        # ONE collective on equal-sized (padded) shards, straight into one tensor (all_gather_into_tensor: no list of
-        # per-rank buffers, no concatenation); when the ranks' shards are equal - M divisible by the world size - the
-        # gathered tensor IS pooled [M, F], otherwise the padding rows of the shorter shards are dropped by one index copy
-        cap = shard_bounds(m, world, 0)[1]               # largest shard
-        if hi - lo == cap:
-            buf = local.contiguous()
-        else:
-            buf = local.new_zeros((cap, local.shape[1]))
-            buf[: hi - lo] = local
-        staged = self._host_staged(buf)
-        if staged:
-            buf = buf.cpu()
-        gathered = buf.new_empty((world * cap, buf.shape[1]))
-        dist.all_gather_into_tensor(gathered, buf, group=self.group)
-        if world * cap != m:
-            keep = torch.cat([torch.arange(r * cap, r * cap + shard_bounds(m, world, r)[1] - shard_bounds(m, world, r)[0])
-                              for r in range(world)]).to(gathered.device)
-            gathered = gathered.index_select(0, keep)
-        return gathered.to(local.device) if staged else gathered
+        return all_gather_rows(local, m, self.group)
 
     def score_rows(self, pooled):
         """This rank's row block of the score matrix: [hi-lo, M]."""

@@ -20,7 +20,7 @@ int raise_lds_limit(LdsLimitOnce* once, const void* kernel, int bytes, const cha
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    if (dev < 64 && (once->done & bit)) return SGPR_OK;
+    if (dev < 64 && (once->done.load(std::memory_order_acquire) & bit)) return SGPR_OK;
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
         int have = 0;
@@ -29,7 +29,7 @@ int raise_lds_limit(LdsLimitOnce* once, const void* kernel, int bytes, const cha
                   std::to_string(dev) + " offers " + std::to_string(have) + " (" + hipGetErrorString(e) + ")");
         return SGPR_E_HIP;
     }
-    if (dev < 64) once->done |= bit;
+    if (dev < 64) once->done.fetch_or(bit, std::memory_order_release);
     return SGPR_OK;
 }
 
@@ -531,6 +531,7 @@ int sgpr_create(const float* weights, size_t n_floats, const sgpr_dims* dims, in
         if (rc != SGPR_OK) {
             (void)hipFree(h->d_blob);
             (void)hipFree(h->d_status);
+            if (h->d_gblob) (void)hipFree(h->d_gblob);      // (allocated, then its upload failed)
             delete h;
             return rc;
         }

@@ -3272,7 +3272,10 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     kr.a.prof = nullptr;
     kr.a.skip = 0;
     // (an "auto" launch may hand this pass many graphs: a workgroup per CU)
-    const int nblk = over_in_redo ? h->num_cus : 64;
+#ifndef SGPR_REDO_BLOCKS
+#define SGPR_REDO_BLOCKS 64   // persistent workgroups of the second pass (A/B builds: what the EMPTY pass costs against its grid)
+#endif
+    const int nblk = over_in_redo ? h->num_cus : SGPR_REDO_BLOCKS;
     const int blocks = a.G < nblk ? a.G : nblk;
     if (plan.kp == 16)
         return kr.p.fmt == FMT_BF3 ? launch_redo_t<16, FMT_BF3>(kr, blocks, stream) : launch_redo_t<16, FMT_F32>(kr, blocks, stream);

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(EMB_THREADS) void generic_embed_kernel(const Generi
             if (branch == 1 && a.rag_off && !a.dense)
                 for (int n = tid; n < ragc; n += EMB_THREADS) {
                     const int lab = a.rag_lab[rag0 + n];
-                    if (lab < 0 || lab >= m.L) atomicOr(a.status, 1);
+                    if (lab < -1 || lab >= m.L) atomicOr(a.status, 1);   // (-1 is padding, as on the padded arrays and in the tuned kernel)
                 }
             __syncthreads();
             float* cur = X0;
@@ -605,40 +605,49 @@ __global__ __launch_bounds__(GEN_THREADS) void generic_knn_kernel(const float* _
             key[q] = __fsub_rn(xi2, fmaf(2.f, dot, -xj2));
         }
     }
+    // total order (key, index) on the order-preserving image of the key: +inf keys (overflowing features) and NaN keys rank
+    // last but ARE ranked - every row gets k distinct indices, as knn_select_row and the tuned kernel give
+    auto image = [](float f) {
+        if (f != f) return 0xffffffffu;                       // NaN after everything
+        f += 0.0f;
+        const unsigned u = __float_as_uint(f);
+        return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+    };
+    unsigned okey[GEN_MAX_PER_LANE];
+    unsigned taken = 0u;                                      // bit q: candidate lane + 64 q is in the list already
+#pragma unroll
+    for (int q = 0; q < GEN_MAX_PER_LANE; ++q) okey[q] = image(key[q]);
     long long* out = idx + ((size_t)b * N + i) * k;
     for (int m = 0; m < k; ++m) {
-        float best = INFINITY;
-        int bj = 0x7fffffff;
+        unsigned long long best = ~0ull;                      // (image << 32 | index): one comparison orders both
 #pragma unroll
         for (int q = 0; q < GEN_MAX_PER_LANE; ++q) {
             const int j = lane + 64 * q;
-            if (j < N && key[q] < best) {
-                best = key[q];
-                bj = j;
-            }
+            const unsigned long long cand = ((unsigned long long)okey[q] << 32) | (unsigned)j;
+            if (j < N && !((taken >> q) & 1u) && cand < best) best = cand;
         }
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
-            const float ob = __shfl_xor(best, sft);
-            const int oj = __shfl_xor(bj, sft);
-            if (ob < best || (ob == best && oj < bj)) {
-                best = ob;
-                bj = oj;
-            }
+            const unsigned long long ob = __shfl_xor(best, sft);
+            if (ob < best) best = ob;
         }
-        if (lane == 0) out[m] = bj == 0x7fffffff ? 0 : bj;
+        const int bj = (int)(unsigned)best;
+        if (lane == 0) out[m] = best == ~0ull ? 0 : bj;
 #pragma unroll
         for (int q = 0; q < GEN_MAX_PER_LANE; ++q)
-            if (lane + 64 * q == bj) key[q] = INFINITY;
+            if (best != ~0ull && lane + 64 * q == bj) taken |= 1u << q;
     }
 }
 
 int launch_knn_any(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream) {
     if (B == 0) return SGPR_OK;
-    hipLaunchKernelGGL(generic_knn_kernel, dim3((N + 3) / 4, B), dim3(GEN_THREADS), 0, stream, x, C, N, k,
-                       reinterpret_cast<long long*>(idx));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "generic_knn_kernel launch");
+    for (int b0 = 0; b0 < B; b0 += 65535) {                   // (grid.y holds 65 535 graphs)
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        hipLaunchKernelGGL(generic_knn_kernel, dim3((N + 3) / 4, nb), dim3(GEN_THREADS), 0, stream, x + (size_t)b0 * C * N, C, N, k,
+                           reinterpret_cast<long long*>(idx) + (size_t)b0 * N * k);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "generic_knn_kernel launch");
+    }
     return SGPR_OK;
 }
 

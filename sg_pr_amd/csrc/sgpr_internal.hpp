@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "sgpr.h"
@@ -224,7 +225,7 @@ int launch_graph_edges(const float* pts, int stride, const int32_t* point_node, 
 // (one bit each; a process that drives several GPUs raises it once on each), with a message that says what did not fit -
 // a part with 64 KB of LDS per workgroup cannot run the kernels that stage a whole graph / histogram in 130 - 160 KB.
 struct LdsLimitOnce {
-    unsigned long long done = 0ull;      // benign race: setting the attribute twice is idempotent
+    std::atomic<unsigned long long> done{0ull};   // (threads that drive different GPUs share it; setting the attribute twice is idempotent)
 };
 int raise_lds_limit(LdsLimitOnce* once, const void* kernel, int bytes, const char* what);
 

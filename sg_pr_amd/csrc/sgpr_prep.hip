@@ -50,62 +50,89 @@ __global__ __launch_bounds__(256) void slots_kernel(const float* __restrict__ ce
 // also never changes a timing from run to run.  info[0] = node_cap (largest count), info[1] = graphs beyond 64 slots.
 __global__ __launch_bounds__(1024) void order_kernel(const int32_t* __restrict__ slots, int G, int32_t* __restrict__ order,
                                                     int32_t* __restrict__ info) {
-    constexpr int NW = 16;
-    __shared__ int start[kBins];                    // first output position of a bin
+    constexpr int NW = 16, NC = 8;                  // NC: groups of 64 graphs whose counts a wave keeps in registers between its passes
+    __shared__ int s_cap, s_over;
+    __shared__ int wsum[8];
     __shared__ int cnt[NW][kBins];                  // per wave: graphs of its index range per bin, then its cursor
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < NW * kBins; e += 1024) (&cnt[0][0])[e] = 0;
-    __syncthreads();
     const int per = (((G + NW - 1) / NW) + 63) & ~63;             // graphs per wave, a multiple of 64
     const int g0 = wave * per, g1 = min(G, g0 + per);
-    for (int g = g0 + lane; g < g1; g += 64) atomicAdd(&cnt[wave][min(max(slots[g], 0), kBins - 1)], 1);
+    int vc[NC];                                     // this lane's graphs of the wave's first NC groups (kBins: none)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int g = g0 + 64 * q + lane;
+        vc[q] = g < g1 ? min(max(slots[g], 0), kBins - 1) : kBins;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+        if (vc[q] < kBins) atomicAdd(&cnt[wave][vc[q]], 1);
+    for (int g = g0 + 64 * NC + lane; g < g1; g += 64) atomicAdd(&cnt[wave][min(max(slots[g], 0), kBins - 1)], 1);
+    __syncthreads();
+    // bins in DESCENDING order of the count (largest graphs first): thread t owns bin kBins - 1 - t; an exclusive scan over t
+    int mine = 0;
+    if (tid < kBins) {
+        for (int w = 0; w < NW; ++w) mine += cnt[w][kBins - 1 - tid];
+    }
+    if (tid == 0) s_cap = s_over = 0;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        incl += lane >= d ? t : 0;
+    }
+    if (lane == 63 && wave < 8) wsum[wave] = incl;
     __syncthreads();
     if (tid < kBins) {
-        int tot = 0;
-        for (int w = 0; w < NW; ++w) tot += cnt[w][tid];
-        start[tid] = tot;                           // (the bin's size for now)
+        int before = incl - mine;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int bin = kBins - 1 - tid;
+        int run = before;                           // ... then the waves' cursors inside the bin, in index order (stable)
+        for (int w = 0; w < NW; ++w) {
+            const int c = cnt[w][bin];
+            cnt[w][bin] = run;
+            run += c;
+        }
+    }
+    if (tid < kBins && mine > 0) {                  // (a one-thread walk over the 258 bins was 11 us of this launch)
+        atomicMax(&s_cap, kBins - 1 - tid);
+        if (kBins - 1 - tid > 64) atomicAdd(&s_over, mine);
     }
     __syncthreads();
     if (tid == 0) {
-        int run = 0, cap = 0, over = 0;
-        for (int v = kBins - 1; v >= 0; --v) {
-            const int c = start[v];
-            if (c > 0 && cap == 0) cap = v;
-            if (v > 64) over += c;
-            start[v] = run;
-            run += c;
-        }
-        info[0] = cap;
-        info[1] = over;
+        info[0] = s_cap;
+        info[1] = s_over;
     }
-    __syncthreads();
-    if (tid < kBins) {
-        int run = start[tid];
-        for (int w = 0; w < NW; ++w) {
-            const int c = cnt[w][tid];
-            cnt[w][tid] = run;
-            run += c;
-        }
-    }
-    __syncthreads();
+    // the scatter, 64 graphs of a wave's range at a time: a lane's rank among the lanes of its group with the SAME count comes
+    // from nine ballots (one per bit of the count: the lanes that agree with mine in every bit), no loop over the distinct
+    // counts of the group; the first lane of each set of equal lanes advances the wave's cursor of that bin
     volatile int* cur = cnt[wave];
-    for (int gb = g0; gb < g1; gb += 64) {
-        const int g = gb + lane;
-        const bool valid = g < g1;
-        const int v = valid ? min(max(slots[g], 0), kBins - 1) : -1;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {                              // one distinct count of this group of 64 per step (wave-uniform)
-            const int src = __ffsll((long long)todo) - 1;
-            const int v0 = __shfl(v, src);
-            const unsigned long long mk = __ballot(v == v0);
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
-            const int at = cur[v0];
-            if (v == v0) order[at + rank] = g;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == src) cur[v0] = at + __popcll(mk);
-            __builtin_amdgcn_wave_barrier();
-            todo &= ~mk;
+    auto place = [&](const int g, const int v) {
+        const bool valid = v < kBins;
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {
+            const unsigned long long has = __ballot((v >> b) & 1);
+            same &= ((v >> b) & 1) ? has : ~has;
         }
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0));
+        const int at = valid ? cur[v] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();             // every lane has read its cursor before a leader moves it
+        if (valid) {
+            order[at + rank] = g;
+            if (rank == 0) cur[v] = at + __popcll(same);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+        if (g0 + 64 * q < g1) place(g0 + 64 * q + lane, vc[q]);              // (wave-uniform)
+    for (int gb = g0 + 64 * NC; gb < g1; gb += 64) {
+        const int g = gb + lane;
+        place(g, g < g1 ? min(max(slots[g], 0), kBins - 1) : kBins);
     }
 }
 

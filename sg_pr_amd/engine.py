@@ -275,6 +275,14 @@ class Engine:
             t = t.to(device=self.device, dtype=dtype).contiguous()
         return t
 
+    def _pooled(self, t, name):
+        """a pooled-vector argument on the device, fp32, contiguous - and of THIS handle's row width: the kernels read
+        row r at p + r * width, so rows of another engine (or a [:, :filters_3] cut) would be read past their end"""
+        t = self._dev(t, torch.float32, name)
+        if t.dim() != 2 or t.shape[1] != self.pw:
+            raise ValueError("%s must be [rows, %d] (this handle's pooled width), got %s" % (name, self.pw, tuple(t.shape)))
+        return t
+
     def _cut(self, emb):
         """node embeddings [.., pooled width] -> [.., filters_3] (a view; identity for the shipped architecture)"""
         return emb if emb is None or self.f3 == self.pw else emb[..., :self.f3]
@@ -372,7 +380,7 @@ class Engine:
         on the device, asynchronous.  Padded arrays (offsets None) or a ragged store's offsets (centers / labels None)."""
         g = (offsets.numel() - 1) if offsets is not None else labels.shape[0]
         order = torch.empty(g, dtype=torch.int32, device=self.device)
-        info = torch.zeros(2, dtype=torch.int32, device=self.device)
+        info = torch.empty(2, dtype=torch.int32, device=self.device)      # (both entries are written by the kernel)
         ws_bytes = self.lib.sgpr_size_order_workspace_bytes(g)
         ws = self._ws(ws_bytes)
         rc = self.lib.sgpr_size_order(self._h, _ptr(centers if offsets is None else None),
@@ -490,8 +498,8 @@ class Engine:
 
     # ------------------------------------------------------------------ pair-coupled half
     def score_pairs(self, pooled1, pooled2, idx1=None, idx2=None, out=None):
-        pooled1 = self._dev(pooled1, torch.float32, "pooled1")
-        pooled2 = self._dev(pooled2, torch.float32, "pooled2")
+        pooled1 = self._pooled(pooled1, "pooled1")
+        pooled2 = self._pooled(pooled2, "pooled2")
         if idx1 is not None:
             idx1 = self._dev(idx1, torch.int32, "idx1")
         if idx2 is not None:
@@ -515,8 +523,8 @@ class Engine:
         """score[p] = SG-tail(pooled_rows[idx1[p]], pooled_cols[idx2[p]]) for the pairs of `plan` (sgpr_score_pair_list):
         the bilinear form hoisted per distinct row graph, a row's listed columns through the matrix cores 16 at a time;
         bit-identical to score_all_pairs' entries at the listed indices."""
-        rows = self._dev(pooled_rows, torch.float32, "pooled_rows")
-        cols = self._dev(pooled_cols, torch.float32, "pooled_cols")
+        rows = self._pooled(pooled_rows, "pooled_rows")
+        cols = self._pooled(pooled_cols, "pooled_cols")
         if rows.shape[0] != plan.num_rows or cols.shape[0] != plan.num_cols:
             raise ValueError("plan was built for %d x %d graphs, got %d x %d"
                              % (plan.num_rows, plan.num_cols, rows.shape[0], cols.shape[0]))
@@ -533,8 +541,8 @@ class Engine:
         return score
 
     def score_all_pairs(self, pooled_rows, pooled_cols, out=None):
-        rows = self._dev(pooled_rows, torch.float32, "pooled_rows")
-        cols = self._dev(pooled_cols, torch.float32, "pooled_cols")
+        rows = self._pooled(pooled_rows, "pooled_rows")
+        cols = self._pooled(pooled_cols, "pooled_cols")
         r, m = rows.shape[0], cols.shape[0]
         score = out if out is not None else torch.empty(r, m, dtype=torch.float32, device=self.device)
         assert score.shape == (r, m) and score.stride(1) == 1
@@ -552,8 +560,8 @@ class Engine:
         (pooled_rows, pooled_cols) or (pooled_rows, pooled_cols, out) -> list of [R, M] score tensors."""
         outs, keep, descr = [], [], []
         for job in jobs:
-            rows = self._dev(job[0], torch.float32, "pooled_rows")
-            cols = self._dev(job[1], torch.float32, "pooled_cols")
+            rows = self._pooled(job[0], "pooled_rows")
+            cols = self._pooled(job[1], "pooled_cols")
             out = job[2] if len(job) > 2 and job[2] is not None else torch.empty(rows.shape[0], cols.shape[0],
                                                                                    dtype=torch.float32, device=self.device)
             assert out.shape == (rows.shape[0], cols.shape[0]) and out.stride(1) == 1

@@ -28,58 +28,74 @@ from .utils import load_paires, pose_distance, tab_printer
 def score_pair_list(trainer, graph_pairs, group=None):
     """[[path_a, path_b], ...] -> (pred float32 [P], gt float64 [P]); embeds each graph once.
 
-    Under torch.distributed (one process per GPU) the list is split contiguously across the ranks (SURVEY.md 8e,
-    "pair-list mode": the reference's loop eval_batch.py:30-36 walks the list in order, so rank r takes pairs
-    [lo_r, hi_r) of it): every rank parses and embeds only the graphs its own pairs name, scores them, and the
-    per-rank `float32[P_r]` / `float64[P_r]` vectors are all-gathered in rank order (two padded tensor collectives,
-    allpairs.all_gather_varlen) - every rank returns the full vectors, identical to the single-process ones: a score
+    Under torch.distributed (one process per GPU) the GRAPHS are sharded, then the list (the reference's
+    loop eval_batch.py:30-36 walks the list in order, utils.py:61-70 names the files): every rank builds the same table
+    of the distinct graphs the list names (first-appearance order: deterministic, no communication), rank r parses and
+    embeds graphs [glo_r, ghi_r) of that table - G / world of them, where a contiguous split of a shuffled LIST would
+    make every rank embed ~85 % of all graphs -, ONE all_gather_into_tensor brings every rank all pooled vectors
+    (G x 128 bytes) and one the poses (the ground truth's x, z), and rank r scores pairs [lo_r, hi_r) of the list against
+    the full table; the per-rank `float32[P_r]` / `float64[P_r]` vectors are all-gathered in rank order
+    (allpairs.all_gather_varlen).  Every rank returns the full vectors, identical to the single-process ones: a score
     depends on its two graphs only, and the tail kernel is chosen by the length of the whole list, not of a shard (the
     grouped kernel's one launch-wide decision - f16 planes or the exact fp32 path - differs between shards only when a
-    pooled vector leaves the f16 range, |pooled| > 6e4: never on real data, ~1e-7 apart when it does)."""
+    pooled vector leaves the f16 range, |pooled| > 6e4: never on real data, ~1e-7 apart when it does).
+    `score_pair_list.last_embedded` = the number of graphs THIS rank embedded in the last call (tests)."""
     from . import allpairs
     world, rank = allpairs._world_of(group)
-    lo, hi = allpairs.shard_bounds(len(graph_pairs), world, rank)
-    mine = graph_pairs[lo:hi]
     index, paths = {}, []
-    ia = np.empty(len(mine), dtype=np.int32)
-    ib = np.empty(len(mine), dtype=np.int32)
-    for p, (a, b) in enumerate(mine):
+    ia = np.empty(len(graph_pairs), dtype=np.int32)
+    ib = np.empty(len(graph_pairs), dtype=np.int32)
+    for p, (a, b) in enumerate(graph_pairs):
         for path in (a, b):
             if path not in index:
                 index[path] = len(paths)
                 paths.append(path)
         ia[p], ib[p] = index[a], index[b]
+    G = len(paths)
+    glo, ghi = allpairs.shard_bounds(G, world, rank)          # the graphs this rank parses and embeds
+    lo, hi = allpairs.shard_bounds(len(graph_pairs), world, rank)   # the pairs this rank scores
     n = int(trainer.args.node_num)
-    centers = np.empty((len(paths), n, 3), dtype=np.float32)
-    labels = np.empty((len(paths), n), dtype=np.int32)
-    poses = []
+    centers = np.empty((ghi - glo, n, 3), dtype=np.float32)
+    labels = np.empty((ghi - glo, n), dtype=np.int32)
+    poses = np.zeros((ghi - glo, 12), dtype=np.float64)
     model = trainer.model
     dev = getattr(model.engine(), "device", None) if world > 1 else None    # (the CPU tests' stand-in has none)
-    err, pred, gt = None, torch.empty(0, device=dev if isinstance(dev, torch.device) else "cpu"), np.empty(0, dtype=np.float64)
+    dev = dev if isinstance(dev, torch.device) else torch.device("cpu")
+    err, pooled = None, None
+    score_pair_list.last_embedded = ghi - glo
     try:
-        for g, path in enumerate(paths):
-            c, l, pose = trainer._load_graph(path)
-            centers[g], labels[g] = c, l
-            poses.append(pose)
-        gt = np.array([trainer.target_from_distance(pose_distance(poses[i], poses[j])) for i, j in zip(ia, ib)],
-                      dtype=np.float64)
+        for g in range(glo, ghi):
+            c, l, pose = trainer._load_graph(paths[g])
+            centers[g - glo], labels[g - glo] = c, l
+            poses[g - glo] = np.asarray(pose, dtype=np.float64).reshape(-1)[:12]
         chunk = max(1, int(trainer.args.batch_size)) * 64
-        if paths:
+        if ghi > glo:
             pooled = torch.cat([model.embed(centers[s:s + chunk], labels[s:s + chunk])[0]
-                                for s in range(0, len(paths), chunk)])
-            # which tail kernel: decided on the WHOLE list's length, not on this rank's shard of it
-            grouped = len(graph_pairs) >= getattr(model, "GROUPED_MIN_PAIRS", 1 << 62)
-            pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia), torch.from_numpy(ib), grouped=grouped).reshape(-1)
+                                for s in range(0, ghi - glo, chunk)])
         model.engine().check_status()      # bad labels / broken node_cap promises are errors, not silent NaNs
     except Exception as e:       # any rank-local failure must reach the agreement below, or the other ranks hang in it
         if world == 1:
             raise
         err = e
+    if world > 1:
+        # a rank-local failure (missing file, label outside 0..11) is raised on every rank instead of stranding the others
+        allpairs.agree_on_error(err, like=torch.empty(0, device=dev) if dev.type == "cuda" else None, group=group)
+        width = int(getattr(model.engine(), "pw", 0)) or (int(pooled.shape[1]) if pooled is not None else 32)
+        if pooled is None:
+            pooled = torch.zeros((0, width), dtype=torch.float32, device=dev)
+        pooled = allpairs.all_gather_rows(pooled.to(torch.float32), G, group)
+        poses_t = torch.from_numpy(poses)
+        poses = allpairs.all_gather_rows(poses_t.to(pooled.device) if pooled.is_cuda else poses_t, G, group).cpu().numpy()
+    gt = np.array([trainer.target_from_distance(pose_distance(poses[i], poses[j])) for i, j in zip(ia[lo:hi], ib[lo:hi])],
+                  dtype=np.float64)
+    pred = torch.empty(0, dtype=torch.float32, device=pooled.device if pooled is not None else dev)
+    if hi > lo:
+        # which tail kernel: decided on the WHOLE list's length, not on this rank's shard of it
+        grouped = len(graph_pairs) >= getattr(model, "GROUPED_MIN_PAIRS", 1 << 62)
+        pred = model.score_pooled(pooled, pooled, torch.from_numpy(ia[lo:hi].copy()), torch.from_numpy(ib[lo:hi].copy()),
+                                  grouped=grouped).reshape(-1)
     if world == 1:
         return pred.cpu().numpy().reshape(-1), gt
-    # a rank-local failure (missing file, label outside 0..11) is raised on every rank instead of stranding the others
-    dev_like = pred if pred.is_cuda else None
-    allpairs.agree_on_error(err, like=dev_like, group=group)
     pred_all, lens = allpairs.all_gather_varlen(pred.to(torch.float32), group)
     gt_t = torch.from_numpy(gt)
     gt_all, _ = allpairs.all_gather_varlen(gt_t.to(pred.device) if pred.is_cuda else gt_t, group)

@@ -229,6 +229,11 @@ def test_error_codes(eng):
     # empty batch is a no-op
     p, _, _ = eng.embed(torch.zeros(0, 64, 3), torch.zeros(0, 64, dtype=torch.int32), 10)
     assert p.shape == (0, 32)
+    # pooled rows of another width would be read past their end: refused by the binding
+    with pytest.raises(ValueError):
+        eng.score_pairs(torch.zeros(4, 16), torch.zeros(4, 16))
+    with pytest.raises(ValueError):
+        eng.score_all_pairs(torch.zeros(4, 32), torch.zeros(4, 31))
 
 
 def test_odd_sizes(eng, oracle, oracle_sd):
@@ -701,10 +706,15 @@ def _two_rank_worker(rank, world, port, ckpt, out_dir):
     plain = scorer.run(dc, dl, chunks=1)                                         # plain gather
     block = scorer.run(dc, dl, gather=False)
     f1 = scorer.f1_max(block, poses)
-    # pair-list mode (eval_batch.py:30-36) sharded over the ranks: 2600 listed pairs per rank -> the grouped kernel
+    # pair-list mode (eval_batch.py:30-36) sharded over the ranks: graphs first (60 of the 120 per rank, one all-gather of
+    # pooled), then 2600 listed pairs per rank -> the grouped kernel
     from sg_pr_amd import eval_batch
     pairs = [l.split() for l in open(os.path.join(out_dir, "pairs.txt")).read().splitlines()]
     pred, gt = eval_batch.score_pair_list(trainer, pairs)
+    # graph-sharded: this rank parsed and embedded ITS half of the distinct graphs (a split of the list alone: nearly all)
+    n_graphs = len({p for ab in pairs for p in ab})
+    lo_g, hi_g = allpairs.shard_bounds(n_graphs, world, rank)
+    assert eval_batch.score_pair_list.last_embedded == hi_g - lo_g <= n_graphs // world + 1
     if rank == 0:
         assert torch.equal(full, plain)
         torch.save({"full": full.cpu(), "f1": f1, "pred": pred, "gt": gt}, os.path.join(out_dir, "two.pt"))
@@ -910,9 +920,14 @@ def test_rccl_ranks_bitwise_equal_one_rank(tmp_path, ckpt_path, golden_dir):
 def test_config4_full_size_on_one_gpu(oracle, oracle_sd, ckpt_path):
     """BASELINE config 4 at FULL size on one GPU: KITTI 00+02+05+06+08-sized sequences, 17 135 graphs, 67.75 M pairs.
     `allpairs.SequenceSet` (one embed launch for all graphs, one pair of launches for the five matrices) gives the
-    matrices of per-sequence runs bit for bit; 16 sampled pairs per sequence are within 1e-4 of the oracle; every
-    matrix has the properties a correct one must have whatever its size (finite, in (0,1), asymmetric, pair-list
-    kernel agreement on sampled pairs)."""
+    matrices of per-sequence runs bit for bit; 2 500 sampled pairs (500 per sequence, over 1 000 distinct graphs each) are
+    within 1e-4 of the oracle or involve a graph with a PROVEN kNN tie (tests/tie_proof.py); every matrix has the
+    properties a correct one must have whatever its size (finite, in (0,1), asymmetric, pair-list kernel agreement on
+    sampled pairs)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tie_proof
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
     from sg_pr_amd import synth, allpairs, sg_net
     from sg_pr_amd.parser_sg import sgpr_args
     frames = (("00", 4541), ("02", 4661), ("05", 2761), ("06", 1101), ("08", 4071))
@@ -932,7 +947,8 @@ def test_config4_full_size_on_one_gpu(oracle, oracle_sd, ckpt_path):
     many = sset.run(embed_fn=lambda c, l: eng.embed(c, l, 10, node_cap=cap, order=order)[0])
     eng.check_status()
     rng = np.random.default_rng(4)
-    worst = 0.0
+    worst, n_checked, n_excused = 0.0, 0, 0
+    NS = 500                                                         # oracle-checked pairs per sequence
     for (name, m), (c, l), (dc, dl), got in zip(frames, host, seqs, many):
         assert got.shape == (m, m)
         one = scorer.run(dc, dl)                                     # the per-sequence job (eval_batch.py:26-36's loop body)
@@ -940,18 +956,33 @@ def test_config4_full_size_on_one_gpu(oracle, oracle_sd, ckpt_path):
         del one
         assert torch.isfinite(got).all() and float(got.min()) >= 0.0 and float(got.max()) <= 1.0
         assert not torch.equal(got[:64, :64], got[:64, :64].t())     # the NTN is asymmetric
-        ii, jj = rng.integers(0, m, size=16), rng.integers(0, m, size=16)
+        ii, jj = rng.integers(0, m, size=NS), rng.integers(0, m, size=NS)
         gi = np.concatenate((ii, jj))
-        rp = oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(c[gi], l[gi])), 10)[0]
-        rs = oracle.score_from_pooled(oracle_sd, rp[:16], rp[16:])
+        rp = torch.cat([oracle.embed(oracle_sd, torch.from_numpy(synth.dense_features(c[gi[s0:s0 + 250]], l[gi[s0:s0 + 250]])), 10)[0]
+                        for s0 in range(0, 2 * NS, 250)])
+        rs = oracle.score_from_pooled(oracle_sd, rp[:NS], rp[NS:])
         sample = got[torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()].cpu()
-        err = (sample - rs).abs().max().item()
-        worst = max(worst, err)
-        assert err <= SCORE_TOL, (name, err)
+        d = (sample - rs).abs().numpy()
         pooled = eng.embed(dc[gi], dl[gi], 10)[0]
-        lst = eng.score_pairs(pooled[:16].contiguous(), pooled[16:].contiguous()).cpu()
-        assert (lst - sample).abs().max().item() <= 2e-6             # pair-list kernel (fp32) vs the dense tail (f16 planes)
-    print("config 4 full size: worst max|dscore| on 5 x 16 oracle-sampled pairs =", worst)
+        dev = (pooled.cpu() - rp).abs().amax(1).numpy()
+        pooled_h = pooled.cpu().numpy()
+        for pi in np.flatnonzero(d > SCORE_TOL):                     # beyond the bar: only through a proven tie
+            reps = []
+            for q in (pi, NS + pi):
+                if dev[q] > 1e-4:
+                    rep = tie_proof.prove_graph(eng, oracle, oracle_sd, c[gi[q]], l[gi[q]], 10, pooled_h[q])
+                    reps.append((int(gi[q]), rep["proven"], rep["reason"]))
+            assert reps and any(ok for _, ok, _ in reps), "%s pair (%d, %d) differs by %.3g without a proven tie: %s" % (
+                name, ii[pi], jj[pi], d[pi], reps)
+            n_excused += 1
+        clean = d <= SCORE_TOL
+        worst = max(worst, float(d[clean].max()))
+        n_checked += NS
+        lst = eng.score_pairs(pooled[:NS].contiguous(), pooled[NS:].contiguous()).cpu()
+        assert (lst - sample).abs().max().item() <= 5e-6             # pair-list kernel (fp32) vs the dense tail (f16 planes): 2.5e-6 over 2 500 pairs
+    assert n_checked >= 2000 and n_excused <= n_checked // 100
+    print("config 4 full size: %d oracle-checked pairs, worst max|dscore| within the bar = %.3e, pairs excused by a proven tie: %d"
+          % (n_checked, worst, n_excused))
 
 
 def _tail_float64(sd, rows, cols):
@@ -1257,7 +1288,7 @@ def test_full_sequence_parity_with_tie_proofs(eng, oracle, oracle_sd):
     assert r["clean_pooled_max"] < 1e-4
     assert r["scores"] == 4541 * 4541
     assert r["scores_off_clean"] == 0 and r["score_max_clean"] < SCORE_TOL       # every score between agreeing graphs
-    assert r["flagged"].size <= 4541 // 100                                       # ties are rare events, not a regime
+    assert r["flagged"].size <= 12                                                # ties are rare events, not a regime (observed: 3 - 6)
     # F1-max.  SURVEY 8d's |dF1| <= 1e-6 presumes score parity everywhere; it does not hold on the full matrix (observed
     # 3.6e-6): the proven-tie graphs move the 2 x 4541 scores of their rows and columns (by up to 5e-2), and scores that
     # agree to 2.5e-5 can still trade places across the best threshold.  Gate: 1e-5 on the full matrix (3 x the
@@ -1924,7 +1955,7 @@ def test_node_num_and_k_beyond_the_tuned_kernels(eng, oracle_sd, oracle):
         for g in np.flatnonzero(~ok.numpy()):
             rep = prove_graph(eng, oracle, oracle_sd, c[g], l[g], K, pooled[g].cpu().numpy())
             assert rep["proven"], (node_num, K, int(g), rep["reason"])
-        assert int(ok.sum()) >= 3 or node_num == 1024, (node_num, K, dev)
+        assert int(ok.sum()) >= (1 if node_num == 1024 else 3), (node_num, K, dev)
         assert (pooled.cpu() - ref_pooled)[ok].abs().max().item() < 2e-4 * max(1.0, float(ref_pooled.abs().max())), (node_num, K)
         assert (att.cpu() - ref_att.reshape(6, node_num))[ok].abs().max().item() < 1e-4
         got, a1, a2 = eng.forward_dense(feats[:3], feats[3:], K)

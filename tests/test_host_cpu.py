@@ -460,6 +460,8 @@ def _pair_list_worker(rank, world, port, golden, out_dir, cfg, break_rank):
         f1 = eval_batch.evaluate_sequence(trainer, "00", args, plots=False)
         pairs = eval_batch.load_paires(os.path.join(args.pair_list_dir, "00.txt"), args.graph_pairs_dir)
         pred, gt = eval_batch.score_pair_list(trainer, pairs)
+        with open(os.path.join(out_dir, "embedded_w%d_r%d.txt" % (world, rank)), "w") as f:
+            f.write(str(eval_batch.score_pair_list.last_embedded))
         np.save(os.path.join(out_dir, "pred_w%d_r%d.npy" % (world, rank)), pred)
         np.save(os.path.join(out_dir, "gt_w%d_r%d.npy" % (world, rank)), gt)
         assert f1 == 1.0
@@ -483,10 +485,11 @@ def _pair_list_worker(rank, world, port, golden, out_dir, cfg, break_rank):
 
 @pytest.mark.timeout(300)
 def test_pair_list_sharded_equals_single_process(tmp_path, golden_dir, ckpt_path, oracle, oracle_sd):
-    """SURVEY 8e pair-list mode: contiguous split of the list over the ranks, per-rank forward, gather of float32[P_r]
-    (gloo, world sizes 2 and 3 - 7 pairs: uneven shards, and more ranks than some shards have distinct graphs).  Every
-    rank ends up with the single-process vectors; rank 0 alone writes the artefacts; a rank-local failure is raised
-    by all ranks."""
+    """SURVEY 8e pair-list mode, graph-sharded: the distinct graphs of the list are split over the ranks (each rank parses
+    and embeds G / world of them), one all-gather of the pooled vectors and of the poses, a contiguous split of the list for
+    the tail, gather of float32[P_r] (gloo, world sizes 2 and 3 - 7 pairs over 3 graphs: uneven shards).  Every rank
+    ends up with the single-process vectors; rank 0 alone writes the artefacts; a rank-local failure is raised by all
+    ranks."""
     import torch.multiprocessing as mp
     from sg_pr_amd import eval_batch, sg_net
     from sg_pr_amd.parser_sg import sgpr_args
@@ -504,6 +507,11 @@ def test_pair_list_sharded_equals_single_process(tmp_path, golden_dir, ckpt_path
     assert want_pred.dtype == np.float32 and want_gt.dtype == np.float64 and len(want_pred) == 7
     for world, port in ((2, 29621), (3, 29623)):
         mp.spawn(_pair_list_worker, args=(world, port, golden_dir, str(tmp_path), cfg, None), nprocs=world, join=True)
+        from sg_pr_amd import allpairs
+        embedded = [int(open(str(tmp_path / ("embedded_w%d_r%d.txt" % (world, r)))).read()) for r in range(world)]
+        # every rank embedded ITS shard of the 3 distinct graphs (a contiguous split of the list alone would have had
+        # each of the 2 ranks embed all 3)
+        assert embedded == [b - a for a, b in (allpairs.shard_bounds(3, world, r) for r in range(world))], embedded
         for r in range(world):
             pred = np.load(str(tmp_path / ("pred_w%d_r%d.npy" % (world, r))))
             gt = np.load(str(tmp_path / ("gt_w%d_r%d.npy" % (world, r))))

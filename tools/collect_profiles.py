@@ -35,6 +35,19 @@ def pmc(name):
     return {k: {c: v / len(calls[k]) for c, v in d.items()} for k, d in agg.items() if "sgpr" in k}
 
 
+def trace_avg_us(name, is_kernel):
+    """average duration (us) of the kernels `is_kernel(name)` accepts in the kernel trace of one --pmc pass"""
+    f = find(name + "_kernel_trace.csv")
+    if not f:
+        return None
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if is_kernel(r["Kernel_Name"])]
+    return sum(d) / len(d) if d else None
+
+
+def is_embed(kname):
+    return ("embed_kernel" in kname or "embed_big_kernel" in kname) and "redo" not in kname
+
+
 def kernel_stats(name, out, header):
     f = find(name + "_kernel_stats.csv")
     if not f:
@@ -131,11 +144,22 @@ for shape, (g, n, k) in shapes.items():
 # instruction mix / issue counters of the dominant kernel (bench.py's roofline.issue), same source hash
 for shape in shapes:
     ins = {}
-    for name in ("sq1_", "sq2_"):
+    for name in ("sq1_", "sq2_", "sq3_"):
         for kname, d in pmc(name + shape).items():
-            if "embed_kernel" in kname:
+            if is_embed(kname):
                 ins.update({c: round(v) for c, v in d.items()})
                 ins["kernel"] = kname
+    # the effective shader clock of THIS kernel under load, two ways (MI355X_MICROARCH.md, DVFS): SQ_BUSY_CYCLES is summed over
+    # the 32 shader engines and counts only while waves are resident (a lower bound: an engine that runs dry early stops
+    # counting), GRBM_GUI_ACTIVE over the 8 XCDs with the collection's own start / stop inside (an upper bound); each
+    # divided by the kernel's duration in the pass that read it
+    t1, t3 = trace_avg_us("sq1_" + shape, is_embed), trace_avg_us("sq3_" + shape, is_embed)
+    if ins.get("SQ_BUSY_CYCLES") and t1:
+        ins["duration_us_sq1_pass"] = round(t1, 2)
+        ins["clock_ghz_from_sq_busy"] = round(ins["SQ_BUSY_CYCLES"] / 32.0 / (t1 * 1e3), 4)
+    if ins.get("GRBM_GUI_ACTIVE") and t3:
+        ins["duration_us_sq3_pass"] = round(t3, 2)
+        ins["clock_ghz_from_grbm"] = round(ins["GRBM_GUI_ACTIVE"] / 8.0 / (t3 * 1e3), 4)
     if ins:
         (hbm if shape == "kitti00" else hbm.setdefault(shape, {}))["embed_kernel_counters"] = ins
     tail = {}
@@ -153,7 +177,7 @@ if pmc_only:
 with open(os.path.join(dst, tag + "_pmc_sq.txt"), "w") as f:
     f.write("# rocprofv3 --pmc (separate passes) on tools/run_embed.py <shape> 3; per-launch averages in millions (" + tag + ")\n")
     for shape in shapes:
-        for name in ("sq1_", "sq2_"):
+        for name in ("sq1_", "sq2_", "sq3_"):
             for kname, d in pmc(name + shape).items():
                 f.write("%-9s %-40s %s\n" % (shape, kname[:40], {c: round(v / 1e6, 3) for c, v in sorted(d.items())}))
 print(json.dumps(hbm, indent=1)[:1500])

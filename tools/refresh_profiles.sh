@@ -17,6 +17,7 @@ for shape in kitti00 stress pairs128; do
   timeout 100 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O -o fetch_$shape -- python $R/tools/run_embed.py $shape 3 > $O/fetch_$shape.log 2>&1 </dev/null
   timeout 100 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O -o write_$shape -- python $R/tools/run_embed.py $shape 3 > $O/write_$shape.log 2>&1 </dev/null
   timeout 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d $O -o sq1_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq1_$shape.log 2>&1 </dev/null
+  timeout 100 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O -o sq3_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq3_$shape.log 2>&1 </dev/null
   timeout 100 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O -o sq2_$shape -- python $R/tools/run_embed.py $shape 3 > $O/sq2_$shape.log 2>&1 </dev/null
 done
 ( cd $R && python tools/collect_profiles.py ${1:-rXX} --pmc-only ) > $O/collect_pmc.log 2>&1
