@@ -498,8 +498,8 @@ def main():
 
     # The same step at the reference's own operand width (extra information, after the timed region): debug bit 13 sends
     # every graph through the wide-range embed instance (three bf16 planes = 24-bit operands, fp32's range) instead of the
-    # default two f16 planes (22 bits); the tail's operands stay two f16 planes (its exact-fp32 form is the one-wave-per-pair
-    # kernel, timed on a sample beside it).
+    # default two f16 planes (22 bits), and the dense all-pairs tail through its three-plane instance as well
+    # (score_all_pairs_wide_kernel; the multi-rectangle and pair-list tails have no such instance and keep f16 planes).
     wide = None
     if world == 1 and not a.no_wide_range:
         try:
@@ -509,10 +509,15 @@ def main():
             wsteps = max(5, min(20, a.steps))
             tw = timed_steps(wsteps, step)
             wide_embed_ms = kernel_ms(dur_calls["embed"], 8)
+            wide_tail_ms = kernel_ms(dur_calls["tail"], 8) if "tail" in dur_calls else None
+            tail_is_wide = a.workload == "kitti00" or (a.workload == "kitti5seq" and a.per_sequence_tails)
             wide = {"ms_per_step": tw / wsteps * 1e3, "value_at_24bit_operands": units * wsteps / tw,
-                    "wide_range_launch_ms": wide_embed_ms, "steps": wsteps,
-                    "note": "embed on the wide-range instance (3 x bf16 planes = 24-bit matrix operands, forced through debug "
-                            "bit 13); tail unchanged (2 x f16 planes, fp32 accumulate)"}
+                    "wide_range_launch_ms": wide_embed_ms, "wide_tail_call_ms": wide_tail_ms, "tail_at_24bit_operands": tail_is_wide,
+                    "steps": wsteps,
+                    "note": "debug bit 13: embed on the wide-range instance and the dense all-pairs tail on its own (3 x bf16 planes = "
+                            "24-bit matrix operands = the reference's fp32 operand width, fp32 accumulate)" if tail_is_wide else
+                            "debug bit 13: embed on the wide-range instance (3 x bf16 planes = 24-bit matrix operands); this workload's "
+                            "tail kernel has no three-plane instance and keeps 2 x f16 planes"}
         except Exception as e:
             wide = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
@@ -525,9 +530,9 @@ def main():
                 _so = torch.empty(1 << 20, dtype=torch.float32, device=dev)
                 t_fp32 = kernel_ms(lambda: eng.score_pairs(_pw, _pw, _gi[0], _gi[1], out=_so), 4)
                 wide["tail_exact_fp32_pairs_per_s"] = (1 << 20) / (t_fp32 * 1e-3)
-                wide["value_at_fp32_everywhere"] = units / (wide_embed_ms * 1e-3 * launches_per_step + units / wide["tail_exact_fp32_pairs_per_s"])
-                wide["note"] += ("; value_at_fp32_everywhere = the wide-range embed + every pair through the exact-fp32 tail kernel "
-                                 "(extrapolated from a 2^20-pair sample)")
+                wide["footnote_fp32_vector_tail"] = ("the tail WITHOUT matrix cores (sgpr_score_pairs: one wave per pair, fp32 FMAs) runs "
+                                                     "%.3g pairs/s on a 2^20-pair sample - context only, not a datapath of the step"
+                                                     % wide["tail_exact_fp32_pairs_per_s"])
             except Exception as e:
                 wide["tail_exact_fp32_error"] = "%s: %s" % (type(e).__name__, e)
 

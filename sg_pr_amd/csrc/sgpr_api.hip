@@ -987,8 +987,9 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
         return SGPR_E_WORKSPACE;
     }
     DeviceGuard guard(h->device);
+    // (debug bit 13 / weights outside the f16 range: the instance with three bf16 planes per operand, as for the embed)
     return launch_score_all_pairs(h, d_pooled_rows, R, d_pooled_cols, M, d_score, ld, d_workspace,
-                                  static_cast<hipStream_t>(stream));
+                                  static_cast<hipStream_t>(stream), wide_range(h));
 }
 
 static int check_jobs(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs) {

@@ -186,7 +186,7 @@ int launch_score_pairs(const sgpr_handle* h, const float* p1, const int32_t* i1,
                        int64_t P, float* score, hipStream_t stream);
 size_t score_all_pairs_ws_bytes(int R, int M);
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
-                           int64_t ld, void* ws, hipStream_t stream);
+                           int64_t ld, void* ws, hipStream_t stream, bool wide = false);
 size_t score_all_pairs_multi_ws_bytes(int n, const sgpr_pairs_job* jobs);
 int launch_score_all_pairs_multi(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs, void* ws, hipStream_t stream);
 size_t score_pair_list_ws_bytes(int NR, int M);

@@ -158,10 +158,12 @@ static inline int ap_prep_groups(int R, int M) {
     return ((R > msb ? R : msb) + 15) / 16;
 }
 
+// (sized for the three bf16 planes of the wide-range instance, score_all_pairs_wide_kernel; the default two f16 planes
+//  use two thirds of the operand regions)
 size_t score_all_pairs_ws_bytes(int R, int M) {
     const size_t nsb = (size_t)(M + AP_SB - 1) / AP_SB;
     return (size_t)R * T * sizeof(float) + (size_t)2 * ap_prep_groups(R, M) * 4 * sizeof(float) +
-           (size_t)R * 2 * 64 * 8 * sizeof(unsigned short) + nsb * 2 * 4 * 64 * 8 * sizeof(unsigned short);
+           (size_t)R * 3 * 64 * 8 * sizeof(unsigned short) + nsb * 3 * 4 * 64 * 8 * sizeof(unsigned short);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -171,6 +173,16 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_f16(float a, _Float16& h, _Float16& l) {
     h = (_Float16)a;                       // round to nearest even
     l = (_Float16)(a - (float)h);          // exact residual, rounded once: |a - (h + l)| <= 2^-23 |a| (or 2^-25 absolute)
+}
+
+// x = hi + mid + lo EXACTLY, as three bf16 planes: each plane is the upper half of what is left (truncation: 8 + 8 + 8 bits =
+// fp32's 24 significant bits; every plane carries x's sign, so a ReLU of x is a ReLU of each plane)
+__device__ __forceinline__ void split3_bf16(float x, unsigned& hb, unsigned& mb, unsigned& lb) {
+    hb = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(hb & 0xffff0000u);
+    mb = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(mb & 0xffff0000u);
+    lb = __float_as_uint(r2);                // (the plane is the upper 16 bits of each word)
 }
 
 __device__ __forceinline__ float wave_max_f32(float v) {
@@ -188,14 +200,15 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // u_r; column graphs get their two-plane copy in super-block order (columns past M are zero-filled).
 // LIST (pair-list mode, score_pair_list_kernel): the R row graphs are rows[row_ids[0 .. R)] (the distinct row graphs of
 // the list, gathered) and the column operands are laid out per graph, Cb [M][2 planes][32] f16, instead of per super-block.
-template <bool LIST>
+// NPL: operand planes - 2 (f16: x = hi + lo, 22 bits) or 3 (bf16, the wide-range instance: x exactly, fp32's range)
+template <bool LIST, int NPL = 2>
 __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* __restrict__ rows, int R,
                                               const float* __restrict__ cols, int M, unsigned short* __restrict__ Ab,
                                               float* __restrict__ ur, float* __restrict__ rng,
                                               unsigned short* __restrict__ Cb, const int block,
                                               const int32_t* __restrict__ row_ids = nullptr) {
     __shared__ float red[4][4];
-    __shared__ __attribute__((aligned(16))) unsigned short stage[16 * 2 * 4 * 8 * 8];   // [graph][plane][j >> 3][t & 7][j & 7]
+    __shared__ __attribute__((aligned(16))) unsigned short stage[16 * NPL * 4 * 8 * 8];   // [graph][plane][j >> 3][t & 7][j & 7]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     // two workgroups per 16 graphs (half of the 32 output tiles each): twice the resident waves for a latency-bound job
@@ -249,13 +262,21 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
                     const float a = acc[r] + wbc;
                     amax = fmaxf(amax, fabsf(a));
                     l1r[r] += fabsf(a);
-                    _Float16 h, l;
-                    split2_f16(a, h, l);
                     // staged through LDS in the operand layout: the lanes hold one f16 each of a 16-byte operand unit
                     // (8 consecutive j of one (graph, plane, t)); 2-byte global stores cost the kernel a quarter of its time
-                    unsigned short* dst = stage + (((4 * lq + r) * 2 * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
-                    dst[0] = __builtin_bit_cast(unsigned short, h);
-                    dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
+                    unsigned short* dst = stage + (((4 * lq + r) * NPL * 4 + (j >> 3)) * 8 + (t & 7)) * 8 + (j & 7);
+                    if constexpr (NPL == 3) {
+                        unsigned hb, mb, lb;
+                        split3_bf16(a, hb, mb, lb);
+                        dst[0] = (unsigned short)(hb >> 16);
+                        dst[4 * 8 * 8] = (unsigned short)(mb >> 16);
+                        dst[2 * 4 * 8 * 8] = (unsigned short)(lb >> 16);
+                    } else {
+                        _Float16 h, l;
+                        split2_f16(a, h, l);
+                        dst[0] = __builtin_bit_cast(unsigned short, h);
+                        dst[4 * 8 * 8] = __builtin_bit_cast(unsigned short, l);
+                    }
                 }
             }
             if (q & 1) {
@@ -274,10 +295,10 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
     if (g0 < R) {
         __syncthreads();
         // 16 graphs x 2 planes x 4 (j >> 3) x 8 t of this half = 1024 units of 16 bytes, 8 consecutive t contiguous in memory
-        for (int u = threadIdx.x; u < 16 * 2 * 4 * 8; u += 256) {
-            const int tl = u & 7, jb = (u >> 3) & 3, pl = (u >> 5) & 1, gi = u >> 6;
+        for (int u = threadIdx.x; u < 16 * NPL * 4 * 8; u += 256) {
+            const int tl = u & 7, jb = (u >> 3) & 3, pl = (u >> 5) % NPL, gi = (u >> 5) / NPL;
             if (g0 + gi < R)
-                *reinterpret_cast<uint4*>(Ab + (((size_t)(g0 + gi) * 2 + pl) * 64 + jb * 16 + half * 8 + tl) * 8) =
+                *reinterpret_cast<uint4*>(Ab + (((size_t)(g0 + gi) * NPL + pl) * 64 + jb * 16 + half * 8 + tl) * 8) =
                     *reinterpret_cast<const uint4*>(stage + (size_t)u * 8);
         }
     }
@@ -306,9 +327,17 @@ __device__ __forceinline__ void ntn_prep_body(const DevWeights& w, const float* 
                 dst[F] = __builtin_bit_cast(unsigned short, l);
             } else {
                 const int sb = g >> 6, cl = g & 63, c15 = cl >> 2, b = cl & 3, j = lane;
-                unsigned short* dst = Cb + ((((size_t)sb * 2) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
-                dst[0] = __builtin_bit_cast(unsigned short, h);
-                dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+                unsigned short* dst = Cb + ((((size_t)sb * NPL) * 4 + b) * 64 + (j >> 3) * 16 + c15) * 8 + (j & 7);
+                if constexpr (NPL == 3) {
+                    unsigned hb, mb, lb;
+                    split3_bf16(x, hb, mb, lb);
+                    dst[0] = (unsigned short)(hb >> 16);
+                    dst[4 * 64 * 8] = (unsigned short)(mb >> 16);
+                    dst[2 * 4 * 64 * 8] = (unsigned short)(lb >> 16);
+                } else {
+                    dst[0] = __builtin_bit_cast(unsigned short, h);
+                    dst[4 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+                }
             }
         }
     }
@@ -335,6 +364,13 @@ __global__ __launch_bounds__(256) void ntn_prep_kernel(const DevWeights w, const
                                                        unsigned short* __restrict__ Ab, float* __restrict__ ur,
                                                        float* __restrict__ rng, unsigned short* __restrict__ Cb) {
     ntn_prep_body<false>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void ntn_prep_wide_kernel(const DevWeights w, const float* __restrict__ rows, int R,
+                                                            const float* __restrict__ cols, int M,
+                                                            unsigned short* __restrict__ Ab, float* __restrict__ ur,
+                                                            float* __restrict__ rng, unsigned short* __restrict__ Cb) {
+    ntn_prep_body<false, 3>(w, rows, R, cols, M, Ab, ur, rng, Cb, (int)blockIdx.x);
 }
 
 // several independent rectangles in one launch (sgpr_score_all_pairs_multi): job j owns the prep workgroups
@@ -764,20 +800,179 @@ __global__ __launch_bounds__(256, OCC) void score_all_pairs_multi_kernel(const D
     }
 }
 
+// ------------------------------------------------------------------ dense all-pairs at the reference's operand width
+// The same rectangle with every matrix operand as THREE bf16 planes (x = hi + mid + lo exactly: 24 bits, fp32's range) on
+// v_mfma_f32_16x16x32_bf16 - the tail of layers_batch.py:70-83 / sg_net.py:131-136 at fp32's own operand width, as the
+// embed kernel's wide-range instance is for dgcnn_conv_pass.  Selected per handle (weights outside the f16 range) or by
+// debug bit 13, never by the data (out-of-range data keeps the exact per-pair path of score_all_pairs_kernel).
+//   layer 1  six significant cross products (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid in a chain of their own - smallest
+//            first, never against the large accumulator -, then hi.hi on u_r), one vector add
+//   layer 2  H = relu(.) cut into three planes by truncation (upper halves of x, x - hi, x - hi - mid: same sign, so the
+//            ReLU is a signed maximum of the fp32 word before the cut); the eight K slots of a lane group carry two planes
+//            per instruction: [Hh | Hm].[W1h | W1h], [Hl | Hh].[W1h | W1m], [Hm | Hh].[W1m | W1l] - again six products
+// Everything else (u_r, the folded head, the lane-swap transpose-reduce, 16-byte stores, the work split) is the f16
+// instance's.  Nine matrix instructions and ~45 vector instructions per (row, 16 columns) against five and ~24.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// {upper half of b, upper half of a} -> one dword: K slot 2i in the low half, 2i + 1 in the high half
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+constexpr int APW_OCC = 3;     // (three row-operand planes of four row graphs: 48 registers; three workgroups per CU)
+
+__global__ __launch_bounds__(256, APW_OCC) void score_all_pairs_wide_kernel(const DevWeights w, int R, int M,
+                                                                            const unsigned short* __restrict__ Ab,
+                                                                            const unsigned short* __restrict__ Cb,
+                                                                            const float* __restrict__ ur,
+                                                                            float* __restrict__ score, int64_t ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    // the head folded into layer 2 (ap_consts), W1 as three planes in the three slot arrangements
+    bf16x8 wa, wb2, wc;
+    float4 b1v, side;
+    {
+        const float s = w.fc2_w[l15];
+        const float4 w1 = *reinterpret_cast<const float4*>(w.fc1_w + l15 * T + 4 * g);
+        const float v[4] = {s * w1.x, s * w1.y, s * w1.z, s * w1.w};
+        unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split3_bf16(v[i], hb[i], mb[i], lb[i]);
+        const unsigned h01 = pack_hi16(hb[0], hb[1]), h23 = pack_hi16(hb[2], hb[3]);
+        const unsigned m01 = pack_hi16(mb[0], mb[1]), m23 = pack_hi16(mb[2], mb[3]);
+        const unsigned l01 = pack_hi16(lb[0], lb[1]), l23 = pack_hi16(lb[2], lb[3]);
+        wa = __builtin_bit_cast(bf16x8, u32x4{h01, h23, h01, h23});
+        wb2 = __builtin_bit_cast(bf16x8, u32x4{h01, h23, m01, m23});
+        wc = __builtin_bit_cast(bf16x8, u32x4{m01, m23, l01, l23});
+        const float4 b1 = *reinterpret_cast<const float4*>(w.fc1_b + 4 * g);
+        const float4 w2 = *reinterpret_cast<const float4*>(w.fc2_w + 4 * g);
+        b1v = make_float4(w2.x * b1.x, w2.y * b1.y, w2.z * b1.z, w2.w * b1.w);
+        side = make_float4(w2.x < 0.f ? -INFINITY : INFINITY, w2.y < 0.f ? -INFINITY : INFINITY,
+                           w2.z < 0.f ? -INFINITY : INFINITY, w2.w < 0.f ? -INFINITY : INFINITY);
+    }
+    const float kL2E = 1.4426950408889634f;
+    const float nb2 = -w.fc2_b[0] * kL2E;
+    const int ncc = (M + AP_COLS - 1) / AP_COLS;
+    const int64_t items = (int64_t)ncc * ((R + AP_ROWS - 1) / AP_ROWS);
+    const unsigned nwg = gridDim.x;
+    const unsigned wg = (nwg & 7u) == 0u ? (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int it0 = (int)(items * wg / nwg), it1 = (int)(items * (wg + 1) / nwg);
+    const int nsb = (M + AP_SB - 1) / AP_SB;
+    bf16x8 ah[AP_RW], am[AP_RW], al[AP_RW];
+    f32x4 u4[AP_RW];
+    int cur_rg = -1, rbase = 0;
+    for (int it = it0; it < it1; ++it) {
+        const int rg = it / ncc, cc = it - rg * ncc;
+        if (rg != cur_rg) {
+            cur_rg = rg;
+            rbase = rg * AP_ROWS + wave * AP_RW;
+#pragma unroll
+            for (int rr = 0; rr < AP_RW; ++rr) {
+                const int r = min(rbase + rr, R - 1);
+                const unsigned short* ap = Ab + ((size_t)r * 3 * 64 + lane) * 8;      // A'_r[t = l15][8g .. 8g+7]
+                ah[rr] = *reinterpret_cast<const bf16x8*>(ap);
+                am[rr] = *reinterpret_cast<const bf16x8*>(ap + 64 * 8);
+                al[rr] = *reinterpret_cast<const bf16x8*>(ap + 2 * 64 * 8);
+                const float4 u = *reinterpret_cast<const float4*>(ur + (size_t)r * T + 4 * g);
+                u4[rr] = f32x4{u.x, u.y, u.z, u.w};
+            }
+        }
+        const int sb0 = cc * (AP_COLS / AP_SB), sb1 = min(nsb, sb0 + AP_COLS / AP_SB);
+        if (rbase >= R) continue;                          // this wave's rows lie past the matrix edge
+        const unsigned short* cp = Cb + (size_t)sb0 * (3 * 4 * 64 * 8) + (size_t)lane * 8;
+        bf16x8 bh = *reinterpret_cast<const bf16x8*>(cp);
+        bf16x8 bm = *reinterpret_cast<const bf16x8*>(cp + 4 * 64 * 8);
+        bf16x8 bl = *reinterpret_cast<const bf16x8*>(cp + 2 * 4 * 64 * 8);
+        for (int sb = sb0; sb < sb1; ++sb) {
+            float zb[4][AP_RW];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int nb = b + 1 < 4 ? b + 1 : 0;
+                const int nsbk = b + 1 < 4 ? sb : min(sb + 1, sb1 - 1);
+                const unsigned short* np = Cb + ((size_t)nsbk * 3 * 4 + nb) * (64 * 8) + (size_t)lane * 8;
+                const bf16x8 nbh = *reinterpret_cast<const bf16x8*>(np);
+                const bf16x8 nbm = *reinterpret_cast<const bf16x8*>(np + 4 * 64 * 8);
+                const bf16x8 nbl = *reinterpret_cast<const bf16x8*>(np + 2 * 4 * 64 * 8);
+#pragma unroll
+                for (int rr = 0; rr < AP_RW; ++rr) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma_bf16(al[rr], bh, c);
+                    c = mfma_bf16(ah[rr], bl, c);
+                    c = mfma_bf16(am[rr], bm, c);
+                    c = mfma_bf16(am[rr], bh, c);
+                    c = mfma_bf16(ah[rr], bm, c);
+                    f32x4 h = mfma_bf16(ah[rr], bh, u4[rr]);
+                    h = h + c;
+                    // relu, then the three planes of each of the lane's four values (t = 4g .. 4g+3)
+                    unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) split3_bf16(relu(h[i]), hb[i], mb[i], lb[i]);
+                    const unsigned h01 = pack_hi16(hb[0], hb[1]), h23 = pack_hi16(hb[2], hb[3]);
+                    const unsigned m01 = pack_hi16(mb[0], mb[1]), m23 = pack_hi16(mb[2], mb[3]);
+                    const unsigned l01 = pack_hi16(lb[0], lb[1]), l23 = pack_hi16(lb[2], lb[3]);
+                    f32x4 qc = {0.f, 0.f, 0.f, 0.f};
+                    qc = mfma_bf16(wc, __builtin_bit_cast(bf16x8, u32x4{m01, m23, h01, h23}), qc);     // Hm.W1m + Hh.W1l
+                    qc = mfma_bf16(wb2, __builtin_bit_cast(bf16x8, u32x4{l01, l23, h01, h23}), qc);    // Hl.W1h + Hh.W1m
+                    f32x4 q = mfma_bf16(wa, __builtin_bit_cast(bf16x8, u32x4{h01, h23, m01, m23}),
+                                        f32x4{b1v.x, b1v.y, b1v.z, b1v.w});                            // Hh.W1h + Hm.W1h
+                    q = q + qc;
+                    const float t0 = __builtin_amdgcn_fmed3f(q[0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[1], 0.f, side.y);
+                    const float t2 = __builtin_amdgcn_fmed3f(q[2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[3], 0.f, side.w);
+                    zb[b][rr] = (t0 + t1) + (t2 + t3);
+                }
+                bh = nbh;
+                bm = nbm;
+                bl = nbl;
+            }
+            float sc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float p02 = swap32_add(zb[b][0], zb[b][2]);
+                const float p13 = swap32_add(zb[b][1], zb[b][3]);
+                const float zsel = swap16_add(p02, p13);
+                sc[b] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(zsel, -kL2E, nb2)));
+            }
+            const int r = rbase + g, c0 = sb * AP_SB + 4 * l15;
+            if (r < R) {
+                float* dst = score + (size_t)r * ld + c0;
+                if (c0 + 3 < M) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f32x4u*>(dst) = f32x4u{sc[0], sc[1], sc[2], sc[3]};
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (c0 + b < M) dst[b] = sc[b];
+                }
+            }
+        }
+    }
+}
+
 int launch_score_all_pairs(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
-                           int64_t ld, void* ws, hipStream_t stream) {
+                           int64_t ld, void* ws, hipStream_t stream, bool wide) {
     if (R == 0 || M == 0) return SGPR_OK;
     const int ngroups = ap_prep_groups(R, M), nrng = 2 * ngroups;
     const size_t nsb = (size_t)(M + AP_SB - 1) / AP_SB;
     float* ur = static_cast<float*>(ws);
     float* rng = ur + (size_t)R * T;
     unsigned short* Ab = reinterpret_cast<unsigned short*>(rng + (size_t)nrng * 4);
-    unsigned short* Cb = Ab + (size_t)R * 2 * 64 * 8;
+    unsigned short* Cb = Ab + (size_t)R * (wide ? 3 : 2) * 64 * 8;
     (void)nsb;
+    const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
+    if (wide) {                                            // three bf16 planes: the reference's operand width, fp32's range
+        hipLaunchKernelGGL(ntn_prep_wide_kernel, dim3(nrng), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, rng, Cb);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "ntn_prep_wide_kernel launch");
+        const int64_t slots = (int64_t)h->num_cus * APW_OCC;
+        const unsigned grid = (unsigned)(items < slots ? items : slots);
+        hipLaunchKernelGGL(score_all_pairs_wide_kernel, dim3(grid), dim3(256), 0, stream, h->w, R, M, Ab, Cb, ur, score, ld);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "score_all_pairs_wide_kernel launch");
+        return SGPR_OK;
+    }
     hipLaunchKernelGGL(ntn_prep_kernel, dim3(nrng), dim3(256), 0, stream, h->w, rows, R, cols, M, Ab, ur, rng, Cb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "ntn_prep_kernel launch");
-    const int64_t items = (int64_t)((M + AP_COLS - 1) / AP_COLS) * ((R + AP_ROWS - 1) / AP_ROWS);
     const int64_t slots = (int64_t)h->num_cus * AP_OCC;   // one resident slot per workgroup: a single, full round
     const unsigned grid = (unsigned)(items < slots ? items : slots);
     hipLaunchKernelGGL((score_all_pairs_kernel<AP_OCC, AP_NI, 0>), dim3(grid), dim3(256), 0, stream, h->w, R, M, Ab, Cb, ur, rng, nrng, rows,
