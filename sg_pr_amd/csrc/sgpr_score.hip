@@ -819,7 +819,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 // {upper half of b, upper half of a} -> one dword: K slot 2i in the low half, 2i + 1 in the high half
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-constexpr int APW_OCC = 3;     // (three row-operand planes of four row graphs: 48 registers; three workgroups per CU)
+#ifndef SGPR_APW_OCC
+#define SGPR_APW_OCC 3
+#endif
+constexpr int APW_OCC = SGPR_APW_OCC;     // (three row-operand planes of four row graphs: 48 registers; three workgroups per CU)
 
 __global__ __launch_bounds__(256, APW_OCC) void score_all_pairs_wide_kernel(const DevWeights w, int R, int M,
                                                                             const unsigned short* __restrict__ Ab,

@@ -93,6 +93,19 @@ if not pmc_only:
                       open(os.path.join(dst, tag + "_wide_bench.json"), "w"), indent=1)
     except (OSError, IndexError, KeyError, ValueError):
         pass
+    f = os.path.join(src, "plain_embed.txt")
+    if os.path.exists(f):
+        with open(os.path.join(dst, tag + "_plain_embed.txt"), "w") as o:
+            o.write("# python tools/run_auto.py 50: sgpr_embed without a node_cap promise (64-row launch + hand-over of larger graphs) against\n"
+                    "# the capped and the ordered launch of the same graphs; host-timed loops of 50 calls (us per call), bitwise = same pooled vectors\n")
+            o.write("".join(l for l in open(f) if "amdgpu.ids" not in l))
+    try:
+        line = [l for l in open(os.path.join(src, "bench_cpu100k.json")) if l.startswith("{")][-1]
+        cb = json.loads(line)["cpu_baseline"]
+        json.dump({"source": "python bench.py --cpu-pairs 100000 --steps 20 --no-end-to-end --no-wide-range (SURVEY.md 8d's CPU sample)",
+                   "cpu_baseline": cb}, open(os.path.join(dst, tag + "_cpu_baseline_100k.json"), "w"), indent=1)
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
     for kind in ("kitti", "world"):
         f = os.path.join(src, "f1_phases_%s.log" % kind)
         if os.path.exists(f):

@@ -47,6 +47,10 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_wid
 timeout 900 python $R/tools/seq_parity.py 4541 $O/seq_parity_both.txt > $O/seq_parity.log 2>&1 </dev/null
 timeout 60 $R/tools/probes/tailmix_probe > $O/tailmix_probe.txt 2>&1
 timeout 300 python $R/tools/run_anyshape.py $O/any_shape.txt > $O/any_shape.log 2>&1 </dev/null
+# plain sgpr_embed (no node_cap promise: lean launch + hand-over) against the capped / ordered launches, five data shapes
+timeout 300 python $R/tools/run_auto.py 50 > $O/plain_embed.txt 2>&1 </dev/null
+# SURVEY.md 8d's calibration sample of the CPU baseline: 100 000 pairs through the oracle (minutes of CPU time; the driver's line keeps the bounded sample)
+timeout 1500 python $R/bench.py --cpu-pairs 100000 --steps 20 --no-end-to-end --no-wide-range > $O/bench_cpu100k.json 2> $O/bench_cpu100k.err </dev/null
 timeout 200 python $R/tools/run_f1.py 10 check > $O/consumers.log 2>&1 </dev/null
 timeout 200 python $R/tools/f1_phases.py kitti > $O/f1_phases_kitti.log 2>&1 </dev/null
 timeout 200 python $R/tools/f1_phases.py world > $O/f1_phases_world.log 2>&1 </dev/null
