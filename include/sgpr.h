@@ -74,8 +74,9 @@ typedef struct sgpr_handle sgpr_handle;
  * an "any-shape" handle: the same entry points on plain-fp32 kernels
  * (sgpr_generic.hip) - correct against the same oracle, not tuned - with device
  * buffers of the model's own width (pooled [G, filters_3], emb [G, N, filters_3]:
- * sgpr_pooled_width).  Not served on such a handle: sgpr_score_pair_list (use
- * sgpr_score_pairs) and sgpr_embed_debug's dumps -> SGPR_E_DIMS.  Beyond the
+ * sgpr_pooled_width).  Not served on such a handle: sgpr_embed_debug's dumps
+ * (-> SGPR_E_DIMS; sgpr_score_pair_list walks its plan pair by pair there: the
+ * bits of sgpr_score_pairs, no workspace).  Beyond the
  * SGPR_ANY_MAX_* limits -> SGPR_E_DIMS at sgpr_create.
  * node_num in (SGPR_MAX_NODES, SGPR_ANY_MAX_NODES] or K in (SGPR_MAX_K,
  * SGPR_ANY_MAX_K] run on the any-shape embed kernel on every handle (the pooled

@@ -948,10 +948,10 @@ int sgpr_score_pair_list(const sgpr_handle* h, const float* d_pooled_rows, int R
         return SGPR_E_INVALID;
     }
     if (P == 0) return SGPR_OK;
-    if (h->generic_only) {
-        set_error("sgpr_score_pair_list: the grouped pair-list kernel is built for tensor networks up to 32 x 32 x 16; a larger "
-                  "architecture scores its lists through sgpr_score_pairs");
-        return SGPR_E_DIMS;
+    if (h->generic_only) {                                   // (an architecture beyond the built shape: the plan walked on the
+        DeviceGuard guard(h->device);                        //  any-shape tail, pair by pair - the bits of sgpr_score_pairs; no workspace)
+        return launch_score_plan_generic(h, d_pooled_rows, d_pooled_cols, d_plan, n_rows, n_items, P, d_score,
+                                         static_cast<hipStream_t>(stream));
     }
     const size_t need = score_pair_list_ws_bytes(n_rows, M);
     if (!d_workspace || workspace_bytes < need) {

@@ -99,6 +99,12 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 #endif                        // of their own.  Measured (tools/run_auto.py, same box): KITTI-00 shape, no oversize graph: 147.7 us per
                               // call against 149 + 5 (the empty launch) - nothing; 693 / 2180 oversize graphs of 4541: 501 / 791 us
                               // against 307 / 443 (one workgroup per CU at the second pass's LDS size instead of two): off
+#ifndef SGPR_BIG_SEM_WAVE
+#define SGPR_BIG_SEM_WAVE 0   // 1 (A/B builds): owned-rows instance, the super-node branch on one otherwise idle wave beside the first
+#endif                        // xyz layer.  Measured (same box, twice): config 5 548.6 / 551.0 -> 572.2 / 575.6 us - bit-identical, SLOWER:
+                              // one wave needs longer for the branch (its 256-thread loops four times over) than the other waves for
+                              // their selection + GEMMs, so they wait for it at their first barrier instead of it hiding behind them
+constexpr int kSemWaveBytes = 16 * PXH + 32 * 68 * 4 + 64 + 64;   // X rows | A rows + keys | norms | label sets
 #ifndef SGPR_BIG_OWNED
 #define SGPR_BIG_OWNED 1      // production plans beyond 64 rows on the owned-rows instance (0: A/B builds on the chunked plans)
 #endif
@@ -121,6 +127,8 @@ __host__ __device__ constexpr void lean_fixed_layout(EmbedPlan& p, bool small_pa
     p.alias_da = 1;
     p.lean = rows;
     p.big = 0;
+    p.sem_wave = 0;
+    p.offSem = 0;
     p.xplanes = 1;
     p.fmt = FMT_H2;
     p.rowb = PXH;
@@ -188,6 +196,8 @@ static bool plan_layout(int N, int NC, int k, int fmt, EmbedPlan* p, bool small_
     // lean plans (NP <= 64, plane layouts): one wave per 16-row tile, 12..16 waves per CU on the <= 128-VGPR kernel instance
     p->lean = 0;
     p->big = 0;
+    p->sem_wave = 0;
+    p->offSem = 0;
     if (planes && p->overlap && p->NP <= 64 && min_nt == 0) {
         int nt3 = 64 * (p->NP / 16);
         if (nt3 < round_up(N, 64)) nt3 = round_up(N, 64);     // one thread per input slot
@@ -238,7 +248,18 @@ static bool plan_big(int N, int NC, int k, EmbedPlan* p) {
     p->nt = 64 * (p->NP / 16);
     if (p->nt < round_up(N, 64)) p->nt = round_up(N, 64);       // one thread per input slot
     p->RC = p->NP;
-    return p->nt <= 1024;
+    if (p->nt > 1024) return false;
+#if SGPR_BIG_SEM_WAVE
+    // the super-node branch on a wave of its own, beside the first xyz layer (embed_graph): 16 rows of X, 32 of A / keys,
+    // norms, label sets = kSemWaveBytes of LDS - and one wave more than the rows need, while the block size allows
+    if (p->lds_bytes + kSemWaveBytes <= kLdsLimit) {
+        p->sem_wave = 1;
+        p->offSem = p->lds_bytes;
+        p->lds_bytes += kSemWaveBytes;
+        if (p->nt == 64 * (p->NP / 16) && p->nt + 64 <= 1024) p->nt += 64;
+    }
+#endif
+    return true;
 }
 
 bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* p, bool wide_range, bool small_park, int min_nt) {
@@ -2135,7 +2156,21 @@ __device__ __forceinline__ void supernode_branch(const DevWeights& w, const int 
         }
         group_sync<WAVE>();                                                   // keys consumed: A may overwrite D
         if (LEAN == 0 && !tab2) {
-            gemm_layer<false, FMT>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave, NW, 0);
+            if constexpr (WAVE) {
+                // (one wave, one row tile: the one-tile form - this instance shares the owned-rows kernel's 128 registers)
+                f32x4 bo[4];
+                if (cout == 64)
+                    gemm_own<4, 64, FMT>(X, A, pitchA, wl, w.tb[Lv], 0, bo);
+                else
+                    gemm_own<4, 32, FMT>(X, A, pitchA, wl, w.tb[Lv], 0, bo);
+                unsigned char* x0 = X + (lane & 15) * XROW;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    if (cb < (cout >> 4))
+                        *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * (lane >> 4)) * 4) = make_float4(bo[cb][0], bo[cb][1], bo[cb][2], bo[cb][3]);
+            } else {
+                gemm_layer<false, FMT>(X, A, pitchA, wl, w.tb[Lv], 64, cout, 1, wave, NW, 0);
+            }
             group_sync<WAVE>();
         }
         const int lpr = cout >> 2;                                         // lanes per row: 16 or 8
@@ -2422,9 +2457,12 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     bool any_bad = false;     // a node without a label, a stray all-zero row among the nodes, no padding: the generic branch
     int my_label_count = 0;   // lanes 0..11 of every wave: nodes that carry label `lane`
     {
-        float* ref = red;                       // 16 floats: the last slot
-        int* wmax = reinterpret_cast<int*>(red + 16);
-        unsigned long long* negm = reinterpret_cast<unsigned long long*>(red + 32);   // [8 waves] slots with a label < 0
+        // (owned-rows instance: in the A region, which nothing touches before the first GEMM - X is then free for the xyz
+        //  staging ahead of the prologue's last barrier, see the super-node wave below)
+        float* pro = (BIG && SGPR_BIG_SEM_WAVE != 0) ? A : red;
+        float* ref = pro;                       // 16 floats: the last slot
+        int* wmax = reinterpret_cast<int*>(pro + 16);
+        unsigned long long* negm = reinterpret_cast<unsigned long long*>(pro + 32);   // [8 waves] slots with a label < 0
         unsigned long long* nm1 = negm + 8;                                           // [8] slots whose label is not -1
         unsigned long long* labm = nm1 + 8;                                           // [8][12] slots per label
         if (tid == NS - 1) {
@@ -2532,6 +2570,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     //      runs for semantic rows that are not one-hot, debug dumps, graphs without >= K padding slots, stray
     //      all-zero rows among the nodes, < 17 slots.
     int L0 = 0;
+    bool sem_conc = false;                                   // owned-rows instance: the super-node branch runs beside the xyz layers
     const signed char* rowlab = nullptr;                     // fast path: table row of every slot (13 = zero row)
     const bool split = LEAN != 0 && DBG == 0 && role == 2;   // this graph's semantic branch runs in another workgroup
     {
@@ -2554,9 +2593,37 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
             // (split launch: the graph's other workgroup computes the branch and needs no counts here)
             if (!split && tid < 16) cnt[tid] = tid == kLabels ? k0 : (tid < kLabels ? my_label_count : 0);
         }
+        if constexpr (BIG && SGPR_BIG_SEM_WAVE != 0) {
+            // ---- the super-node branch on ONE wave (the first one the graph's row tiles leave idle), in LDS of its own,
+            //      while the other waves run the coordinate layer's selection and GEMMs: with one workgroup per CU nothing
+            //      else would hide its barriers and round trips (31 of 521 us per config-5 launch).  The xyz input is
+            //      staged HERE, ahead of the barrier, so that the xyz waves meet no barrier before the one behind their
+            //      first GEMMs - by which time the branch is done (its wave then only keeps the barrier count).
+            sem_conc = fast && p.sem_wave && nrt < NW;
+            if (sem_conc && tid < NP) {
+                const bool live = tid < N;
+                unsigned char* xr = X + tid * XROW;
+                xstore<FMT>(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                xzero<FMT>(xr, 4);
+                xzero<FMT>(xr, 8);
+                xzero<FMT>(xr, 12);
+                const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));   // as torch.sum(x ** 2)
+                *reinterpret_cast<float4*>(xr + XROW - 16) = live ? make_float4(fx, fy, fz, n2) : make_float4(0.f, 0.f, 0.f, INFINITY);
+            }
+        }
         __syncthreads();       // the prologue's scratch (in the X region) is dead; counts and row labels are visible
         if (fast) {
-            if (!split) {
+            if ((BIG && SGPR_BIG_SEM_WAVE != 0) && sem_conc) {
+                if constexpr (BIG && SGPR_BIG_SEM_WAVE != 0) {
+                    if (wave == nrt) {
+                        unsigned char* sX = smem + p.offSem;
+                        float* sA = reinterpret_cast<float*>(sX + 16 * XROW);
+                        float* sxx = sA + 32 * 68;
+                        int* svm = reinterpret_cast<int*>(sxx + 16);
+                        supernode_branch<FMT, 0, true>(kp.w, k0, skip, sX, sxx, sA, sA + 16 * 68, 68, 20, cnt, svm, park, lane, 0, 64, 1, vmax);
+                    }
+                }
+            } else if (!split) {
                 supernode_branch<FMT, (BIG ? -1 : LEAN), false>(kp.w, k0, skip, X, xx, A, D, p.pitchA, p.pitchD, cnt, vmask, park, tid, wave, NT, NW, vmax);
 #if SGPR_EXP_DOUBLE & 8
                 __syncthreads();
@@ -2614,7 +2681,7 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
         lane = tid & 63;
         l15 = lane & 15;
         lq = lane >> 4;
-        if (L == 3) {
+        if (L == 3 && !((BIG && SGPR_BIG_SEM_WAVE != 0) && sem_conc)) {
             // ---- stage the second branch's input (xyz, zero padded to 16 channels / NP rows) + (x, y, z, |x|^2) in fp32
             if (tid < NP) {
                 const bool live = tid < N;

@@ -446,6 +446,52 @@ __global__ __launch_bounds__(TAIL_THREADS) void generic_score_list_kernel(const 
     }
 }
 
+// grouped list (sgpr_score_pair_list's plan, sgpr.h: row_ids | item_row | item_beg | cols | pos): a workgroup walks work
+// items (<= 16 listed pairs of ONE row graph); every pair through the list kernel's arithmetic, so a grouped list gives the
+// bits of sgpr_score_pairs on the same pairs
+__global__ __launch_bounds__(TAIL_THREADS) void generic_score_plan_kernel(const GenericModel m, const float* __restrict__ rows,
+                                                                          const float* __restrict__ colsv,
+                                                                          const int32_t* __restrict__ row_ids,
+                                                                          const int32_t* __restrict__ item_row,
+                                                                          const int32_t* __restrict__ item_beg,
+                                                                          const int32_t* __restrict__ cols,
+                                                                          const int32_t* __restrict__ pos, const int NI,
+                                                                          float* __restrict__ score, const int pw) {
+    extern __shared__ __attribute__((aligned(16))) float tail_smem[];
+    float* prod = tail_smem;                                      // [F * T]
+    float* se = prod + m.f3 * m.T;                                // [2 F]
+    float* hbuf = se + 2 * m.f3;                                  // [T]
+    float* gbuf = hbuf + m.T;                                     // [B]
+    for (int it = blockIdx.x; it < NI; it += gridDim.x) {
+        const int64_t r1 = row_ids[item_row[it]];
+        for (int q = item_beg[it]; q < item_beg[it + 1]; ++q) {
+            pair_ntn_wg(m.ntn_w, m.ntn_wb, m.ntn_bias, rows + r1 * pw, colsv + (int64_t)cols[q] * pw, m.f3, m.T, prod, se, hbuf);
+            const float z = pair_head_wg(m, hbuf, gbuf);
+            if (threadIdx.x == 0) score[pos[q]] = z;
+        }
+    }
+}
+
+int launch_score_plan_generic(const sgpr_handle* h, const float* rows, const float* cols, const int32_t* plan, int NR, int NI,
+                              int64_t P, float* score, hipStream_t stream) {
+    if (P == 0 || NI == 0) return SGPR_OK;
+    const GenericModel& m = h->gm;
+    const int pw = h->generic_only ? m.f3 : kF3;
+    const int32_t* row_ids = plan;
+    const int32_t* item_row = row_ids + NR;
+    const int32_t* item_beg = item_row + NI;
+    const int32_t* pc = item_beg + NI + 1;
+    const int32_t* pos = pc + P;
+    const int64_t cap = (int64_t)16 * h->num_cus;
+    const unsigned blocks = (unsigned)(NI < cap ? NI : cap);
+    const size_t lds = ((size_t)m.f3 * m.T + 2 * m.f3 + m.T + m.B) * sizeof(float);
+    hipLaunchKernelGGL(generic_score_plan_kernel, dim3(blocks), dim3(TAIL_THREADS), lds, stream, m, rows, cols, row_ids, item_row,
+                       item_beg, pc, pos, NI, score, pw);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "generic_score_plan_kernel launch");
+    return SGPR_OK;
+}
+
 // dense rectangle R x M: a workgroup owns one row graph and a range of column tiles.  The bilinear form is hoisted per
 // row (as the tuned tail does): App[j][t] = sum_i e1[i] W[i][j][t] + Wb[t][F + j], u[t] = Wb[t][:F] . e1 + bias[t]; a
 // pair is then s_t = sum_j App[j][t] e2[j] + u[t] - F * T multiply-adds per pair instead of F * F * T - and the head.

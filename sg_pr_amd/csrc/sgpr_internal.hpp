@@ -131,6 +131,8 @@ struct EmbedPlan {
     int fmt;         // X layout: 2 = two f16 planes (272 B rows, the default), 1 = three bf16 planes (400 B), 0 = fp32 rows
     int rowb;        // bytes per X row
     int offX, offA, offD, offPark, offXX, offRed, offIdx;  // byte offsets into dynamic LDS
+    int sem_wave;    // big != 0 only: the super-node branch has LDS of its own (offSem) and runs on ONE otherwise idle wave beside
+    int offSem;      // the first xyz layer's selection (embed_graph); 0: on the whole workgroup, ahead of the xyz layers
     int lds_bytes;
 };
 bool make_embed_plan(int N, int node_cap, int k, EmbedPlan* plan, bool wide_range = false, bool small_park = false,
@@ -203,6 +205,8 @@ int launch_ntn_any(const float* w, const float* wb, const float* bias, const flo
                    int T, float* out, hipStream_t stream);
 int launch_score_generic(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,
                          int64_t P, int M, float* score, int64_t ld, hipStream_t stream);
+int launch_score_plan_generic(const sgpr_handle* h, const float* rows, const float* cols, const int32_t* plan, int NR, int NI,
+                              int64_t P, float* score, hipStream_t stream);
 int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,
                float* out, hipStream_t stream);
 int launch_knn(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);

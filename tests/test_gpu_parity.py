@@ -1920,8 +1920,9 @@ def test_larger_architectures_run_on_the_any_shape_kernels(oracle):
         assert (pairs - mat[torch.arange(12), torch.arange(12, 24)]).abs().max().item() < 5e-5
         outs = eng.score_all_pairs_multi([(pooled[:7], pooled), (pooled[7:], pooled[:5])])
         assert torch.equal(outs[0], mat[:7]) and torch.equal(outs[1], mat[7:, :5])
-        with pytest.raises(SgprError, match="SGPR_E_DIMS"):
-            eng.score_pair_list(pooled, pooled, eng.pair_plan(i1, i2, 24, 24))
+        # the grouped entry point on an any-shape handle: the plan walked pair by pair - the bits of sgpr_score_pairs
+        grouped = eng.score_pair_list(pooled, pooled, eng.pair_plan(i1, i2, 24, 24))
+        assert torch.equal(grouped, eng.score_pairs(pooled, pooled, torch.from_numpy(i1), torch.from_numpy(i2))), tag
         with pytest.raises(SgprError, match="SGPR_E_DIMS"):
             eng.embed(c, l, K, debug=True)
         eng.check_status()
