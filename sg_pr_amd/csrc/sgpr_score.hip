@@ -822,6 +822,10 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 #ifndef SGPR_APW_OCC
 #define SGPR_APW_OCC 3
 #endif
+#ifndef SGPR_APW_NI
+#define SGPR_APW_NI 1         // (2: same time, same box - 226.9 / 230.1 against 226.9 / 226.5 us - and 12 registers more)
+#endif
+constexpr int APW_NI = SGPR_APW_NI;       // row graphs interleaved in program order (1, 2 or 4)
 constexpr int APW_OCC = SGPR_APW_OCC;     // (three row-operand planes of four row graphs: 48 registers; three workgroups per CU)
 
 __global__ __launch_bounds__(256, APW_OCC) void score_all_pairs_wide_kernel(const DevWeights w, int R, int M,
@@ -897,31 +901,52 @@ __global__ __launch_bounds__(256, APW_OCC) void score_all_pairs_wide_kernel(cons
                 const bf16x8 nbm = *reinterpret_cast<const bf16x8*>(np + 4 * 64 * 8);
                 const bf16x8 nbl = *reinterpret_cast<const bf16x8*>(np + 2 * 4 * 64 * 8);
 #pragma unroll
-                for (int rr = 0; rr < AP_RW; ++rr) {
-                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                    c = mfma_bf16(al[rr], bh, c);
-                    c = mfma_bf16(ah[rr], bl, c);
-                    c = mfma_bf16(am[rr], bm, c);
-                    c = mfma_bf16(am[rr], bh, c);
-                    c = mfma_bf16(ah[rr], bm, c);
-                    f32x4 h = mfma_bf16(ah[rr], bh, u4[rr]);
-                    h = h + c;
-                    // relu, then the three planes of each of the lane's four values (t = 4g .. 4g+3)
-                    unsigned hb[4], mb[4], lb[4];
+                for (int r0 = 0; r0 < AP_RW; r0 += APW_NI) {
+                    // APW_NI row graphs interleaved in program order: their dependent MFMA -> vector -> MFMA chains overlap
+                    f32x4 c[APW_NI], h[APW_NI], qc[APW_NI], q[APW_NI];
+                    unsigned h01[APW_NI], h23[APW_NI], m01[APW_NI], m23[APW_NI], l01[APW_NI], l23[APW_NI];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) split3_bf16(relu(h[i]), hb[i], mb[i], lb[i]);
-                    const unsigned h01 = pack_hi16(hb[0], hb[1]), h23 = pack_hi16(hb[2], hb[3]);
-                    const unsigned m01 = pack_hi16(mb[0], mb[1]), m23 = pack_hi16(mb[2], mb[3]);
-                    const unsigned l01 = pack_hi16(lb[0], lb[1]), l23 = pack_hi16(lb[2], lb[3]);
-                    f32x4 qc = {0.f, 0.f, 0.f, 0.f};
-                    qc = mfma_bf16(wc, __builtin_bit_cast(bf16x8, u32x4{m01, m23, h01, h23}), qc);     // Hm.W1m + Hh.W1l
-                    qc = mfma_bf16(wb2, __builtin_bit_cast(bf16x8, u32x4{l01, l23, h01, h23}), qc);    // Hl.W1h + Hh.W1m
-                    f32x4 q = mfma_bf16(wa, __builtin_bit_cast(bf16x8, u32x4{h01, h23, m01, m23}),
-                                        f32x4{b1v.x, b1v.y, b1v.z, b1v.w});                            // Hh.W1h + Hm.W1h
-                    q = q + qc;
-                    const float t0 = __builtin_amdgcn_fmed3f(q[0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[1], 0.f, side.y);
-                    const float t2 = __builtin_amdgcn_fmed3f(q[2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[3], 0.f, side.w);
-                    zb[b][rr] = (t0 + t1) + (t2 + t3);
+                    for (int i = 0; i < APW_NI; ++i) c[i] = mfma_bf16(al[r0 + i], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) h[i] = mfma_bf16(ah[r0 + i], bh, u4[r0 + i]);
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) c[i] = mfma_bf16(ah[r0 + i], bl, c[i]);
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) c[i] = mfma_bf16(am[r0 + i], bm, c[i]);
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) c[i] = mfma_bf16(am[r0 + i], bh, c[i]);
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) c[i] = mfma_bf16(ah[r0 + i], bm, c[i]);
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) {
+                        h[i] = h[i] + c[i];
+                        // relu, then the three planes of each of the lane's four values (t = 4g .. 4g+3)
+                        unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) split3_bf16(relu(h[i][v]), hb[v], mb[v], lb[v]);
+                        h01[i] = pack_hi16(hb[0], hb[1]);
+                        h23[i] = pack_hi16(hb[2], hb[3]);
+                        m01[i] = pack_hi16(mb[0], mb[1]);
+                        m23[i] = pack_hi16(mb[2], mb[3]);
+                        l01[i] = pack_hi16(lb[0], lb[1]);
+                        l23[i] = pack_hi16(lb[2], lb[3]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i)                                                       // Hm.W1m + Hh.W1l
+                        qc[i] = mfma_bf16(wc, __builtin_bit_cast(bf16x8, u32x4{m01[i], m23[i], h01[i], h23[i]}), f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i)                                                       // Hh.W1h + Hm.W1h
+                        q[i] = mfma_bf16(wa, __builtin_bit_cast(bf16x8, u32x4{h01[i], h23[i], m01[i], m23[i]}), f32x4{b1v.x, b1v.y, b1v.z, b1v.w});
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i)                                                       // Hl.W1h + Hh.W1m
+                        qc[i] = mfma_bf16(wb2, __builtin_bit_cast(bf16x8, u32x4{l01[i], l23[i], h01[i], h23[i]}), qc[i]);
+#pragma unroll
+                    for (int i = 0; i < APW_NI; ++i) {
+                        q[i] = q[i] + qc[i];
+                        const float t0 = __builtin_amdgcn_fmed3f(q[i][0], 0.f, side.x), t1 = __builtin_amdgcn_fmed3f(q[i][1], 0.f, side.y);
+                        const float t2 = __builtin_amdgcn_fmed3f(q[i][2], 0.f, side.z), t3 = __builtin_amdgcn_fmed3f(q[i][3], 0.f, side.w);
+                        zb[b][r0 + i] = (t0 + t1) + (t2 + t3);
+                    }
                 }
                 bh = nbh;
                 bm = nbm;
