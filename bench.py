@@ -290,7 +290,8 @@ def main():
             dur_calls["embed"] = lambda: j0["scorer"].embed_fn(j0["d_centers"][lo0:hi0], j0["d_labels"][lo0:hi0])
             _c0, _l0 = j0["d_centers"][lo0:hi0].contiguous(), j0["d_labels"][lo0:hi0].contiguous()
             _ord0 = eng.size_order_device(_c0, _l0, None, n, k)[0]
-            dur_calls["embed_plain"] = lambda: eng.embed(_c0, _l0, k)[0]
+            dur_calls["embed_plain"] = lambda: eng.embed(_c0, _l0, k, auto_order=False)[0]    # the plain C-ABI call
+            dur_calls["embed_engine_default"] = lambda: eng.embed(_c0, _l0, k)[0]           # + the binding's cached device order
             dur_calls["embed_order_only"] = lambda: eng.embed(_c0, _l0, k, order=_ord0)[0]
             dur_calls["size_order"] = lambda: eng.size_order_device(_c0, _l0, None, n, k)[0]
         if seqset is not None and not a.per_sequence_tails and world == 1:
@@ -468,6 +469,7 @@ def main():
     if world == 1 and "embed_plain" in dur_calls:
         embed_forms = {"ordered_with_node_cap": embed_ms,
                        "plain_no_promise": kernel_ms(dur_calls["embed_plain"], launches_timed),
+                       "engine_embed_default": kernel_ms(dur_calls["embed_engine_default"], launches_timed),
                        "ordered_no_promise": kernel_ms(dur_calls["embed_order_only"], launches_timed),
                        "size_order_launches": kernel_ms(dur_calls["size_order"], launches_timed)}
     tail_ms = kernel_ms(dur_calls["tail"], launches_timed) if "tail" in dur_calls else None

@@ -138,7 +138,8 @@ int sgpr_embed(const sgpr_handle* h, const float* d_centers, const int32_t* d_la
 /* sgpr_embed with a promise about the input: no graph of the batch needs more than `node_cap` PROCESSED slots
  * (= slots before the trailing run of m identical padding slots, + 1 when m >= k, + m otherwise; 0 = no promise).
  * The kernel sizes its LDS for node_cap instead of N: caps <= 64 (<= 48) select a fixed 64-row (48-row) layout that
- * runs four (five) workgroups per CU.  A graph that breaks the promise gets a NaN pooled vector and
+ * runs four (five) workgroups per CU; caps of 65 .. 96 (K <= 16, more graphs than CUs) keep the graphs of up to 64 slots
+ * on that layout and run only the others on the instance sized for node_cap; beyond, one launch sized for node_cap.  A graph that breaks the promise gets a NaN pooled vector and
  * sgpr_check_status returns SGPR_E_NODES.  Results are otherwise identical to sgpr_embed.
  * On the any-shape kernels (an architecture beyond the built shape, N > SGPR_MAX_NODES, K > SGPR_MAX_K) node_cap is
  * advisory: they size nothing by it and do not check it. */

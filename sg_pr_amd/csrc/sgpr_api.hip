@@ -693,8 +693,18 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     // workgroups per CU, what KITTI-like data fits into - and a graph with more processed slots is handed to the
     // owned-rows instance sized for node_num in the same call (launch_embed), instead of every graph paying for the
     // largest one could be.  (The reference has no such prerequisite either: sg_net.py:503-525.)
+    // A promise of 65 .. kTwoTierCap slots (K <= 16) takes the same two tiers: the graphs of up to 64 slots on the lean plan,
+    // the others on the owned-rows instance sized for the PROMISED cap - a mixed data set no longer pays every graph at the
+    // size of its largest; the promise stays enforced (a graph beyond it: NaN + SGPR_E_NODES).  Measured (tools/run_auto.py,
+    // ordered launches, 4541 graphs of node_num 100): 25..70 nodes (cap 71, 15 % above 64 slots) 322 -> 207 us, 40..85
+    // nodes (cap 86, 48 %) 352 -> 334; but 2048 graphs of 20..120 nodes in 256 slots (cap 121, 56 % above 64 and most of the
+    // work in them) 153 -> 188: two launches that each under-fill the device.  The library sees the cap, not the data: the
+    // two tiers stop at a cap of 96 (six row tiles), where an oversize graph costs little more than a lean one.
+    constexpr int kTwoTierCap = 96;
     bool auto_lean = false;
-    if (!promised && production && !wide_range(h) && a.G > h->num_cus && N > 64 && SGPR_AUTO_LEAN) {
+    const int over_cap = promised ? node_cap : N;
+    if ((!promised || (node_cap > 64 && node_cap <= kTwoTierCap)) && production && !wide_range(h) && a.G > h->num_cus && N > 64 &&
+        SGPR_AUTO_LEAN) {
         EmbedPlan lean;
         if (make_embed_plan(N, 64, k, &lean, false, true) && lean.lean) {
             node_cap = 64;
@@ -714,6 +724,7 @@ static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int nod
     a.redo_count = embed_redo_count(a.redo, gtot);
     a.over_count = a.redo_count + 1;                 // (the second word of the 8 bytes behind the flags)
     a.auto_over = auto_lean ? 1 : 0;
+    a.over_cap = over_cap;
     a.park_ws = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot));
     unsigned char* sem = static_cast<unsigned char*>(ws) + embed_flag_bytes(gtot) + embed_park_bytes(gtot, N);
     a.sem_flag = reinterpret_cast<unsigned long long*>(sem);               // indexed by launch slot (< a.G <= num_cus / 2)

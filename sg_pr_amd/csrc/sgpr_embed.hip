@@ -3303,7 +3303,8 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
         if (!(plan.fmt == FMT_H2 && plan.lean && a.redo && a.over_count)) {
             kp.a.auto_over = 0;
         } else {
-            over_launch = make_embed_plan(plan.N, 0, plan.k, &over_plan, false, true) && over_plan.big;
+            const int ocap = (kp.a.over_cap > 64 && kp.a.over_cap < plan.N) ? kp.a.over_cap : 0;
+            over_launch = make_embed_plan(plan.N, ocap, plan.k, &over_plan, false, true) && over_plan.big;
             if (!over_launch) {
                 kp.a.over_count = nullptr;                        // (no owned-rows instance for this K: the second pass's full plan)
             } else if (over_plan.nt <= 512 && plan.k == 10 && SGPR_OVER_IN_REDO) {

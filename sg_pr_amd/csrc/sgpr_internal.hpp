@@ -164,6 +164,7 @@ struct EmbedArgs {
     // or a plain second-pass request when over_count is NULL
     unsigned* over_count;
     int auto_over;          // 1: the hand-over above applies; 2 (embed_big_kernel only): persistent launch over the slots flagged 3
+    int over_cap;           // slots the hand-over launch is sized for: the caller's node_cap when one above 64 was promised, else node_num
     // split launch (sgpr_embed.hip): workgroup s < G (a PRODUCER: the semantic half of launch slot s) publishes the 16
     // sem3 rows of the slot in sem_tab[s][16][32] and sem_flag[s] = token(s); workgroup G + s (the CONSUMER: the xyz half)
     // picks them up before conv_end.  Producers own the lower block indices and are therefore dispatched first - the

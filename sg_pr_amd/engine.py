@@ -248,6 +248,8 @@ class Engine:
         self._h = h
         self.pw = int(self.lib.sgpr_pooled_width(h))
         self.any_shape = bool(self.lib.sgpr_is_any_shape(h))
+        self.num_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        self._order_cache = []            # (data pointers, shape, versions, K) -> device launch order, see embed()
 
     def close(self):
         if self._h is not None:
@@ -389,14 +391,46 @@ class Engine:
         self._check(rc)
         return order, info
 
-    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None):
+    def _cached_order(self, centers, labels, k):
+        """The largest-first launch order and the node_cap of a RESIDENT batch (sgpr_size_order, asynchronous), remembered per
+        (data pointers, shape, torch's in-place version counters, K), so that evaluating the same packed store again costs
+        nothing -> (order, node_cap or 0).  The order is used at once; the node_cap travels to pinned host memory behind an
+        event and is used from the first later call that finds the copy complete (no synchronisation, ever).  A stale entry
+        (memory reused at the same address with the same counters) is still a permutation of the batch's graphs, and a
+        stale node_cap a promise the kernel checks (a graph beyond it: NaN + SGPR_E_NODES, never a wrong result).  A
+        data-set property kept by the binding; the C-ABI stays stateless."""
+        key = (centers.data_ptr(), labels.data_ptr(), tuple(labels.shape), centers._version, labels._version, int(k))
+        for kk, order, info_h, ev in self._order_cache:
+            if kk == key:
+                return order, (int(info_h[0]) if ev.query() else 0)
+        order, info = self.size_order_device(centers, labels, None, labels.shape[1], k)
+        info_h = torch.empty(2, dtype=torch.int32).pin_memory()
+        info_h.copy_(info, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._order_cache = self._order_cache[-3:] + [(key, order, info_h, ev)]
+        return order, 0
+
+    def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None, auto_order=True):
         """centers [G,N,3] f32, labels [G,N] i32 (-1 = pad) -> pooled [G,32] (+ att [G,N], emb [G,N,32]).
         node_cap: optional promise on the processed slots per graph (node_cap_of); 0 = none.
-        order: optional i32 launch order (size_order) - graphs not listed keep uninitialised output rows."""
+        order: optional i32 launch order (size_order) - graphs not listed keep uninitialised output rows.
+        auto_order: no order given and the arrays already resident on this device (more graphs than CUs, the tuned kernels'
+        node_num): launch in the largest-first order sgpr_size_order makes on the device, computed once per tensor pair
+        (_cached_order) - same bits, ~5 % faster than storage order on KITTI-like data; from the second call on the batch's
+        node_cap (made by the same kernels) is promised as well; False = the plain C-ABI call."""
+        resident = (isinstance(centers, torch.Tensor) and isinstance(labels, torch.Tensor) and centers.device == self.device
+                    and labels.device == self.device and centers.dtype == torch.float32 and labels.dtype == torch.int32
+                    and centers.is_contiguous() and labels.is_contiguous())
         centers = self._dev(centers, torch.float32, "centers")
         labels = self._dev(labels, torch.int32, "labels")
         g, n = labels.shape
         assert centers.shape == (g, n, 3), "centers must be [G, N, 3]"
+        if (order is None and auto_order and resident and not debug and g > self.num_cus and n <= MAX_NODES and k <= n
+                and not self.any_shape):
+            order, cap = self._cached_order(centers, labels, k)
+            if node_cap == 0 and 0 < cap < n:
+                node_cap = cap
         pooled = torch.empty(g, self.pw, dtype=torch.float32, device=self.device)
         att = torch.empty(g, n, dtype=torch.float32, device=self.device) if (want_att or debug) else None
         emb = torch.empty(g, n, self.pw, dtype=torch.float32, device=self.device) if (want_emb or debug) else None

@@ -40,11 +40,12 @@ for name, c, l, k in cases:
     order, cap = eng.size_order(c, l, k)
     eff = eng.processed_slots(c, l, k)
     dc, dl = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
-    plain, t_plain = timed(lambda: eng.embed(dc, dl, k)[0])
+    plain, t_plain = timed(lambda: eng.embed(dc, dl, k, auto_order=False)[0])
     eng.check_status()
-    capped, t_cap = timed(lambda: eng.embed(dc, dl, k, node_cap=cap)[0])
+    capped, t_cap = timed(lambda: eng.embed(dc, dl, k, node_cap=cap, auto_order=False)[0])
     ordered, t_ord = timed(lambda: eng.embed(dc, dl, k, node_cap=cap, order=order)[0])
+    default, t_def = timed(lambda: eng.embed(dc, dl, k)[0])           # the binding's default: plain call + cached device order
     eng.check_status()
-    print("%-34s cap %3d  >64: %4d  plain %8.1f us  capped %8.1f  ordered %8.1f  plain/ordered %.3f  bitwise %s" % (
-        name, cap, int((eff > 64).sum()), t_plain, t_cap, t_ord, t_plain / t_ord,
-        bool(torch.equal(plain, capped) and torch.equal(plain, ordered))))
+    print("%-34s cap %3d  >64: %4d  plain %8.1f us  capped %8.1f  ordered %8.1f  engine default %8.1f  plain/ordered %.3f  default/ordered %.3f  bitwise %s" % (
+        name, cap, int((eff > 64).sum()), t_plain, t_cap, t_ord, t_def, t_plain / t_ord, t_def / t_ord,
+        bool(torch.equal(plain, capped) and torch.equal(plain, ordered) and torch.equal(plain, default))))
