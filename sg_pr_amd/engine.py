@@ -249,7 +249,7 @@ class Engine:
         self.pw = int(self.lib.sgpr_pooled_width(h))
         self.any_shape = bool(self.lib.sgpr_is_any_shape(h))
         self.num_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
-        self._order_cache = []            # (data pointers, shape, versions, K) -> device launch order, see embed()
+        self._order_cache = []            # (tensor objects, offsets, shape, versions, K) -> device launch order + node_cap, see embed()
 
     def close(self):
         if self._h is not None:
@@ -393,22 +393,35 @@ class Engine:
 
     def _cached_order(self, centers, labels, k):
         """The largest-first launch order and the node_cap of a RESIDENT batch (sgpr_size_order, asynchronous), remembered per
-        (data pointers, shape, torch's in-place version counters, K), so that evaluating the same packed store again costs
-        nothing -> (order, node_cap or 0).  The order is used at once; the node_cap travels to pinned host memory behind an
-        event and is used from the first later call that finds the copy complete (no synchronisation, ever).  A stale entry
-        (memory reused at the same address with the same counters) is still a permutation of the batch's graphs, and a
-        stale node_cap a promise the kernel checks (a graph beyond it: NaN + SGPR_E_NODES, never a wrong result).  A
-        data-set property kept by the binding; the C-ABI stays stateless."""
-        key = (centers.data_ptr(), labels.data_ptr(), tuple(labels.shape), centers._version, labels._version, int(k))
-        for kk, order, info_h, ev in self._order_cache:
-            if kk == key:
-                return order, (int(info_h[0]) if ev.query() else 0)
+        tensor pair, so that evaluating the same packed store again costs nothing -> (order, node_cap or 0).  An entry
+        belongs to the tensors' base OBJECTS (weak references: a new tensor that happens to reuse the address of a freed
+        one is a different object), their storage offsets / shapes, torch's in-place version counters and K.  The order is
+        used at once; the node_cap travels to pinned host memory behind an event and is used from the first later call
+        that finds the copy complete (no synchronisation, ever).  Whatever the cache says, the kernels check it: an order
+        is a permutation of the batch's graphs (it decides when a graph runs, never what it yields), a node_cap a
+        promise (a graph beyond it: NaN + SGPR_E_NODES, never a wrong result).  A data-set property kept by the binding;
+        the C-ABI stays stateless."""
+        import weakref
+        bc = centers._base if centers._base is not None else centers
+        bl = labels._base if labels._base is not None else labels
+        key = (centers.storage_offset(), labels.storage_offset(), tuple(labels.shape), centers._version, labels._version, int(k))
+        live = []
+        hit = None
+        for rc, rl, kk, order, info_h, ev in self._order_cache:
+            if rc() is None or rl() is None:
+                continue                                   # a tensor of the entry is gone
+            live.append((rc, rl, kk, order, info_h, ev))
+            if kk == key and rc() is bc and rl() is bl:
+                hit = (order, int(info_h[0]) if ev.query() else 0)
+        self._order_cache = live
+        if hit is not None:
+            return hit
         order, info = self.size_order_device(centers, labels, None, labels.shape[1], k)
         info_h = torch.empty(2, dtype=torch.int32).pin_memory()
         info_h.copy_(info, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self._order_cache = self._order_cache[-3:] + [(key, order, info_h, ev)]
+        self._order_cache = self._order_cache[-7:] + [(weakref.ref(bc), weakref.ref(bl), key, order, info_h, ev)]
         return order, 0
 
     def embed(self, centers, labels, k, want_att=False, want_emb=False, debug=False, node_cap=0, order=None, auto_order=True):

@@ -376,10 +376,19 @@ def test_plain_embed_hands_oversize_graphs_on(eng):
     dl[5, 70:] = -1
     dc[5, 70:] = 0.0
     changed = eng.embed(dc, dl, 10)[0]
-    assert eng._order_cache[-1][0][3:5] == (dc._version, dl._version)                            # recomputed
+    assert eng._order_cache[-1][2][3:5] == (dc._version, dl._version)                            # recomputed
     torch.cuda.synchronize()
     assert eng._cached_order(dc, dl, 10)[1] == int(eng.processed_slots(dc, dl, 10).max())       # ... and its node_cap arrives
     assert torch.equal(changed, eng.embed(dc.cpu().numpy(), dl.cpu().numpy(), 10)[0])
+    eng.check_status()
+    # an entry belongs to tensor OBJECTS: another data set of the same shape (whatever address the allocator gives it) is a
+    # miss, so a remembered node_cap can never be promised for data it was not computed from
+    other_c, other_l, _ = synth.make_graphs(1200, 100, 60, 95, 78)
+    del dc, dl
+    oc, ol = torch.from_numpy(other_c).cuda(), torch.from_numpy(other_l).cuda()
+    assert torch.equal(eng.embed(oc, ol, 10)[0], eng.embed(other_c, other_l, 10)[0])
+    torch.cuda.synchronize()
+    assert torch.equal(eng.embed(oc, ol, 10)[0], eng.embed(other_c, other_l, 10)[0])               # (now with its own node_cap)
     eng.check_status()
     # a promise above 64 slots: two tiers as well (the small graphs on the 64-row layout, the others on the instance sized
     # for the promise) - same bits; broken: loud
