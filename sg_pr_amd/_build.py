@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libsgpr_hip.so")
 SOURCES = ["sgpr_embed.hip", "sgpr_score.hip", "sgpr_metrics.hip", "sgpr_modules.hip", "sgpr_cluster.hip",
-           "sgpr_generic.hip", "sgpr_prep.hip", "sgpr_api.hip"]
+           "sgpr_generic.hip", "sgpr_wide.hip", "sgpr_prep.hip", "sgpr_api.hip"]
 HEADERS = [os.path.join(REPO, "include", "sgpr.h"), os.path.join(CSRC, "sgpr_internal.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 

@@ -182,6 +182,9 @@ static void split3_host(float w, unsigned short (&pl)[3]) {
     pl[2] = bf16_rne_host(r);
 }
 
+#ifndef SGPR_WIDE_EMBED
+#define SGPR_WIDE_EMBED 1     // any-shape handles inside sgpr_wide.hip's limits embed on the matrix cores (0: A/B builds, plain fp32 only)
+#endif
 // The any-shape model of a blob (GenericModel): BatchNorm folded in double precision at the model's own dimensions,
 // uploaded as one allocation.  Blob order: s_conv1, f_conv1, s_conv2, f_conv2, s_conv3, f_conv3, conv_end, tail tensors.
 static int build_generic_model(const float* weights, const sgpr_dims* d, sgpr_handle* h) {
@@ -262,6 +265,92 @@ static int build_generic_model(const float* weights, const sgpr_dims* d, sgpr_ha
     m.fc1_b = q;    q += bn;
     m.fc2_w = q;    q += bn;
     m.fc2_b = q;
+    // ---- the matrix-core form of the same folded weights (WideModel, sgpr_wide.hip) for moderately larger architectures:
+    //      widths padded to 32 with zeros, two f16 planes (w = hi + lo, 22 bits) in MFMA operand order.  Only for an
+    //      any-shape handle (the built shape runs on the tuned kernels) inside the limits and the f16 range.
+    WideModel& wm = h->wm;
+    memset(&wm, 0, sizeof(wm));
+    h->d_wblob = nullptr;
+    float wmax = 0.f;
+    for (size_t i = 0; i < off_tail; ++i) wmax = std::max(wmax, fabsf(host[i]));
+    if (h->generic_only && m.L <= SGPR_WIDE_MAX_LABELS && m.f1 <= SGPR_WIDE_MAX_FILTERS && m.f2 <= SGPR_WIDE_MAX_FILTERS &&
+        m.f3 <= SGPR_WIDE_MAX_F3 && wmax < 60000.f && SGPR_WIDE_EMBED) {
+        auto p32 = [](int v) { return (v + 31) & ~31; };
+        std::vector<unsigned short> planes;
+        std::vector<float> tbs;
+        size_t off_wh[7], off_tbp[7];
+        auto put = [&planes](float v, size_t at_hi, size_t at_lo) {
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            memcpy(&planes[at_hi], &hi, 2);
+            memcpy(&planes[at_lo], &lo, 2);
+        };
+        for (int l = 0; l < 6; ++l) {
+            const int cin = m.cin[l], cout = m.cout[l], cout8 = (cout + 7) & ~7;
+            const int cinP = p32(cin), coutP = p32(cout), nct = 2 * coutP / 16, ks = cinP / 32;
+            wm.cinP[l] = cinP;
+            wm.coutP[l] = coutP;
+            off_wh[l] = planes.size();
+            planes.resize(planes.size() + (size_t)nct * ks * 2 * 512, 0);
+            off_tbp[l] = tbs.size();
+            tbs.resize(tbs.size() + coutP, 0.f);
+            for (int c = 0; c < cout; ++c) tbs[off_tbp[l] + c] = host[off_tb[l] + c];
+            for (int ct = 0; ct < nct; ++ct)
+                for (int st = 0; st < ks; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int row = ct * 16 + (lane & 15), ch = 32 * st + 8 * (lane >> 4) + e8;
+                            const bool brow = row >= coutP;                         // b rows follow the a rows
+                            const int oc = brow ? row - coutP : row;
+                            float v = 0.f;
+                            if (oc < cout && ch < cin) v = host[(brow ? off_wb[l] : off_wa[l]) + (size_t)ch * cout8 + oc];
+                            const size_t base = off_wh[l] + ((size_t)(ct * ks + st) * 2) * 512 + (size_t)lane * 8 + e8;
+                            put(v, base, base + 512);
+                        }
+        }
+        {   // conv_end on cat(xyz3 [F3P], sem3 [F3P]): input channel F3P + c is the reference's f3 + c
+            const int f3 = m.f3, F3P = p32(f3), f8 = (f3 + 7) & ~7, nct = F3P / 16, ks = 2 * F3P / 32;
+            wm.F3P = F3P;
+            off_wh[6] = planes.size();
+            planes.resize(planes.size() + (size_t)nct * ks * 2 * 512, 0);
+            off_tbp[6] = tbs.size();
+            tbs.resize(tbs.size() + F3P, 0.f);
+            for (int c = 0; c < f3; ++c) tbs[off_tbp[6] + c] = host[off_tend + c];
+            for (int ct = 0; ct < nct; ++ct)
+                for (int st = 0; st < ks; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int oc = ct * 16 + (lane & 15), ch = 32 * st + 8 * (lane >> 4) + e8;
+                            const int half = ch >= F3P ? 1 : 0, c = ch - half * F3P;
+                            float v = 0.f;
+                            if (oc < f3 && c < f3) v = host[off_wend + (size_t)(half * f3 + c) * f8 + oc];
+                            const size_t base = off_wh[6] + ((size_t)(ct * ks + st) * 2) * 512 + (size_t)lane * 8 + e8;
+                            put(v, base, base + 512);
+                        }
+        }
+        const size_t plane_bytes = (planes.size() * 2 + 255) & ~(size_t)255;
+        e = hipMalloc(&h->d_wblob, plane_bytes + tbs.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->d_wblob, planes.data(), planes.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(static_cast<char*>(h->d_wblob) + plane_bytes, tbs.data(), tbs.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (h->d_wblob) (void)hipFree(h->d_wblob);
+            h->d_wblob = nullptr;
+            return hip_fail(e, "sgpr_create: matrix-core form of the any-shape model");
+        }
+        const unsigned short* pv = static_cast<const unsigned short*>(h->d_wblob);
+        const float* tv = reinterpret_cast<const float*>(static_cast<const char*>(h->d_wblob) + plane_bytes);
+        for (int l = 0; l < 6; ++l) {
+            wm.wh[l] = pv + off_wh[l];
+            wm.tbp[l] = tv + off_tbp[l];
+        }
+        wm.wh_end = pv + off_wh[6];
+        wm.tbp_end = tv + off_tbp[6];
+        wm.att_w = m.att_w;
+        wm.L = m.L;
+        wm.f3 = m.f3;
+        wm.ok = 1;
+    }
     return SGPR_OK;
 }
 
@@ -544,6 +633,7 @@ void sgpr_destroy(sgpr_handle* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     if (h->d_gblob) (void)hipFree(h->d_gblob);
+    if (h->d_wblob) (void)hipFree(h->d_wblob);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_status) (void)hipFree(h->d_status);
     delete h;
@@ -625,10 +715,17 @@ static bool generic_nk_ok(int N, int k) {
 }
 static int pooled_width(const sgpr_handle* h) { return h->generic_only ? h->gm.f3 : kF3; }
 
+// the matrix-core any-shape embed (sgpr_wide.hip) flags the graphs it hands to the plain-fp32 kernel: one byte per launch slot
+// ahead of that kernel's scratch area
+static size_t wide_flag_bytes(const sgpr_handle* h, int G, int N, int k) {
+    return (h->generic_only && h->wm.ok && k == 10 && N <= SGPR_WIDE_MAX_NODES) ? (((size_t)G + 255) & ~(size_t)255) : 0;
+}
+
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
     EmbedPlan p;
     if (!h || G < 0) return 0;
-    if (needs_generic(h, N, k)) return generic_nk_ok(N, k) ? generic_embed_ws_bytes(h, G, N, k) + 256 : 0;
+    if (needs_generic(h, N, k))
+        return generic_nk_ok(N, k) ? generic_embed_ws_bytes(h, G, N, k) + wide_flag_bytes(h, G, N, k) + 256 : 0;
     if (!make_embed_plan(N, 0, k, &p)) return 0;
     return embed_ws_bytes(h, G, N);
 }
@@ -662,7 +759,8 @@ static int embed_generic(const sgpr_handle* h, EmbedArgs a, int N, int k, void* 
         set_error("K " + std::to_string(k) + " outside [1, min(node_num, " + std::to_string(SGPR_GENERIC_MAX_K) + ")]");
         return SGPR_E_K;
     }
-    const size_t need = generic_embed_ws_bytes(h, a.G, N, k);
+    const size_t flags = wide_flag_bytes(h, a.G, N, k);
+    const size_t need = generic_embed_ws_bytes(h, a.G, N, k) + flags;
     if (need > 0 && (!ws || ws_bytes < need)) {
         set_error("sgpr_embed: workspace of " + std::to_string(need) + " bytes required (sgpr_embed_workspace_bytes)");
         return SGPR_E_WORKSPACE;
@@ -671,7 +769,15 @@ static int embed_generic(const sgpr_handle* h, EmbedArgs a, int N, int k, void* 
     a.num_labels = h->dims.num_labels;
     a.skip = h->dbg_skip;                // (bits 24..27: ablation of the any-shape kernel's phases, tools/run_anyshape.py)
     DeviceGuard guard(h->device);
-    return launch_embed_generic(h, a, N, k, ws, static_cast<hipStream_t>(stream));
+    // a moderately larger architecture (labels <= 32, filters <= 128 / 128 / 64) at node_num <= 112, K = 10: the matrix-core
+    // embed; the plain-fp32 kernel then takes only the graphs it flagged (values outside the f16 range)
+    if (flags > 0 && wide_embed_serves(h, a, N, k)) {
+        a.redo = static_cast<unsigned char*>(ws);
+        const int rc = launch_embed_wide(h, a, N, k, static_cast<hipStream_t>(stream));
+        if (rc != SGPR_OK) return rc;
+        a.auto_over = 7;
+    }
+    return launch_embed_generic(h, a, N, k, static_cast<unsigned char*>(ws) + flags, static_cast<hipStream_t>(stream));
 }
 
 static int embed_common(const sgpr_handle* h, EmbedArgs a, int N, int k, int node_cap, void* ws, size_t ws_bytes,

@@ -84,6 +84,24 @@ struct GenericModel {
     const float* fc2_b;                 // [1]
 };
 
+// Matrix-core form of a GenericModel for MODERATELY larger architectures (sgpr_wide.hip): labels <= 32, filters_1 / 2 <= 128,
+// filters_3 <= 64; every width padded to a multiple of 32 with zero weights (exact: a padded channel is lrelu(0 + 0) = 0
+// and meets zero weights in the next layer).  Weights as two f16 planes in MFMA operand order, like DevWeights::wh.
+#define SGPR_WIDE_MAX_LABELS 32
+#define SGPR_WIDE_MAX_FILTERS 128
+#define SGPR_WIDE_MAX_F3 64
+#define SGPR_WIDE_MAX_NODES 112
+struct WideModel {
+    int ok;                                // 0: this architecture / these weights are not served (limits, f16 range)
+    int L, f3, F3P;                        // F3P = filters_3 padded
+    int cinP[6], coutP[6];                 // GenericModel's layer order: xyz layers 0..2, semantic 3..5
+    const unsigned short* wh[6];           // [2 coutP / 16 column tiles: a rows, then b rows][cinP / 32 k-steps][2 planes][64 lanes][8]
+    const float* tbp[6];                   // [coutP]
+    const unsigned short* wh_end;          // [F3P / 16][2 F3P / 32][2][64][8]: conv_end on cat(xyz3 [F3P], sem3 [F3P])
+    const float* tbp_end;                  // [F3P]
+    const float* att_w;                    // [f3][f3] (the GenericModel's)
+};
+
 }  // namespace sgpr
 
 struct sgpr_handle {
@@ -101,6 +119,8 @@ struct sgpr_handle {
     int generic_only;    // the architecture is larger than the built shape: every call runs on the any-shape kernels
     float* d_gblob;      // owns the any-shape model's weights
     sgpr::GenericModel gm;
+    void* d_wblob;       // owns the matrix-core form of the any-shape model (wm.ok != 0)
+    sgpr::WideModel wm;
 };
 
 namespace sgpr {
@@ -199,6 +219,11 @@ int generic_embed_slots(const sgpr_handle* h, int G);
 size_t generic_embed_ws_bytes(const sgpr_handle* h, int G, int N, int k);   // 0: the working memory fits LDS
 size_t generic_embed_lds_bytes(const sgpr_handle* h, int N, int k);
 int launch_embed_generic(const sgpr_handle* h, const EmbedArgs& a, int N, int k, void* ws, hipStream_t stream);
+// the matrix-core any-shape embed: does this handle / launch take it, its LDS, the launch (flags the graphs whose values
+// leave the f16 range in a.redo - the plain-fp32 kernel then embeds those, launch_embed_generic with a.auto_over == 7)
+bool wide_embed_serves(const sgpr_handle* h, const EmbedArgs& a, int N, int k);
+size_t wide_embed_lds_bytes(int N);
+int launch_embed_wide(const sgpr_handle* h, const EmbedArgs& a, int N, int k, hipStream_t stream);
 // list form (M == 0: pair p = (i1 ? i1[p] : p, i2 ? i2[p] : p) -> score[p]) or dense rectangle (M > 0: P = R * M pairs -> score[r * ld + c])
 int launch_knn_any(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);
 int launch_attention_any(const float* w, const float* emb, int B, int N, int F, float* rep, float* att, hipStream_t stream);

@@ -1,0 +1,607 @@
+// Matrix-core embed for architectures MODERATELY larger than the built shape (the reference builds any
+// width: sg_net.py:40-76, parser_sg.py:12-18): labels <= 32, filters_1 / filters_2 <= 128, filters_3 <= 64, node_num <= 112,
+// K = 10.  SG.dgcnn_conv_pass + AttentionModule (sg_net.py:79-110, dgcnn.py:14-49, layers_batch.py:28-39) in the
+// formulation of the tuned kernels - eval BatchNorm folded, W.[x_j - x_i ; x_i] = W1.x_j + (W2 - W1).x_i, the max over the
+// neighbours taken on the first term - with every matrix product on v_mfma_f32_16x16x32_f16 and both operands as two f16
+// planes (x = hi + lo, 22 bits), and the organisation of embed_big_kernel (sgpr_embed.hip): one workgroup per graph, one
+// wave per 16-row tile; a wave takes the Gram tiles of its rows against every candidate tile from the accumulators (at
+// most 7 tiles = 28 keys per lane: all in registers, one pass), selects, computes its own row tile of the per-node
+// GEMMs (b waits in registers for the barrier behind which nobody reads X any more) and gathers its own rows.  None of the
+// tuned path's compressions (no duplicate-slot collapse, no super-nodes): every slot is processed, like the plain-fp32
+// any-shape kernel (sgpr_generic.hip), which stays the path for everything outside these limits and for a graph whose
+// values leave the f16 range (flagged here, embedded again there in the same call).  Widths are padded to multiples of
+// 32 with zero weights at sgpr_create (WideModel): a padded channel is lrelu(0 + 0) = 0 and meets zero weights.
+// Coordinate-layer keys restate the reference's fp32 arithmetic operation for operation (bit-identical neighbour sets
+// there), as every other kernel of this library does.
+#include <math.h>
+
+#include "sgpr_internal.hpp"
+
+namespace sgpr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WCW = SGPR_WIDE_MAX_FILTERS;       // channels an X row holds (two f16 planes of WCW each)
+constexpr int WXR = 4 * WCW + 16;                // bytes per X row: planes + (x, y, z, |x|^2) of the coordinate layer; b (fp32) overlays the planes
+constexpr int WPA = WCW + 4;                     // floats per row of the gather target A (and of E)
+constexpr int WPP = SGPR_WIDE_MAX_F3 + 4;        // floats per row of the parked first-branch output
+constexpr int WKS = WCW / 32;                    // k-steps of the widest layer
+constexpr int WK = 10;                           // K (the reference's): the selection's lists are cut to it at compile time
+constexpr int WNP = SGPR_WIDE_MAX_NODES;         // rows (a multiple of 16)
+constexpr int WTILES = WNP / 16;                 // 7 row tiles = 7 waves
+constexpr float kWideF16Safe = 60000.f;
+
+struct Frag {
+    f16x8 h, l;
+};
+
+__device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// k-step `st` of the row at `row` (byte pointer): channels 32 st + 8 lq .. + 7 of both planes
+__device__ __forceinline__ Frag xfrag(const unsigned char* row, int st, int lq) {
+    Frag f;
+    f.h = *reinterpret_cast<const f16x8*>(row + 64 * st + 16 * lq);
+    f.l = *reinterpret_cast<const f16x8*>(row + 2 * WCW + 64 * st + 16 * lq);
+    return f;
+}
+
+// sum over ks k-steps of a . b with the correction products in a chain of their own (smallest terms never meet the large
+// accumulator), like tile16 of sgpr_embed.hip; ks is wave-uniform
+__device__ __forceinline__ f32x4 dotk(const Frag (&a)[WKS], const Frag (&b)[WKS], const int ks) {
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < WKS; ++st)
+        if (st < ks) {
+            lo = mfma(a[st].l, b[st].h, lo);
+            lo = mfma(a[st].h, b[st].l, lo);
+        }
+#pragma unroll
+    for (int st = 0; st < WKS; ++st)
+        if (st < ks) hi = mfma(a[st].h, b[st].h, hi);
+    return hi + lo;
+}
+
+// four consecutive channels of one row -> the two f16 planes (hi = the value truncated to f16, lo = f16(v - hi): 22 bits);
+// vmax tracks the largest magnitude stored (a graph that reaches the f16 range is embedded again in plain fp32)
+__device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v, float& vmax) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l01), "=&v"(l23)
+        : "v"(h01), "v"(h23), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    *reinterpret_cast<uint2*>(row + 2 * ch) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(row + 2 * WCW + 2 * ch) = make_uint2(l01, l23);
+    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+
+__device__ __forceinline__ float kmin(float a, float b) {
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float kmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void cswap(float& a, float& b) {
+    const float lo = kmin(a, b);
+    b = kmax(a, b);
+    a = lo;
+}
+// Batcher's odd-even merge sort of N values, ascending (entries >= NV are +inf and never move: their comparators are not generated)
+template <int N, int NV>
+__device__ __forceinline__ void batcher_sort(float (&v)[N]) {
+#pragma unroll
+    for (int p = 1; p < N; p *= 2)
+#pragma unroll
+        for (int k = p; k >= 1; k /= 2)
+#pragma unroll
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && i + j + k < NV) cswap(v[i + j], v[i + j + k]);
+}
+template <int N>
+__device__ __forceinline__ void bitonic_merge(float (&v)[N]) {
+#pragma unroll
+    for (int j = N / 2; j > 0; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if ((i & j) == 0) cswap(v[i], v[i | j]);
+}
+
+// candidate index of bit u of a lane's mask: tile u >> 2, lane group lq, element u & 3
+__device__ __forceinline__ int cand_of(int u, int lq) { return 16 * (u >> 2) + 4 * lq + (u & 3); }
+__device__ __forceinline__ void emit(unsigned take, int lq, unsigned short* __restrict__ out, int& pos) {
+    while (take) {
+        const int u = __ffs(take) - 1;
+        take &= take - 1;
+        out[pos++] = (unsigned short)cand_of(u, lq);
+    }
+}
+__device__ __forceinline__ int prefix4(int v, int lq) {      // inclusive prefix over the four lanes of a row (16 lanes apart)
+    const int t1 = __shfl_up(v, 16);
+    v += lq >= 1 ? t1 : 0;
+    const int t2 = __shfl_up(v, 32);
+    v += lq >= 2 ? t2 : 0;
+    return v;
+}
+
+// The K nearest of the wave's 16 rows (row tile `wave`) among the graph's n slots, as a SET: nbr[row][0..K) = candidate
+// indices.  Lane (l15, lq) holds the keys of row 16 wave + l15 for candidates 16 tj + 4 lq + r (the accumulator layout of
+// candidates-as-A, rows-as-B), <= 28 of them: sorted in registers, the K-th smallest key of the row by a butterfly over
+// its four lanes, then one mask per lane; ties across the cut take the lowest candidate indices (the rule of every kernel
+// of the library and of sgpr_knn).  coord: the coordinate layer - the reference's own fp32 operations on (x, y, z, |x|^2).
+__device__ __forceinline__ void select_wide(const unsigned char* __restrict__ X, const float* __restrict__ xx,
+                                            unsigned short* __restrict__ nbr, const int n, const int nrt, const int ks,
+                                            const int wave, const bool coord) {
+    constexpr int K = WK, KP = 16;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+    const int i = 16 * wave + l15;
+    const bool active = i < n;
+    float d[32];
+    if (coord) {
+        const float4 ci = *reinterpret_cast<const float4*>(X + i * WXR + (WXR - 16));
+#pragma unroll
+        for (int tj = 0; tj < 8; ++tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float key = INFINITY;
+                if (tj < nrt) {
+                    const float4 cj = *reinterpret_cast<const float4*>(X + (16 * tj + 4 * lq + r) * WXR + (WXR - 16));
+                    const float dot = fmaf(ci.z, cj.z, fmaf(ci.y, cj.y, __fmul_rn(ci.x, cj.x)));
+                    const float t = fmaf(2.f, dot, -cj.w);
+                    key = __fsub_rn(ci.w, t);            // (+inf for a slot the graph does not have: its |x|^2 is)
+                }
+                d[4 * tj + r] = key;
+            }
+        }
+    } else {
+        Frag b[WKS];
+#pragma unroll
+        for (int st = 0; st < WKS; ++st)
+            if (st < ks) b[st] = xfrag(X + i * WXR, st, lq);
+#pragma unroll
+        for (int tj = 0; tj < 8; ++tj) {
+            float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            if (tj < nrt) {
+                Frag a[WKS];
+#pragma unroll
+                for (int st = 0; st < WKS; ++st)
+                    if (st < ks) a[st] = xfrag(X + (16 * tj + l15) * WXR, st, lq);
+                const f32x4 g = dotk(a, b, ks);
+                __builtin_amdgcn_sched_barrier(0);       // (one candidate tile's operands in registers at a time)
+                const float4 xj = *reinterpret_cast<const float4*>(xx + 16 * tj + 4 * lq);   // (+inf beyond the graph's slots)
+                key[0] = fmaf(-2.f, g[0], xj.x);
+                key[1] = fmaf(-2.f, g[1], xj.y);
+                key[2] = fmaf(-2.f, g[2], xj.z);
+                key[3] = fmaf(-2.f, g[3], xj.w);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[4 * tj + r] = key[r];
+        }
+    }
+    // ---- this lane's K smallest, ascending (two sorted halves, the smaller halves of their bitonic merge)
+    float L[KP];
+    {
+        float lo[16], hi[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            lo[u] = d[u];
+            hi[u] = d[16 + u];
+        }
+        batcher_sort<16, 16>(lo);
+        if (nrt > 4) {                                   // (wave-uniform)
+            batcher_sort<16, 16>(hi);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) L[u] = kmin(lo[u], hi[15 - u]);
+            bitonic_merge<KP>(L);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) L[u] = lo[u];
+        }
+    }
+    {   // butterfly over the row's four lanes: 16 lanes away the merged list, 32 away only the K-th key
+        float o[KP];
+#pragma unroll
+        for (int s = 0; s < KP; ++s) o[s] = (KP - 1 - s < K) ? __shfl_xor(L[KP - 1 - s], 16) : INFINITY;
+#pragma unroll
+        for (int s = 0; s < KP; ++s) L[s] = s < K ? ((KP - 1 - s < K) ? kmin(L[s], o[s]) : L[s]) : o[s];
+        bitonic_merge<KP>(L);
+    }
+    float tau = -INFINITY;                               // the K-th smallest key of the row
+#pragma unroll
+    for (int s = 0; s < K; ++s) tau = kmax(tau, kmin(L[s], __shfl_xor(L[K - 1 - s], 32)));
+    unsigned short* out = nbr + i * 16;
+    // ---- the common case: exactly K keys at or below tau -> one mask, a prefix over the row's lanes, emission
+    unsigned gt = 0u;
+#pragma unroll
+    for (int u = 31; u >= 0; --u) gt = __builtin_amdgcn_alignbit(gt, __float_as_uint(tau - d[u]), 31);
+    const unsigned valid = nrt >= 8 ? ~0u : ((1u << (4 * nrt)) - 1u);
+    const unsigned le = ~gt & valid;
+    const int n_le = __popc(le);
+    const int incl = prefix4(n_le, lq);
+    const int total_le = __shfl(incl, 48 + l15);
+    if (__ballot(active && total_le != K) == 0ull) {
+        if (active) {
+            int pos = incl - n_le;
+            emit(le, lq, out, pos);
+        }
+        return;
+    }
+    // ---- ties across the cut: everything below tau, then the first T candidates AT tau in candidate-index order
+    //      = (tile, lane group, element) order
+    unsigned lt = 0u;
+#pragma unroll
+    for (int u = 31; u >= 0; --u) lt = __builtin_amdgcn_alignbit(lt, __float_as_uint(d[u] - tau), 31);
+    lt &= valid;
+    const unsigned eq = ~(lt | gt) & valid;              // (inf - inf is a positive NaN: a missing slot at an infinite tau is "equal")
+    const int n_less = __popc(lt);
+    const int less_incl = prefix4(n_less, lq);
+    const int total_less = __shfl(less_incl, 48 + l15);
+    const int T = K - total_less;                        // ties to accept
+    if (active) {
+        int pos = less_incl - n_less;
+        emit(lt, lq, out, pos);
+    }
+    int before = 0;                                      // ties in the tiles before the current one
+#pragma unroll 1
+    for (int tj = 0; tj < nrt; ++tj) {                   // (every lane runs the exchanges; only active rows emit)
+        const unsigned bits0 = (eq >> (4 * tj)) & 0xfu;
+        const int own = __popc(bits0);
+        const int tin = prefix4(own, lq);
+        const int all = __shfl(tin, 48 + l15);
+        const int start = before + tin - own;
+        const int take_n = max(0, min(own, T - start));
+        unsigned bits = bits0, keep = 0u;
+        for (int c = 0; c < take_n; ++c) {
+            const unsigned low = bits & (0u - bits);
+            keep |= low;
+            bits ^= low;
+        }
+        if (active) {
+            int tpos = total_less + min(start, T);
+            emit(keep << (4 * tj), lq, out, tpos);
+        }
+        before += all;
+    }
+}
+
+__device__ __forceinline__ float lrelu(float y) { return fmaxf(y, 0.2f * y); }
+
+struct WideArgs {
+    WideModel m;
+    EmbedArgs a;
+    int N, NP, pw;
+};
+
+// LDS: X [NP][WXR] | A [NP][WPA] f32 | park [NP][WPP] f32 | xx [NP] f32 | nbr [NP][16] u16 | red [2 * 64 + 16] f32
+__global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const WideModel& m = p.m;
+    const EmbedArgs& a = p.a;
+    const int N = p.N, NP = p.NP, nrt = NP >> 4;
+    unsigned char* X = smem;
+    float* A = reinterpret_cast<float*>(X + NP * WXR);
+    float* park = A + NP * WPA;
+    float* xx = park + NP * WPP;
+    unsigned short* nbr = reinterpret_cast<unsigned short*>(xx + NP);
+    float* red = reinterpret_cast<float*>(nbr + NP * 16);
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = blockDim.x;
+    const int slot = blockIdx.x;
+    const int g = a.ids ? a.ids[slot] : slot;
+    float vmax = 0.f;
+    // ---- one slot per thread: xyz and the semantic row (one-hot of the label, or the dense tensor's own values)
+    long long rag0 = 0, ragc = 0;
+    bool rag_bad = false;
+    if (a.rag_off && !a.dense) {
+        rag0 = a.rag_off[g];
+        ragc = a.rag_off[g + 1] - rag0;
+        rag_bad = ragc < 0 || ragc > N;
+    }
+    if (rag_bad) {                                       // a graph with more nodes than slots: loud, like every other path
+        if (tid == 0) {
+            atomicOr(a.status, 8);
+            a.redo[slot] = 0;
+        }
+        for (int c = tid; c < p.pw; c += NT) a.pooled[(size_t)g * p.pw + c] = __int_as_float(0x7fc00000);
+        return;
+    }
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (tid < NP) {
+        unsigned char* xr = X + tid * WXR;
+        const bool live = tid < N;
+        int lab = -1;                                    // packed input: this slot's label
+        const float* dn = nullptr;                       // dense input: this slot's column of the tensor
+        if (live) {
+            if (a.dense) {
+                const bool second = a.dense2 && g >= a.g_split;
+                dn = (second ? a.dense2 : a.dense) + (size_t)(second ? g - a.g_split : g) * (3 + m.L) * N + tid;
+                fx = dn[0];
+                fy = dn[N];
+                fz = dn[2 * N];
+            } else {
+                if (a.rag_off) {
+                    if (tid < ragc) {
+                        const float* c3 = a.centers + (size_t)(rag0 + tid) * 3;
+                        fx = c3[0];
+                        fy = c3[1];
+                        fz = c3[2];
+                        lab = a.rag_lab[rag0 + tid];
+                    }
+                } else {
+                    const float* c3 = a.centers + ((size_t)g * N + tid) * 3;
+                    fx = c3[0];
+                    fy = c3[1];
+                    fz = c3[2];
+                    lab = a.labels[(size_t)g * N + tid];
+                }
+                if (lab < -1 || lab >= m.L) {
+                    atomicOr(a.status, 1);               // KeyError in the reference (sg_net.py:277)
+                    lab = -1;
+                }
+            }
+        }
+        // the semantic branch's input: <= 32 channels = one k-step (one-hot of the label, or the dense tensor's own values)
+        float s = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < SGPR_WIDE_MAX_LABELS; c += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = dn ? (c + u < m.L ? dn[(size_t)(3 + c + u) * N] : 0.f) : (lab == c + u ? 1.f : 0.f);
+            xstore(xr, c, make_float4(v[0], v[1], v[2], v[3]), vmax);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s = __fadd_rn(s, __fmul_rn(v[u], v[u]));
+        }
+        xx[tid] = live ? s : INFINITY;
+    }
+    __syncthreads();
+
+    // ---- the semantic branch (GenericModel layers 3..5) first, parked; then the xyz branch (0..2)
+    for (int pass = 0; pass < 6; ++pass) {
+        const int L = pass < 3 ? 3 + pass : pass - 3;                 // GenericModel's index
+        const bool coord = L == 0;
+        const bool last = (L == 2 || L == 5);
+        if (pass == 3) {
+            // stage the xyz branch's input: (x, y, z) in channels 0..2 of one k-step, (x, y, z, |x|^2) in fp32 behind the planes
+            if (tid < NP) {
+                unsigned char* xr = X + tid * WXR;
+                const bool live = tid < N;
+                xstore(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+#pragma unroll
+                for (int c = 4; c < 32; c += 4) xstore(xr, c, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));   // as torch.sum(x ** 2)
+                *reinterpret_cast<float4*>(xr + WXR - 16) = live ? make_float4(fx, fy, fz, n2) : make_float4(0.f, 0.f, 0.f, INFINITY);
+            }
+            __syncthreads();
+        }
+        const int ks = m.cinP[L] >> 5, coutP = m.coutP[L];
+        const int nca = coutP >> 4;                                   // a-type column tiles (= b-type)
+        // ---- selection of the wave's rows, then the a half of its own row tile of [a | b] = x . [W1' | (W2 - W1)'] -> A
+        select_wide(X, xx, nbr, N, nrt, ks, wave, coord);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            Frag xf[WKS];
+            const unsigned char* x0 = X + (wave * 16 + l15) * WXR;
+#pragma unroll
+            for (int st = 0; st < WKS; ++st)
+                if (st < ks) xf[st] = xfrag(x0, st, lq);
+            float* a0 = A + (wave * 16 + l15) * WPA + 4 * lq;
+            const unsigned short* wl = m.wh[L] + (size_t)lane * 8;
+#pragma unroll 1
+            for (int ct = 0; ct < nca; ++ct) {
+                Frag w[WKS];
+#pragma unroll
+                for (int st = 0; st < WKS; ++st)
+                    if (st < ks) {
+                        const unsigned short* wp = wl + ((size_t)(ct * ks + st) * 2) * 512;
+                        w[st].h = *reinterpret_cast<const f16x8*>(wp);
+                        w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
+                    }
+                const f32x4 r = dotk(w, xf, ks);                      // r[c] = a[channel ct*16 + 4 lq + c][node 16 wave + l15]
+                *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+        __syncthreads();                                              // A is complete; X has been read by everyone as candidates
+        {
+            // the b half: the wave's own rows are read as the operand (into registers) before its first tile replaces them -
+            // b = x . (W2 - W1)' + t overlays the row's planes in place (fp32), no other wave reads these rows any more
+            Frag xf[WKS];
+            unsigned char* x0 = X + (wave * 16 + l15) * WXR;
+#pragma unroll
+            for (int st = 0; st < WKS; ++st)
+                if (st < ks) xf[st] = xfrag(x0, st, lq);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned short* wl = m.wh[L] + (size_t)lane * 8;
+#pragma unroll 1
+            for (int cb = 0; cb < nca; ++cb) {
+                Frag w[WKS];
+#pragma unroll
+                for (int st = 0; st < WKS; ++st)
+                    if (st < ks) {
+                        const unsigned short* wp = wl + ((size_t)((nca + cb) * ks + st) * 2) * 512;
+                        w[st].h = *reinterpret_cast<const f16x8*>(wp);
+                        w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
+                    }
+                const float4 t4 = *reinterpret_cast<const float4*>(m.tbp[L] + cb * 16 + 4 * lq);
+                const f32x4 r = dotk(w, xf, ks);
+                *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * lq) * 4) = make_float4(r[0] + t4.x, r[1] + t4.y, r[2] + t4.z, r[3] + t4.w);
+            }
+        }
+        // ---- gather-max of the wave's own rows (its lists and its b rows are its own LDS traffic: program order): 16 lanes
+        //      per row, 4 channels per lane and pass of 64 channels, four rows at a time
+        {
+            const int sub = lane >> 4, cl = (lane & 15) * 4;
+            const int npass = (coutP + 63) >> 6;
+#pragma unroll 1
+            for (int r0 = 0; r0 < 16; r0 += 4) {
+                const int ia = 16 * wave + r0 + sub;
+                const unsigned short* nw = nbr + ia * 16;
+                float4 y[2];
+                float sq = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    y[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int c4 = cl + 64 * cc;
+                    if (cc < npass && c4 < coutP) {
+                        float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+                        for (int q = 0; q < WK; ++q) {
+                            const float4 v = *reinterpret_cast<const float4*>(A + (int)nw[q] * WPA + c4);
+                            mx.x = fmaxf(mx.x, v.x);
+                            mx.y = fmaxf(mx.y, v.y);
+                            mx.z = fmaxf(mx.z, v.z);
+                            mx.w = fmaxf(mx.w, v.w);
+                        }
+                        const float4 bv = *reinterpret_cast<const float4*>(X + ia * WXR + 4 * c4);
+                        y[cc] = make_float4(lrelu(mx.x + bv.x), lrelu(mx.y + bv.y), lrelu(mx.z + bv.z), lrelu(mx.w + bv.w));
+                        sq += fmaf(y[cc].x, y[cc].x, fmaf(y[cc].y, y[cc].y, fmaf(y[cc].z, y[cc].z, y[cc].w * y[cc].w)));
+                    }
+                }
+                // (every lane of the row has read its b above: the planes / the parked row may now replace it)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c4 = cl + 64 * cc;
+                    if (cc < npass && c4 < coutP) {
+                        if (L == 5)
+                            *reinterpret_cast<float4*>(park + ia * WPP + c4) = y[cc];     // sem3 waits for conv_end
+                        else
+                            xstore(X + ia * WXR, c4, y[cc], vmax);
+                    }
+                }
+                if (!last) {                                          // squared norms of the next layer's input rows
+                    sq += __shfl_xor(sq, 1);
+                    sq += __shfl_xor(sq, 2);
+                    sq += __shfl_xor(sq, 4);
+                    sq += __shfl_xor(sq, 8);
+                    if ((lane & 15) == 0) xx[ia] = ia < N ? sq : INFINITY;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- X channels [0, F3P) hold xyz3; sem3 joins them at [F3P, 2 F3P): X = cat(xyz3, sem3) (sg_net.py:104)
+    const int F3P = m.F3P;
+    for (int e = tid; e < NP * (F3P >> 2); e += NT) {
+        const int i = e / (F3P >> 2), c4 = (e - i * (F3P >> 2)) * 4;
+        xstore(X + i * WXR, F3P + c4, *reinterpret_cast<const float4*>(park + i * WPP + c4), vmax);
+    }
+    __syncthreads();
+    // ---- conv_end: 2 F3P -> F3P, folded BatchNorm, LeakyReLU -> E (in the A region); a wave per row tile
+    float* E = A;
+    {
+        const int ks = (2 * F3P) >> 5, nct = F3P >> 4;
+        Frag xf[WKS];
+        const unsigned char* x0 = X + (wave * 16 + l15) * WXR;
+#pragma unroll
+        for (int st = 0; st < WKS; ++st)
+            if (st < ks) xf[st] = xfrag(x0, st, lq);
+        const unsigned short* wl = m.wh_end + (size_t)lane * 8;
+#pragma unroll 1
+        for (int ct = 0; ct < nct; ++ct) {
+            Frag w[WKS];
+#pragma unroll
+            for (int st = 0; st < WKS; ++st)
+                if (st < ks) {
+                    const unsigned short* wp = wl + ((size_t)(ct * ks + st) * 2) * 512;
+                    w[st].h = *reinterpret_cast<const f16x8*>(wp);
+                    w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
+                }
+            const f32x4 r = dotk(w, xf, ks);
+            const float4 t4 = *reinterpret_cast<const float4*>(m.tbp_end + ct * 16 + 4 * lq);
+            *reinterpret_cast<float4*>(E + (wave * 16 + l15) * WPA + ct * 16 + 4 * lq) =
+                make_float4(lrelu(r[0] + t4.x), lrelu(r[1] + t4.y), lrelu(r[2] + t4.z), lrelu(r[3] + t4.w));
+        }
+    }
+    __syncthreads();
+    // ---- attention pooling over all N slots (layers_batch.py:28-39: no pad mask, divisor N)
+    const int f3 = m.f3;
+    float* mean = red;                                   // [64]
+    float* ctx = red + 64;                               // [64]
+    for (int c = wave; c < f3; c += NT >> 6) {
+        float s = 0.f;
+        for (int n = lane; n < N; n += 64) s += E[n * WPA + c];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
+        if (lane == 0) mean[c] = s / (float)N;
+    }
+    __syncthreads();
+    for (int c = tid; c < f3; c += NT) {
+        float gsum = 0.f;
+        for (int r = 0; r < f3; ++r) gsum = fmaf(mean[r], m.att_w[(size_t)r * f3 + c], gsum);
+        ctx[c] = tanhf(gsum);
+    }
+    __syncthreads();
+    float* sig = xx;
+    for (int n = tid; n < N; n += NT) {
+        float dsum = 0.f;
+        for (int c = 0; c < f3; ++c) dsum = fmaf(E[n * WPA + c], ctx[c], dsum);
+        sig[n] = 1.f / (1.f + expf(-dsum));
+    }
+    __syncthreads();
+    for (int c = wave; c < p.pw; c += NT >> 6) {
+        float s = 0.f;
+        if (c < f3)
+            for (int n = lane; n < N; n += 64) s = fmaf(sig[n], E[n * WPA + c], s);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
+        if (lane == 0) a.pooled[(size_t)g * p.pw + c] = s;
+    }
+    if (a.att)
+        for (int n = tid; n < N; n += NT) a.att[(size_t)g * N + n] = sig[n];
+    if (a.emb)
+        for (int e = tid; e < N * p.pw; e += NT) {
+            const int n = e / p.pw, c = e - n * p.pw;
+            a.emb[((size_t)g * N + n) * p.pw + c] = c < f3 ? E[n * WPA + c] : 0.f;
+        }
+    // a graph whose values reached the f16 range (or NaN): flagged for the plain-fp32 kernel
+    const unsigned long long bad = __ballot(!(vmax < kWideF16Safe));
+    int* flag = reinterpret_cast<int*>(red + 128);
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (bad && lane == 0) atomicOr(flag, 1);
+    __syncthreads();
+    if (tid == 0) a.redo[slot] = *flag ? 1 : 0;
+}
+
+size_t wide_lds(int NP) {
+    return (size_t)NP * WXR + (size_t)NP * WPA * 4 + (size_t)NP * WPP * 4 + (size_t)NP * 4 + (size_t)NP * 16 * 2 + (2 * 64 + 16) * 4;
+}
+
+}  // namespace
+
+size_t wide_embed_lds_bytes(int N) { return wide_lds((N + 15) & ~15); }
+
+bool wide_embed_serves(const sgpr_handle* h, const EmbedArgs& a, int N, int k) {
+    return h->generic_only && h->wm.ok && k == WK && N >= k && N <= SGPR_WIDE_MAX_NODES && !a.dbg_layers && !a.dbg_knn &&
+           !(h->dbg_skip & (1 << 23));                      // (debug bit 23: plain fp32 only - tests compare the two)
+}
+
+int launch_embed_wide(const sgpr_handle* h, const EmbedArgs& a, int N, int k, hipStream_t stream) {
+    (void)k;
+    if (a.G == 0) return SGPR_OK;
+    WideArgs p;
+    p.m = h->wm;
+    p.a = a;
+    p.N = N;
+    p.NP = (N + 15) & ~15;
+    p.pw = h->gm.f3;
+    const size_t lds = wide_lds(p.NP);
+    static LdsLimitOnce once;
+    if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&wide_embed_kernel), 160 * 1024, "wide_embed_kernel")) return rc;
+    hipLaunchKernelGGL(wide_embed_kernel, dim3(a.G), dim3(64 * (p.NP >> 4)), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "wide_embed_kernel launch");
+    return SGPR_OK;
+}
+
+}  // namespace sgpr

@@ -1993,6 +1993,59 @@ def test_larger_architectures_run_on_the_any_shape_kernels(oracle):
         assert torch.equal(torch.gather(pd, 2, got), torch.gather(pd, 2, want)), (n, k)
 
 
+def test_matrix_core_any_shape_embed(oracle):
+    """sgpr_wide.hip: an any-shape handle inside its limits (labels <= 32, filters <= 128 / 128 / 64, node_num <= 112, K = 10)
+    embeds on the matrix cores (two f16 planes per operand), everything else - and a graph whose values leave the f16
+    range - on the plain-fp32 kernel (debug bit 23 forces that one).  Both against the oracle and against each other;
+    packed, ragged and dense input give the same bits; the fallback's results ARE the plain kernel's."""
+    from sg_pr_amd import sg_net, synth
+    from sg_pr_amd.allpairs import RaggedGraphs
+    from sg_pr_amd.parser_sg import sgpr_args
+    for labels, f1, f2, f3, node_num in ((12, 128, 128, 64, 100), (25, 80, 112, 48, 112), (13, 64, 64, 32, 37)):
+        args = sgpr_args()
+        args.filters_1, args.filters_2, args.filters_3, args.tensor_neurons, args.bottle_neck_neurons = f1, f2, f3, 16, 16
+        args.node_num, args.K = node_num, 10
+        torch.manual_seed(labels + f1)
+        model, sd = _randomised(sg_net.SG(args, labels))
+        eng = model.engine()
+        assert eng.any_shape and eng.pw == f3
+        c, l = _label_sorted_graphs(40, node_num, node_num // 3, node_num - 10, labels, seed=labels + f3)
+        feats = torch.from_numpy(synth.dense_features(c, l, num_labels=labels))
+        ref_pooled, ref_att = oracle.embed(sd, feats, 10)[:2]
+        ref_emb = oracle.conv_pass(sd, feats, 10)
+        scale = max(1.0, float(ref_pooled.abs().max()))
+        wide = eng.embed(c, l, 10, want_att=True, want_emb=True)
+        eng.set_skip_mask(1 << 23)
+        try:
+            plain = eng.embed(c, l, 10, want_att=True, want_emb=True)
+        finally:
+            eng.set_skip_mask(0)
+        tag = (labels, f1, f2, f3, node_num)
+        for got in (wide, plain):
+            assert (got[0].cpu() - ref_pooled).abs().max().item() < 2e-4 * scale, tag
+            assert (got[1].cpu() - ref_att.reshape(40, node_num)).abs().max().item() < 1e-4, tag
+            assert (got[2].cpu() - ref_emb).abs().max().item() < 1e-4 * max(1.0, float(ref_emb.abs().max())), tag
+        assert not torch.equal(wide[0], plain[0])                      # (two datapaths, not one)
+        assert (wide[0] - plain[0]).abs().max().item() < 1e-4 * scale, tag
+        # the other input forms: the same bits
+        rag = RaggedGraphs.from_padded(c, l, device="cuda", num_labels=labels)
+        assert torch.equal(model.embed(rag, None)[0], wide[0])
+        assert torch.equal(eng.embed_dense(feats, 10)[0], wide[0])
+        # values outside the f16 range: the graph is flagged and embedded by the plain-fp32 kernel in the same call
+        big = c.copy()
+        big[3] *= 3000.0                                               # coordinates of ~1e5: beyond f16's 65504
+        mixed = eng.embed(big, l, 10)[0]
+        eng.set_skip_mask(1 << 23)
+        try:
+            plain_big = eng.embed(big, l, 10)[0]
+        finally:
+            eng.set_skip_mask(0)
+        assert torch.equal(mixed[3], plain_big[3]) and torch.isfinite(mixed).all(), tag
+        keep = [g for g in range(40) if g != 3]
+        assert torch.equal(mixed[keep], wide[0][keep]), tag
+        eng.check_status()
+
+
 def test_node_num_and_k_beyond_the_tuned_kernels(eng, oracle_sd, oracle):
     """parser_sg.py:19-22: node_num and K are free.  Beyond the tuned kernels' 256 slots / 32 neighbours the shipped
     checkpoint embeds on the any-shape kernel (pooled rows keep the handle's width, so the tuned tails score them);
