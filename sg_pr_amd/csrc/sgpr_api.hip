@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <exception>
 #include <string>
 #include <vector>
@@ -718,7 +719,7 @@ static int pooled_width(const sgpr_handle* h) { return h->generic_only ? h->gm.f
 // the matrix-core any-shape embed (sgpr_wide.hip) flags the graphs it hands to the plain-fp32 kernel: one byte per launch slot
 // ahead of that kernel's scratch area
 static size_t wide_flag_bytes(const sgpr_handle* h, int G, int N, int k) {
-    return (h->generic_only && h->wm.ok && k == 10 && N <= SGPR_WIDE_MAX_NODES) ? (((size_t)G + 255) & ~(size_t)255) : 0;
+    return (h->generic_only && h->wm.ok && k == 10 && N <= SGPR_WIDE_MAX_NODES) ? (((size_t)G + 8 + 255) & ~(size_t)255) : 0;   // (+ the token word)
 }
 
 size_t sgpr_embed_workspace_bytes(const sgpr_handle* h, int G, int N, int k) {
@@ -773,6 +774,13 @@ static int embed_generic(const sgpr_handle* h, EmbedArgs a, int N, int k, void* 
     // embed; the plain-fp32 kernel then takes only the graphs it flagged (values outside the f16 range)
     if (flags > 0 && wide_embed_serves(h, a, N, k)) {
         a.redo = static_cast<unsigned char*>(ws);
+        a.redo_count = reinterpret_cast<unsigned*>(a.redo + flags - 8);
+        {
+            static std::atomic<unsigned> epoch{0u};         // this call's token (a value the word cannot hold from an earlier call)
+            unsigned e = ++epoch;
+            if (e == 0u) e = ++epoch;
+            a.sem_epoch = e;
+        }
         const int rc = launch_embed_wide(h, a, N, k, static_cast<hipStream_t>(stream));
         if (rc != SGPR_OK) return rc;
         a.auto_over = 7;

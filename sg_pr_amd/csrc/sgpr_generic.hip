@@ -225,8 +225,10 @@ __global__ __launch_bounds__(EMB_THREADS) void generic_embed_kernel(const Generi
     float* Y3 = A + (size_t)N * m.cmax;                           // [f3][N] the xyz branch's output
     float* xx = Y3 + (size_t)N * m.f3;
     int* idx = reinterpret_cast<int*>(xx + N);                    // [k][N]
+    // behind the matrix-core embed of sgpr_wide.hip: only the graphs it flagged (values outside the f16 range) - none, as a
+    // rule: one load of the word that launch stores its token in, and out
+    if (a.auto_over == 7 && *a.redo_count != a.sem_epoch) return;
     for (int slot = blockIdx.x; slot < a.G; slot += gridDim.x) {
-        // (behind the matrix-core embed of sgpr_wide.hip: only the graphs it flagged - values outside the f16 range)
         if (a.auto_over == 7 && a.redo[slot] != 1) continue;
         const int g = a.ids ? a.ids[slot] : slot;
         // ---- input (transfer_to_torch's tensor, sg_net.py:250-299): xyz and the semantic rows of every slot

@@ -48,7 +48,8 @@ __device__ __forceinline__ Frag xfrag(const unsigned char* row, int st, int lq) 
 }
 
 // sum over ks k-steps of a . b with the correction products in a chain of their own (smallest terms never meet the large
-// accumulator), like tile16 of sgpr_embed.hip; ks is wave-uniform
+// accumulator), like tile16 of sgpr_embed.hip; ks is wave-uniform.  (Each chain split over even / odd k-steps - half the
+// dependent depth, three more vector adds - was measured: 476 -> 530 us per 1024 graphs of the 128-wide model; it spills.)
 __device__ __forceinline__ f32x4 dotk(const Frag (&a)[WKS], const Frag (&b)[WKS], const int ks) {
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -386,9 +387,23 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
         }
         const int ks = m.cinP[L] >> 5, coutP = m.coutP[L];
         const int nca = coutP >> 4;                                   // a-type column tiles (= b-type)
-        // ---- selection of the wave's rows, then the a half of its own row tile of [a | b] = x . [W1' | (W2 - W1)'] -> A
+        // ---- selection of the wave's rows, then the a half of its own row tile of [a | b] = x . [W1' | (W2 - W1)'] -> A.
+        //      Weight tiles stream from L2 / L1 (all waves read the same ones) one tile AHEAD of the matrix instructions
+        //      that consume them (two register buffers; the tile count is even: widths are padded to 32)
+        const unsigned short* wl = m.wh[L] + (size_t)lane * 8;
+        auto load_w = [&](Frag (&w)[WKS], const int tile) {
+#pragma unroll
+            for (int st = 0; st < WKS; ++st)
+                if (st < ks) {
+                    const unsigned short* wp = wl + ((size_t)(tile * ks + st) * 2) * 512;
+                    w[st].h = *reinterpret_cast<const f16x8*>(wp);
+                    w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
+                }
+        };
+        Frag w0[WKS], w1[WKS];
         select_wide(X, xx, nbr, N, nrt, ks, wave, coord);
         __builtin_amdgcn_sched_barrier(0);
+        load_w(w0, 0);
         {
             Frag xf[WKS];
             const unsigned char* x0 = X + (wave * 16 + l15) * WXR;
@@ -396,19 +411,14 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
             for (int st = 0; st < WKS; ++st)
                 if (st < ks) xf[st] = xfrag(x0, st, lq);
             float* a0 = A + (wave * 16 + l15) * WPA + 4 * lq;
-            const unsigned short* wl = m.wh[L] + (size_t)lane * 8;
 #pragma unroll 1
-            for (int ct = 0; ct < nca; ++ct) {
-                Frag w[WKS];
-#pragma unroll
-                for (int st = 0; st < WKS; ++st)
-                    if (st < ks) {
-                        const unsigned short* wp = wl + ((size_t)(ct * ks + st) * 2) * 512;
-                        w[st].h = *reinterpret_cast<const f16x8*>(wp);
-                        w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
-                    }
-                const f32x4 r = dotk(w, xf, ks);                      // r[c] = a[channel ct*16 + 4 lq + c][node 16 wave + l15]
+            for (int ct = 0; ct < nca; ct += 2) {
+                load_w(w1, ct + 1);
+                const f32x4 r = dotk(w0, xf, ks);                     // r[c] = a[channel ct*16 + 4 lq + c][node 16 wave + l15]
                 *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r[0], r[1], r[2], r[3]);
+                load_w(w0, ct + 2);                                   // (behind the last a tile: the first b tile, which follows them)
+                const f32x4 r1 = dotk(w1, xf, ks);
+                *reinterpret_cast<float4*>(a0 + (ct + 1) * 16) = make_float4(r1[0], r1[1], r1[2], r1[3]);
             }
         }
         __syncthreads();                                              // A is complete; X has been read by everyone as candidates
@@ -421,20 +431,17 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
             for (int st = 0; st < WKS; ++st)
                 if (st < ks) xf[st] = xfrag(x0, st, lq);
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned short* wl = m.wh[L] + (size_t)lane * 8;
+            const float* tb = m.tbp[L] + 4 * lq;
 #pragma unroll 1
-            for (int cb = 0; cb < nca; ++cb) {
-                Frag w[WKS];
-#pragma unroll
-                for (int st = 0; st < WKS; ++st)
-                    if (st < ks) {
-                        const unsigned short* wp = wl + ((size_t)((nca + cb) * ks + st) * 2) * 512;
-                        w[st].h = *reinterpret_cast<const f16x8*>(wp);
-                        w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
-                    }
-                const float4 t4 = *reinterpret_cast<const float4*>(m.tbp[L] + cb * 16 + 4 * lq);
-                const f32x4 r = dotk(w, xf, ks);
+            for (int cb = 0; cb < nca; cb += 2) {
+                load_w(w1, nca + cb + 1);
+                const float4 t4 = *reinterpret_cast<const float4*>(tb + cb * 16);
+                const f32x4 r = dotk(w0, xf, ks);
                 *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * lq) * 4) = make_float4(r[0] + t4.x, r[1] + t4.y, r[2] + t4.z, r[3] + t4.w);
+                if (cb + 2 < nca) load_w(w0, nca + cb + 2);
+                const float4 t5 = *reinterpret_cast<const float4*>(tb + (cb + 1) * 16);
+                const f32x4 r1 = dotk(w1, xf, ks);
+                *reinterpret_cast<float4*>(x0 + ((cb + 1) * 16 + 4 * lq) * 4) = make_float4(r1[0] + t5.x, r1[1] + t5.y, r1[2] + t5.z, r1[3] + t5.w);
             }
         }
         // ---- gather-max of the wave's own rows (its lists and its b rows are its own LDS traffic: program order): 16 lanes
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
                 for (int cc = 0; cc < 2; ++cc) {
                     y[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int c4 = cl + 64 * cc;
-                    if (cc < npass && c4 < coutP) {
+                    if (cc < npass && c4 < coutP && ia < N) {         // (a row beyond the graph's slots has no list: it stays zero)
                         float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
                         for (int q = 0; q < WK; ++q) {
@@ -570,7 +577,11 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
     __syncthreads();
     if (bad && lane == 0) atomicOr(flag, 1);
     __syncthreads();
-    if (tid == 0) a.redo[slot] = *flag ? 1 : 0;
+    if (tid == 0) {
+        a.redo[slot] = *flag ? 1 : 0;
+        // ... and this launch's token in one word: the plain-fp32 pass behind this launch returns at once while nobody stored it
+        if (*flag) __hip_atomic_store(a.redo_count, a.sem_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 size_t wide_lds(int NP) {
