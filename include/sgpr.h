@@ -72,7 +72,9 @@ typedef struct sgpr_handle sgpr_handle;
  * missing channels are 0; dense features are [G, 3 + num_labels, N]).
  * A LARGER architecture (any of the six, up to the SGPR_ANY_MAX_* limits) gets
  * an "any-shape" handle: the same entry points on plain-fp32 kernels
- * (sgpr_generic.hip) - correct against the same oracle, not tuned - with device
+ * (sgpr_generic.hip) - correct against the same oracle, not tuned; the embed of
+ * a model with <= 32 labels and filters <= 128 / 128 / 64 runs on the matrix
+ * cores for node_num <= 112, K = 10 (sgpr_wide.hip) - with device
  * buffers of the model's own width (pooled [G, filters_3], emb [G, N, filters_3]:
  * sgpr_pooled_width).  Not served on such a handle: sgpr_embed_debug's dumps
  * (-> SGPR_E_DIMS; sgpr_score_pair_list walks its plan pair by pair there: the
