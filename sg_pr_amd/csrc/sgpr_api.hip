@@ -776,9 +776,11 @@ static int embed_generic(const sgpr_handle* h, EmbedArgs a, int N, int k, void* 
         a.redo = static_cast<unsigned char*>(ws);
         a.redo_count = reinterpret_cast<unsigned*>(a.redo + flags - 8);
         {
-            static std::atomic<unsigned> epoch{0u};         // this call's token (a value the word cannot hold from an earlier call)
-            unsigned e = ++epoch;
-            if (e == 0u) e = ++epoch;
+            // this call's token: a counter spread over 32 bits (a fresh workspace holds stale small integers - labels, flags,
+            // earlier counters - which a bare counter meets by chance; a match costs the pass a scan of the flags, never a result)
+            static std::atomic<unsigned> epoch{0u};
+            unsigned e = (++epoch) * 0x9E3779B1u;
+            if (e == 0u) e = 0x9E3779B1u;
             a.sem_epoch = e;
         }
         const int rc = launch_embed_wide(h, a, N, k, static_cast<hipStream_t>(stream));

@@ -3320,9 +3320,12 @@ int launch_embed(const sgpr_handle* h, const EmbedPlan& plan, const EmbedArgs& a
     const bool can_split = plan.fmt == FMT_H2 && plan.lean && !a.dense && !a.dbg_layers && !a.dbg_knn && !a.prof &&
                            !(a.skip & ~(8192 | (1 << 20))) && a.sem_tab && a.sem_flag && 2 * a.G <= h->num_cus;
     {
-        static std::atomic<unsigned> epoch{0u};                    // this launch's token (split-launch flags, redo_count)
-        unsigned e = ++epoch;
-        if (e == 0u) e = ++epoch;
+        // this launch's token (split-launch flags, redo_count, over_count): a counter spread over 32 bits - a fresh workspace
+        // holds stale small integers (labels, flags), which a bare counter meets by chance in a process's first launches; a
+        // match costs a second pass its scan of the flags, never a result
+        static std::atomic<unsigned> epoch{0u};
+        unsigned e = (++epoch) * 0x9E3779B1u;
+        if (e == 0u) e = 0x9E3779B1u;
         kp.a.sem_epoch = e;
     }
     if (!can_split) {

@@ -23,11 +23,19 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WCW = SGPR_WIDE_MAX_FILTERS;       // channels an X row holds (two f16 planes of WCW each)
-constexpr int WXR = 4 * WCW + 16;                // bytes per X row: planes + (x, y, z, |x|^2) of the coordinate layer; b (fp32) overlays the planes
-constexpr int WPA = WCW + 4;                     // floats per row of the gather target A (and of E)
-constexpr int WPP = SGPR_WIDE_MAX_F3 + 4;        // floats per row of the parked first-branch output
-constexpr int WKS = WCW / 32;                    // k-steps of the widest layer
+// Two instances: CW = channels an X row holds (two f16 planes of CW each) = the widest padded layer, F3W = the widest
+// padded filters_3.  <128, 64> serves filters up to 128 / 128 / 64 (155 KB of LDS at node_num 100: one workgroup per CU);
+// <64, 32> the built widths under more labels / neurons (80 KB: two per CU).
+template <int CW, int F3W>
+struct WideCfg {
+    static constexpr int XR = 4 * CW + 16;       // bytes per X row: planes + (x, y, z, |x|^2) of the coordinate layer; b (fp32) overlays the planes
+    static constexpr int PA = CW + 4;            // floats per row of the gather target A (and of E)
+    static constexpr int PP = F3W + 4;           // floats per row of the parked first-branch output
+    static constexpr int KS = CW / 32;           // k-steps of the widest layer
+};
+#ifndef SGPR_WIDE_NARROW_OCC
+#define SGPR_WIDE_NARROW_OCC 4                   // waves per SIMD the narrow instance is built for: 4 = two 7-wave workgroups per CU (A/B builds: 2)
+#endif
 constexpr int WK = 10;                           // K (the reference's): the selection's lists are cut to it at compile time
 constexpr int WNP = SGPR_WIDE_MAX_NODES;         // rows (a multiple of 16)
 constexpr int WTILES = WNP / 16;                 // 7 row tiles = 7 waves
@@ -40,32 +48,35 @@ struct Frag {
 __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // k-step `st` of the row at `row` (byte pointer): channels 32 st + 8 lq .. + 7 of both planes
+template <int CW>
 __device__ __forceinline__ Frag xfrag(const unsigned char* row, int st, int lq) {
     Frag f;
     f.h = *reinterpret_cast<const f16x8*>(row + 64 * st + 16 * lq);
-    f.l = *reinterpret_cast<const f16x8*>(row + 2 * WCW + 64 * st + 16 * lq);
+    f.l = *reinterpret_cast<const f16x8*>(row + 2 * CW + 64 * st + 16 * lq);
     return f;
 }
 
 // sum over ks k-steps of a . b with the correction products in a chain of their own (smallest terms never meet the large
 // accumulator), like tile16 of sgpr_embed.hip; ks is wave-uniform.  (Each chain split over even / odd k-steps - half the
 // dependent depth, three more vector adds - was measured: 476 -> 530 us per 1024 graphs of the 128-wide model; it spills.)
-__device__ __forceinline__ f32x4 dotk(const Frag (&a)[WKS], const Frag (&b)[WKS], const int ks) {
+template <int KS>
+__device__ __forceinline__ f32x4 dotk(const Frag (&a)[KS], const Frag (&b)[KS], const int ks) {
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int st = 0; st < WKS; ++st)
+    for (int st = 0; st < KS; ++st)
         if (st < ks) {
             lo = mfma(a[st].l, b[st].h, lo);
             lo = mfma(a[st].h, b[st].l, lo);
         }
 #pragma unroll
-    for (int st = 0; st < WKS; ++st)
+    for (int st = 0; st < KS; ++st)
         if (st < ks) hi = mfma(a[st].h, b[st].h, hi);
     return hi + lo;
 }
 
 // four consecutive channels of one row -> the two f16 planes (hi = the value truncated to f16, lo = f16(v - hi): 22 bits);
 // vmax tracks the largest magnitude stored (a graph that reaches the f16 range is embedded again in plain fp32)
+template <int CW>
 __device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v, float& vmax) {
     const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
     const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
@@ -77,7 +88,7 @@ __device__ __forceinline__ void xstore(unsigned char* row, int ch, float4 v, flo
         : "=&v"(l01), "=&v"(l23)
         : "v"(h01), "v"(h23), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
     *reinterpret_cast<uint2*>(row + 2 * ch) = make_uint2(h01, h23);
-    *reinterpret_cast<uint2*>(row + 2 * WCW + 2 * ch) = make_uint2(l01, l23);
+    *reinterpret_cast<uint2*>(row + 2 * CW + 2 * ch) = make_uint2(l01, l23);
     vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 
@@ -120,11 +131,11 @@ __device__ __forceinline__ void bitonic_merge(float (&v)[N]) {
 
 // candidate index of bit u of a lane's mask: tile u >> 2, lane group lq, element u & 3
 __device__ __forceinline__ int cand_of(int u, int lq) { return 16 * (u >> 2) + 4 * lq + (u & 3); }
-__device__ __forceinline__ void emit(unsigned take, int lq, unsigned short* __restrict__ out, int& pos) {
+__device__ __forceinline__ void emit(unsigned take, int lq, unsigned char* __restrict__ out, int& pos) {
     while (take) {
         const int u = __ffs(take) - 1;
         take &= take - 1;
-        out[pos++] = (unsigned short)cand_of(u, lq);
+        out[pos++] = (unsigned char)cand_of(u, lq);      // (candidate indices < 128)
     }
 }
 __device__ __forceinline__ int prefix4(int v, int lq) {      // inclusive prefix over the four lanes of a row (16 lanes apart)
@@ -140,10 +151,11 @@ __device__ __forceinline__ int prefix4(int v, int lq) {      // inclusive prefix
 // candidates-as-A, rows-as-B), <= 28 of them: sorted in registers, the K-th smallest key of the row by a butterfly over
 // its four lanes, then one mask per lane; ties across the cut take the lowest candidate indices (the rule of every kernel
 // of the library and of sgpr_knn).  coord: the coordinate layer - the reference's own fp32 operations on (x, y, z, |x|^2).
+template <int CW>
 __device__ __forceinline__ void select_wide(const unsigned char* __restrict__ X, const float* __restrict__ xx,
-                                            unsigned short* __restrict__ nbr, const int n, const int nrt, const int ks,
+                                            unsigned char* __restrict__ nbr, const int n, const int nrt, const int ks,
                                             const int wave, const bool coord) {
-    constexpr int K = WK, KP = 16;
+    constexpr int K = WK, KP = 16, WXR = 4 * CW + 16, WKS = CW / 32;
     const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
     const int i = 16 * wave + l15;
     const bool active = i < n;
@@ -168,7 +180,7 @@ __device__ __forceinline__ void select_wide(const unsigned char* __restrict__ X,
         Frag b[WKS];
 #pragma unroll
         for (int st = 0; st < WKS; ++st)
-            if (st < ks) b[st] = xfrag(X + i * WXR, st, lq);
+            if (st < ks) b[st] = xfrag<CW>(X + i * WXR, st, lq);
 #pragma unroll
         for (int tj = 0; tj < 8; ++tj) {
             float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
@@ -176,8 +188,8 @@ __device__ __forceinline__ void select_wide(const unsigned char* __restrict__ X,
                 Frag a[WKS];
 #pragma unroll
                 for (int st = 0; st < WKS; ++st)
-                    if (st < ks) a[st] = xfrag(X + (16 * tj + l15) * WXR, st, lq);
-                const f32x4 g = dotk(a, b, ks);
+                    if (st < ks) a[st] = xfrag<CW>(X + (16 * tj + l15) * WXR, st, lq);
+                const f32x4 g = dotk<WKS>(a, b, ks);
                 __builtin_amdgcn_sched_barrier(0);       // (one candidate tile's operands in registers at a time)
                 const float4 xj = *reinterpret_cast<const float4*>(xx + 16 * tj + 4 * lq);   // (+inf beyond the graph's slots)
                 key[0] = fmaf(-2.f, g[0], xj.x);
@@ -220,7 +232,7 @@ __device__ __forceinline__ void select_wide(const unsigned char* __restrict__ X,
     float tau = -INFINITY;                               // the K-th smallest key of the row
 #pragma unroll
     for (int s = 0; s < K; ++s) tau = kmax(tau, kmin(L[s], __shfl_xor(L[K - 1 - s], 32)));
-    unsigned short* out = nbr + i * 16;
+    unsigned char* out = nbr + i * 16;
     // ---- the common case: exactly K keys at or below tau -> one mask, a prefix over the row's lanes, emission
     unsigned gt = 0u;
 #pragma unroll
@@ -283,8 +295,10 @@ struct WideArgs {
     int N, NP, pw;
 };
 
-// LDS: X [NP][WXR] | A [NP][WPA] f32 | park [NP][WPP] f32 | xx [NP] f32 | nbr [NP][16] u16 | red [2 * 64 + 16] f32
-__global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs p) {
+// LDS: X [NP][XR] | A [NP][PA] f32 | park [NP][PP] f32 | xx [NP] f32 | nbr [NP][16] u8 | red [2 * 64 + 16] f32
+template <int CW, int F3W>
+__global__ __launch_bounds__(64 * WTILES, (CW <= 64 ? SGPR_WIDE_NARROW_OCC : 2)) void wide_embed_kernel(const WideArgs p) {
+    constexpr int WXR = WideCfg<CW, F3W>::XR, WPA = WideCfg<CW, F3W>::PA, WPP = WideCfg<CW, F3W>::PP, WKS = WideCfg<CW, F3W>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const WideModel& m = p.m;
     const EmbedArgs& a = p.a;
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
     float* A = reinterpret_cast<float*>(X + NP * WXR);
     float* park = A + NP * WPA;
     float* xx = park + NP * WPP;
-    unsigned short* nbr = reinterpret_cast<unsigned short*>(xx + NP);
+    unsigned char* nbr = reinterpret_cast<unsigned char*>(xx + NP);
     float* red = reinterpret_cast<float*>(nbr + NP * 16);
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = dn ? (c + u < m.L ? dn[(size_t)(3 + c + u) * N] : 0.f) : (lab == c + u ? 1.f : 0.f);
-            xstore(xr, c, make_float4(v[0], v[1], v[2], v[3]), vmax);
+            xstore<CW>(xr, c, make_float4(v[0], v[1], v[2], v[3]), vmax);
 #pragma unroll
             for (int u = 0; u < 4; ++u) s = __fadd_rn(s, __fmul_rn(v[u], v[u]));
         }
@@ -377,9 +391,9 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
             if (tid < NP) {
                 unsigned char* xr = X + tid * WXR;
                 const bool live = tid < N;
-                xstore(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                xstore<CW>(xr, 0, live ? make_float4(fx, fy, fz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f), vmax);
 #pragma unroll
-                for (int c = 4; c < 32; c += 4) xstore(xr, c, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
+                for (int c = 4; c < 32; c += 4) xstore<CW>(xr, c, make_float4(0.f, 0.f, 0.f, 0.f), vmax);
                 const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));   // as torch.sum(x ** 2)
                 *reinterpret_cast<float4*>(xr + WXR - 16) = live ? make_float4(fx, fy, fz, n2) : make_float4(0.f, 0.f, 0.f, INFINITY);
             }
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
                 }
         };
         Frag w0[WKS], w1[WKS];
-        select_wide(X, xx, nbr, N, nrt, ks, wave, coord);
+        select_wide<CW>(X, xx, nbr, N, nrt, ks, wave, coord);
         __builtin_amdgcn_sched_barrier(0);
         load_w(w0, 0);
         {
@@ -409,15 +423,15 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
             const unsigned char* x0 = X + (wave * 16 + l15) * WXR;
 #pragma unroll
             for (int st = 0; st < WKS; ++st)
-                if (st < ks) xf[st] = xfrag(x0, st, lq);
+                if (st < ks) xf[st] = xfrag<CW>(x0, st, lq);
             float* a0 = A + (wave * 16 + l15) * WPA + 4 * lq;
 #pragma unroll 1
             for (int ct = 0; ct < nca; ct += 2) {
                 load_w(w1, ct + 1);
-                const f32x4 r = dotk(w0, xf, ks);                     // r[c] = a[channel ct*16 + 4 lq + c][node 16 wave + l15]
+                const f32x4 r = dotk<WKS>(w0, xf, ks);                     // r[c] = a[channel ct*16 + 4 lq + c][node 16 wave + l15]
                 *reinterpret_cast<float4*>(a0 + ct * 16) = make_float4(r[0], r[1], r[2], r[3]);
                 load_w(w0, ct + 2);                                   // (behind the last a tile: the first b tile, which follows them)
-                const f32x4 r1 = dotk(w1, xf, ks);
+                const f32x4 r1 = dotk<WKS>(w1, xf, ks);
                 *reinterpret_cast<float4*>(a0 + (ct + 1) * 16) = make_float4(r1[0], r1[1], r1[2], r1[3]);
             }
         }
@@ -429,18 +443,18 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
             unsigned char* x0 = X + (wave * 16 + l15) * WXR;
 #pragma unroll
             for (int st = 0; st < WKS; ++st)
-                if (st < ks) xf[st] = xfrag(x0, st, lq);
+                if (st < ks) xf[st] = xfrag<CW>(x0, st, lq);
             __builtin_amdgcn_sched_barrier(0);
             const float* tb = m.tbp[L] + 4 * lq;
 #pragma unroll 1
             for (int cb = 0; cb < nca; cb += 2) {
                 load_w(w1, nca + cb + 1);
                 const float4 t4 = *reinterpret_cast<const float4*>(tb + cb * 16);
-                const f32x4 r = dotk(w0, xf, ks);
+                const f32x4 r = dotk<WKS>(w0, xf, ks);
                 *reinterpret_cast<float4*>(x0 + (cb * 16 + 4 * lq) * 4) = make_float4(r[0] + t4.x, r[1] + t4.y, r[2] + t4.z, r[3] + t4.w);
                 if (cb + 2 < nca) load_w(w0, nca + cb + 2);
                 const float4 t5 = *reinterpret_cast<const float4*>(tb + (cb + 1) * 16);
-                const f32x4 r1 = dotk(w1, xf, ks);
+                const f32x4 r1 = dotk<WKS>(w1, xf, ks);
                 *reinterpret_cast<float4*>(x0 + ((cb + 1) * 16 + 4 * lq) * 4) = make_float4(r1[0] + t5.x, r1[1] + t5.y, r1[2] + t5.z, r1[3] + t5.w);
             }
         }
@@ -452,11 +466,12 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
 #pragma unroll 1
             for (int r0 = 0; r0 < 16; r0 += 4) {
                 const int ia = 16 * wave + r0 + sub;
-                const unsigned short* nw = nbr + ia * 16;
-                float4 y[2];
+                const unsigned char* nw = nbr + ia * 16;
+                constexpr int NPASS = CW / 64;                        // passes of 64 channels
+                float4 y[NPASS];
                 float sq = 0.f;
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
+                for (int cc = 0; cc < NPASS; ++cc) {
                     y[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int c4 = cl + 64 * cc;
                     if (cc < npass && c4 < coutP && ia < N) {         // (a row beyond the graph's slots has no list: it stays zero)
@@ -476,13 +491,13 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
                 }
                 // (every lane of the row has read its b above: the planes / the parked row may now replace it)
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
+                for (int cc = 0; cc < NPASS; ++cc) {
                     const int c4 = cl + 64 * cc;
                     if (cc < npass && c4 < coutP) {
                         if (L == 5)
                             *reinterpret_cast<float4*>(park + ia * WPP + c4) = y[cc];     // sem3 waits for conv_end
                         else
-                            xstore(X + ia * WXR, c4, y[cc], vmax);
+                            xstore<CW>(X + ia * WXR, c4, y[cc], vmax);
                     }
                 }
                 if (!last) {                                          // squared norms of the next layer's input rows
@@ -500,7 +515,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
     const int F3P = m.F3P;
     for (int e = tid; e < NP * (F3P >> 2); e += NT) {
         const int i = e / (F3P >> 2), c4 = (e - i * (F3P >> 2)) * 4;
-        xstore(X + i * WXR, F3P + c4, *reinterpret_cast<const float4*>(park + i * WPP + c4), vmax);
+        xstore<CW>(X + i * WXR, F3P + c4, *reinterpret_cast<const float4*>(park + i * WPP + c4), vmax);
     }
     __syncthreads();
     // ---- conv_end: 2 F3P -> F3P, folded BatchNorm, LeakyReLU -> E (in the A region); a wave per row tile
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
         const unsigned char* x0 = X + (wave * 16 + l15) * WXR;
 #pragma unroll
         for (int st = 0; st < WKS; ++st)
-            if (st < ks) xf[st] = xfrag(x0, st, lq);
+            if (st < ks) xf[st] = xfrag<CW>(x0, st, lq);
         const unsigned short* wl = m.wh_end + (size_t)lane * 8;
 #pragma unroll 1
         for (int ct = 0; ct < nct; ++ct) {
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
                     w[st].h = *reinterpret_cast<const f16x8*>(wp);
                     w[st].l = *reinterpret_cast<const f16x8*>(wp + 512);
                 }
-            const f32x4 r = dotk(w, xf, ks);
+            const f32x4 r = dotk<WKS>(w, xf, ks);
             const float4 t4 = *reinterpret_cast<const float4*>(m.tbp_end + ct * 16 + 4 * lq);
             *reinterpret_cast<float4*>(E + (wave * 16 + l15) * WPA + ct * 16 + 4 * lq) =
                 make_float4(lrelu(r[0] + t4.x), lrelu(r[1] + t4.y), lrelu(r[2] + t4.z), lrelu(r[3] + t4.w));
@@ -584,13 +599,32 @@ __global__ __launch_bounds__(64 * WTILES) void wide_embed_kernel(const WideArgs 
     }
 }
 
+template <int CW, int F3W>
 size_t wide_lds(int NP) {
-    return (size_t)NP * WXR + (size_t)NP * WPA * 4 + (size_t)NP * WPP * 4 + (size_t)NP * 4 + (size_t)NP * 16 * 2 + (2 * 64 + 16) * 4;
+    typedef WideCfg<CW, F3W> C;
+    return (size_t)NP * C::XR + (size_t)NP * C::PA * 4 + (size_t)NP * C::PP * 4 + (size_t)NP * 4 + (size_t)NP * 16 + (2 * 64 + 16) * 4;
+}
+// the narrow instance: every padded width of the model is at most 64 / 32
+bool wide_narrow(const WideModel& m) {
+    for (int l = 0; l < 6; ++l)
+        if (m.cinP[l] > 64 || m.coutP[l] > 64) return false;
+    return m.F3P <= 32;
+}
+
+template <int CW, int F3W>
+int launch_wide_t(const WideArgs& p, hipStream_t stream) {
+    static LdsLimitOnce once;
+    if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&wide_embed_kernel<CW, F3W>), 160 * 1024, "wide_embed_kernel")) return rc;
+    const size_t lds = wide_lds<CW, F3W>(p.NP);
+    hipLaunchKernelGGL((wide_embed_kernel<CW, F3W>), dim3(p.a.G), dim3(64 * (p.NP >> 4)), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "wide_embed_kernel launch");
+    return SGPR_OK;
 }
 
 }  // namespace
 
-size_t wide_embed_lds_bytes(int N) { return wide_lds((N + 15) & ~15); }
+size_t wide_embed_lds_bytes(int N) { return wide_lds<SGPR_WIDE_MAX_FILTERS, SGPR_WIDE_MAX_F3>((N + 15) & ~15); }
 
 bool wide_embed_serves(const sgpr_handle* h, const EmbedArgs& a, int N, int k) {
     return h->generic_only && h->wm.ok && k == WK && N >= k && N <= SGPR_WIDE_MAX_NODES && !a.dbg_layers && !a.dbg_knn &&
@@ -606,13 +640,7 @@ int launch_embed_wide(const sgpr_handle* h, const EmbedArgs& a, int N, int k, hi
     p.N = N;
     p.NP = (N + 15) & ~15;
     p.pw = h->gm.f3;
-    const size_t lds = wide_lds(p.NP);
-    static LdsLimitOnce once;
-    if (int rc = raise_lds_limit(&once, reinterpret_cast<const void*>(&wide_embed_kernel), 160 * 1024, "wide_embed_kernel")) return rc;
-    hipLaunchKernelGGL(wide_embed_kernel, dim3(a.G), dim3(64 * (p.NP >> 4)), lds, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "wide_embed_kernel launch");
-    return SGPR_OK;
+    return wide_narrow(h->wm) ? launch_wide_t<64, 32>(p, stream) : launch_wide_t<SGPR_WIDE_MAX_FILTERS, SGPR_WIDE_MAX_F3>(p, stream);
 }
 
 }  // namespace sgpr
