@@ -1092,7 +1092,21 @@ int sgpr_score_pair_list(const sgpr_handle* h, const float* d_pooled_rows, int R
 
 size_t sgpr_score_all_pairs_workspace_bytes(const sgpr_handle* h, int R, int M) {
     if (!h || R < 0 || M < 0) return 0;
+    if (h->generic_only && h->wm.ok) return std::max(score_all_pairs_ws_bytes(R, M), wide_tail_ws_bytes(R, M));
     return score_all_pairs_ws_bytes(R, M);
+}
+
+// One rectangle of an any-shape handle: a moderately larger tensor network (pooled width <= 64, <= 32 neurons) on the matrix
+// cores (sgpr_wide.hip) when the caller brought its workspace; the plain-fp32 kernel behind it runs only if the inputs left
+// the f16 range (a device word).  Handles beyond those limits: the plain-fp32 kernel alone, no workspace.
+static int score_rect_any_shape(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score, int64_t ld,
+                                void* ws, size_t ws_bytes, hipStream_t stream) {
+    const unsigned* gate = nullptr;
+    if (wide_tail_serves(h) && ws && ws_bytes >= wide_tail_ws_bytes(R, M)) {
+        const int rc = launch_score_all_pairs_wide_any(h, rows, R, cols, M, score, ld, ws, &gate, stream);
+        if (rc != SGPR_OK) return rc;
+    }
+    return launch_score_generic(h, rows, nullptr, cols, nullptr, (int64_t)R * M, M, score, ld, stream, gate);
 }
 
 int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R, const float* d_pooled_cols, int M,
@@ -1103,9 +1117,9 @@ int sgpr_score_all_pairs(const sgpr_handle* h, const float* d_pooled_rows, int R
         return SGPR_E_INVALID;
     }
     if (R == 0 || M == 0) return SGPR_OK;
-    if (h->generic_only) {                                   // (no workspace: one wave per pair of the rectangle)
+    if (h->generic_only) {
         DeviceGuard guard(h->device);
-        return launch_score_generic(h, d_pooled_rows, nullptr, d_pooled_cols, nullptr, (int64_t)R * M, M, d_score, ld,
+        return score_rect_any_shape(h, d_pooled_rows, R, d_pooled_cols, M, d_score, ld, d_workspace, workspace_bytes,
                                     static_cast<hipStream_t>(stream));
     }
     const size_t need = score_all_pairs_ws_bytes(R, M);
@@ -1137,7 +1151,10 @@ static int check_jobs(const sgpr_handle* h, int n, const sgpr_pairs_job* jobs) {
 
 size_t sgpr_score_all_pairs_multi_workspace_bytes(const sgpr_handle* h, int n_jobs, const sgpr_pairs_job* jobs) {
     if (check_jobs(h, n_jobs, jobs) != SGPR_OK) return 0;
-    return score_all_pairs_multi_ws_bytes(n_jobs, jobs);
+    size_t any = 0;
+    if (h->generic_only && h->wm.ok)
+        for (int j = 0; j < n_jobs; ++j) any = std::max(any, wide_tail_ws_bytes(jobs[j].R, jobs[j].M));
+    return std::max(any, score_all_pairs_multi_ws_bytes(n_jobs, jobs));
 }
 
 int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pairs_job* jobs, void* d_workspace,
@@ -1148,9 +1165,9 @@ int sgpr_score_all_pairs_multi(const sgpr_handle* h, int n_jobs, const sgpr_pair
         DeviceGuard guard(h->device);
         for (int j = 0; j < n_jobs && rc == SGPR_OK; ++j)
             if (jobs[j].R > 0 && jobs[j].M > 0)
-                rc = launch_score_generic(h, jobs[j].d_pooled_rows, nullptr, jobs[j].d_pooled_cols, nullptr,
-                                          (int64_t)jobs[j].R * jobs[j].M, jobs[j].M, jobs[j].d_score, jobs[j].ld,
-                                          static_cast<hipStream_t>(stream));
+                rc = score_rect_any_shape(h, jobs[j].d_pooled_rows, jobs[j].R, jobs[j].d_pooled_cols, jobs[j].M, jobs[j].d_score,
+                                          jobs[j].ld, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));   // (stream order
+                                                                                     // lets the jobs share one workspace)
         return rc;
     }
     const size_t need = score_all_pairs_multi_ws_bytes(n_jobs, jobs);

@@ -505,8 +505,9 @@ template <int TMAX>
 __global__ __launch_bounds__(TAIL_THREADS) void generic_score_rect_kernel(const GenericModel m, const float* __restrict__ rows,
                                                                           const float* __restrict__ cols, const int R, const int M,
                                                                           float* __restrict__ score, const int64_t ld, const int pw,
-                                                                          const int tiles_per_wg) {
+                                                                          const int tiles_per_wg, const unsigned* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) float tail_smem[];
+    if (gate && *gate == 0u) return;      // behind the matrix-core tail (sgpr_wide.hip): only a rectangle it left to this kernel
     const int F = m.f3, T = m.T, B = m.B, tid = threadIdx.x;
     float* App = tail_smem;                                       // [F][TMAX]
     float* u = App + F * TMAX;                                    // [TMAX]
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void generic_score_rect_kernel(const 
 
 template <int TMAX>
 static int launch_rect(const sgpr_handle* h, const float* rows, const float* cols, int R, int M, float* score, int64_t ld,
-                       int pw, hipStream_t stream) {
+                       int pw, hipStream_t stream, const unsigned* gate) {
     const GenericModel& m = h->gm;
     const int tiles = (M + TAIL_THREADS - 1) / TAIL_THREADS;
     // enough workgroups to fill the GPU (8 per CU), as few recomputations of a row's hoisted form as that allows
@@ -599,7 +600,7 @@ static int launch_rect(const sgpr_handle* h, const float* rows, const float* col
     for (int r0 = 0; r0 < R; r0 += 65535) {                       // (gridDim.y)
         const int rn = R - r0 < 65535 ? R - r0 : 65535;
         hipLaunchKernelGGL(generic_score_rect_kernel<TMAX>, dim3(gx, rn), dim3(TAIL_THREADS), lds, stream, m,
-                           rows + (size_t)r0 * pw, cols, rn, M, score + (size_t)r0 * ld, ld, pw, tiles_per_wg);
+                           rows + (size_t)r0 * pw, cols, rn, M, score + (size_t)r0 * ld, ld, pw, tiles_per_wg, gate);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "generic_score_rect_kernel launch");
     }
@@ -607,15 +608,15 @@ static int launch_rect(const sgpr_handle* h, const float* rows, const float* col
 }
 
 int launch_score_generic(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,
-                         int64_t P, int M, float* score, int64_t ld, hipStream_t stream) {
+                         int64_t P, int M, float* score, int64_t ld, hipStream_t stream, const unsigned* d_gate) {
     if (P == 0) return SGPR_OK;
     const int pw = h->generic_only ? h->gm.f3 : kF3;
     const GenericModel& m = h->gm;
     if (M > 0) {                                                  // dense rectangle: p1 = rows [P / M], p2 = columns [M]
         const int R = (int)(P / M);
-        if (m.T <= 16) return launch_rect<16>(h, p1, p2, R, M, score, ld, pw, stream);
-        if (m.T <= 32) return launch_rect<32>(h, p1, p2, R, M, score, ld, pw, stream);
-        return launch_rect<64>(h, p1, p2, R, M, score, ld, pw, stream);
+        if (m.T <= 16) return launch_rect<16>(h, p1, p2, R, M, score, ld, pw, stream, d_gate);
+        if (m.T <= 32) return launch_rect<32>(h, p1, p2, R, M, score, ld, pw, stream, d_gate);
+        return launch_rect<64>(h, p1, p2, R, M, score, ld, pw, stream, d_gate);
     }
     const int64_t cap = (int64_t)16 * h->num_cus;
     const unsigned blocks = (unsigned)(P < cap ? P : cap);

@@ -224,13 +224,19 @@ int launch_embed_generic(const sgpr_handle* h, const EmbedArgs& a, int N, int k,
 bool wide_embed_serves(const sgpr_handle* h, const EmbedArgs& a, int N, int k);
 size_t wide_embed_lds_bytes(int N);
 int launch_embed_wide(const sgpr_handle* h, const EmbedArgs& a, int N, int k, hipStream_t stream);
+// ... and its dense all-pairs tail (pooled width <= 64, tensor / bottleneck neurons <= 32): *d_gate = the device word the
+// plain-fp32 kernel behind the call tests (non-zero: inputs outside the f16 range, the rectangle is its)
+bool wide_tail_serves(const sgpr_handle* h);
+size_t wide_tail_ws_bytes(int R, int M);
+int launch_score_all_pairs_wide_any(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
+                                    int64_t ld, void* ws, const unsigned** d_gate, hipStream_t stream);
 // list form (M == 0: pair p = (i1 ? i1[p] : p, i2 ? i2[p] : p) -> score[p]) or dense rectangle (M > 0: P = R * M pairs -> score[r * ld + c])
 int launch_knn_any(const float* x, int B, int C, int N, int k, int64_t* idx, hipStream_t stream);
 int launch_attention_any(const float* w, const float* emb, int B, int N, int F, float* rep, float* att, hipStream_t stream);
 int launch_ntn_any(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t P, int F,
                    int T, float* out, hipStream_t stream);
 int launch_score_generic(const sgpr_handle* h, const float* p1, const int32_t* i1, const float* p2, const int32_t* i2,
-                         int64_t P, int M, float* score, int64_t ld, hipStream_t stream);
+                         int64_t P, int M, float* score, int64_t ld, hipStream_t stream, const unsigned* d_gate = nullptr);
 int launch_score_plan_generic(const sgpr_handle* h, const float* rows, const float* cols, const int32_t* plan, int NR, int NI,
                               int64_t P, float* score, hipStream_t stream);
 int launch_ntn(const float* w, const float* wb, const float* bias, const float* e1, const float* e2, int64_t B,

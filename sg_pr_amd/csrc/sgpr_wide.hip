@@ -15,6 +15,8 @@
 // there), as every other kernel of this library does.
 #include <math.h>
 
+#include <algorithm>
+
 #include "sgpr_internal.hpp"
 
 namespace sgpr {
@@ -622,7 +624,305 @@ int launch_wide_t(const WideArgs& p, hipStream_t stream) {
     return SGPR_OK;
 }
 
+
+// ------------------------------------------------------------------ dense all-pairs tail on the matrix cores
+// TenorNetworkModule.forward + FC head (layers_batch.py:70-83, sg_net.py:131-136) for the same moderately larger models:
+// pooled width <= 64, tensor neurons <= 32, bottleneck neurons <= 32 (every width padded with zeros: exact).  The tuned
+// tail's formulation (sgpr_score.hip): the bilinear form and the column half of the block term hoisted per row graph -
+// A'_r[t][j] = sum_i e1[i] W[i][j][t] + Wb[t][F + j], u_r[t] = Wb[t][:F] . e1 + bias[t] -, both dense layers on
+// v_mfma_f32_16x16x32_f16 with two f16 planes per operand, layer 2 fed straight from layer 1's accumulator layout, the
+// scoring weight folded into layer 2.  At 64 x 64 x 32 a block of 16 pairs costs 12 + 8 matrix instructions (the built
+// shape: 3 + 2).  One wave per (row graph, 256 columns) item; inputs outside the f16 range leave the whole rectangle to
+// the plain-fp32 kernel (a gate word).
+constexpr int TFP = 64, TTP = 32, TBP = 32;
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split2(float a, unsigned short& h, unsigned short& l) {
+    const _Float16 hh = (_Float16)a;
+    const _Float16 ll = (_Float16)(a - (float)hh);
+    h = __builtin_bit_cast(unsigned short, hh);
+    l = __builtin_bit_cast(unsigned short, ll);
+}
+// max |v| over the wave -> one atomic (bit patterns of non-negative floats order like the floats; +inf stands for NaN)
+__device__ __forceinline__ void atomic_max_abs(unsigned* dst, float v) {
+    unsigned u = __float_as_uint(fabsf(v));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, m));
+    if ((threadIdx.x & 63) == 0 && u != 0u) atomicMax(dst, u);
+}
+
+// header words of the workspace: max |A'|, max |u|, max |e2| (bit patterns of non-negative floats), the gate
+struct TailHdr {
+    unsigned amax, umax, emax, gate;
+};
+
+// eight fp32 values -> their hi / lo f16 planes, eight halves (16 bytes) each
+__device__ __forceinline__ void split2x8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned short h0, l0, h1, l1;
+        split2(v[2 * q], h0, l0);
+        split2(v[2 * q + 1], h1, l1);
+        hi[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lo[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+}
+
+// blocks [0, 4 nrg): 16 row graphs per FOUR workgroups - A' as a small fp32-matrix-core GEMM ([16 graphs x 64] x [64 x 2048]):
+// each of the 16 waves owns eight consecutive columns j of one half of the neurons (eight accumulators), so that a lane's
+// eight values of a graph are the 16 contiguous bytes of the operand planes the tail reads; wave i of the 16 also computes
+// u_r of graph i.  Blocks [4 nrg, ...): 64 column graphs each - their planes, 16 bytes per thread and plane.
+__global__ __launch_bounds__(256) void wide_tail_prep_kernel(const GenericModel m, const float* __restrict__ rows, const int R,
+                                                             const float* __restrict__ cols, const int M, const int pw, const int nrg,
+                                                             unsigned short* __restrict__ Ab, float* __restrict__ ur,
+                                                             unsigned short* __restrict__ Cb, TailHdr* __restrict__ hdr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int F = m.f3, T = m.T;
+    if ((int)blockIdx.x >= 4 * nrg) {
+        const int c0 = ((int)blockIdx.x - 4 * nrg) * 64;
+        float emax = 0.f;
+        for (int e = threadIdx.x; e < 64 * (TFP / 8); e += 256) {
+            const int c = c0 + (e >> 3), jo = e & 7;
+            if (c >= ((M + 15) & ~15)) continue;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float x = (c < M && 8 * jo + q < F) ? cols[(size_t)c * pw + 8 * jo + q] : 0.f;
+                emax = fmaxf(emax, fabsf(x));
+                if (x != x) emax = INFINITY;
+                v[q] = x;
+            }
+            u32x4 hi, lo;
+            split2x8(v, hi, lo);
+            unsigned short* dst = Cb + ((size_t)(c >> 4) * 2 + (jo >> 2)) * 2 * 512 + (16 * (jo & 3) + (c & 15)) * 8;
+            *reinterpret_cast<u32x4*>(dst) = hi;
+            *reinterpret_cast<u32x4*>(dst + 512) = lo;
+        }
+        atomic_max_abs(&hdr->emax, emax);
+        return;
+    }
+    const int g0 = ((int)blockIdx.x >> 2) * 16, gid = ((int)blockIdx.x & 3) * 4 + wave;
+    const int jo = gid >> 1, th = gid & 1, t = 16 * th + l15;
+    float amax = 0.f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (8 * jo < F && 16 * th < T) {                          // (wave-uniform; the planes of padding columns / neurons: zeros)
+        const int g = min(g0 + l15, R - 1);
+        const float* er = rows + (size_t)g * pw;
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {
+            // A operand of the fp32 16x16x4 matrix instruction: E[g0 + l15][4 st + lq]; B: W[i][j][t] of the eight columns
+            const int i = 4 * st + lq;
+            const float ea = i < F ? er[i] : 0.f;
+            float b[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                b[jj] = (i < F && 8 * jo + jj < F && t < T) ? m.ntn_w[((size_t)i * F + 8 * jo + jj) * T + t] : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea, b[jj], acc[jj], 0, 0, 0);
+        }
+    }
+    float wbc[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) wbc[jj] = (8 * jo + jj < F && t < T) ? m.ntn_wb[(size_t)t * 2 * F + F + 8 * jo + jj] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                            // acc[jj][r] = (e1^T W)_{g0 + 4 lq + r}[8 jo + jj][t]
+        const int g = g0 + 4 * lq + r;
+        if (g >= R) continue;
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            v[jj] = acc[jj][r] + wbc[jj];
+            amax = fmaxf(amax, fabsf(v[jj]));
+            if (v[jj] != v[jj]) amax = INFINITY;
+        }
+        u32x4 hi, lo;
+        split2x8(v, hi, lo);
+        unsigned short* dst = Ab + ((((size_t)g * 2 + th) * 2 + (jo >> 2)) * 2) * 512 + (16 * (jo & 3) + l15) * 8;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + 512) = lo;
+    }
+    atomic_max_abs(&hdr->amax, amax);
+    // u_r[t] = Wb[t][:F] . e1 + bias[t] of graph g0 + gid: lane = (half of the F terms, t)
+    const int g = g0 + gid;
+    if (g < R) {
+        const int tt = lane & 31, hf = lane >> 5;
+        float s = 0.f;
+        if (tt < T)
+            for (int q = 32 * hf; q < 32 * hf + 32; ++q)
+                if (q < F) s = fmaf(m.ntn_wb[(size_t)tt * 2 * F + q], rows[(size_t)g * pw + q], s);
+        s += __shfl_xor(s, 32);
+        if (tt < T) s += m.ntn_bias[tt];
+        if (hf == 0) ur[(size_t)g * TTP + tt] = tt < T ? s : 0.f;
+        atomic_max_abs(&hdr->umax, (s != s) ? INFINITY : s);
+    }
+}
+
+// relu(h[0..3]) -> the layer-2 B operand {hi01, hi23, lo01, lo23} (sgpr_score.hip, split_relu4: truncated hi plane, the
+// low plane from one mixed-precision FMA per value, the ReLU as a packed signed-integer maximum with 0 per plane)
+__device__ __forceinline__ f16x8 split_relu4(f32x4 h) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
+    unsigned l01, l23;
+    const i16x2 z = {0, 0};
+    const unsigned a = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, h01), z));
+    const unsigned b = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, h23), z));
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l01), "=&v"(l23)
+        : "v"(h01), "v"(h23), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    const unsigned c = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l01), z));
+    const unsigned d = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, l23), z));
+    return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
+}
+
+// can every f16 this rectangle forms be represented?  |A'|, |e2| and |H| <= |u| + 64 max|A'| max|e2|
+__device__ __forceinline__ bool tail_in_range(const TailHdr* hdr) {
+    const float am = __uint_as_float(hdr->amax), um = __uint_as_float(hdr->umax), em = __uint_as_float(hdr->emax);
+    return (am < kWideF16Safe) && (em < kWideF16Safe) && (um + (float)TFP * am * em < kWideF16Safe);
+}
+
+__global__ __launch_bounds__(256) void wide_tail_kernel(const GenericModel m, const int R, const int M,
+                                                        const unsigned short* __restrict__ Ab, const float* __restrict__ ur,
+                                                        const unsigned short* __restrict__ Cb, TailHdr* __restrict__ hdr,
+                                                        float* __restrict__ score, const int64_t ld) {
+    if (!tail_in_range(hdr)) {                               // the plain-fp32 kernel behind this launch takes the rectangle
+        if (threadIdx.x == 0) hdr->gate = 1u;
+        return;
+    }
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+    const int T = m.T, B = m.B;
+    // the head folded into layer 2 (sgpr_score.hip, ap_consts), per (o tile, t tile)
+    f16x8 w1hi[2][2], w1lo[2][2];
+    f32x4 b1v[2], side[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        const int o = 16 * ot + l15;                         // the A operand's row
+        const float s = o < B ? m.fc2_w[o] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * tt + 4 * g + i;
+                w[i] = (o < B && t < T) ? s * m.fc1_w[(size_t)o * T + t] : 0.f;
+            }
+            const _Float16 h0 = (_Float16)w[0], h1 = (_Float16)w[1], h2 = (_Float16)w[2], h3 = (_Float16)w[3], z16 = (_Float16)0.f;
+            w1hi[ot][tt] = f16x8{h0, h1, h2, h3, h0, h1, h2, h3};        // meets H's hi and lo planes
+            w1lo[ot][tt] = f16x8{(_Float16)(w[0] - (float)h0), (_Float16)(w[1] - (float)h1), (_Float16)(w[2] - (float)h2),
+                                 (_Float16)(w[3] - (float)h3), z16, z16, z16, z16};   // meets the hi plane only
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                        // the accumulator's rows are o = 16 ot + 4 g + r
+            const int oo = 16 * ot + 4 * g + r;
+            const float w2 = oo < B ? m.fc2_w[oo] : 0.f;
+            b1v[ot][r] = oo < B ? w2 * m.fc1_b[oo] : 0.f;
+            side[ot][r] = w2 < 0.f ? -INFINITY : INFINITY;
+        }
+    }
+    const float kL2E = 1.4426950408889634f;
+    const float nb2 = -m.fc2_b[0] * kL2E;
+    const int nblk = (M + 15) >> 4, nch = (nblk + 15) >> 4;  // 16-column blocks; chunks of 16 blocks
+    const long long items = (long long)R * nch;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    for (long long it = wid; it < items; it += nw) {
+        const int r = (int)(it / nch), ch = (int)(it - (long long)r * nch);
+        f16x8 ah[2][2], al[2][2];
+        f32x4 u4[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short* ap = Ab + ((((size_t)r * 2 + tt) * 2 + ks) * 2) * 512 + (size_t)lane * 8;
+                ah[tt][ks] = *reinterpret_cast<const f16x8*>(ap);
+                al[tt][ks] = *reinterpret_cast<const f16x8*>(ap + 512);
+            }
+            const float4 u = *reinterpret_cast<const float4*>(ur + (size_t)r * TTP + 16 * tt + 4 * g);
+            u4[tt] = f32x4{u.x, u.y, u.z, u.w};
+        }
+        const int b0 = ch * 16, b1 = min(nblk, b0 + 16);
+#pragma unroll 1
+        for (int blk = b0; blk < b1; ++blk) {
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short* cp = Cb + (((size_t)blk * 2 + ks) * 2) * 512 + (size_t)lane * 8;
+                bh[ks] = *reinterpret_cast<const f16x8*>(cp);
+                bl[ks] = *reinterpret_cast<const f16x8*>(cp + 512);
+            }
+            f16x8 hb[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 h = u4[tt];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    h = mfma(al[tt][ks], bh[ks], h);
+                    h = mfma(ah[tt][ks], bl[ks], h);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) h = mfma(ah[tt][ks], bh[ks], h);
+                hb[tt] = split_relu4(h);                     // H[t = 16 tt + 4 g + i][column l15]
+            }
+            float z = 0.f;
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                f32x4 q = b1v[ot];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    q = mfma(w1lo[ot][tt], hb[tt], q);
+                    q = mfma(w1hi[ot][tt], hb[tt], q);
+                }
+                const float t0 = __builtin_amdgcn_fmed3f(q[0], 0.f, side[ot][0]), t1 = __builtin_amdgcn_fmed3f(q[1], 0.f, side[ot][1]);
+                const float t2 = __builtin_amdgcn_fmed3f(q[2], 0.f, side[ot][2]), t3 = __builtin_amdgcn_fmed3f(q[3], 0.f, side[ot][3]);
+                z += (t0 + t1) + (t2 + t3);                  // partial over o = 16 ot + 4 g .. + 3, column l15
+            }
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 32);
+            const float sc = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(z, -kL2E, nb2)));
+            const int c = 16 * blk + l15;
+            if (g == 0 && c < M) score[(size_t)r * ld + c] = sc;
+        }
+    }
+}
+
+size_t wide_tail_ws(int R, int M) {
+    const size_t nblk = ((size_t)M + 15) >> 4;
+    return 256 + (size_t)R * 8 * 1024 + (size_t)R * TTP * sizeof(float) + nblk * 4 * 1024;
+}
+
 }  // namespace
+
+bool wide_tail_serves(const sgpr_handle* h) {
+    return h->generic_only && h->wm.ok && h->gm.f3 <= TFP && h->gm.T <= TTP && h->gm.B <= TBP && !(h->dbg_skip & (1 << 23));
+}
+size_t wide_tail_ws_bytes(int R, int M) { return wide_tail_ws(R, M); }
+
+// returns through *d_gate the device word the plain-fp32 kernel behind this call must test (non-zero: the rectangle is its)
+int launch_score_all_pairs_wide_any(const sgpr_handle* h, const float* rows, int R, const float* cols, int M, float* score,
+                                    int64_t ld, void* ws, const unsigned** d_gate, hipStream_t stream) {
+    TailHdr* hdr = static_cast<TailHdr*>(ws);
+    unsigned short* Ab = reinterpret_cast<unsigned short*>(static_cast<unsigned char*>(ws) + 256);
+    float* ur = reinterpret_cast<float*>(Ab + (size_t)R * 8 * 512);
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(ur + (size_t)R * TTP);
+    hipError_t e = hipMemsetAsync(hdr, 0, sizeof(TailHdr), stream);
+    if (e != hipSuccess) return hip_fail(e, "wide tail: header");
+    const int nrg = (R + 15) / 16, ncb = (((M + 15) & ~15) + 63) / 64, pw = h->gm.f3;
+    hipLaunchKernelGGL(wide_tail_prep_kernel, dim3(4 * nrg + ncb), dim3(256), 0, stream, h->gm, rows, R, cols, M, pw, nrg, Ab, ur, Cb, hdr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "wide_tail_prep_kernel launch");
+    const long long items = (long long)R * ((((M + 15) >> 4) + 15) >> 4);
+    const long long slots = (long long)h->num_cus * 8;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((items + 3) / 4, slots));
+    hipLaunchKernelGGL(wide_tail_kernel, dim3(grid), dim3(256), 0, stream, h->gm, R, M, Ab, ur, Cb, hdr, score, ld);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "wide_tail_kernel launch");
+    *d_gate = &hdr->gate;
+    return SGPR_OK;
+}
 
 size_t wide_embed_lds_bytes(int N) { return wide_lds<SGPR_WIDE_MAX_FILTERS, SGPR_WIDE_MAX_F3>((N + 15) & ~15); }
 

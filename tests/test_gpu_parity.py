@@ -2044,6 +2044,36 @@ def test_matrix_core_any_shape_embed(oracle):
         keep = [g for g in range(40) if g != 3]
         assert torch.equal(mixed[keep], wide[0][keep]), tag
         eng.check_status()
+        # the dense all-pairs tail of such a handle: matrix cores (two f16 planes) against the plain-fp32 kernel and the oracle
+        # on the SAME pooled vectors (at two scales: the randomised weights saturate the sigmoid at the first); ragged
+        # sizes; inputs outside the f16 range leave the rectangle to the plain kernel (its bits)
+        differs, spread = False, 0.0
+        for sc_ in (1.0, 0.03):
+            pooled = (wide[0] * sc_).contiguous()
+            mat = eng.score_all_pairs(pooled, pooled)
+            ref_mat = oracle.score_all_pairs(sd, pooled.cpu(), pooled.cpu())
+            eng.set_skip_mask(1 << 23)
+            try:
+                mat_plain = eng.score_all_pairs(pooled, pooled)
+            finally:
+                eng.set_skip_mask(0)
+            differs = differs or not torch.equal(mat, mat_plain)
+            spread = max(spread, float(mat.max() - mat.min()))
+            assert (mat - mat_plain).abs().max().item() < 2e-5, (tag, sc_)
+            assert (mat.cpu() - ref_mat).abs().max().item() < SCORE_TOL, (tag, sc_)
+            for r_, c_ in ((1, 1), (17, 33), (40, 16), (5, 40)):
+                sub = eng.score_all_pairs(pooled[:r_].contiguous(), pooled[:c_].contiguous())
+                assert torch.equal(sub, mat[:r_, :c_]), (tag, sc_, r_, c_)
+            outs = eng.score_all_pairs_multi([(pooled[:7], pooled), (pooled[7:], pooled[:5])])
+            assert torch.equal(outs[0], mat[:7]) and torch.equal(outs[1], mat[7:, :5]), (tag, sc_)
+        assert differs and spread > 1e-3, (tag, spread)                # (two datapaths, and not only saturated scores)
+        pooled = wide[0]
+        eng.set_skip_mask(1 << 23)
+        try:
+            big_plain = eng.score_all_pairs(pooled[:7] * 3000.0, pooled * 3000.0)
+        finally:
+            eng.set_skip_mask(0)
+        assert torch.equal(eng.score_all_pairs(pooled[:7] * 3000.0, pooled * 3000.0), big_plain), tag
 
 
 def test_node_num_and_k_beyond_the_tuned_kernels(eng, oracle_sd, oracle):

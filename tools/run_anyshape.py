@@ -64,11 +64,18 @@ log("KITTI-00 shape (4541 graphs, node_num 100, K 10), shipped weights: embed (b
     "profiles/*_seq_parity.txt: 24-bit against fp32 keys), max %.2e"
     % (t_t, t_a, t_a / t_t, float(dev.median()), int((dev > 2e-4).sum()), float(dev.max())))
 s_t = timed(lambda: tuned.score_all_pairs(p_t, p_t))
+any13.set_skip_mask(1 << 23)
 s_a = timed(lambda: any13.score_all_pairs(p_t, p_t), reps=3)
 m_t, m_a = tuned.score_all_pairs(p_t, p_t), any13.score_all_pairs(p_t, p_t)
-log("all-pairs tail 4541 x 4541: tuned %.1f us (%.1f G pairs/s), any-shape %.1f us (%.2f G pairs/s, %.0f x); max |d score| %.2e"
+any13.set_skip_mask(0)
+s_w = timed(lambda: any13.score_all_pairs(p_t, p_t), reps=3)
+m_w = any13.score_all_pairs(p_t, p_t)
+log("all-pairs tail 4541 x 4541: tuned %.1f us (%.1f G pairs/s), any-shape plain fp32 %.1f us (%.2f G pairs/s, %.0f x); max |d score| %.2e"
     % (s_t, 4541 ** 2 / s_t / 1e3, s_a, 4541 ** 2 / s_a / 1e3, s_a / s_t, float((m_t - m_a).abs().max())))
-del m_t, m_a
+log("... the same handle's tail on the matrix cores (sgpr_wide.hip, three launches: prep, tail, the gated plain kernel): %.1f us "
+    "(%.2f G pairs/s, %.1f x the tuned kernel, %.1f x faster than plain fp32); max |d score| against plain fp32 %.2e"
+    % (s_w, 4541 ** 2 / s_w / 1e3, s_w / s_t, s_a / s_w, float((m_w - m_a).abs().max())))
+del m_t, m_a, m_w
 
 # beyond the tuned kernels' node_num / K on the shipped checkpoint
 for n, k, g in ((512, 20, 1024), (1024, 10, 512), (100, 40, 1024)):
@@ -96,9 +103,15 @@ for labels, f1, f2, f3, tn, bn in ((12, 128, 128, 64, 32, 32), (30, 256, 256, 12
     eng.set_skip_mask(0)
     dv = (p - p_plain).abs().amax(1) / p_plain.abs().amax().clamp(min=1.0)
     s = timed(lambda: eng.score_all_pairs(p, p), reps=3)
+    m_w = eng.score_all_pairs(p, p)
+    eng.set_skip_mask(1 << 23)
+    s_plain = timed(lambda: eng.score_all_pairs(p, p), reps=3)
+    d_tail = float((m_w - eng.score_all_pairs(p, p)).abs().max())
+    eng.set_skip_mask(0)
     log("architecture {%d labels, filters %d/%d/%d, %d tensor / %d bottleneck neurons}, 1024 graphs of node_num 100: embed %.1f us "
         "(%.2f us per graph; plain fp32 only: %.1f us = %.2f us per graph; relative |d pooled| between the two: median %.1e, max %.1e), "
-        "all-pairs 1024 x 1024 %.1f us (%.3f G pairs/s)" % (labels, f1, f2, f3, tn, bn, t, t / 1024, t_plain, t_plain / 1024,
-                                                            float(dv.median()), float(dv.max()), s, 1024 ** 2 / s / 1e3))
+        "all-pairs 1024 x 1024 %.1f us (%.3f G pairs/s; plain fp32 only: %.1f us; max |d score| between the two %.1e)"
+        % (labels, f1, f2, f3, tn, bn, t, t / 1024, t_plain, t_plain / 1024, float(dv.median()), float(dv.max()), s,
+           1024 ** 2 / s / 1e3, s_plain, d_tail))
 if len(sys.argv) > 1:
     open(sys.argv[1], "w").write("\n".join(lines) + "\n")
