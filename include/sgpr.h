@@ -74,7 +74,10 @@ typedef struct sgpr_handle sgpr_handle;
  * an "any-shape" handle: the same entry points on plain-fp32 kernels
  * (sgpr_generic.hip) - correct against the same oracle, not tuned; the embed of
  * a model with <= 32 labels and filters <= 128 / 128 / 64 runs on the matrix
- * cores for node_num <= 112, K = 10 (sgpr_wide.hip) - with device
+ * cores for node_num <= 112, K = 10, and so does sgpr_score_all_pairs(_multi)
+ * when filters_3 <= 64 and tensor / bottleneck neurons <= 32 and the caller
+ * passes the workspace the _workspace_bytes call asks for (sgpr_wide.hip;
+ * without a workspace: the plain-fp32 kernel) - with device
  * buffers of the model's own width (pooled [G, filters_3], emb [G, N, filters_3]:
  * sgpr_pooled_width).  Not served on such a handle: sgpr_embed_debug's dumps
  * (-> SGPR_E_DIMS; sgpr_score_pair_list walks its plan pair by pair there: the
