@@ -368,7 +368,10 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 // Everything the steps decide lives in a control block on the device; the host reads 8 doubles at the end.  Rectangles
 // the device path is not built for (more than 2^20 positives, more than F1_PICK values to settle - a flat curve) are
 // reported in the status word and the caller falls back to the multi-call path (sg_pr_amd/metrics.py).
-constexpr int F1_SH = 17;                                        // key = bit pattern >> 17: sign, exponent, 6 mantissa bits
+#ifndef SGPR_F1_SH
+#define SGPR_F1_SH 17
+#endif
+constexpr int F1_SH = SGPR_F1_SH;                                // key = bit pattern >> 17: sign, exponent, 6 mantissa bits
 constexpr int F1_HALF = 0x3F000000 >> F1_SH;                     // 8064 bins for s in [0, 1/2)
 constexpr int F1_ONE = 2 * F1_HALF;                              // the bin of s == 1
 constexpr int F1_NB = F1_ONE + 1 + ((0x7F800000 - 0x3F800000) >> F1_SH) + 1;   // 24 322 bins: ... and s in (1, +inf]
@@ -416,28 +419,15 @@ __device__ __forceinline__ double f1_of(double tp, double fp, double pos) {
 #ifndef SGPR_F1_ROWS
 #define SGPR_F1_ROWS 4
 #endif
+#ifndef SGPR_F1_CULL
+#define SGPR_F1_CULL 1         // strips culled by bounding box (pass A) / by the thresholds' range (pass B); 0: A/B builds
+#endif
 #ifndef SGPR_F1_WGB
-#define SGPR_F1_WGB 2          // workgroups per CU of pass B (A/B builds)
+#define SGPR_F1_WGB 1          // workgroups per CU of pass B (2: 27.4 against 24.1 us - twice the closing atomics)
 #endif
 constexpr int F1_ROWS = SGPR_F1_ROWS;                                       // rows per task = rows in flight per wave (5 tasks per wave on a KITTI-00 matrix)
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
-
-struct StripTask {
-    int c0, r0, r1;
-    __device__ __forceinline__ bool init(const PairScan& sc, long long task, int lane) {
-        const int strips = (sc.M + 255) >> 8;
-        const long long chunk = task / strips;
-        const int strip = (int)(task - chunk * strips);
-        r0 = (int)chunk * F1_ROWS;
-        r1 = min(sc.R, r0 + F1_ROWS);
-        c0 = strip * 256 + 4 * lane;
-        return r0 < sc.R;
-    }
-};
-__device__ __forceinline__ long long strip_tasks(const PairScan& sc) {
-    return (long long)((sc.M + 255) >> 8) * ((sc.R + F1_ROWS - 1) / F1_ROWS);
-}
 
 __device__ __forceinline__ void load_row4(const PairScan& sc, int r, int c0, float (&s)[4]) {
     const float* sp = sc.score + (int64_t)r * sc.ld + c0;
@@ -474,46 +464,58 @@ struct ColPoses {
     }
 };
 
-// everything a task reads from memory, requested together: the column poses and the task's four rows
-struct StripData {
-    StripTask t;
-    ColPoses cp;
+// A wave's place in a streaming pass: virtual wave v of strips * groups owns strip v % strips and the row quads
+// v / strips, + groups, + 2 groups, ... of it (neighbouring waves: neighbouring kilobytes of the same rows).  With at
+// least as many waves as strips (always, short of a million columns) every wave has one strip for the whole pass.
+struct StripWalk {
+    int strips, groups, nquads;
+    long long nvirt;
+    __device__ __forceinline__ StripWalk(const PairScan& sc, long long nwaves) {
+        strips = (sc.M + 255) >> 8;
+        nquads = (sc.R + F1_ROWS - 1) / F1_ROWS;
+        groups = (int)max(1ll, min((long long)nquads, nwaves / strips));
+        nvirt = (long long)strips * groups;
+    }
+};
+
+// four rows of a strip: 16 bytes per lane and row, requested together (with the rows' poses in pose mode: scalar loads)
+template <typename PT>          // PT: float (the bounding-box test), double (the pair-by-pair arithmetic)
+struct RowQuad {
     float s[F1_ROWS][4];
-    unsigned cb[F1_ROWS];        // pass B: the class bytes pass A left for the rows (0xff = all four pairs ignored)
-    bool inb;
-    // cls_in == nullptr: pass A (loads the column poses); else pass B (loads the rows' class bytes instead)
-    __device__ __forceinline__ void fetch(const PairScan& sc, long long task, long long ntasks, int lane, float fill,
-                                          const unsigned char* __restrict__ cls_in = nullptr) {
-        t.r0 = t.r1 = 0;
-        t.c0 = 0;
-        inb = false;
+    PT px[F1_ROWS], pz[F1_ROWS];
+    int r0, r1;
+    __device__ __forceinline__ void fetch(const PairScan& sc, int quad, int nquads, int c0, float fill, bool poses) {
+        r0 = r1 = 0;
 #pragma unroll
         for (int u = 0; u < F1_ROWS; ++u) {
-            cb[u] = 0xffu;
+            px[u] = pz[u] = (PT)0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[u][q] = fill;
         }
-        if (task >= ntasks) return;
-        t.init(sc, task, lane);
-        inb = t.c0 < sc.M;
-        if (!inb) return;
-        if (!cls_in) cp.load(sc.truth, t.c0, sc.M);
-        const size_t cw = (size_t)(sc.M + 3) >> 2;
+        if (quad >= nquads) return;                       // (wave-uniform)
+        r0 = quad * F1_ROWS;
+        r1 = min(sc.R, r0 + F1_ROWS);
+        if (poses) {
 #pragma unroll
-        for (int u = 0; u < F1_ROWS; ++u)
-            if (t.r0 + u < t.r1) {
-                load_row4(sc, t.r0 + u, t.c0, s[u]);
-                if (cls_in) cb[u] = cls_in[(size_t)(t.r0 + u) * cw + (t.c0 >> 2)];
+            for (int u = 0; u < F1_ROWS; ++u) {
+                const f64x2u v = *reinterpret_cast<const f64x2u*>(sc.truth.pose + 2 * (size_t)(sc.truth.row0 + min(r0 + u, r1 - 1)));
+                px[u] = (PT)v[0];
+                pz[u] = (PT)v[1];
             }
+        }
+        if (c0 < sc.M) {
+#pragma unroll
+            for (int u = 0; u < F1_ROWS; ++u)
+                if (r0 + u < r1) load_row4(sc, r0 + u, c0, s[u]);
+        }
     }
 };
 
 // classes (1 positive, 0 negative, -1 ignored / outside the matrix) of the pairs (r, c0 .. c0 + 3); classify_pair's
 // arithmetic (utils.py:36 in float64, operation by operation) on the preloaded column poses
-__device__ __forceinline__ void classify_row4(const PairTruth& t, const ColPoses& cp, int r, int c0, int M, double lo2, double hi2,
-                                              int (&cls)[4]) {
-    if (t.pose) {
-        const double px = t.pose[2 * (t.row0 + r)], pz = t.pose[2 * (t.row0 + r) + 1];     // wave-uniform
+__device__ __forceinline__ void classify_row4(const PairTruth& t, const ColPoses& cp, const double px, const double pz, int r, int c0,
+                                              int M, double lo2, double hi2, int (&cls)[4]) {
+    if (t.pose) {                                        // (px, pz: the row's pose, wave-uniform, requested with its scores)
         // Almost every pair lies far from both thresholds: the float64 differences, squared and summed in fp32 (relative error
         // below 4 x 2^-24 = 2.4e-7), decide it when they clear a threshold by a relative 4e-6.  The float64 arithmetic of the
         // reference (utils.py:36) runs for a wave only when one of its pairs is closer to a threshold than that (or not
@@ -558,13 +560,76 @@ __device__ __forceinline__ void classify_row4(const PairTruth& t, const ColPoses
     }
 }
 
+// f1_key for a score in [0, 1] (bit pattern <= 1.0f's), times four: the byte offset of its bin
+__device__ __forceinline__ unsigned f1_key01_x4(float s) {
+    const bool low = __float_as_uint(s) < 0x3F000000u;
+    const unsigned k4 = (__float_as_uint(low ? s : 1.0f - s) >> (F1_SH - 2)) & ~3u;
+    return low ? k4 : 4u * F1_ONE - k4;
+}
+
+// min / max over the 16 lanes of a row of the wave (every lane gets the result): quad permutes, then the two mirrors
+template <bool MAX, int CTRL>
+__device__ __forceinline__ float dpp_minmax(float v) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    return MAX ? fmaxf(v, o) : fminf(v, o);
+}
+template <bool MAX>
+__device__ __forceinline__ float row16_reduce(float v) {
+    v = dpp_minmax<MAX, 0xB1>(v);        // quad_perm [1, 0, 3, 2]
+    v = dpp_minmax<MAX, 0x4E>(v);        // quad_perm [2, 3, 0, 1]
+    v = dpp_minmax<MAX, 0x141>(v);       // row_half_mirror
+    return dpp_minmax<MAX, 0x140>(v);    // row_mirror
+}
+
+// The planar bounding box (fp32) of the 64 columns of a lane's row of the wave, and whether a row pose is so far from it
+// that every pair (row, one of those columns) is a NEGATIVE without looking at it: almost every strip of a trajectory's
+// matrix.  The box and the row pose are rounded to fp32 (relative 2^-24 each) and the gaps computed in fp32: the gap is
+// cut by 2^-21 of the largest magnitude involved and the squared distance must clear d_neg^2 by 0.1 % - far beyond those
+// roundings, so a strip passes only if the reference's float64 distance (utils.py:36) is >= d_neg for each of its pairs.
+struct StripBox {
+    float xlo, xhi, zlo, zhi, amax;
+    __device__ __forceinline__ void init(const ColPoses& cp) {
+        float a = (float)cp.x[0], b = a, c = (float)cp.z[0], d = c;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float x = (float)cp.x[q], z = (float)cp.z[q];
+            a = fminf(a, x);
+            b = fmaxf(b, x);
+            c = fminf(c, z);
+            d = fmaxf(d, z);
+        }
+        xlo = row16_reduce<false>(a);
+        xhi = row16_reduce<true>(b);
+        zlo = row16_reduce<false>(c);
+        zhi = row16_reduce<true>(d);
+        amax = fmaxf(fmaxf(fabsf(xlo), fabsf(xhi)), fmaxf(fabsf(zlo), fabsf(zhi)));
+    }
+    // (NaN / infinite poses: a comparison with NaN is false -> not far -> the per-pair arithmetic decides)
+    __device__ __forceinline__ bool far(float px, float pz, float cut2) const {
+        const float e = fmaxf(fmaxf(amax, fabsf(px)), fabsf(pz)) * 4.76837158e-7f;          // 2^-21
+        const float gx = fmaxf(fmaxf(xlo - px, px - xhi) - e, 0.f);
+        const float gz = fmaxf(fmaxf(zlo - pz, pz - zhi) - e, 0.f);
+        return fmaf(gx, gx, gz * gz) > cut2;
+    }
+};
+
 // ---- A: negatives by key bin (LDS histogram of the workgroup -> its slab), positives appended to `pos` (count[0] of
 //      them; count[1] = positives with a negative / NaN score); slab tail word 0 = negatives with such a score.
 //      No workgroup barrier inside the loop: the positives are staged per WAVE (512 floats each, appended with a ballot
 //      prefix, flushed with one global atomic by the wave).
 constexpr int F1_WBUF = F1_PBUF / (F1_THREADS / 64);          // 512 staged positives per wave
+constexpr int F1_SLOWQ = 1024;                                // a workgroup's list of quads left to the pair-by-pair code
 //      The classes of a lane's four pairs leave as one byte (2 bits each: 0 negative, 1 positive, 3 ignored) into
 //      cls_out [R][(M + 3) / 4]: pass B reads that byte instead of repeating the pose arithmetic.
+#ifndef SGPR_F1_SCAN_STAMPS
+#define SGPR_F1_SCAN_STAMPS 0  // 1: every wave of pass A leaves six time stamps (tools/exp/f1_scan_timeline.py; variant builds only)
+#endif
+#if SGPR_F1_SCAN_STAMPS
+__device__ unsigned long long f1_scan_stamps[8192 * 8];
+#define F1A_STAMP(i) if ((threadIdx.x & 63) == 0) f1_scan_stamps[((size_t)blockIdx.x * (F1_THREADS / 64) + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();
+#else
+#define F1A_STAMP(i)
+#endif
 __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, unsigned* __restrict__ slabs, int slab_words,
                                                              float* __restrict__ pos, long long cap,
                                                              unsigned long long* __restrict__ count,
@@ -572,11 +637,16 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
     extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
     unsigned* hist = reinterpret_cast<unsigned*>(f1_smem);                  // [F1_NBP]
     float* buf = reinterpret_cast<float*>(hist + F1_NBP) + (threadIdx.x >> 6) * F1_WBUF;   // this wave's staging area
-    __shared__ unsigned nbad_neg;
+    __shared__ unsigned nbad_neg, nslow, ntaken;
+    __shared__ int wave_nst[F1_THREADS / 64];
+    __shared__ unsigned long long wg_base;
+    __shared__ int slow_strip[F1_SLOWQ], slow_quad[F1_SLOWQ];
     const int tid = threadIdx.x, lane = tid & 63;
+    F1A_STAMP(0)
     for (int i = tid; i < F1_NBP; i += F1_THREADS) hist[i] = 0u;
-    if (tid == 0) nbad_neg = 0u;
+    if (tid == 0) nbad_neg = nslow = ntaken = 0u;
     __syncthreads();
+    F1A_STAMP(1)
     int nst = 0;                                          // staged positives of this wave (wave-uniform)
     auto flush = [&]() {
         unsigned long long g = 0ull;
@@ -592,18 +662,19 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
     const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
     const size_t cw = (size_t)(sc.M + 3) >> 2;            // class bytes per row
     unsigned bad_pos = 0u, bad_neg = 0u;
-    const long long ntasks = strip_tasks(sc);
+    const float cut2 = (float)hi2 * 1.001f;
     const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
-    for (long long task = wave0; task < ntasks; task += nwaves) {
-        StripData cur;                                    // (requesting task i + 1 before processing task i was measured: no
-        cur.fetch(sc, task, ntasks, lane, 0.f);           //  gain for this pass, 63 -> 73 us for pass B - dropped)
+    const StripWalk walk(sc, nwaves);
+    // the four rows of a quad pair by pair (float64 pose arithmetic near the thresholds, positives staged)
+    auto classic = [&](const RowQuad<double>& cur, const int c0, const ColPoses& cp) {
+        const bool inb = c0 < sc.M;
 #pragma unroll
         for (int u = 0; u < F1_ROWS; ++u) {
-            if (cur.t.r0 + u >= cur.t.r1) break;          // (wave-uniform)
+            if (cur.r0 + u >= cur.r1) break;              // (wave-uniform)
             int cls[4] = {-1, -1, -1, -1};
-            if (cur.inb) {
-                classify_row4(sc.truth, cur.cp, cur.t.r0 + u, cur.t.c0, sc.M, lo2, hi2, cls);
-                cls_out[(size_t)(cur.t.r0 + u) * cw + (cur.t.c0 >> 2)] =
+            if (inb) {
+                classify_row4(sc.truth, cp, cur.px[u], cur.pz[u], cur.r0 + u, c0, sc.M, lo2, hi2, cls);
+                cls_out[(size_t)(cur.r0 + u) * cw + (c0 >> 2)] =
                     (unsigned char)((cls[0] & 3) | ((cls[1] & 3) << 2) | ((cls[2] & 3) << 4) | ((cls[3] & 3) << 6));
             }
 #pragma unroll
@@ -627,18 +698,145 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
             }
             if (nst > F1_WBUF - 256) flush();             // (wave-uniform) room for one more row is gone
         }
-    }
-    if (nst) flush();
+    };
+    // A strip that lies inside the matrix gets its columns' bounding boxes (one per 64 columns): a quad of rows far from
+    // all four is 1024 negatives - no per-pair pose arithmetic, and scores in [0, 1] take the short form of the key.  The
+    // wave streams down its strip counting such quads (the next quad's kilobytes on their way meanwhile) and leaves the
+    // others - the neighbourhood of the diagonal and of every revisit, about a tenth; every quad of a strip without boxes
+    // - in the WORKGROUP's list, which its waves share out afterwards (a wave working off its own strip's took up to 30 us
+    // after a 17 us stream: those quads cluster by strip).  Kept apart so that the streaming loop stays small in
+    // registers; a full list ends the round for the wave that meets it (it resumes at that quad in the next one).
+    auto push = [&](const int strip, const int quad) {
+        unsigned at = 0u;
+        if (lane == 0) at = atomicAdd(&nslow, 1u);
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (at >= (unsigned)F1_SLOWQ) return false;
+        if (lane == 0) {
+            slow_strip[at] = strip;
+            slow_quad[at] = quad;
+        }
+        return true;
+    };
+    long long vw = wave0;
+    int quad = -1;                                        // (-1: the strip of vw is not begun)
+    int more;
+    do {
+        bool full = false;
+        while (vw < walk.nvirt && !full) {
+            const int strip = __builtin_amdgcn_readfirstlane((int)(vw % walk.strips));
+            if (quad < 0) quad = __builtin_amdgcn_readfirstlane((int)(vw / walk.strips));
+            const int c0 = strip * 256 + 4 * lane;
+            if (!(SGPR_F1_CULL && sc.truth.pose && strip * 256 + 256 <= sc.M)) {
+                for (; quad < walk.nquads; quad += walk.groups)
+                    if (!push(strip, quad)) {
+                        full = true;
+                        break;
+                    }
+            } else {
+                StripBox box;
+                {
+                    ColPoses cp;
+                    cp.load(sc.truth, c0, sc.M);
+                    box.init(cp);
+                }
+                RowQuad<float> cur;
+                cur.fetch(sc, quad, walk.nquads, c0, 0.f, true);
+                while (quad < walk.nquads) {
+                    RowQuad<float> nxt;
+                    nxt.fetch(sc, quad + walk.groups, walk.nquads, c0, 0.f, true);
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < F1_ROWS; ++u) {
+                        const unsigned mx = max(max(__float_as_uint(cur.s[u][0]), __float_as_uint(cur.s[u][1])),
+                                                max(__float_as_uint(cur.s[u][2]), __float_as_uint(cur.s[u][3])));
+                        // (the rows past the matrix' last one repeat its pose and carry the fill value 0)
+                        ok = ok && box.far(cur.px[u], cur.pz[u], cut2) && mx <= 0x3F800000u;
+                    }
+                    if (__ballot(!ok) == 0ull) {
+#pragma unroll
+                        for (int u = 0; u < F1_ROWS; ++u) {
+                            if (cur.r0 + u >= cur.r1) break;  // (wave-uniform)
+                            cls_out[(size_t)(cur.r0 + u) * cw + (c0 >> 2)] = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                atomicAdd(reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(hist) + f1_key01_x4(cur.s[u][q])), 1u);
+                        }
+                    } else if (!push(strip, quad)) {
+                        full = true;
+                        break;
+                    }
+                    quad += walk.groups;
+                    cur = nxt;
+                }
+            }
+            if (!full) {
+                vw += nwaves;
+                quad = -1;
+            }
+        }
+        F1A_STAMP(2)
+        __syncthreads();                                  // the round's list is complete
+        {
+            const int n = (int)min(nslow, (unsigned)F1_SLOWQ);
+            auto take = [&]() {
+                unsigned i = 0u;
+                if (lane == 0) i = atomicAdd(&ntaken, 1u);
+                return (int)__builtin_amdgcn_readfirstlane(i);
+            };
+            int e = take();
+            while (e < n) {
+                const int strip = slow_strip[e], sq_quad = slow_quad[e];
+                const int c0 = strip * 256 + 4 * lane;
+                ColPoses cp;
+                if (c0 < sc.M) cp.load(sc.truth, c0, sc.M);
+                RowQuad<double> sq;
+                sq.fetch(sc, sq_quad, walk.nquads, c0, 0.f, sc.truth.pose != nullptr);
+                e = take();                               // (the next entry's number is on its way meanwhile)
+                classic(sq, c0, cp);
+            }
+        }
+        __syncthreads();                                  // the list is worked off
+        if (tid == 0) nslow = ntaken = 0u;
+        more = __syncthreads_or(vw < walk.nvirt ? 1 : 0);
+    } while (more);
+    F1A_STAMP(3)
+    // what the waves still hold joins the list with ONE reservation per workgroup: a returning atomic per wave on the one
+    // counter - 4096 of them, ~10 ns each, one after the other - was the last 20 us of this kernel
+    if (lane == 0) wave_nst[tid >> 6] = nst;
     if (bad_pos) atomicAdd(&count[1], (unsigned long long)bad_pos);
     if (bad_neg) atomicAdd(&nbad_neg, bad_neg);
     __syncthreads();
+    if (tid == 0) {
+        unsigned total = 0u;
+        for (int w = 0; w < F1_THREADS / 64; ++w) total += (unsigned)wave_nst[w];
+        wg_base = total ? atomicAdd(&count[0], (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    {
+        long long at = (long long)wg_base;
+        for (int w = 0; w < (tid >> 6); ++w) at += wave_nst[w];
+        for (int i = lane; i < nst; i += 64) {
+            if (at + i < cap) pos[at + i] = buf[i];
+            atomicAdd(&posb_g[f1_tslot(f1_key(buf[i]))], 1u);
+        }
+    }
+    F1A_STAMP(4)
+    F1A_STAMP(5)
+    // (one 64-bit atomic per occupied bin straight into the sums instead of the slab: 54 -> 81 us for this kernel - a few
+    // thousand device-scope atomics per workgroup cost more than the 25 MB of slabs and the kernel that adds them up)
     unsigned* slab = slabs + (size_t)blockIdx.x * slab_words;
     for (int i = tid; i < F1_NBP; i += F1_THREADS) slab[i] = hist[i];
     if (tid == 0) {
         reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[0] = nbad_neg;
         reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[1] = 0ull;
     }
+    F1A_STAMP(6)
 }
+#if SGPR_F1_SCAN_STAMPS
+extern "C" int sgpr_debug_f1_scan_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(f1_scan_stamps), sizeof(f1_scan_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // block-wide sums of two 64-bit values per thread -> exclusive prefix over the threads in DESCENDING thread order (suffix
 // sums: thread t gets the total of the threads above it); sh: [2][1024 / 64 + 1] scratch
@@ -718,6 +916,10 @@ struct F1Thr {
 };
 
 constexpr int F1_HASH = 8192;                                    // slots of the de-duplication table (> F1_PICK + F1_THREADS)
+// the plan kernel's first LDS area: the positives' histogram, then the edge values [F1_PER][F1_THREADS], then the hash table
+// and the suffix sums
+constexpr int f1_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+constexpr int F1_PLAN_WORDS = (f1_max3(F1_NBP, F1_PER * F1_THREADS, 2 * F1_HASH + F1_SORT + 1) + 3) & ~3;   // (16-byte reads of what follows)
 __device__ __forceinline__ unsigned f1_hash(unsigned bits) { return (bits * 2654435761u) >> 19; }
 
 // ---- P: one workgroup.  negb [F1_NBP + 2] (uint64, from slab_sum_kernel; [F1_NBP] = negatives with unusable scores).
@@ -738,7 +940,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     unsigned* hkey = posb;                                                  //   [F1_HASH] bit patterns of the distinct values
     unsigned* hcnt = posb + F1_HASH;                                        //   [F1_HASH] positive pairs that carry each
     unsigned* ssum = posb + 2 * F1_HASH;                                    //   [F1_SORT + 1] pairs of the sorted entries >= i
-    float* v = reinterpret_cast<float*>(posb + F1_NBP);                     // [F1_SORT] the values pass B settles
+    float* v = reinterpret_cast<float*>(posb + F1_PLAN_WORDS);              // [F1_SORT] the values pass B settles
     unsigned* mark = reinterpret_cast<unsigned*>(v + F1_SORT);              // [F1_NBP / 32 + 1]
     __shared__ unsigned long long sh[2][17];
     __shared__ double shd[16];
@@ -1027,7 +1229,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
 //      Same strips as pass A; a pair's class comes from the byte pass A stored (no pose arithmetic here).
 __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc, const unsigned* __restrict__ mark_in,
                                                                const float* __restrict__ thr_in, const int* __restrict__ dT2,
-                                                               unsigned* __restrict__ slabs, int slab_words,
+                                                               unsigned long long* __restrict__ neg2,
                                                                const unsigned char* __restrict__ cls_in) {
     __shared__ unsigned mark[F1_NBP / 32 + 1];
     __shared__ float thr[F1_SORT];
@@ -1038,38 +1240,105 @@ __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = mark_in[i];
     for (int i = tid; i < F1_SORT; i += F1_THREADS) thr[i] = i < T ? thr_in[i] : INFINITY;
     for (int i = tid; i <= F1_SORT; i += F1_THREADS) cnt[i] = 0u;
-    __syncthreads();
-    const long long ntasks = strip_tasks(sc);
-    const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
-    for (long long task = wave0; task < ntasks; task += nwaves) {
-        StripData cur;
-        cur.fetch(sc, task, ntasks, lane, -1.f, cls_in);
-#pragma unroll
-        for (int u = 0; u < F1_ROWS; ++u) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                                  // (unrolled: a rolled loop would index the
-                                                                           //  register arrays dynamically = scratch)
-                if (((cur.cb[u] >> (2 * q)) & 3u) != 0u) continue;         // pass A's class: not a negative (or outside)
-                const float x = cur.s[u][q];
-                if (__float_as_uint(x) > 0x7f800000u) continue;
-                const int b = f1_key(x);
-                if (!((mark[b >> 5] >> (b & 31)) & 1u)) continue;          // not in a candidate bin: nothing to settle
-                int lo = 0, hi = T;                                        // thr[lo-1] <= x < thr[hi]
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (thr[mid] <= x) lo = mid + 1; else hi = mid;
-                }
-                // counted only when it is >= a threshold OF ITS OWN BIN: a negative below every threshold of its bin
-                // belongs to no threshold there (the bins above a threshold's bin are accounted through fp_above), and
-                // bucket lo then names the bin of thr[lo - 1] unambiguously
-                if (lo > 0 && f1_key(thr[lo - 1]) == f1_key(x)) atomicAdd(&cnt[lo], 1u);
-            }
+    // Only a score in [thr[0], the upper edge of thr[T - 1]'s bin) can be counted below (bit patterns of non-negative
+    // floats order like the floats; the key is monotone: the edge by bisection on the pattern): a row of a strip with no
+    // such score - almost every one when the candidate bins are few - costs two 3-input extrema and two comparisons.
+    __shared__ unsigned range[2];
+    __shared__ float queue_x[(F1_THREADS / 64) * 128];
+    __shared__ int queue_r[(F1_THREADS / 64) * 128], queue_c[(F1_THREADS / 64) * 128];
+    if (tid == 0) {
+        const float t_hi = thr_in[T - 1];
+        const int k_hi = f1_key(t_hi);
+        unsigned lo = __float_as_uint(t_hi), hi = 0x7f800001u;             // first pattern with a larger key (none: past +inf)
+        while (lo + 1 < hi) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            if (f1_key(__uint_as_float(mid)) > k_hi) hi = mid; else lo = mid;
         }
+        range[0] = __float_as_uint(thr_in[0]);
+        range[1] = hi;
     }
     __syncthreads();
-    unsigned* slab = slabs + (size_t)blockIdx.x * slab_words;
-    for (int i = tid; i <= T; i += F1_THREADS) slab[i] = cnt[i];
-    if (tid < 2) reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[tid] = 0ull;
+    const unsigned b_lo = SGPR_F1_CULL ? range[0] : 0u, b_hi = SGPR_F1_CULL ? range[1] : 0xffffffffu;
+    const size_t cw = (size_t)(sc.M + 3) >> 2;            // class bytes per row
+    const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
+    const StripWalk walk(sc, nwaves);
+    // A pair inside the range (half a percent of a KITTI-00 matrix, yet some lane of a wave holds one in most rows) is
+    // QUEUED by its wave - score, row, column - and the queue is settled sixty-four entries at a time with every lane
+    // busy: class byte, key, candidate-bin test, bisection.  A pair outside costs two comparisons.
+    float* qx = queue_x + (tid >> 6) * 128;
+    int* qr = queue_r + (tid >> 6) * 128;
+    int* qc = queue_c + (tid >> 6) * 128;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int nq = 0;                                           // queued, wave-uniform
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (program order inside the wave is all it takes)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto settle = [&](const int e) {
+        const float x = qx[e];
+        const int r = qr[e], c = qc[e];
+        const unsigned cb = cls_in[(size_t)r * cw + (c >> 2)];
+        if (((cb >> (2 * (c & 3))) & 3u) != 0u) return;                // pass A's class: not a negative
+        if (__float_as_uint(x) > 0x7f800000u) return;
+        const int b = f1_key(x);
+        if (!((mark[b >> 5] >> (b & 31)) & 1u)) return;                // not in a candidate bin: nothing to settle
+        int lo = 0, hi = T;                                            // thr[lo-1] <= x < thr[hi]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (thr[mid] <= x) lo = mid + 1; else hi = mid;
+        }
+        // counted only when it is >= a threshold OF ITS OWN BIN: a negative below every threshold of its bin belongs to
+        // no threshold there (the bins above a threshold's bin are accounted through fp_above), and bucket lo then names
+        // the bin of thr[lo - 1] unambiguously
+        // (one device-scope atomic per candidate straight into the sums instead - ~100 000 of them on a few hundred
+        // addresses - took this kernel from 27 to 60 us)
+        if (lo > 0 && f1_key(thr[lo - 1]) == b) atomicAdd(&cnt[lo], 1u);
+    };
+    for (long long vw = wave0; vw < walk.nvirt; vw += nwaves) {
+        const int strip = __builtin_amdgcn_readfirstlane((int)(vw % walk.strips)), g0 = __builtin_amdgcn_readfirstlane((int)(vw / walk.strips));
+        const int c0 = strip * 256 + 4 * lane;
+        RowQuad<float> cur;
+        cur.fetch(sc, g0, walk.nquads, c0, -1.f, false);
+        for (int quad = g0; quad < walk.nquads; quad += walk.groups) {
+            RowQuad<float> nxt;
+            nxt.fetch(sc, quad + walk.groups, walk.nquads, c0, -1.f, false);
+#pragma unroll
+            for (int u = 0; u < F1_ROWS; ++u) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned b = __float_as_uint(cur.s[u][q]);   // (the fill value -1.f: its pattern is >= b_hi)
+                    const bool in = b >= b_lo && b < b_hi && c0 + q < sc.M;
+                    const unsigned long long m = __ballot(in);
+                    if (m) {                                           // (wave-uniform)
+                        if (in) {
+                            const int at = nq + __popcll(m & lt_mask);
+                            qx[at] = cur.s[u][q];
+                            qr[at] = cur.r0 + u;
+                            qc[at] = c0 + q;
+                        }
+                        nq += __popcll(m);
+                        if (nq >= 64) {
+                            wave_sync();
+                            settle(nq - 64 + lane);                    // the last 64 queued
+                            wave_sync();
+                            nq -= 64;
+                        }
+                    }
+                }
+            }
+            cur = nxt;
+        }
+    }
+    wave_sync();
+    if (lane < nq) settle(lane);
+    __syncthreads();
+    // the few hundred occupied buckets of the workgroup: one 64-bit atomic each straight into the sums (slabs and the
+    // kernel that added them up: 21.4 + 10 us against 26.9)
+    for (int i = tid; i <= T; i += F1_THREADS) {
+        const unsigned n = cnt[i];
+        if (n) atomicAdd(&neg2[i], (unsigned long long)n);
+    }
 }
 
 // ---- F: one workgroup.  negc2[b] (uint64) = negatives of the candidate bins with exactly b thresholds <= their score
@@ -1322,16 +1591,15 @@ static F1Layout f1_layout(const sgpr_handle* h, int R, int M) {
     size_t off = 256;                                                       // header
     L.off_posb = off;  off += a256((size_t)F1_THREADS * ((F1_NBP + F1_THREADS - 1) / F1_THREADS) * sizeof(unsigned));   // (zeroed with the header)
     L.off_negb = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
-    L.off_negbt = off; off += a256((size_t)F1_THREADS * F1_PER * sizeof(unsigned long long));     // the same sums, transposed
+    L.off_negbt = off; off += a256((size_t)F1_THREADS * F1_PER * sizeof(unsigned long long));     // negatives by bin, transposed
+    L.off_neg2 = off;  off += a256((F1_SORT + 4) * sizeof(unsigned long long));                   // (zeroed up to here)
     L.off_tpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_fpge = off;  off += a256((F1_NBP + 4) * sizeof(unsigned long long));
     L.off_mark = off;  off += a256((F1_NBP / 32 + 1) * sizeof(unsigned));
     L.off_thr = off;   off += a256(F1_SORT * sizeof(float));
     L.off_info = off;  off += a256(F1_SORT * sizeof(F1Thr));
-    L.off_neg2 = off;  off += a256((F1_SORT + 4) * sizeof(unsigned long long));
     L.off_pos = off;   off += a256((size_t)L.cap * sizeof(float));
-    const size_t sa = (size_t)L.slabs_a * L.words_a, sb = (size_t)L.slabs_b * L.words_b;
-    L.off_slabs = off; off += a256((sa > sb ? sa : sb) * sizeof(unsigned));
+    L.off_slabs = off; off += a256((size_t)L.slabs_a * L.words_a * sizeof(unsigned));   // pass A's histograms (pass B: atomics)
     L.off_cls = off;   off += a256((size_t)R * (((size_t)M + 3) >> 2));     // one class byte per four pairs (pass A -> pass B)
     L.total = off;
     return L;
@@ -1376,15 +1644,14 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     unsigned char* cls = ws + L.off_cls;
     static_assert(sizeof(F1Ctrl) <= 128, "control block");
     const size_t lds_scan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_PBUF * sizeof(float);
-    const size_t lds_plan = (size_t)F1_NBP * sizeof(unsigned) + (size_t)F1_SORT * sizeof(float) +
+    const size_t lds_plan = (size_t)F1_PLAN_WORDS * sizeof(unsigned) + (size_t)F1_SORT * sizeof(float) +
                             (size_t)(F1_NBP / 32 + 1) * sizeof(unsigned);
-    static_assert(2 * F1_HASH + F1_SORT + 1 <= F1_NBP, "the hash table and the suffix sums reuse the positives' histogram");
     static LdsLimitOnce once_scan, once_plan;
     if (int rc = raise_lds_limit(&once_scan, reinterpret_cast<const void*>(&f1_scan_kernel), (int)lds_scan, "sgpr_f1_max (f1_scan_kernel)"))
         return rc;
     if (int rc = raise_lds_limit(&once_plan, reinterpret_cast<const void*>(&f1_plan_kernel), (int)lds_plan, "sgpr_f1_max (f1_plan_kernel)"))
         return rc;
-    hipError_t e = hipMemsetAsync(ws, 0, L.off_negb, s);                               // counts, control block, sizes, positives by bin
+    hipError_t e = hipMemsetAsync(ws, 0, L.off_tpge, s);       // counts, control block, sizes, every sum the passes add to
     if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max: memset");
     if ((int64_t)R * M == 0) {                       // an empty rectangle: F1-max 0 over 0 positive / 0 negative pairs, status 0
         e = hipMemsetAsync(d_result, 0, 8 * sizeof(double), s);
@@ -1396,8 +1663,7 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb, nullptr, negb_t, F1_PER);
     hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
                        ctrl, reinterpret_cast<unsigned long long*>(ws + 128), posb, negb_t);
-    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, slabs, L.words_b, cls);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_SORT + 3 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_b, L.words_b, 0, neg2, dT2);
+    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, neg2, cls);
     hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(F1_THREADS), 0, s, neg2, info, ctrl, d_result);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max launches");
