@@ -352,7 +352,7 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 // histogram on the score's bit pattern replaces the threshold search tree (13 dependent LDS reads per score, two passes
 // of ~85 us each) and the separate scan for the positives:
 //   A  f1_scan_kernel      ONE streaming pass: every pair is classified once; a negative costs one shift and one LDS
-//                          atomic (bin = f1_key(score): a monotone map of the bit pattern with 6 mantissa bits of
+//                          atomic (bin = f1_key(score): a monotone map of the bit pattern with 5 mantissa bits of
 //                          resolution in s below 1/2 and in 1 - s above - sigmoid scores crowd towards 1), a positive is
 //                          appended to the (short) list of positive scores
 //   .  slab_sum_kernel     the workgroups' histograms added up
@@ -364,23 +364,24 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const unsigned* __restri
 //   B  f1_refine_kernel    second streaming pass: a negative outside the candidate bins costs one bit test; inside, a
 //                          bisection among the thresholds and one LDS atomic
 //   .  slab_sum_kernel
-//   F  f1_final_kernel     exact FP, hence exact F1, at every threshold; the maximum with the edge values is exact.
+//   F  f1_final            (the workgroup of pass B that finishes last) exact FP, hence exact F1, at every threshold; the
+//                          maximum with the edge values is exact.
 // Everything the steps decide lives in a control block on the device; the host reads 8 doubles at the end.  Rectangles
 // the device path is not built for (more than 2^20 positives, more than F1_PICK values to settle - a flat curve) are
 // reported in the status word and the caller falls back to the multi-call path (sg_pr_amd/metrics.py).
 #ifndef SGPR_F1_SH
-#define SGPR_F1_SH 17
-#endif
-constexpr int F1_SH = SGPR_F1_SH;                                // key = bit pattern >> 17: sign, exponent, 6 mantissa bits
-constexpr int F1_HALF = 0x3F000000 >> F1_SH;                     // 8064 bins for s in [0, 1/2)
+#define SGPR_F1_SH 18          // (17, twice the bins: 126.6 against 120.2 us per KITTI-00 matrix - the plan kernel walks them,
+#endif                         //  the histograms are written and added up; 389 against 506 values left to pass B)
+constexpr int F1_SH = SGPR_F1_SH;                                // key = bit pattern >> 18: sign, exponent, 5 mantissa bits
+constexpr int F1_HALF = 0x3F000000 >> F1_SH;                     // 4032 bins for s in [0, 1/2)
 constexpr int F1_ONE = 2 * F1_HALF;                              // the bin of s == 1
-constexpr int F1_NB = F1_ONE + 1 + ((0x7F800000 - 0x3F800000) >> F1_SH) + 1;   // 24 322 bins: ... and s in (1, +inf]
+constexpr int F1_NB = F1_ONE + 1 + ((0x7F800000 - 0x3F800000) >> F1_SH) + 1;   // 12 162 bins: ... and s in (1, +inf]
 constexpr int F1_NBP = (F1_NB + 3) & ~3;
 constexpr int F1_PICK = 4095;                                    // values pass B settles at most (a 4096-entry sort)
 constexpr int F1_SORT = 4096;
 constexpr int F1_PBUF = 8192;                                    // staged positives per workgroup between two flushes
 constexpr int F1_THREADS = 1024;
-constexpr int F1_PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;   // 24 consecutive bins per thread of the plan kernel
+constexpr int F1_PER = (F1_NBP + F1_THREADS - 1) / F1_THREADS;   // 12 consecutive bins per thread of the plan kernel
 // where the plan kernel's thread bin / F1_PER finds the count of `bin` in the transposed per-bin arrays
 __device__ __forceinline__ int f1_tslot(int bin) { return (bin % F1_PER) * F1_THREADS + bin / F1_PER; }
 
@@ -1225,17 +1226,80 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
 #undef F1_STAMP
 }
 
+// ---- F: the closing step, by the workgroup of pass B that finishes last (a launch of its own: 5.4 us).
+//      negc2[b] (uint64) = negatives of the candidate bins with exactly b thresholds <= their score - sums that device-scope
+//      atomics of this launch built: read past this XCD's L2.  G [F1_SORT + 2], sh [2][17], shd [16]: LDS of the caller.
+__device__ __forceinline__ void f1_final(const unsigned long long* __restrict__ negc2, const F1Thr* __restrict__ info,
+                                         const F1Ctrl* __restrict__ ctrl, double* __restrict__ result, unsigned long long* G,
+                                         unsigned long long (*sh)[17], double* shd) {
+    const int tid = threadIdx.x;
+    double best = ctrl->best1;
+    int passes = 1;
+    if (ctrl->status == 0 && ctrl->n2 > 0) {
+        const int T = ctrl->T2;
+        constexpr int PER = (F1_SORT + 1 + F1_THREADS - 1) / F1_THREADS;   // 5
+        unsigned long long part[PER], sn = 0ull, dummy = 0ull;
+        for (int q = PER - 1; q >= 0; --q) {
+            const int b = tid * PER + q;
+            sn += b <= T ? __hip_atomic_load(&negc2[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            part[q] = sn;
+        }
+        unsigned long long an = sn;
+        suffix_scan2(an, dummy, sh);
+        for (int q = 0; q < PER; ++q) {
+            const int b = tid * PER + q;
+            if (b <= F1_SORT + 1) G[b] = b <= T ? part[q] + an : 0ull;
+        }
+        __syncthreads();
+        const double P = (double)ctrl->P;
+        double b2 = 0.0;
+        for (int q = tid; q < T; q += F1_THREADS) {
+            const F1Thr e = info[q];
+            // negatives >= thr[q]: those above the bin + those of the bin with a bucket in (q, seg_end]
+            const unsigned long long fp = e.fp_above + (G[q + 1] - G[e.seg_end + 1]);
+            b2 = fmax(b2, f1_of((double)e.tp, (double)fp, P));
+        }
+        best = fmax(best, block_max(b2, shd));
+        passes = 2;
+    }
+    if (tid == 0) {
+        result[0] = ctrl->status == 0 ? fmax(best, 0.0) : 0.0;
+        result[1] = (double)ctrl->status;
+        result[2] = (double)ctrl->P;
+        result[3] = (double)ctrl->N;
+        result[4] = (double)passes;
+        result[5] = (double)F1_NB;
+        result[6] = (double)ctrl->n2;
+        result[7] = 0.0;
+    }
+}
+
 // ---- B: negatives of the candidate bins by threshold bucket b = #{thr <= s}; everything else costs one bit test.
 //      Same strips as pass A; a pair's class comes from the byte pass A stored (no pose arithmetic here).
 __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc, const unsigned* __restrict__ mark_in,
                                                                const float* __restrict__ thr_in, const int* __restrict__ dT2,
                                                                unsigned long long* __restrict__ neg2,
-                                                               const unsigned char* __restrict__ cls_in) {
+                                                               const unsigned char* __restrict__ cls_in, const F1Thr* __restrict__ info,
+                                                               const F1Ctrl* __restrict__ ctrl, unsigned* __restrict__ done,
+                                                               double* __restrict__ result) {
     __shared__ unsigned mark[F1_NBP / 32 + 1];
     __shared__ float thr[F1_SORT];
-    __shared__ unsigned cnt[F1_SORT + 1];
+    // (one area: the counters and the waves' queues during the pass, the closing step's suffix sums after it)
+    constexpr int QW = (F1_THREADS / 64) * 128;
+    __shared__ __attribute__((aligned(16))) unsigned area[F1_SORT + 4 + 3 * QW];
+    static_assert(sizeof(unsigned) * (F1_SORT + 4 + 3 * QW) >= sizeof(unsigned long long) * (F1_SORT + 2), "the closing step's sums");
+    unsigned* cnt = area;                                                   // [F1_SORT + 1]
+    float* queue_x = reinterpret_cast<float*>(area + F1_SORT + 4);
+    int* queue_r = reinterpret_cast<int*>(area + F1_SORT + 4 + QW);
+    int* queue_c = reinterpret_cast<int*>(area + F1_SORT + 4 + 2 * QW);
+    __shared__ unsigned long long fsh[2][17];
+    __shared__ double fshd[16];
+    __shared__ unsigned last;
     const int T = *dT2;
-    if (T < 0) return;
+    if (T < 0) {                                                            // no second pass: the closing step alone
+        if (blockIdx.x == 0) f1_final(neg2, info, ctrl, result, reinterpret_cast<unsigned long long*>(area), fsh, fshd);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = mark_in[i];
     for (int i = tid; i < F1_SORT; i += F1_THREADS) thr[i] = i < T ? thr_in[i] : INFINITY;
@@ -1244,8 +1308,6 @@ __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc
     // floats order like the floats; the key is monotone: the edge by bisection on the pattern): a row of a strip with no
     // such score - almost every one when the candidate bins are few - costs two 3-input extrema and two comparisons.
     __shared__ unsigned range[2];
-    __shared__ float queue_x[(F1_THREADS / 64) * 128];
-    __shared__ int queue_r[(F1_THREADS / 64) * 128], queue_c[(F1_THREADS / 64) * 128];
     if (tid == 0) {
         const float t_hi = thr_in[T - 1];
         const int k_hi = f1_key(t_hi);
@@ -1339,54 +1401,15 @@ __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc
         const unsigned n = cnt[i];
         if (n) atomicAdd(&neg2[i], (unsigned long long)n);
     }
-}
-
-// ---- F: one workgroup.  negc2[b] (uint64) = negatives of the candidate bins with exactly b thresholds <= their score
-__global__ __launch_bounds__(F1_THREADS) void f1_final_kernel(const unsigned long long* __restrict__ negc2, const F1Thr* __restrict__ info,
-                                                              const F1Ctrl* __restrict__ ctrl, double* __restrict__ result) {
-    __shared__ unsigned long long G[F1_SORT + 2];                          // G[b] = negatives with a bucket >= b
-    __shared__ unsigned long long sh[2][17];
-    __shared__ double shd[16];
-    const int tid = threadIdx.x;
-    double best = ctrl->best1;
-    int passes = 1;
-    if (ctrl->status == 0 && ctrl->n2 > 0) {
-        const int T = ctrl->T2;
-        constexpr int PER = (F1_SORT + 1 + F1_THREADS - 1) / F1_THREADS;   // 5
-        unsigned long long part[PER], sn = 0ull, dummy = 0ull;
-        for (int q = PER - 1; q >= 0; --q) {
-            const int b = tid * PER + q;
-            sn += b <= T ? negc2[b] : 0ull;
-            part[q] = sn;
-        }
-        unsigned long long an = sn;
-        suffix_scan2(an, dummy, sh);
-        for (int q = 0; q < PER; ++q) {
-            const int b = tid * PER + q;
-            if (b <= F1_SORT + 1) G[b] = b <= T ? part[q] + an : 0ull;
-        }
-        __syncthreads();
-        const double P = (double)ctrl->P;
-        double b2 = 0.0;
-        for (int q = tid; q < T; q += F1_THREADS) {
-            const F1Thr e = info[q];
-            // negatives >= thr[q]: those above the bin + those of the bin with a bucket in (q, seg_end]
-            const unsigned long long fp = e.fp_above + (G[q + 1] - G[e.seg_end + 1]);
-            b2 = fmax(b2, f1_of((double)e.tp, (double)fp, P));
-        }
-        best = fmax(best, block_max(b2, shd));
-        passes = 2;
-    }
-    if (tid == 0) {
-        result[0] = ctrl->status == 0 ? fmax(best, 0.0) : 0.0;
-        result[1] = (double)ctrl->status;
-        result[2] = (double)ctrl->P;
-        result[3] = (double)ctrl->N;
-        result[4] = (double)passes;
-        result[5] = (double)F1_NB;
-        result[6] = (double)ctrl->n2;
-        result[7] = 0.0;
-    }
+    // This workgroup's sums are out before it is counted as done: they are device-scope atomics (performed past the L2),
+    // so waiting for their acknowledgements is all it takes - an agent-scope release fence would also write this XCD's
+    // L2 back (24 -> 81 us for this kernel).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) f1_final(neg2, info, ctrl, result, reinterpret_cast<unsigned long long*>(area), fsh, fshd);
 }
 
 // ------------------------------------------------------------------ top-K per row
@@ -1663,8 +1686,8 @@ int sgpr_f1_max(const sgpr_handle* h, const float* d_score, int R, int M, int64_
     hipLaunchKernelGGL(slab_sum_kernel, dim3((F1_NBP + 2 + 31) / 32), dim3(1024), 0, s, slabs, L.slabs_a, L.words_a, F1_NBP - 1, negb, nullptr, negb_t, F1_PER);
     hipLaunchKernelGGL(f1_plan_kernel, dim3(1), dim3(F1_THREADS), lds_plan, s, negb, pos, count, L.cap, tpge, fpge, mark, thr, info, dT2,
                        ctrl, reinterpret_cast<unsigned long long*>(ws + 128), posb, negb_t);
-    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, neg2, cls);
-    hipLaunchKernelGGL(f1_final_kernel, dim3(1), dim3(F1_THREADS), 0, s, neg2, info, ctrl, d_result);
+    hipLaunchKernelGGL(f1_refine_kernel, dim3(L.slabs_b), dim3(F1_THREADS), 0, s, sc, mark, thr, dT2, neg2, cls, info, ctrl,
+                       reinterpret_cast<unsigned*>(ws + 200), d_result);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "sgpr_f1_max launches");
     return SGPR_OK;

@@ -1746,7 +1746,7 @@ def test_reference_pair_lists_full_size(eng, golden_dir, ckpt_path, oracle, orac
 
 
 def test_f1_max_bit_pattern_bins_at_their_edges(eng):
-    """sgpr_f1_max bins the negatives by the score's bit pattern (f1_key: 6 mantissa bits of s below 1/2, of 1 - s above,
+    """sgpr_f1_max bins the negatives by the score's bit pattern (f1_key: 5 mantissa bits of s below 1/2, of 1 - s above,
     of s again beyond 1).  Scores ON the seams of that map - 0, subnormals, 1/2, 1, the neighbours of each, values beyond
     1, +inf - and whole matrices squeezed into one or two bins must still give the sorted host computation exactly."""
     from sg_pr_amd import metrics
