@@ -816,20 +816,31 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
     {
         long long at = (long long)wg_base;
         for (int w = 0; w < (tid >> 6); ++w) at += wave_nst[w];
-        for (int i = lane; i < nst; i += 64) {
+        for (int i = lane; i < nst; i += 64)
             if (at + i < cap) pos[at + i] = buf[i];
-            atomicAdd(&posb_g[f1_tslot(f1_key(buf[i]))], 1u);
-        }
     }
     F1A_STAMP(4)
-    F1A_STAMP(5)
     // (one 64-bit atomic per occupied bin straight into the sums instead of the slab: 54 -> 81 us for this kernel - a few
     // thousand device-scope atomics per workgroup cost more than the 25 MB of slabs and the kernel that adds them up)
     unsigned* slab = slabs + (size_t)blockIdx.x * slab_words;
-    for (int i = tid; i < F1_NBP; i += F1_THREADS) slab[i] = hist[i];
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) {
+        slab[i] = hist[i];
+        hist[i] = 0u;
+    }
     if (tid == 0) {
         reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[0] = nbad_neg;
         reinterpret_cast<unsigned long long*>(slab + slab_words - 4)[1] = 0ull;
+    }
+    F1A_STAMP(5)
+    // The positives by bin, for the plan kernel: the workgroup's are counted in the (now free) histogram first and leave
+    // as one device-scope atomic per occupied bin - a sigmoid's positives crowd into a few bins, and one atomic per
+    // positive pair on those few addresses was the last 10 - 15 us of this kernel.
+    __syncthreads();
+    for (int i = lane; i < nst; i += 64) atomicAdd(&hist[f1_key(buf[i])], 1u);
+    __syncthreads();
+    for (int i = tid; i < F1_NBP; i += F1_THREADS) {
+        const unsigned n = hist[i];
+        if (n) atomicAdd(&posb_g[f1_tslot(i)], n);
     }
     F1A_STAMP(6)
 }
