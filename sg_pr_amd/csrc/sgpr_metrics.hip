@@ -585,19 +585,25 @@ __device__ __forceinline__ float row16_reduce(float v) {
 // The planar bounding box (fp32) of the 64 columns of a lane's row of the wave, and whether a row pose is so far from it
 // that every pair (row, one of those columns) is a NEGATIVE without looking at it: almost every strip of a trajectory's
 // matrix.  The box and the row pose are rounded to fp32 (relative 2^-24 each) and the gaps computed in fp32: the gap is
-// cut by 2^-21 of the largest magnitude involved and the squared distance must clear d_neg^2 by 0.1 % - far beyond those
+// cut by 2^-21 of the largest magnitude involved and the squared distance must clear max(d_neg, d_pos)^2 by 0.1 % - far beyond those
 // roundings, so a strip passes only if the reference's float64 distance (utils.py:36) is >= d_neg for each of its pairs.
 struct StripBox {
     float xlo, xhi, zlo, zhi, amax;
     __device__ __forceinline__ void init(const ColPoses& cp) {
         float a = (float)cp.x[0], b = a, c = (float)cp.z[0], d = c;
+        bool nan = a != a || c != c;
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
             const float x = (float)cp.x[q], z = (float)cp.z[q];
+            nan = nan || x != x || z != z;
             a = fminf(a, x);
             b = fmaxf(b, x);
             c = fminf(c, z);
             d = fmaxf(d, z);
+        }
+        if (nan) {                                        // (fmin / fmax drop a NaN: a column without a pose is IGNORED by the
+            a = c = -INFINITY;                            //  reference, never a negative - its group's box covers the plane,
+            b = d = INFINITY;                             //  no row is far from it)
         }
         xlo = row16_reduce<false>(a);
         xhi = row16_reduce<true>(b);
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_scan_kernel(const PairScan sc, 
     const double lo2 = sc.truth.d_pos * sc.truth.d_pos, hi2 = sc.truth.d_neg * sc.truth.d_neg;
     const size_t cw = (size_t)(sc.M + 3) >> 2;            // class bytes per row
     unsigned bad_pos = 0u, bad_neg = 0u;
-    const float cut2 = (float)hi2 * 1.001f;
+    const float cut2 = (float)fmax(hi2, lo2) * 1.001f;    // (a positive comes first: with d_neg < d_pos "far" means beyond d_pos)
     const long long wave0 = (long long)blockIdx.x * (F1_THREADS / 64) + (tid >> 6), nwaves = (long long)gridDim.x * (F1_THREADS / 64);
     const StripWalk walk(sc, nwaves);
     // the four rows of a quad pair by pair (float64 pose arithmetic near the thresholds, positives staged)

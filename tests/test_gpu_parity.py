@@ -1588,6 +1588,64 @@ def test_f1_max_one_call(eng):
     assert res[1] in (0, 1) and (res[1] == 1 or abs(res[0] - f1) < 1e-12)
 
 
+def test_f1_max_strips_culled_by_bounding_box(eng):
+    """sgpr_f1_max in pose mode calls whole (4 rows x 256 columns) blocks negative from fp32 bounding boxes of the columns'
+    poses, without the reference's float64 arithmetic per pair (utils.py:36) - so the classes it implies must be the
+    reference's wherever a pair is near a threshold or a pose is degenerate: trajectories far from the origin (fp32
+    rounding of the coordinates: metres at 1e9), frames exactly d_neg apart, clusters where nothing is far, NaN / infinite
+    poses, other thresholds, ragged sizes, a row shard.  Counts of positives / negatives and F1-max against the host."""
+    from sg_pr_amd import metrics
+    rng = np.random.default_rng(321)
+
+    def classes(xz, r0, r1, d_pos, d_neg):
+        dx = xz[r0:r1, None, 0] - xz[None, :, 0]
+        dz = xz[r0:r1, None, 1] - xz[None, :, 1]
+        with np.errstate(invalid="ignore", over="ignore"):
+            d = np.sqrt(dx * dx + dz * dz)
+            return np.where(d <= d_pos, 1, np.where(d >= d_neg, 0, -1)).astype(np.int8)
+
+    def check(xz, what, d_pos=3.0, d_neg=20.0, rows=None):
+        n = xz.shape[0]
+        r0, r1 = rows if rows else (0, n)
+        sc = torch.rand(r1 - r0, n, generator=torch.Generator().manual_seed(n + r0)) ** 2
+        lab = classes(xz, r0, r1, d_pos, d_neg)
+        res = eng.f1_max(sc.cuda(), row0=r0, pose_xz=torch.from_numpy(xz), d_pos=d_pos, d_neg=d_neg)
+        assert res[2] == int((lab == 1).sum()) and res[3] == int((lab == 0).sum()), (what, res.tolist(), int((lab == 1).sum()), int((lab == 0).sum()))
+        if res[1] == 0:
+            keep = lab.ravel() >= 0
+            want = metrics.f1_max(lab.ravel()[keep], sc.numpy().ravel()[keep]) if keep.any() else 0.0
+            assert abs(res[0] - want) < 1e-12, (what, res.tolist(), want)
+        else:
+            assert res[1] == 1, (what, res.tolist())       # (a flat curve: the multi-call path's business)
+
+    def walk(n, step=1.2, turn=0.15):
+        heading = np.cumsum(rng.normal(0.0, turn, size=n))
+        return np.cumsum(np.stack([np.cos(heading), np.sin(heading)], axis=1) * step, axis=0)
+
+    base = walk(1500)
+    base[-400:] = base[200:600] + rng.normal(0.0, 0.4, size=(400, 2))       # a revisit
+    check(base, "trajectory")
+    check(base[:777], "ragged size")
+    check(base, "row shard", rows=(301, 655))
+    for off in (1e4, 1e6, 1e9):
+        check(base + np.array([off, -0.37 * off]), "far from the origin %g" % off)
+    check(base, "thresholds 0.5 / 2", d_pos=0.5, d_neg=2.0)
+    check(base, "thresholds 50 / 400", d_pos=50.0, d_neg=400.0)
+    check(base, "d_neg below d_pos", d_pos=20.0, d_neg=3.0)
+    grid = np.stack(np.meshgrid(np.arange(40) * 20.0, np.arange(30) * 20.0), axis=-1).reshape(-1, 2).astype(np.float64)
+    check(grid, "frames exactly d_neg apart")
+    check(grid * (1.0 - 1e-9), "a hair closer than d_neg")
+    check(grid + 3e5, "the same grid far from the origin")
+    check(rng.normal(0.0, 4.0, size=(600, 2)), "one cluster")
+    line = np.stack([np.arange(1200) * 0.05, np.zeros(1200)], axis=1)
+    check(line, "a slow straight line")
+    bad = base.copy()
+    bad[[5, 300, 301, 1499]] = np.nan
+    bad[[17, 900]] = np.inf
+    bad[600, 0] = -np.inf
+    check(bad, "NaN and infinite poses")
+
+
 def test_bench_on_real_graph_directory(golden_dir):
     """bench.py --data-dir packs a directory of real graph JSONs once (graph_store.pack_directory) and benchmarks their
     all-pairs matrix: the three shipped graphs here, $SG_PR_DATA/graphs_sk/00 on a machine that has KITTI mounted."""
