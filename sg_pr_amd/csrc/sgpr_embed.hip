@@ -3114,11 +3114,27 @@ __device__ __forceinline__ void embed_graph(const KParams& kp, const EmbedPlan& 
     }
 }
 
+#ifndef SGPR_EMBED_STAMPS
+#define SGPR_EMBED_STAMPS 0    // 1 (variant builds): every workgroup of embed_kernel leaves its start / end time and where it ran
+#endif                         // (tools/exp/embed_timeline.py)
+#if SGPR_EMBED_STAMPS
+__device__ unsigned long long embed_stamps[32768 * 4];
+extern "C" int sgpr_debug_embed_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(embed_stamps), sizeof(embed_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int KP, int DBG, int LEAN, int FMT, int KC = 0>
 #ifndef SGPR_EXP_LDS32
 #define SGPR_EXP_LDS32 0
 #endif
 __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN == 48 || SGPR_EXP_LDS32) ? 5 : 4) : 3) : 1) void embed_kernel(const KParams kp) {
+#if SGPR_EMBED_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 32768) {
+        embed_stamps[blockIdx.x * 4 + 0] = wall_clock64();
+        embed_stamps[blockIdx.x * 4 + 1] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // XCC_ID | HW_ID
+    }
+#endif
     // (ONE call site: two inlined copies of embed_graph would double the kernel's footprint in the instruction cache)
     int slot = (int)blockIdx.x, role = 0;
     if constexpr (LEAN != 0 && DBG == 0) {
@@ -3134,6 +3150,10 @@ __global__ __launch_bounds__(LEAN ? kLeanNT : NT_MAX, LEAN ? (DBG == 0 ? ((LEAN 
         if (role == 0 && s2 < kp.a.G) g_ahead = kp.a.ids ? kp.a.ids[s2] : s2;
     }
     embed_graph<KP, DBG, LEAN, FMT, KC>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, role, g_ahead);
+#if SGPR_EMBED_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 32768) embed_stamps[blockIdx.x * 4 + 2] = wall_clock64();
+#endif
 }
 
 // Owned rows beyond 64 slots: up to sixteen waves (one per 16-row tile) under a 128-register budget

@@ -395,6 +395,26 @@ __device__ __forceinline__ int f1_key(float s) {
     return b < 0x3F000000u ? lo : (b <= 0x3F800000u ? mid : hi);
 }
 
+// The first bit pattern (a non-negative float's) whose key is >= want; 0x7f800001 (past +inf) when there is none.  Called
+// by a whole wave: sixty-four probes per round, six rounds (one thread bisecting took 31 dependent rounds = 3 us with a
+// workgroup waiting at the next barrier).
+__device__ __forceinline__ unsigned f1_first_pattern(int want) {
+    if (f1_key(0.f) >= want) return 0u;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned lo = 0u, hi = 0x7f800001u;                    // key(lo) < want; hi: key >= want or the sentinel
+    while (hi - lo > 1u) {
+        const unsigned step = (hi - lo + 63u) >> 6;
+        const unsigned long long c64 = (unsigned long long)lo + (unsigned long long)(lane + 1u) * step;
+        const unsigned cand = c64 >= hi ? hi : (unsigned)c64;
+        const bool ok = cand == 0x7f800001u || f1_key(__uint_as_float(cand)) >= want;
+        const int first = __builtin_ctzll(__ballot(ok));   // (lane 63 probes hi: the vote is never empty)
+        const unsigned below = first > 0 ? (unsigned)__shfl((int)cand, first - 1) : lo;
+        hi = (unsigned)__shfl((int)cand, first);
+        lo = below;
+    }
+    return hi;
+}
+
 struct F1Ctrl {
     int T2;                      // thresholds of pass B (-1: pass not needed)
     int n2;                      // positives inside the candidate bins
@@ -962,7 +982,8 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     unsigned* mark = reinterpret_cast<unsigned*>(v + F1_SORT);              // [F1_NBP / 32 + 1]
     __shared__ unsigned long long sh[2][17];
     __shared__ double shd[16];
-    __shared__ unsigned ndist, nv;
+    __shared__ unsigned ndist, nv, bspan[2];
+    __shared__ int kspan[2];
     __shared__ unsigned long long tot[2];
     const int tid = threadIdx.x;
     const long long na = (long long)count[0];
@@ -978,7 +999,11 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     constexpr int PER = F1_PER;                                             // 24 bins per thread
     static_assert(PER % 2 == 0, "bins per thread");
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark[i] = 0u;
-    if (tid == 0) ndist = nv = 0u;
+    if (tid == 0) {
+        ndist = nv = 0u;
+        kspan[0] = F1_NBP;
+        kspan[1] = -1;
+    }
     // positives by bin: counted by pass A where it found them (one global atomic per positive pair; round 4 spent 14 us
     // of this single workgroup on a pass over the list with LDS atomics); negatives by bin: slab_sum_kernel's sums.  Both
     // arrive transposed ([q][thread]): 48 coalesced loads per thread (in the bins' own order - 96 / 192 bytes between
@@ -1065,6 +1090,8 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
             rp += ps[q];
             if (ps[q] != 0u && g32(rp, fp_above) >= gcut) {
                 atomicOr(&mark[b >> 5], 1u << (b & 31));
+                atomicMin(&kspan[0], b);                 // (a few dozen bins at most)
+                atomicMax(&kspan[1], b);
                 tpge[b + 1] = tp_above;                  // (only what the thresholds of this bin will need: a store per bin
                 fpge[b + 1] = fp_above;                  //  from 1024 threads in 192-byte strides was 20 us of this kernel)
             }
@@ -1075,7 +1102,14 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
     F1_STAMP(2)
     for (int i = tid; i <= F1_NBP / 32; i += F1_THREADS) mark_out[i] = mark[i];
     for (int i = tid; i < 2 * F1_HASH; i += F1_THREADS) posb[i] = i < F1_HASH ? 0xffffffffu : 0u;   // empty = a NaN pattern
+    // the candidate bins' span as bit patterns [first pattern of the lowest bin, first pattern past the highest): one
+    // positive in a hundred lies inside, the others are turned away by two comparisons instead of key + bit test
+    if (tid < 128) {                                                       // (waves 0 and 1)
+        const unsigned edge = f1_first_pattern(tid < 64 ? kspan[0] : kspan[1] + 1);
+        if ((tid & 63) == 0) bspan[tid >> 6] = edge;
+    }
     __syncthreads();
+    const unsigned b_lo = bspan[0], b_hi = bspan[1];
     // ---- the positives of the candidate bins: distinct values (and the pairs that carry each) through a hash table
     auto insert = [&](float x) {
         const unsigned bits = __float_as_uint(x);
@@ -1110,7 +1144,7 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 bool hit = false;
-                if (x[u] >= 0.f) {
+                if (__float_as_uint(x[u]) >= b_lo && __float_as_uint(x[u]) < b_hi) {     // (-1.f, the filler: beyond b_hi)
                     const int b = f1_key(x[u]);
                     hit = (mark[b >> 5] >> (b & 31)) & 1u;
                 }
@@ -1177,14 +1211,18 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         // ones, counted against the whole array with broadcast 16-byte LDS reads - is its place.  Two barriers instead of
         // the bitonic network's 45 dependent steps (12.5 -> ~4 us of this phase).
         __syncthreads();
-        const float mine = tid < (int)n2 ? v[tid] : INFINITY;
+        // (up to 512 values: two threads per value, half the array each)
+        const int per = np2 <= F1_THREADS / 2 ? 2 : 1, e = per == 2 ? tid >> 1 : tid, part = per == 2 ? tid & 1 : 0;
+        const int half = per == 2 ? (((int)n2 + 7) >> 3) << 2 : (int)n2;   // a multiple of 4
+        const float mine = e < (int)n2 ? v[e] : INFINITY;
         int rank = 0;
-        for (int j = 0; j < (int)n2; j += 4) {                    // (v is padded with +inf up to np2 >= n2 rounded up to 4)
+        for (int j = part * half; j < min((int)n2, (part + 1) * half); j += 4) {   // (v is padded with +inf up to np2 >= n2 rounded up to 4)
             const float4 w = *reinterpret_cast<const float4*>(v + j);
             rank += (w.x < mine ? 1 : 0) + (w.y < mine ? 1 : 0) + (w.z < mine ? 1 : 0) + (w.w < mine ? 1 : 0);
         }
+        if (per == 2) rank += __shfl_xor(rank, 1);
         __syncthreads();
-        if (tid < (int)n2) v[rank] = mine;
+        if (e < (int)n2 && part == 0) v[rank] = mine;
         __syncthreads();
     } else {
         lds_bitonic_sort(v, np2);
@@ -1325,16 +1363,12 @@ __global__ __launch_bounds__(F1_THREADS) void f1_refine_kernel(const PairScan sc
     // floats order like the floats; the key is monotone: the edge by bisection on the pattern): a row of a strip with no
     // such score - almost every one when the candidate bins are few - costs two 3-input extrema and two comparisons.
     __shared__ unsigned range[2];
-    if (tid == 0) {
-        const float t_hi = thr_in[T - 1];
-        const int k_hi = f1_key(t_hi);
-        unsigned lo = __float_as_uint(t_hi), hi = 0x7f800001u;             // first pattern with a larger key (none: past +inf)
-        while (lo + 1 < hi) {
-            const unsigned mid = lo + ((hi - lo) >> 1);
-            if (f1_key(__uint_as_float(mid)) > k_hi) hi = mid; else lo = mid;
+    if (tid < 64) {
+        const unsigned edge = f1_first_pattern(f1_key(thr_in[T - 1]) + 1);   // first pattern with a larger key
+        if (tid == 0) {
+            range[0] = __float_as_uint(thr_in[0]);
+            range[1] = edge;
         }
-        range[0] = __float_as_uint(thr_in[0]);
-        range[1] = hi;
     }
     __syncthreads();
     const unsigned b_lo = SGPR_F1_CULL ? range[0] : 0u, b_hi = SGPR_F1_CULL ? range[1] : 0xffffffffu;
