@@ -93,6 +93,18 @@ if not pmc_only:
                       open(os.path.join(dst, tag + "_wide_bench.json"), "w"), indent=1)
     except (OSError, IndexError, KeyError, ValueError):
         pass
+    for nm, out, head in (
+            ("fuzz_f1.txt", "_fuzz_f1.txt", "# python tools/exp/fuzz_f1_one_call.py <seed> 120, seeds 41 42 43: sgpr_f1_max against the sorted host computation\n"),
+            ("fuzz_anyshape_wide.txt", "_any_shape_fuzz_wide.txt", "# python tools/exp/fuzz_anyshape.py 40 wide: random architectures inside sgpr_wide.hip's "
+             "limits (matrix-core any-shape embed + dense tail) against the oracle\n"),
+            ("f1_scan_timeline.txt", "_f1_scan_timeline.txt", "# SGPR_HIP_LIB=variants/libsgpr_stamps.so (tools/build_variant.sh stamps -DSGPR_F1_SCAN_STAMPS=1) "
+             "python tools/exp/f1_scan_timeline.py kitti|world\n# per-wave time stamps of sgpr_f1_max's first pass (4096 waves), us from the first wave's start; "
+             "before this round's changes (HISTORY 14):\n# streamed median 17 / max 25, classified p90 35 / max 53, flushed p90 49 / max 52, kernel 54 us\n"),
+            ("embed_timeline.txt", "_embed_timeline.txt", "# SGPR_HIP_LIB=variants/libsgpr_estamps.so (tools/build_variant.sh estamps -DSGPR_EMBED_STAMPS=1) "
+             "python tools/exp/embed_timeline.py  (KITTI-00 shape, ordered launch)\n")):
+        f = os.path.join(src, nm)
+        if os.path.exists(f) and os.path.getsize(f) > 0:
+            open(os.path.join(dst, tag + out), "w").write(head + open(f).read())
     f = os.path.join(src, "plain_embed.txt")
     if os.path.exists(f):
         with open(os.path.join(dst, tag + "_plain_embed.txt"), "w") as o:

@@ -36,6 +36,6 @@ for i, n in enumerate(names):
     col = us[:, i]
     print("%-13s min %6.1f  median %6.1f  p90 %6.1f  max %6.1f us" % (n, col.min(), np.median(col), np.percentile(col, 90), col.max()))
 d = us[:, 3] - us[:, 2]
-print("classic phase per wave: median %.1f, p90 %.1f, max %.1f us; waves with one: %d of %d" % (np.median(d), np.percentile(d, 90), d.max(), int((d > 0.3).sum()), len(d)))
+print("stream end -> classified (barrier + the shared list) per wave: median %.1f, p90 %.1f, max %.1f us; waves with one: %d of %d" % (np.median(d), np.percentile(d, 90), d.max(), int((d > 0.3).sum()), len(d)))
 d = us[:, 2] - us[:, 1]
 print("streaming phase per wave: median %.1f, p90 %.1f, max %.1f us" % (np.median(d), np.percentile(d, 90), d.max()))

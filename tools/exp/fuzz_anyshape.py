@@ -2,7 +2,7 @@
 """Fuzz: the any-shape kernels (sgpr_generic.hip) vs the CPU oracle on random ARCHITECTURES, node_num and K - through the
 reference's SG API: embeddings, attention, pooled vectors, all-pairs / list / pair scores, packed = ragged = dense inputs.
 Graphs get at least K padding slots (one-hot rows tie exactly across labels otherwise: torch.topk's tie order decides).
-  python tools/exp/fuzz_anyshape.py [trials]"""
+  python tools/exp/fuzz_anyshape.py [trials] [wide]   (wide: architectures inside sgpr_wide.hip's matrix-core limits)"""
 import os
 import sys
 
@@ -15,6 +15,7 @@ from sg_pr_amd.parser_sg import sgpr_args  # noqa: E402
 from oracle import sgpr_oracle as oracle  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+wide = len(sys.argv) > 2 and sys.argv[2] == "wide"
 rng = np.random.default_rng(77)
 worst = {"emb": 0.0, "att": 0.0, "pooled": 0.0, "score": 0.0}
 for trial in range(trials):
@@ -28,6 +29,13 @@ for trial in range(trials):
         labels = int(rng.integers(13, 65))
     n = int(rng.integers(2, 200)) if trial % 5 else int(rng.integers(257, 700))
     k = int(rng.integers(1, min(64, max(1, n // 2)) + 1))
+    if wide:            # inside sgpr_wide.hip's limits: the matrix-core any-shape embed and its dense tail
+        labels = int(rng.integers(1, 33))
+        f1, f2, f3 = int(rng.integers(1, 129)), int(rng.integers(1, 129)), int(rng.integers(1, 65))
+        t, bn = int(rng.integers(1, 33)), int(rng.integers(1, 33))
+        if max(labels - 12, f1 - 64, f2 - 64, f3 - 32, t - 16, bn - 16) <= 0:
+            f1 = int(rng.integers(65, 129))
+        n, k = int(rng.integers(21, 113)), 10
     args = sgpr_args()
     args.filters_1, args.filters_2, args.filters_3, args.tensor_neurons, args.bottle_neck_neurons = f1, f2, f3, t, bn
     args.node_num, args.K = n, k

@@ -57,4 +57,15 @@ timeout 200 python $R/tools/f1_phases.py world > $O/f1_phases_world.log 2>&1 </d
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_consumers -- python $R/tools/run_f1.py 3 > $O/kt_consumers.log 2>&1 </dev/null
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O -o sq_consumers -- python $R/tools/run_f1.py 1 > $O/sq_consumers.log 2>&1 </dev/null
 for c in FETCH_SIZE WRITE_SIZE; do timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o ${c}_consumers -- python $R/tools/run_f1.py 1 > $O/${c}_consumers.log 2>&1 </dev/null; done
+# fuzzers on the round's new paths: sgpr_f1_max (3 x 120 cases, a third in pose mode) and architectures inside sgpr_wide.hip's limits
+( for sd in 41 42 43; do timeout 400 python $R/tools/exp/fuzz_f1_one_call.py $sd 120 2>&1 | grep -v amdgpu.ids | tail -1; done ) > $O/fuzz_f1.txt 2>&1 </dev/null
+( cd $R && timeout 900 python tools/exp/fuzz_anyshape.py 40 wide 2>&1 | grep -v amdgpu.ids ) > $O/fuzz_anyshape_wide.txt 2>&1 </dev/null
+# per-wave / per-workgroup time stamps, when the variant libraries travelled along (tools/build_variant.sh stamps
+# -DSGPR_F1_SCAN_STAMPS=1; ... estamps -DSGPR_EMBED_STAMPS=1)
+if [ -f $R/variants/libsgpr_stamps.so ]; then
+  for k in kitti world; do echo "== $k"; SGPR_HIP_LIB=$R/variants/libsgpr_stamps.so timeout 200 python $R/tools/exp/f1_scan_timeline.py $k 2>&1 | grep -v amdgpu.ids; done > $O/f1_scan_timeline.txt
+fi
+if [ -f $R/variants/libsgpr_estamps.so ]; then
+  SGPR_HIP_LIB=$R/variants/libsgpr_estamps.so timeout 200 python $R/tools/exp/embed_timeline.py 2>&1 | grep -v amdgpu.ids > $O/embed_timeline.txt
+fi
 ls $O | head -80
