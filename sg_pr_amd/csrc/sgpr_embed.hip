@@ -3172,7 +3172,18 @@ __global__ __launch_bounds__(1024) void embed_big_kernel(const KParams kp) {
         return;
     }
     const int slot = (int)blockIdx.x;
+#if SGPR_EMBED_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 32768) {
+        embed_stamps[blockIdx.x * 4 + 0] = wall_clock64();
+        embed_stamps[blockIdx.x * 4 + 1] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // XCC_ID | HW_ID
+    }
+#endif
     embed_graph<KP, 0, 0, FMT_H2, KC, true>(kp, kp.p, kp.a.ids ? kp.a.ids[slot] : slot, slot, 0, -1);
+#if SGPR_EMBED_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 32768) embed_stamps[blockIdx.x * 4 + 2] = wall_clock64();
+#endif
 }
 
 // Second pass over the launch slots the f16 instance flagged (kp.a.redo):

@@ -8,17 +8,22 @@ import numpy as np, torch
 from sg_pr_amd import engine, synth
 sd = torch.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "model.pth"), map_location="cpu")
 eng = engine.Engine(sd)
-g = 4541
-c, l, _, _ = synth.kitti_like_sequence(g, 100, 0)
-order, cap = eng.size_order(c, l, 10)
+stress = len(sys.argv) > 1 and sys.argv[1] == "stress"      # BASELINE config 5 (embed_big_kernel: one workgroup per CU)
+if stress:
+    c, l, _ = synth.config5_pairs(seed=0)
+    g, K, SLOTS = c.shape[0], 20, 1
+else:
+    g, K, SLOTS = 4541, 10, 4
+    c, l, _, _ = synth.kitti_like_sequence(g, 100, 0)
+order, cap = eng.size_order(c, l, K)
 cd, ld = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
 for _ in range(30):
-    p = eng.embed(cd, ld, 10, node_cap=cap, order=order)[0]
+    p = eng.embed(cd, ld, K, node_cap=cap, order=order)[0]
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20):
-    p = eng.embed(cd, ld, 10, node_cap=cap, order=order)[0]
+    p = eng.embed(cd, ld, K, node_cap=cap, order=order)[0]
 e1.record()
 torch.cuda.synchronize()
 print("embed call %.1f us (events, 20 calls; stamps cost two barriers + three stores per workgroup)" % (e0.elapsed_time(e1) / 20 * 1e3))
@@ -39,8 +44,8 @@ dur = end - start
 n = (l >= 0).sum(1)[order.cpu().numpy() if hasattr(order, "cpu") else order]
 print("launch: first start 0.0, last end %.1f us; workgroup duration mean %.2f median %.2f p90 %.2f max %.2f us" % (
     end.max(), dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max()))
-print("sum of durations / (CUs x 4 slots) = %.1f us of %.1f us: %.1f %% of the slot time is inside a workgroup" % (
-    dur.sum() / (eng.num_cus * 4), end.max(), 100.0 * dur.sum() / (eng.num_cus * 4) / end.max()))
+print("sum of durations / (CUs x SLOTS slots) = %.1f us of %.1f us: %.1f %% of the slot time is inside a workgroup" % (
+    dur.sum() / (eng.num_cus * SLOTS), end.max(), 100.0 * dur.sum() / (eng.num_cus * SLOTS) / end.max()))
 places = np.unique(place)
 per_place = np.unique(place, return_counts=True)[1]
 print("distinct places (XCD, SE, SH, CU): %d; workgroups per place min %d max %d" % (len(places), per_place.min(), per_place.max()))
@@ -65,7 +70,7 @@ print("slot refill gap (end of a workgroup -> start of the next on that CU): mea
     gaps.mean(), np.median(gaps), np.percentile(gaps, 90), len(gaps)))
 be = np.array(busy_end)
 print("last end per CU: min %.1f median %.1f max %.1f us (ragged end: %.1f us)" % (be.min(), np.median(be), be.max(), be.max() - be.min()))
-for lo in (0, 25, 50, 75, 100, 120):
-    m = (start >= lo) & (start < lo + 5)
+for lo in ((0, 100, 200, 300, 400, 480) if stress else (0, 25, 50, 75, 100, 120)):
+    m = (start >= lo) & (start < lo + (20 if stress else 5))
     if m.any():
         print("  workgroups starting in [%3d, %3d) us: %4d, mean duration %.2f us, mean slots of their graphs %.1f" % (lo, lo + 5, int(m.sum()), dur[m].mean(), n[m].mean()))
