@@ -1109,10 +1109,14 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
         if ((tid & 63) == 0) bspan[tid >> 6] = edge;
     }
     __syncthreads();
-    const unsigned b_lo = bspan[0], b_hi = bspan[1];
+    const unsigned b_lo = bspan[0], b_hi = bspan[1], b_width = b_hi > b_lo ? b_hi - b_lo : 0u;   // (no candidate bin: empty)
     // ---- the positives of the candidate bins: distinct values (and the pairs that carry each) through a hash table
     auto insert = [&](float x) {
         const unsigned bits = __float_as_uint(x);
+        {
+            const int b = f1_key(x);                                           // (inside the span; in a candidate bin?)
+            if (!((mark[b >> 5] >> (b & 31)) & 1u)) return;
+        }
         unsigned hslot = f1_hash(bits);
         // (more distinct values than pass B settles: stop - the table never fills, at most one more value per thread)
         while (__hip_atomic_load(&ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned)F1_PICK) {
@@ -1143,11 +1147,10 @@ __global__ __launch_bounds__(F1_THREADS) void f1_plan_kernel(const unsigned long
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                bool hit = false;
-                if (__float_as_uint(x[u]) >= b_lo && __float_as_uint(x[u]) < b_hi) {     // (-1.f, the filler: beyond b_hi)
-                    const int b = f1_key(x[u]);
-                    hit = (mark[b >> 5] >> (b & 31)) & 1u;
-                }
+                // (queued on the span alone - one subtraction, one comparison; key and candidate-bin test wait for the
+                //  insertion, sixty-four values at a time: this loop is one CU's vector pipe, 35 instructions per value
+                //  and wave were 7 us of it.  -1.f, the filler: beyond b_hi)
+                const bool hit = __float_as_uint(x[u]) - b_lo < b_width;
                 const unsigned long long m = __ballot(hit);
                 if (m) {                                                       // (wave-uniform)
                     if (hit) wq[nq + __popcll(m & lt_mask)] = x[u];
