@@ -547,7 +547,8 @@ def main():
             # arrived (sgpr_size_order, no read-back) and the launch makes no node_cap promise (the 64-row layout + the
             # hand-over of larger graphs)
             ragged = [eng.to_ragged(c, l) for c, l, _ in host_inputs]
-            pinned = [tuple(torch.from_numpy(x).pin_memory() for x in r) for r in ragged]
+            # (one pinned buffer per job - offsets | centers | labels -, one H2D copy: Engine.ragged_blob)
+            pinned = [eng.ragged_blob(*r) for r in ragged]
             h2d_bytes = sum(x.nbytes for r in ragged for x in r)
             host_out = [torch.empty(j["m"], j["m"], dtype=torch.float32).pin_memory() for j in jobs]
             xz = [allpairs.pose_xz(p).to(dev) for _, _, p in host_inputs]
@@ -558,8 +559,8 @@ def main():
             dev_out = [torch.empty(j["m"], j["m"], dtype=torch.float32, device=dev) for j in jobs]
 
             def e2e(consumer):
-                for j, (pc, pl, po), ho, do, pz in zip(jobs, pinned, host_out, dev_out, xz):
-                    dc, dl, do_ = pc.to(dev, non_blocking=True), pl.to(dev, non_blocking=True), po.to(dev, non_blocking=True)
+                for j, (blob, layout), ho, do, pz in zip(jobs, pinned, host_out, dev_out, xz):
+                    dc, dl, do_ = eng.ragged_views(blob.to(dev, non_blocking=True), layout)
                     order_r = eng.size_order_device(None, None, do_, n, k)[0] if a.embed_mode == "ordered" else None
                     pooled = eng.embed_ragged(dc, dl, do_, n, k, node_cap=0, order=order_r)[0]
                     if consumer == "d2h":
@@ -587,7 +588,7 @@ def main():
                     e2e(consumer)
                 te = (time.perf_counter() - t0) / reps
                 end_to_end[consumer] = {"ms_per_step": te * 1e3, "value": units / te}
-            end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB) + the launch order on "
+            end_to_end["note"] = ("per step: H2D of the graphs as a ragged store from pinned host memory (%.1f MB, one copy) + the launch order on "
                                   "the device from the offsets that arrived + the step without a node_cap promise + either "
                                   "the D2H copy of the score matrices into pinned memory (%.1f MB, in %d row blocks whose copies "
                                   "overlap the scoring of the next block; `d2h`) or the device-side F1-max over them in one "

@@ -778,3 +778,19 @@ def test_pair_plan_groups_a_list_by_row_graph():
             engine.PairPlan(Host, bad[0], bad[1], 5, 7)
     with pytest.raises(ValueError):
         engine.PairPlan(Host, [0, 1], [0], 5, 7)
+
+
+def test_ragged_blob_round_trip():
+    """Engine.ragged_blob / ragged_views: the ragged store as one host buffer (one H2D copy) gives back the three arrays
+    of to_ragged, each part 16-byte aligned; an empty store is a valid blob."""
+    import numpy as np
+    from sg_pr_amd import engine, synth
+    c, l, _, _ = synth.kitti_like_sequence(37, 100, 3)
+    rc, rl, off = engine.Engine.to_ragged(c, l)
+    blob, lay = engine.Engine.ragged_blob(rc, rl, off, pin=False)
+    vc, vl, vo = engine.Engine.ragged_views(blob, lay)
+    assert np.array_equal(vc.numpy(), rc) and np.array_equal(vl.numpy(), rl) and np.array_equal(vo.numpy(), off)
+    assert all(st % 16 == 0 for st, _ in lay.values())
+    blob, lay = engine.Engine.ragged_blob(rc[:0], rl[:0], off[:1], pin=False)
+    vc, vl, vo = engine.Engine.ragged_views(blob, lay)
+    assert vc.shape == (0, 3) and vl.shape == (0,) and vo.tolist() == [0]
