@@ -742,7 +742,13 @@ class Engine:
         rc = self.lib.sgpr_f1_max(self._h, _ptr(score), r, m, score.stride(0), int(row0), _ptr(pose_xz), float(d_pos),
                                   float(d_neg), _ptr(gt), m, _ptr(res), _ptr(ws), ws_bytes, self._stream())
         self._check(rc)
-        return res.cpu().numpy()
+        # (the 64 bytes land in a pinned buffer of this engine: a pageable copy is staged by the runtime)
+        host = getattr(self, "_f1_host", None)
+        if host is None:
+            host = self._f1_host = torch.empty(8, dtype=torch.float64).pin_memory()
+        host.copy_(res, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return host.numpy().copy()
 
     def topk_rows(self, score, k=1, row0=0, window=-1):
         """Best k columns per row outside |col - (row0 + row)| <= window -> (values f32 [R,k], indices i32 [R,k])."""
