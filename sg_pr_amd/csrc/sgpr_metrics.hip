@@ -645,7 +645,10 @@ struct StripBox {
 //      No workgroup barrier inside the loop: the positives are staged per WAVE (512 floats each, appended with a ballot
 //      prefix, flushed with one global atomic by the wave).
 constexpr int F1_WBUF = F1_PBUF / (F1_THREADS / 64);          // 512 staged positives per wave
-constexpr int F1_SLOWQ = 1024;                                // a workgroup's list of quads left to the pair-by-pair code
+#ifndef SGPR_F1_SLOWQ
+#define SGPR_F1_SLOWQ 1024     // (variant builds with a tiny list exercise the several-rounds path: tools/gpu_r6t.sh TEST_VARIANT)
+#endif
+constexpr int F1_SLOWQ = SGPR_F1_SLOWQ;                                // a workgroup's list of quads left to the pair-by-pair code
 //      The classes of a lane's four pairs leave as one byte (2 bits each: 0 negative, 1 positive, 3 ignored) into
 //      cls_out [R][(M + 3) / 4]: pass B reads that byte instead of repeating the pose arithmetic.
 #ifndef SGPR_F1_SCAN_STAMPS
